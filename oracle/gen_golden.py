@@ -1,0 +1,199 @@
+"""TEST INFRASTRUCTURE — generate the golden fixtures in tests/golden by running the REAL
+reference (imported from /root/reference, CPU) on the hashed inputs of ``oracle.cases``.
+
+Run in the build container only:   python -m oracle.gen_golden [--big]
+Only outputs (data) are stored; weights / inputs / eps are regenerated from their names.
+
+  ops_c8.npz      G1/G2: single-module calls (gru cells, dual cells, p_model+sample, encoder,
+                  decoder, ConvNeXt block, DeepLabHead, SpatialGRU, ode_step euler/midpoint)
+  fpode.npz       G3/G5: NNFOwithBayesianJumps.forward + FuturePredictionODE.forward outputs
+  schedules.json  G4: (kind, dt) op lists + selection indices produced by the reference's own
+                  control flow (temporal_ode_bayes.py:508-620) with its numerics stubbed out
+  big_stats.json  G7: statistics of the C=64, 200x200 forward (tensors are 72 MB)
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import cases, hashfill, refimport
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _np(t):
+    return t.detach().contiguous().numpy().astype(np.float32)
+
+
+def build_ref(m, C, solver="euler", impute=True, variable=True, delta_t=0.05):
+    cfg = refimport.make_cfg(C, impute=impute, solver=solver, variable=variable)
+    net = m.FuturePredictionODE(in_channels=C, latent_dim=C, n_future=4, cfg=cfg, mixture=True,
+                                n_gru_blocks=2, n_res_layers=1, delta_t=delta_t).eval()
+    sd = cases.fpode_state_dict(net.state_dict())
+    net.load_state_dict(sd)
+    return net, sd
+
+
+def gen_ops(m):
+    """G1/G2 at C=8, latent 12x12 (BEV 48x48)."""
+    C, h, w = 8, 12, 12
+    out = {}
+    net, _ = build_ref(m, C)
+    ode = net.gru_ode
+    x = hashfill.normal("op_x", (1, C, h, w), 11)
+    s = hashfill.normal("op_s", (1, C, h, w), 12) * 0.5
+    with torch.no_grad():
+        out["spatial_gru_cell"] = _np(net.spatial_grus[0].gru_cell(x, s))
+        out["dual_ode_cell"] = _np(ode.gru_c(x, s))
+        out["dual_obs_cell"] = _np(ode.gru_obs(s, None, x)[0])
+        with refimport.patched_standard_normal(hashfill.HashedNoise(cases.EPS_SEED)):
+            y0, q = ode.infer_state(s)
+        out["infer_state_y"], out["infer_state_q"] = _np(y0), _np(q)
+        bev = hashfill.normal("op_bev", (1, 2, C, 4 * h, 4 * w), 13)
+        out["srvp_encode"] = _np(ode.srvp_encode(bev)[0])
+        lat = hashfill.normal("op_lat", (1, 2, C, h, w), 14) * 0.5
+        out["srvp_decode"] = _np(ode.srvp_decode(lat))
+        frames = hashfill.normal("op_frames", (3, C, 4 * h, 4 * w), 15)
+        out["convnext_block"] = _np(net.res_blocks[0](frames))
+        out["deeplab_head"] = _np(net.res_blocks[1](frames))
+        seq = hashfill.normal("op_seq", (1, 3, C, 4 * h, 4 * w), 16)
+        out["spatial_gru_seq"] = _np(net.spatial_grus[1](seq, seq[:, 0]))
+        for solver in ("euler", "midpoint"):
+            for impute in (True, False):
+                ode.solver, ode.impute = solver, impute
+                for dt in (0.05, torch.tensor(0.37, dtype=torch.float64)):
+                    with refimport.patched_standard_normal(hashfill.HashedNoise(cases.EPS_SEED)):
+                        st, inp, ct, _, _ = ode.ode_step(s, x, dt, 0.0)
+                    tag = f"ode_step_{solver}_{'imp' if impute else 'noimp'}_{float(dt):.2f}"
+                    out[tag + "_state"], out[tag + "_input"] = _np(st), _np(inp)
+    np.savez_compressed(os.path.join(OUT, "ops_c8.npz"), **out)
+    print("ops_c8.npz", {k: v.shape for k, v in out.items()})
+
+
+def gen_fpode(m):
+    out = {}
+    for name, (C, H, W, ts, solver, impute, variable, eps0) in cases.FPODE_CASES.items():
+        cts, lts, tts, dt = cases.timeset(ts)
+        net, _ = build_ref(m, C, solver, impute, variable, dt)
+        cam, lid = cases.bev_inputs(C, H, W, cts.shape[1], lts.shape[1])
+        x_in = cases.present_input(cam, lid)
+        grabbed = {}
+        hook = net.gru_ode.register_forward_hook(lambda mod, a, o: grabbed.__setitem__("nnfo", o))
+        with torch.no_grad(), refimport.patched_standard_normal(hashfill.HashedNoise(cases.EPS_SEED, zero=eps0)):
+            y, aux = net(x_in, cam, lid, cts, lts, tts)
+        hook.remove()
+        assert aux == 0
+        out[name + "/out"] = _np(y)
+        out[name + "/nnfo_state"] = _np(grabbed["nnfo"][0])
+        out[name + "/nnfo_x"] = _np(grabbed["nnfo"][2])
+        print(name, y.shape, float(y.abs().max()))
+    np.savez_compressed(os.path.join(OUT, "fpode.npz"), **out)
+
+
+def reference_schedule(m, times, T, delta_t, variable):
+    """Run the reference's own ``NNFOwithBayesianJumps.forward`` control flow with every numeric
+    sub-call stubbed (state value == number of ops applied so far)."""
+    tob = m.tob
+    ode = tob.NNFOwithBayesianJumps(8, 8, refimport.make_cfg(8, variable=variable))
+    ops = []
+
+    class FakeObs(torch.nn.Module):
+        def forward(self, state, p, X_obs):
+            ops.append(["jump", None])
+            return state + 1, None
+
+    def fake_step(state, inp, dt, current_time):
+        ops.append(["step", float(dt)])
+        current_time += dt
+        return state + 1, inp, current_time, torch.zeros(1, dtype=torch.float64), torch.zeros(1)
+
+    ode.gru_obs = FakeObs()
+    ode.ode_step = fake_step
+    ode.srvp_encode = lambda x: (x, None)
+    ode.srvp_decode = lambda x, skip=None: x
+    ode.infer_state = lambda x, deterministic=False: (x, None)
+    n = len(times)
+    obs = torch.zeros(1, n, 1, 1, 1)
+    inp = torch.zeros(1, 1, 1, 1, 1)
+    _, _, x = ode.forward(times, inp, obs, delta_t, T)
+    sel = [int(v) for v in x.reshape(-1).tolist()]
+    return ops, sel
+
+
+def gen_schedules(m):
+    from .ref_torch import merge_observations
+    out = {}
+    for name in cases.TIMESETS:
+        cts, lts, tts, dt = cases.timeset(name)
+        C = 1
+        cam = torch.zeros(1, cts.shape[1], C, 1, 1)
+        lid = torch.zeros(1, lts.shape[1], C, 1, 1)
+        # the merge itself is FuturePredictionODE.forward:37-49; reproduce it with the
+        # reference's exact statements (dict of 0-d tensor keys, sorted) to get `times`.
+        obs_feature_with_time = {}
+        for index in range(cts.shape[1]):
+            obs_feature_with_time[cts[0, index]] = ("cam", index)
+        for index in range(lts.shape[1]):
+            obs_feature_with_time[lts[0, index]] = ("lidar", index)
+        obs = dict(sorted(obs_feature_with_time.items(), key=lambda v: v[0]))
+        times = torch.tensor(list(obs.keys()))
+        order = [[s, i] for (s, i) in obs.values()]
+        for variable in (True, False):
+            ops, sel = reference_schedule(m, times, tts[0], dt, variable)
+            out[f"{name}/{'variable' if variable else 'fixed'}"] = {
+                "camera_ts": cts[0].tolist(), "lidar_ts": lts[0].tolist(), "target_ts": tts[0].tolist(),
+                "delta_t": dt, "variable": variable, "obs_order": order,
+                "ops": ops, "select_nops": sel,
+                "n_steps": sum(o[0] == "step" for o in ops), "n_jumps": sum(o[0] == "jump" for o in ops)}
+            print(name, variable, out[f"{name}/{'variable' if variable else 'fixed'}"]["n_steps"], sel)
+    with open(os.path.join(OUT, "schedules.json"), "w") as f:
+        json.dump(out, f, indent=0)
+
+
+def gen_big(m):
+    """G7: C=64, BEV 200x200, shipped schedule — statistics only."""
+    C, H, W = 64, 200, 200
+    cts, lts, tts, dt = cases.timeset("shipped")
+    net, _ = build_ref(m, C, "euler", True, True, dt)
+    cam, lid = cases.bev_inputs(C, H, W, 3, 5)
+    x_in = cases.present_input(cam, lid)
+    grabbed = {}
+    net.gru_ode.register_forward_hook(lambda mod, a, o: grabbed.__setitem__("nnfo", o))
+    with torch.no_grad(), refimport.patched_standard_normal(hashfill.HashedNoise(cases.EPS_SEED)):
+        y, _ = net(x_in, cam, lid, cts, lts, tts)
+    stats = {}
+    for k, t in (("out", y), ("nnfo_state", grabbed["nnfo"][0]), ("nnfo_x", grabbed["nnfo"][2])):
+        flat = t.reshape(-1).double()
+        idx = torch.linspace(0, flat.numel() - 1, 256).long()
+        stats[k] = {"shape": list(t.shape), "mean": flat.mean().item(), "absmax": flat.abs().max().item(),
+                    "std": flat.std().item(), "sum": flat.sum().item(),
+                    "sample_idx": idx.tolist(), "samples": flat[idx].tolist()}
+        print(k, stats[k]["shape"], stats[k]["mean"], stats[k]["absmax"], stats[k]["std"])
+    with open(os.path.join(OUT, "big_stats.json"), "w") as f:
+        json.dump(stats, f)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--big", action="store_true", help="also generate the C=64 200x200 statistics (slow)")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    m = refimport.modules()
+    todo = a.only.split(",") if a.only else ["ops", "fpode", "schedules"]
+    if "ops" in todo:
+        gen_ops(m)
+    if "fpode" in todo:
+        gen_fpode(m)
+    if "schedules" in todo:
+        gen_schedules(m)
+    if a.big or "big" in todo:
+        gen_big(m)
+
+
+if __name__ == "__main__":
+    sys.exit(main())
