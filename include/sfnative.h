@@ -1,0 +1,199 @@
+/* sfnative.h — C ABI of libsfnative.so: the MI355X (gfx950) native GRU-ODE future-state path of
+ * StreamingFlow.  Every entry point takes raw device pointers, sizes and a hipStream_t (passed as
+ * void*), enqueues work on that stream and returns 0 on success or a negative sf_status.  No
+ * entry point allocates, synchronises or keeps global mutable state, so a caller may capture any
+ * sequence of them into a hipGraph (sf_graph_* below).
+ *
+ * The reference (synsin0/StreamingFlow) is pure Python/PyTorch on this path — it has no FFI.  The
+ * functions below are therefore the operator boundary a maintainer would bind (ctypes stub in
+ * INTEGRATION.md); each cites the reference function it replaces (paths relative to the reference
+ * root).
+ *
+ * Data layout.  Activations are fp32 NHWC: a tensor of n images is [n][H][W][C] contiguous, C a
+ * multiple of 8.  The reference API is NCHW; sf_nchw_to_nhwc / sf_nhwc_to_nchw convert at the
+ * module boundary.
+ *
+ * Packed convolution weights (sf_conv_w).  A reference Conv2d weight [cout][cin][kh][kw] is stored
+ * as w[cout_pad][kh*kw*cin_pad] with k = (ky*kw + kx)*cin_pad + c, cin_pad = round_up(cin, 32),
+ * cout_pad = round_up(cout, 16), zero filled.  cin = c0 + c1 is the channel concat of the (up to)
+ * two input tensors a layer reads.  scale/bias hold the per-output-channel affine applied to the
+ * accumulator (conv bias, eval-mode BatchNorm fold, or LayerNorm weight/bias), length cout_pad.
+ * ConvTranspose2d(k3,s1,p1) layers are stored as the equivalent convolution (spatially flipped,
+ * in/out swapped).  The last p_model convolution is stored with its output rows interleaved
+ * (row 16T+4g+r  <->  r<2: loc channel 8T+2g+r, r>=2: raw-scale channel 8T+2g+r-2).
+ */
+#ifndef SFNATIVE_H
+#define SFNATIVE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sf_status {
+  SF_OK = 0,
+  SF_ERR_INVALID = -1,    /* bad argument (null pointer, unsupported shape) */
+  SF_ERR_WORKSPACE = -2,  /* workspace too small */
+  SF_ERR_LAUNCH = -3,     /* HIP launch / runtime error */
+  SF_ERR_UNSUPPORTED = -4
+} sf_status;
+
+enum { SF_ACT_NONE = 0, SF_ACT_LRELU = 1, SF_ACT_RELU = 2, SF_ACT_TANH = 3, SF_ACT_SIGMOID = 4, SF_ACT_GELU = 5 };
+enum { SF_SOLVER_EULER = 0, SF_SOLVER_MIDPOINT = 1, SF_SOLVER_RK4 = 2 };
+enum { SF_OP_JUMP = 0, SF_OP_STEP = 1 };
+/* One coefficient record per ODE step, fp32, computed on the host in float64 and rounded once:
+ * {dt, dt/2, dt/6, dt/3,  dt/2, dt/6,  dt/2, dt/3,  dt, dt/3,  dt/6, 0} (the last 8 = RK4 stage pairs) */
+#define SF_COEF_STRIDE 12
+
+typedef struct sf_conv_w {
+  const float* w;
+  const float* scale; /* may be NULL (= 1) */
+  const float* bias;  /* may be NULL (= 0) */
+  int32_t cout, cout_pad, c0, c1, cin_pad, kh, kw, dil, stride, pad, act;
+} sf_conv_w;
+
+/* conv-GRU cell: SpatialGRU.gru_cell (streamingflow/layers/temporal.py:44-57) */
+typedef struct sf_gru_w {
+  sf_conv_w gates;    /* [conv_update ; conv_reset] stacked on cout (2*hidden), sigmoid */
+  sf_conv_w cand;     /* conv_state_tilde */
+  sf_conv_w decoder;  /* 1x1 conv_decoder, w == NULL if absent */
+} sf_gru_w;
+
+/* DualGRUODECell / DualGRUCell (streamingflow/layers/temporal_ode_bayes.py:64-161 / 211-305) */
+typedef struct sf_dual_w {
+  sf_conv_w gates1, cand1;   /* gru_cell_1 on cat[x, s] */
+  sf_conv_w gates2, cand2;   /* gru_cell_2 on cat[s, s]; gates2 has the duplicate input folded (cin = C) */
+  sf_conv_w dec2;            /* conv_decoder_2 */
+  sf_conv_w tg7, tgproj;     /* trusting_gate.0.layers.0 (7x7, LN in scale/bias), .projection.0 (1x1, GELU) */
+  sf_conv_w tg1, tg3;        /* .layers.3 (1x1 + LN), .layers.6 (3x3 + LN) */
+  const float* w_logit;      /* trusting_gate.1: [2][C] */
+  int32_t C;
+} sf_dual_w;
+
+/* ResBlock (streamingflow/layers/res_models.py:52-79) */
+typedef struct sf_res_w {
+  sf_conv_w conv1, conv2, proj; /* proj.w == NULL when in == out */
+} sf_res_w;
+
+/* ConvNet p_model + rsample (res_models.py:168-180, models/model_utils.py:60-109) */
+typedef struct sf_pmodel_w {
+  sf_res_w rb0, rb1;
+  const float *se0_fc0, *se0_fc2, *se1_fc0, *se1_fc2; /* SELayer fc weights [2C/8][2C], [2C][2C/8] */
+  sf_conv_w last;                                     /* interleaved rows, LeakyReLU */
+  int32_t C;
+} sf_pmodel_w;
+
+/* SmallEncoder / SmallDecoder (res_models.py:82-147) */
+typedef struct sf_encoder_w { sf_res_w blocks[5]; sf_conv_w last; int32_t C, F; } sf_encoder_w;
+typedef struct sf_decoder_w { sf_conv_w first; sf_res_w blocks[5]; sf_conv_w last0, last1; int32_t C, F; } sf_decoder_w;
+
+/* ConvNeXt Block (streamingflow/layers/convolutions.py:310-346) */
+typedef struct sf_convnext_w {
+  const float *dw_w /*[49][C]*/, *dw_b, *ln_w, *ln_b;
+  sf_conv_w pw1, pw2; /* pw2: scale = gamma, bias = gamma*b2 */
+  int32_t C;
+} sf_convnext_w;
+
+/* DeepLabHead / ASPP (convolutions.py:217-280) */
+typedef struct sf_deeplab_w {
+  sf_conv_w branch[4];   /* 1x1 and the three dilated 3x3, BN+ReLU */
+  const float *pool_w /*[hid][C]*/, *pool_scale, *pool_bias; /* ASPPPooling conv + BN */
+  const float* proj_pool_w; /* [hid][hid]: projection weights of the pooled branch */
+  sf_conv_w project;     /* 1x1 over the 4 spatial branches (cin = 4*hid), BN+ReLU */
+  sf_conv_w conv3, cls;  /* 3x3+BN+ReLU, final 1x1 (+bias) */
+  int32_t C, hid;
+} sf_deeplab_w;
+
+int sf_version(void);
+const char* sf_status_string(int status);
+
+/* layout: [n][C][HW] <-> [n][HW][C] */
+int sf_nchw_to_nhwc(const float* src, float* dst, int n, int C, int HW, void* stream);
+int sf_nhwc_to_nchw(const float* src, float* dst, int n, int C, int HW, void* stream);
+
+/* generic fused conv (test hook and building block): y = act(conv(cat[in0,in1])*scale + bias) + add */
+int sf_conv2d_fwd(const sf_conv_w* w, const float* in0, const float* in1, const float* add, float* out,
+                  int n_img, int Hin, int Win, int in_up, void* stream);
+
+/* SpatialGRU.gru_cell — temporal.py:44-57.  x [P][Cx], s [P][C] -> out [P][C] (P = n*H*W) */
+int sf_gru_cell_fwd(const sf_gru_w* w, const float* x, const float* s, float* out, int n_img, int H, int W,
+                    float* ws, size_t ws_bytes, void* stream);
+size_t sf_gru_cell_ws_bytes(int C, int n_img, int H, int W);
+
+/* SpatialGRU.forward — temporal.py:26-42.  x [T][H*W][Cx], state0 [H*W][C] -> out [T][H*W][Cx] */
+int sf_spatial_gru_fwd(const sf_gru_w* w, const float* x, const float* state0, float* out, int T, int H, int W,
+                       float* ws, size_t ws_bytes, void* stream);
+size_t sf_spatial_gru_ws_bytes(int C, int H, int W);
+
+/* DualGRUODECell.forward (derivative != 0) / DualGRUCell.forward (derivative == 0) —
+ * temporal_ode_bayes.py:92-131 / :239-275, fused with the integrator update:
+ *   derivative: out = base + coef[0]*(cur - s); optional out2 = (acc2 ? out2 : base) + coef[1]*(cur - s)
+ *   jump:       out = cur
+ * coef points at device fp32 scalars.  out may not alias x/s/base. */
+int sf_dual_cell_fwd(const sf_dual_w* w, const float* x, const float* s, float* out, int derivative,
+                     const float* base, const float* coef, float* out2, int acc2, int H, int W,
+                     float* ws, size_t ws_bytes, void* stream);
+size_t sf_dual_cell_ws_bytes(int C, int H, int W);
+
+/* NNFOwithBayesianJumps.infer_state — temporal_ode_bayes.py:463-477: p = loc + eps*(softplus(raw)+1e-8).
+ * q_out (raw p_model output, [P][2C], reference channel order) may be NULL. */
+int sf_infer_state_fwd(const sf_pmodel_w* w, const float* s, const float* eps, float* p_out, float* q_out,
+                       int H, int W, float* ws, size_t ws_bytes, void* stream);
+size_t sf_infer_state_ws_bytes(int C, int H, int W);
+
+/* NNFOwithBayesianJumps.ode_step — temporal_ode_bayes.py:436-461 (euler, midpoint) and the
+ * build-defined classical RK4.  coef: one device coefficient record (SF_COEF_STRIDE floats).  eps: [n_draws][P][C]
+ * with n_draws = 1 (euler), 2 (midpoint), 4 (rk4).  If impute == 0 the cell input is zeros
+ * (:442-443).  state_out / p_out must not alias state_in / p_in. */
+int sf_ode_step_fwd(const sf_dual_w* gru_c, const sf_pmodel_w* pm, int solver, int impute, const float* state_in,
+                    const float* p_in, const float* coef, const float* eps, float* state_out, float* p_out,
+                    int H, int W, float* ws, size_t ws_bytes, void* stream);
+size_t sf_ode_step_ws_bytes(int C, int H, int W);
+
+/* The observation/prediction loop of NNFOwithBayesianJumps.forward — temporal_ode_bayes.py:539-604,
+ * driven by a schedule computed on the host (streamingflow_amd.schedule).  ops[2*i] = SF_OP_JUMP
+ * (ops[2*i+1] = observation index) or SF_OP_STEP (ops[2*i+1] = record index into coef).
+ * After op i (1-based count k = i+1) the state is copied to out_states[t] for every target t with
+ * sel_nops[t] == k (:606-622).  hx_obs [n_obs][P][C]; eps [n_draws][P][C] in reference draw order. */
+int sf_nnfo_rollout_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const sf_pmodel_w* pm, int solver,
+                        int impute, const int32_t* ops, int n_ops, const float* hx_obs, const float* eps,
+                        const float* coef, const int32_t* sel_nops, int n_targets, float* out_states,
+                        float* final_state, int H, int W, float* ws, size_t ws_bytes, void* stream);
+size_t sf_nnfo_rollout_ws_bytes(int C, int H, int W);
+
+/* SmallEncoder.forward — res_models.py:98-109: [n][H][W][C] -> [n][H/4][W/4][C] */
+int sf_small_encoder_fwd(const sf_encoder_w* w, const float* x, float* out, int n, int H, int W,
+                         float* ws, size_t ws_bytes, void* stream);
+size_t sf_small_encoder_ws_bytes(int C, int F, int n, int H, int W);
+/* SmallDecoder.forward — res_models.py:134-147: [n][h][w][C] -> [n][4h][4w][C] */
+int sf_small_decoder_fwd(const sf_decoder_w* w, const float* z, float* out, int n, int h, int wd,
+                         float* ws, size_t ws_bytes, void* stream);
+size_t sf_small_decoder_ws_bytes(int C, int F, int n, int h, int w);
+
+/* ConvNeXt Block.forward — convolutions.py:333-346 */
+int sf_convnext_block_fwd(const sf_convnext_w* w, const float* x, float* out, int n, int H, int W,
+                          float* ws, size_t ws_bytes, void* stream);
+size_t sf_convnext_block_ws_bytes(int C, int n, int H, int W);
+/* DeepLabHead.forward — convolutions.py:272-280 */
+int sf_deeplab_head_fwd(const sf_deeplab_w* w, const float* x, float* out, int n, int H, int W,
+                        float* ws, size_t ws_bytes, void* stream);
+size_t sf_deeplab_head_ws_bytes(int C, int hid, int n, int H, int W);
+
+/* hipGraph capture of whatever the caller enqueues between begin and end on `stream` (must not be
+ * the legacy default stream). */
+int sf_graph_begin(void* stream);
+int sf_graph_end(void* stream, void** graph_exec_out);
+int sf_graph_launch(void* graph_exec, void* stream);
+int sf_graph_destroy(void* graph_exec);
+
+/* hipEvent timing helper for bench.py (events recorded on the stream the kernels run on) */
+int sf_event_create(void** ev);
+int sf_event_record(void* ev, void* stream);
+int sf_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+int sf_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFNATIVE_H */

@@ -167,7 +167,7 @@ def gen_big(m):
     stats = {}
     for k, t in (("out", y), ("nnfo_state", grabbed["nnfo"][0]), ("nnfo_x", grabbed["nnfo"][2])):
         flat = t.reshape(-1).double()
-        idx = torch.linspace(0, flat.numel() - 1, 256).long()
+        idx = torch.linspace(0, flat.numel() - 1, 256, dtype=torch.float64).long().clamp(max=flat.numel() - 1)
         stats[k] = {"shape": list(t.shape), "mean": flat.mean().item(), "absmax": flat.abs().max().item(),
                     "std": flat.std().item(), "sum": flat.sum().item(),
                     "sample_idx": idx.tolist(), "samples": flat[idx].tolist()}

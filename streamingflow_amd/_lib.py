@@ -1,0 +1,129 @@
+"""ctypes binding of libsfnative.so (C ABI: include/sfnative.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  `lib()` raises if the shared
+object is missing or does not export every symbol the header declares.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsfnative.so")
+
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int32)
+
+SF_COEF_STRIDE = 12
+ACT = {"none": 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4, "gelu": 5}
+SOLVER = {"euler": 0, "midpoint": 1, "rk4": 2}
+OP_JUMP, OP_STEP = 0, 1
+
+
+class ConvW(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p),
+                ("cout", C.c_int32), ("cout_pad", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
+                ("cin_pad", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("dil", C.c_int32),
+                ("stride", C.c_int32), ("pad", C.c_int32), ("act", C.c_int32)]
+
+
+class GruW(C.Structure):
+    _fields_ = [("gates", ConvW), ("cand", ConvW), ("decoder", ConvW)]
+
+
+class DualW(C.Structure):
+    _fields_ = [("gates1", ConvW), ("cand1", ConvW), ("gates2", ConvW), ("cand2", ConvW), ("dec2", ConvW),
+                ("tg7", ConvW), ("tgproj", ConvW), ("tg1", ConvW), ("tg3", ConvW),
+                ("w_logit", C.c_void_p), ("C", C.c_int32)]
+
+
+class ResW(C.Structure):
+    _fields_ = [("conv1", ConvW), ("conv2", ConvW), ("proj", ConvW)]
+
+
+class PModelW(C.Structure):
+    _fields_ = [("rb0", ResW), ("rb1", ResW), ("se0_fc0", C.c_void_p), ("se0_fc2", C.c_void_p),
+                ("se1_fc0", C.c_void_p), ("se1_fc2", C.c_void_p), ("last", ConvW), ("C", C.c_int32)]
+
+
+class EncoderW(C.Structure):
+    _fields_ = [("blocks", ResW * 5), ("last", ConvW), ("C", C.c_int32), ("F", C.c_int32)]
+
+
+class DecoderW(C.Structure):
+    _fields_ = [("first", ConvW), ("blocks", ResW * 5), ("last0", ConvW), ("last1", ConvW),
+                ("C", C.c_int32), ("F", C.c_int32)]
+
+
+class ConvNextW(C.Structure):
+    _fields_ = [("dw_w", C.c_void_p), ("dw_b", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p),
+                ("pw1", ConvW), ("pw2", ConvW), ("C", C.c_int32)]
+
+
+class DeepLabW(C.Structure):
+    _fields_ = [("branch", ConvW * 4), ("pool_w", C.c_void_p), ("pool_scale", C.c_void_p),
+                ("pool_bias", C.c_void_p), ("proj_pool_w", C.c_void_p), ("project", ConvW),
+                ("conv3", ConvW), ("cls", ConvW), ("C", C.c_int32), ("hid", C.c_int32)]
+
+
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+# name -> (restype, argtypes); every symbol declared in include/sfnative.h
+SIGNATURES = {
+    "sf_version": (_i, []),
+    "sf_status_string": (C.c_char_p, [_i]),
+    "sf_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sf_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sf_conv2d_fwd": (_i, [C.POINTER(ConvW), _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sf_gru_cell_fwd": (_i, [C.POINTER(GruW), _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_gru_cell_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "sf_spatial_gru_fwd": (_i, [C.POINTER(GruW), _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_spatial_gru_ws_bytes": (_sz, [_i, _i, _i]),
+    "sf_dual_cell_fwd": (_i, [C.POINTER(DualW), _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_dual_cell_ws_bytes": (_sz, [_i, _i, _i]),
+    "sf_infer_state_fwd": (_i, [C.POINTER(PModelW), _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "sf_infer_state_ws_bytes": (_sz, [_i, _i, _i]),
+    "sf_ode_step_fwd": (_i, [C.POINTER(DualW), C.POINTER(PModelW), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+                             _vp, _sz, _vp]),
+    "sf_ode_step_ws_bytes": (_sz, [_i, _i, _i]),
+    "sf_nnfo_rollout_fwd": (_i, [C.POINTER(DualW), C.POINTER(DualW), C.POINTER(PModelW), _i, _i, i32p, _i, _vp, _vp,
+                                 _vp, i32p, _i, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "sf_nnfo_rollout_ws_bytes": (_sz, [_i, _i, _i]),
+    "sf_small_encoder_fwd": (_i, [C.POINTER(EncoderW), _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_small_encoder_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "sf_small_decoder_fwd": (_i, [C.POINTER(DecoderW), _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_small_decoder_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "sf_convnext_block_fwd": (_i, [C.POINTER(ConvNextW), _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_convnext_block_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "sf_deeplab_head_fwd": (_i, [C.POINTER(DeepLabW), _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_deeplab_head_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "sf_graph_begin": (_i, [_vp]),
+    "sf_graph_end": (_i, [_vp, C.POINTER(_vp)]),
+    "sf_graph_launch": (_i, [_vp, _vp]),
+    "sf_graph_destroy": (_i, [_vp]),
+    "sf_event_create": (_i, [C.POINTER(_vp)]),
+    "sf_event_record": (_i, [_vp, _vp]),
+    "sf_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
+    "sf_event_destroy": (_i, [_vp]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises RuntimeError when the HIP library is absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m streamingflow_amd.build` "
+                "(hipcc --offload-arch=gfx950). streamingflow_amd has no CPU fallback.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)     # AttributeError => missing export
+            fn.restype, fn.argtypes = res, args
+        _LIB = h
+    return _LIB
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().sf_status_string(status).decode()
+        raise RuntimeError(f"libsfnative {what}: {msg} ({status})")

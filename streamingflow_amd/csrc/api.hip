@@ -1,0 +1,587 @@
+// Host orchestration + C ABI (include/sfnative.h) of libsfnative.so.  gfx950 only.
+// Every function only enqueues kernels on the caller's stream: no allocation, no sync, no
+// global mutable state (graph-capture safe).
+#include "sf_device.h"
+#include "../../include/sfnative.h"
+
+#include <cstring>
+
+namespace sf {
+hipError_t launch_conv(const ConvLaunch& L, int epi, int cfg, hipStream_t stream);
+hipError_t launch_transpose(const float* in, float* out, int n, int rows, int cols, hipStream_t s);
+hipError_t launch_maxpool2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s);
+hipError_t launch_upsample2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s);
+hipError_t launch_se_fc(const float* chansum, int ntile, int C, int Cr, int hw, const float* fc0,
+                        const float* fc2, float* scale, hipStream_t s);
+hipError_t launch_dwconv7_ln(const float* in, float* out, const float* wdw, const float* bdw, const float* lnw,
+                             const float* lnb, int n, int H, int W, int C, float eps, hipStream_t s);
+hipError_t launch_aspp_pool(const float* in, float* part, float* bias_img, int n, int HW, int C, int hid,
+                            const float* w1, const float* s1, const float* b1, const float* wp, const float* ps,
+                            const float* pb, int nslab, hipStream_t s);
+}  // namespace sf
+
+using namespace sf;
+
+namespace {
+
+#define SF_TRY(expr)                                   \
+  do {                                                 \
+    int _st = (expr);                                  \
+    if (_st != SF_OK) return _st;                      \
+  } while (0)
+#define SF_HIP(expr)                                   \
+  do {                                                 \
+    if ((expr) != hipSuccess) return SF_ERR_LAUNCH;    \
+  } while (0)
+
+struct Arena {
+  float* base;
+  size_t cap, off;
+  Arena(float* b, size_t bytes) : base(b), cap(bytes / sizeof(float)), off(0) {}
+  float* take(size_t n) {
+    size_t a = (n + 63) & ~size_t(63);
+    if (!base || off + a > cap) { off = cap + 1; return nullptr; }
+    float* p = base + off;
+    off += a;
+    return p;
+  }
+  bool ok() const { return off <= cap; }
+};
+inline size_t al(size_t n) { return (n + 63) & ~size_t(63); }
+
+constexpr int LARGE_P = 8192;   // pixels from which the 64x64 / 64x128 tiles are used
+constexpr int ASPP_SLABS = 64;
+
+int pick_cfg(int P, int epi) {
+  if (epi == EPI_LNG || epi == EPI_TRUST) return P >= LARGE_P ? 2 : 0;
+  return P >= LARGE_P ? 1 : 0;
+}
+
+// Fill a problem from a packed layer + geometry.  Output spatial size follows the conv formula.
+ConvProblem problem(const sf_conv_w& w, const float* in0, const float* in1, float* out, int n_img, int Hin,
+                    int Win, int in_up = 0) {
+  ConvProblem p;
+  std::memset(&p, 0, sizeof(p));
+  p.in0 = in0; p.in1 = in1; p.w = w.w; p.scale = w.scale; p.bias = w.bias; p.out = out;
+  p.c0 = w.c0; p.c1 = w.c1; p.in0_cs = w.c0; p.in1_cs = w.c1;
+  p.n_img = n_img; p.Hin = Hin; p.Win = Win; p.in_up = in_up;
+  const int Hl = Hin << in_up, Wl = Win << in_up;
+  p.KH = w.kh; p.KW = w.kw; p.dil = w.dil; p.stride = w.stride; p.pad = w.pad;
+  p.Hout = (Hl + 2 * w.pad - w.dil * (w.kh - 1) - 1) / w.stride + 1;
+  p.Wout = (Wl + 2 * w.pad - w.dil * (w.kw - 1) - 1) / w.stride + 1;
+  p.cin_pad = w.cin_pad; p.ktot = w.kh * w.kw * w.cin_pad;
+  p.cout = w.cout; p.cout_pad = w.cout_pad; p.act = w.act;
+  p.add_cs = w.cout; p.out_cs = w.cout; p.out_co = 0; p.out2_cs = w.cout;
+  p.eps = 1e-6f;
+  return p;
+}
+
+bool valid_w(const sf_conv_w& w) {
+  return w.w && w.cout > 0 && (w.cout % 4) == 0 && (w.cout_pad % 16) == 0 && w.cout_pad >= w.cout &&
+         (w.cin_pad % 32) == 0 && w.cin_pad >= w.c0 + w.c1 && (w.c0 % 4) == 0 && (w.c1 % 4) == 0 && w.kh > 0 &&
+         w.kw > 0 && w.stride > 0 && w.dil > 0;
+}
+
+int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
+  ConvLaunch L;
+  std::memset(&L, 0, sizeof(L));
+  if (n < 1 || n > SF_MAX_GROUP) return SF_ERR_INVALID;
+  int P = 0;
+  for (int i = 0; i < n; ++i) {
+    L.p[i] = ps[i];
+    int Pi = ps[i].n_img * ps[i].Hout * ps[i].Wout;
+    if (Pi > P) P = Pi;
+    if ((epi == EPI_LNG || epi == EPI_TRUST) && ps[i].cout_pad > 64) return SF_ERR_UNSUPPORTED;
+  }
+  L.nprob = n;
+  if (P <= 0) return SF_OK;
+  SF_HIP(launch_conv(L, epi, pick_cfg(P, epi), st));
+  return SF_OK;
+}
+int run1(const ConvProblem& p, int epi, hipStream_t st) { return run(&p, 1, epi, st); }
+
+// ---- modules ---------------------------------------------------------------------------------
+
+// conv-GRU cell (temporal.py:44-57): gates -> blend.  gates buffer g: [P][2C] = [u | r]
+int gru_cell(const sf_gru_w& w, const float* x, const float* s, float* out, float* g, int n, int H, int W,
+             hipStream_t st) {
+  const int C = w.cand.cout;
+  ConvProblem a = problem(w.gates, x, s, g, n, H, W);
+  SF_TRY(run1(a, EPI_AFFINE, st));
+  ConvProblem b = problem(w.cand, x, s, out, n, H, W);
+  b.gate = g; b.gate_cs = 2 * C; b.gate_co = C;
+  b.e0 = g; b.e0_cs = 2 * C; b.e1 = s; b.e1_cs = C;
+  return run1(b, EPI_BLEND, st);
+}
+
+size_t dual_ws_floats(int C, int P) { return 2 * al((size_t)P * 2 * C) + 6 * al((size_t)P * C); }
+
+// temporal_ode_bayes.py:92-131 / :239-275
+int dual_cell(const sf_dual_w& w, const float* x, const float* s, float* out, int derivative, const float* base,
+              const float* coef, float* out2, int acc2, int H, int W, Arena& A, hipStream_t st) {
+  const int C = w.C, P = H * W;
+  float* g1 = A.take((size_t)P * 2 * C);
+  float* g2 = A.take((size_t)P * 2 * C);
+  float* h1 = A.take((size_t)P * C);
+  float* h2 = A.take((size_t)P * C);
+  float* r2 = A.take((size_t)P * C);
+  float* t1 = A.take((size_t)P * C);
+  float* sk = A.take((size_t)P * C);
+  float* t2 = A.take((size_t)P * C);
+  if (!A.ok()) return SF_ERR_WORKSPACE;
+  ConvProblem ps[2];
+  // gates of both cells (cell 2 sees cat[s,s]: duplicate input folded into the packed weights)
+  ps[0] = problem(w.gates1, x, s, g1, 1, H, W);
+  ps[1] = problem(w.gates2, s, nullptr, g2, 1, H, W);
+  SF_TRY(run(ps, 2, EPI_AFFINE, st));
+  // candidates + blend
+  ps[0] = problem(w.cand1, x, s, h1, 1, H, W);
+  ps[0].gate = g1; ps[0].gate_cs = 2 * C; ps[0].gate_co = C; ps[0].e0 = g1; ps[0].e0_cs = 2 * C; ps[0].e1 = s; ps[0].e1_cs = C;
+  ps[1] = problem(w.cand2, s, s, h2, 1, H, W);
+  ps[1].gate = g2; ps[1].gate_cs = 2 * C; ps[1].gate_co = C; ps[1].e0 = g2; ps[1].e0_cs = 2 * C; ps[1].e1 = s; ps[1].e1_cs = C;
+  SF_TRY(run(ps, 2, EPI_BLEND, st));
+  // rnn_state2 = conv_decoder_2(h2)
+  SF_TRY(run1(problem(w.dec2, h2, nullptr, r2, 1, H, W), EPI_AFFINE, st));
+  // trusting gate: 7x7 + LN + GELU  ||  1x1 projection + GELU
+  ps[0] = problem(w.tg7, h1, r2, t1, 1, H, W); ps[0].mode = 1;
+  ps[1] = problem(w.tgproj, h1, r2, sk, 1, H, W); ps[1].mode = 0;
+  SF_TRY(run(ps, 2, EPI_LNG, st));
+  ConvProblem q = problem(w.tg1, t1, nullptr, t2, 1, H, W); q.mode = 1;
+  SF_TRY(run1(q, EPI_LNG, st));
+  ConvProblem f = problem(w.tg3, t2, nullptr, out, 1, H, W);
+  f.e0 = sk; f.e1 = w.w_logit; f.e2 = r2; f.e3 = h1; f.e4 = s; f.e5 = base ? base : s;
+  f.coef = coef; f.out2 = out2; f.mode = (derivative ? 1 : 0) | (acc2 ? 2 : 0);
+  if (derivative && !coef) return SF_ERR_INVALID;
+  return run1(f, EPI_TRUST, st);
+}
+
+size_t infer_ws_floats(int C, int P) {
+  int nt = (P + 15) / 16;
+  return al((size_t)P * C) + 4 * al((size_t)P * 2 * C) + 2 * al((size_t)nt * 2 * C) + 2 * al(2 * C);
+}
+
+// temporal_ode_bayes.py:463-477
+int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p_out, float* q_out, int H, int W,
+                Arena& A, hipStream_t st) {
+  const int C = w.C, C2 = 2 * C, P = H * W, nt = (P + 15) / 16;
+  float* a = A.take((size_t)P * C);
+  float* pr = A.take((size_t)P * C2);
+  float* y1 = A.take((size_t)P * C2);
+  float* b = A.take((size_t)P * C2);
+  float* y2 = A.take((size_t)P * C2);
+  float* cs1 = A.take((size_t)nt * C2);
+  float* cs2 = A.take((size_t)nt * C2);
+  float* sc1 = A.take(C2);
+  float* sc2 = A.take(C2);
+  if (!A.ok()) return SF_ERR_WORKSPACE;
+  if (!w.rb0.proj.w || w.rb1.proj.w) return SF_ERR_INVALID;
+  ConvProblem ps[2];
+  ps[0] = problem(w.rb0.conv1, s, nullptr, a, 1, H, W);
+  ps[1] = problem(w.rb0.proj, s, nullptr, pr, 1, H, W);
+  SF_TRY(run(ps, 2, EPI_AFFINE, st));
+  ConvProblem c2 = problem(w.rb0.conv2, a, nullptr, y1, 1, H, W);
+  c2.add = pr; c2.chansum = cs1;
+  SF_TRY(run1(c2, EPI_AFFINE, st));
+  SF_HIP(launch_se_fc(cs1, nt, C2, C2 / 8, P, w.se0_fc0, w.se0_fc2, sc1, st));
+  ConvProblem c3 = problem(w.rb1.conv1, y1, nullptr, b, 1, H, W);
+  c3.in_scale = sc1;
+  SF_TRY(run1(c3, EPI_AFFINE, st));
+  ConvProblem c4 = problem(w.rb1.conv2, b, nullptr, y2, 1, H, W);
+  c4.add = y1; c4.add_scale = sc1; c4.chansum = cs2;
+  SF_TRY(run1(c4, EPI_AFFINE, st));
+  SF_HIP(launch_se_fc(cs2, nt, C2, C2 / 8, P, w.se1_fc0, w.se1_fc2, sc2, st));
+  ConvProblem c5 = problem(w.last, y2, nullptr, p_out, 1, H, W);
+  c5.in_scale = sc2; c5.e0 = eps; c5.out2 = q_out;
+  return run1(c5, EPI_SAMPLE, st);
+}
+
+// temporal_ode_bayes.py:436-461 (+ build-defined RK4).  `zeros`: [P][C] zero tensor (IMPUTE=False).
+// Scratch: k (P*C), pk (P*C), acc (P*C) + cell/infer workspaces.
+int ode_step(const sf_dual_w& gc, const sf_pmodel_w& pm, int solver, int impute, const float* s_in,
+             const float* p_in, const float* coef, const float* eps, float* s_out, float* p_out, const float* zeros,
+             int skip_dead_infer, int H, int W, Arena& A0, hipStream_t st) {
+  const int C = gc.C;
+  const size_t PC = (size_t)H * W * C;
+  const float* x = impute ? p_in : zeros;
+  auto cell = [&](const float* xx, const float* ss, float* out, const float* base, const float* cf, float* out2,
+                  int acc2) {
+    Arena A = A0;
+    return dual_cell(gc, xx, ss, out, 1, base, cf, out2, acc2, H, W, A, st);
+  };
+  auto infer = [&](const float* ss, int draw, float* po) {
+    Arena A = A0;
+    return infer_state(pm, ss, eps + (size_t)draw * PC, po, nullptr, H, W, A, st);
+  };
+  if (solver == SF_SOLVER_EULER) {
+    SF_TRY(cell(x, s_in, s_out, s_in, coef + 0, nullptr, 0));
+    if (!(skip_dead_infer && !impute)) SF_TRY(infer(s_out, 0, p_out));
+    return SF_OK;
+  }
+  float* k = A0.take(PC);
+  float* pk = A0.take(PC);
+  float* acc = A0.take(PC);
+  if (!A0.ok()) return SF_ERR_WORKSPACE;
+  if (solver == SF_SOLVER_MIDPOINT) {
+    SF_TRY(cell(x, s_in, k, s_in, coef + 1, nullptr, 0));              // k = s + dt/2 f(p, s)
+    if (impute) SF_TRY(infer(k, 0, pk));
+    SF_TRY(cell(impute ? pk : zeros, k, s_out, s_in, coef + 0, nullptr, 0));   // s' = s + dt f(pk, k)
+    if (!(skip_dead_infer && !impute)) SF_TRY(infer(s_out, 1, p_out));
+    return SF_OK;
+  }
+  if (solver == SF_SOLVER_RK4) {
+    // coef = {dt, dt/2, dt/6, dt/3}.  acc = s + dt/6 k1 + dt/3 k2 + dt/3 k3 ; s' = acc + dt/6 k4
+    float* s2 = k;
+    float* s3 = A0.take(PC);
+    if (!A0.ok()) return SF_ERR_WORKSPACE;
+    // stage coefficient pairs {out coef, out2 coef} follow the four scalars in the coef record:
+    // {dt/2, dt/6}, {dt/2, dt/3}, {dt, dt/3}, {dt/6, 0}   (see SF_COEF_STRIDE in sfnative.h)
+    const float* rk = coef + 4;
+    SF_TRY(cell(x, s_in, s2, s_in, rk + 0, acc, 0));
+    if (impute) SF_TRY(infer(s2, 0, pk));
+    SF_TRY(cell(impute ? pk : zeros, s2, s3, s_in, rk + 2, acc, 1));
+    if (impute) SF_TRY(infer(s3, 1, pk));
+    SF_TRY(cell(impute ? pk : zeros, s3, s2, s_in, rk + 4, acc, 1));   // s4 reuses s2
+    if (impute) SF_TRY(infer(s2, 2, pk));
+    SF_TRY(cell(impute ? pk : zeros, s2, s_out, acc, rk + 6, nullptr, 0));
+    if (!(skip_dead_infer && !impute)) SF_TRY(infer(s_out, 3, p_out));
+    return SF_OK;
+  }
+  return SF_ERR_INVALID;
+}
+
+size_t ode_step_ws_floats(int C, int P) {
+  size_t cellw = dual_ws_floats(C, P), inf = infer_ws_floats(C, P);
+  return 4 * al((size_t)P * C) + (cellw > inf ? cellw : inf);
+}
+
+// ResBlock (res_models.py:74-79) on n images; t: [P][cin] scratch, pr: [P][cout] scratch (if proj)
+int res_block(const sf_res_w& w, const float* x, float* out, float* t, float* pr, int n, int Hin, int Win, int in_up,
+              hipStream_t st) {
+  ConvProblem ps[2];
+  ps[0] = problem(w.conv1, x, nullptr, t, n, Hin, Win, in_up);
+  int np = 1;
+  if (w.proj.w) { ps[1] = problem(w.proj, x, nullptr, pr, n, Hin, Win, in_up); np = 2; }
+  SF_TRY(run(ps, np, EPI_AFFINE, st));
+  if (!w.proj.w && in_up) return SF_ERR_INVALID;   // residual of an upsampled input needs it materialised
+  ConvProblem c2 = problem(w.conv2, t, nullptr, out, n, Hin << in_up, Win << in_up);
+  c2.add = w.proj.w ? pr : x;
+  return run1(c2, EPI_AFFINE, st);
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int sf_version(void) { return 100; }
+
+const char* sf_status_string(int s) {
+  switch (s) {
+    case SF_OK: return "ok";
+    case SF_ERR_INVALID: return "invalid argument";
+    case SF_ERR_WORKSPACE: return "workspace too small";
+    case SF_ERR_LAUNCH: return "HIP launch/runtime error";
+    case SF_ERR_UNSUPPORTED: return "unsupported shape";
+  }
+  return "unknown";
+}
+
+int sf_nchw_to_nhwc(const float* src, float* dst, int n, int C, int HW, void* stream) {
+  if (!src || !dst) return SF_ERR_INVALID;
+  SF_HIP(launch_transpose(src, dst, n, C, HW, (hipStream_t)stream));
+  return SF_OK;
+}
+int sf_nhwc_to_nchw(const float* src, float* dst, int n, int C, int HW, void* stream) {
+  if (!src || !dst) return SF_ERR_INVALID;
+  SF_HIP(launch_transpose(src, dst, n, HW, C, (hipStream_t)stream));
+  return SF_OK;
+}
+
+int sf_conv2d_fwd(const sf_conv_w* w, const float* in0, const float* in1, const float* add, float* out, int n_img,
+                  int Hin, int Win, int in_up, void* stream) {
+  if (!w || !valid_w(*w) || !in0 || !out || (w->c1 > 0 && !in1)) return SF_ERR_INVALID;
+  ConvProblem p = problem(*w, in0, in1, out, n_img, Hin, Win, in_up);
+  p.add = add;
+  return run1(p, EPI_AFFINE, (hipStream_t)stream);
+}
+
+size_t sf_gru_cell_ws_bytes(int C, int n_img, int H, int W) { return al((size_t)n_img * H * W * 2 * C) * sizeof(float); }
+int sf_gru_cell_fwd(const sf_gru_w* w, const float* x, const float* s, float* out, int n_img, int H, int W, float* ws,
+                    size_t ws_bytes, void* stream) {
+  if (!w || !x || !s || !out || !valid_w(w->gates) || !valid_w(w->cand)) return SF_ERR_INVALID;
+  Arena A(ws, ws_bytes);
+  float* g = A.take((size_t)n_img * H * W * 2 * w->cand.cout);
+  if (!A.ok()) return SF_ERR_WORKSPACE;
+  return gru_cell(*w, x, s, out, g, n_img, H, W, (hipStream_t)stream);
+}
+
+size_t sf_spatial_gru_ws_bytes(int C, int H, int W) {
+  return (al((size_t)H * W * 2 * C) + 2 * al((size_t)H * W * C)) * sizeof(float);
+}
+int sf_spatial_gru_fwd(const sf_gru_w* w, const float* x, const float* state0, float* out, int T, int H, int W,
+                       float* ws, size_t ws_bytes, void* stream) {
+  if (!w || !x || !state0 || !out || !valid_w(w->gates) || !valid_w(w->cand) || !valid_w(w->decoder)) return SF_ERR_INVALID;
+  const int C = w->cand.cout, Cx = w->gates.c0;
+  const size_t P = (size_t)H * W;
+  Arena A(ws, ws_bytes);
+  float* g = A.take(P * 2 * C);
+  float* sa = A.take(P * C);
+  float* sb = A.take(P * C);
+  if (!A.ok()) return SF_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const float* cur = state0;
+  for (int t = 0; t < T; ++t) {   // temporal.py:35-39
+    float* nxt = (t & 1) ? sb : sa;
+    SF_TRY(gru_cell(*w, x + t * P * Cx, cur, nxt, g, 1, H, W, st));
+    SF_TRY(run1(problem(w->decoder, nxt, nullptr, out + t * P * w->decoder.cout, 1, H, W), EPI_AFFINE, st));
+    cur = nxt;
+  }
+  return SF_OK;
+}
+
+size_t sf_dual_cell_ws_bytes(int C, int H, int W) { return dual_ws_floats(C, H * W) * sizeof(float); }
+int sf_dual_cell_fwd(const sf_dual_w* w, const float* x, const float* s, float* out, int derivative, const float* base,
+                     const float* coef, float* out2, int acc2, int H, int W, float* ws, size_t ws_bytes, void* stream) {
+  if (!w || !x || !s || !out || w->C <= 0 || (w->C % 8)) return SF_ERR_INVALID;
+  if (w->C > 64) return SF_ERR_UNSUPPORTED;
+  Arena A(ws, ws_bytes);
+  return dual_cell(*w, x, s, out, derivative, base, coef, out2, acc2, H, W, A, (hipStream_t)stream);
+}
+
+size_t sf_infer_state_ws_bytes(int C, int H, int W) { return infer_ws_floats(C, H * W) * sizeof(float); }
+int sf_infer_state_fwd(const sf_pmodel_w* w, const float* s, const float* eps, float* p_out, float* q_out, int H, int W,
+                       float* ws, size_t ws_bytes, void* stream) {
+  if (!w || !s || !eps || !p_out || w->C <= 0 || (w->C % 8)) return SF_ERR_INVALID;
+  Arena A(ws, ws_bytes);
+  return infer_state(*w, s, eps, p_out, q_out, H, W, A, (hipStream_t)stream);
+}
+
+size_t sf_ode_step_ws_bytes(int C, int H, int W) { return (ode_step_ws_floats(C, H * W) + al((size_t)H * W * C)) * sizeof(float); }
+int sf_ode_step_fwd(const sf_dual_w* gru_c, const sf_pmodel_w* pm, int solver, int impute, const float* state_in,
+                    const float* p_in, const float* coef, const float* eps, float* state_out, float* p_out, int H, int W,
+                    float* ws, size_t ws_bytes, void* stream) {
+  if (!gru_c || !pm || !state_in || !p_in || !coef || !eps || !state_out || !p_out) return SF_ERR_INVALID;
+  if (gru_c->C > 64 || (gru_c->C % 8)) return SF_ERR_UNSUPPORTED;
+  Arena A(ws, ws_bytes);
+  const size_t PC = (size_t)H * W * gru_c->C;
+  float* zeros = A.take(PC);
+  if (!A.ok()) return SF_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  if (!impute) SF_HIP(hipMemsetAsync(zeros, 0, PC * sizeof(float), st));
+  return ode_step(*gru_c, *pm, solver, impute, state_in, p_in, coef, eps, state_out, p_out, zeros, 0, H, W, A, st);
+}
+
+size_t sf_nnfo_rollout_ws_bytes(int C, int H, int W) {
+  return (ode_step_ws_floats(C, H * W) + 5 * al((size_t)H * W * C)) * sizeof(float);
+}
+int sf_nnfo_rollout_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const sf_pmodel_w* pm, int solver, int impute,
+                        const int32_t* ops, int n_ops, const float* hx_obs, const float* eps, const float* coef,
+                        const int32_t* sel_nops, int n_targets, float* out_states, float* final_state, int H, int W,
+                        float* ws, size_t ws_bytes, void* stream) {
+  if (!gru_c || !gru_obs || !pm || !ops || !hx_obs || !eps || !sel_nops || !out_states) return SF_ERR_INVALID;
+  if (gru_c->C > 64 || (gru_c->C % 8)) return SF_ERR_UNSUPPORTED;
+  const int C = gru_c->C;
+  const size_t PC = (size_t)H * W * C;
+  Arena A(ws, ws_bytes);
+  float* zeros = A.take(PC);
+  float* sA = A.take(PC);
+  float* sB = A.take(PC);
+  float* pA = A.take(PC);
+  float* pB = A.take(PC);
+  if (!A.ok()) return SF_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  SF_HIP(hipMemsetAsync(zeros, 0, PC * sizeof(float), st));
+  SF_HIP(hipMemsetAsync(sA, 0, PC * sizeof(float), st));   // state = zeros  (temporal_ode_bayes.py:507)
+  SF_HIP(hipMemsetAsync(pA, 0, PC * sizeof(float), st));   // input: overwritten by the first jump (:565,574)
+  float *s = sA, *s2 = sB, *p = pA, *p2 = pB;
+  int draw = 0;
+  const int draws_per_step = solver == SF_SOLVER_EULER ? 1 : (solver == SF_SOLVER_MIDPOINT ? 2 : 4);
+  for (int i = 0; i < n_ops; ++i) {
+    const int kind = ops[2 * i], arg = ops[2 * i + 1];
+    if (kind == SF_OP_JUMP) {   // :562-574
+      Arena B = A;
+      SF_TRY(dual_cell(*gru_obs, hx_obs + (size_t)arg * PC, s, s2, 0, nullptr, nullptr, nullptr, 0, H, W, B, st));
+      if (impute) {   // with IMPUTE off the imputed input is never read (:442-443): skip the dead pass
+        Arena D = A;
+        SF_TRY(infer_state(*pm, s2, eps + (size_t)draw * PC, p, nullptr, H, W, D, st));
+      }
+      draw += 1;
+      float* t = s; s = s2; s2 = t;
+    } else if (kind == SF_OP_STEP) {
+      Arena B = A;
+      const int stride = SF_COEF_STRIDE;
+      // the imputed input after the very last op is never consumed -> skip that p_model pass only
+      // when IMPUTE is off (then no later derivative evaluation reads it either)
+      SF_TRY(ode_step(*gru_c, *pm, solver, impute, s, p, coef + (size_t)arg * stride, eps + (size_t)draw * PC, s2, p2,
+                      zeros, 1, H, W, B, st));
+      draw += draws_per_step;
+      float* t = s; s = s2; s2 = t;
+      t = p; p = p2; p2 = t;
+    } else {
+      return SF_ERR_INVALID;
+    }
+    for (int t = 0; t < n_targets; ++t)
+      if (sel_nops[t] == i + 1)
+        SF_HIP(hipMemcpyAsync(out_states + (size_t)t * PC, s, PC * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  if (final_state) SF_HIP(hipMemcpyAsync(final_state, s, PC * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return SF_OK;
+}
+
+// ---- SmallEncoder / SmallDecoder ------------------------------------------------------------------
+size_t sf_small_encoder_ws_bytes(int C, int F, int n, int H, int W) {
+  size_t P0 = (size_t)n * H * W;
+  int Cm = C > F ? C : F;
+  // level 0: t (C), pr (F), o0 (F), pooled (F@1/4); level 1 at P0/4: t (F), pr (2F), o (2F), pooled@1/16;
+  // level 2 at P0/16: t (4F)... be generous: 4 buffers of the largest tensor per level
+  size_t lvl0 = 3 * al(P0 * Cm), lvl1 = 4 * al(P0 / 4 * 2 * F + 64), lvl2 = 6 * al(P0 / 16 * 4 * F + 64);
+  return (lvl0 + lvl1 + lvl2) * sizeof(float);
+}
+int sf_small_encoder_fwd(const sf_encoder_w* w, const float* x, float* out, int n, int H, int W, float* ws,
+                         size_t ws_bytes, void* stream) {
+  if (!w || !x || !out) return SF_ERR_INVALID;
+  const int C = w->C, F = w->F;
+  hipStream_t st = (hipStream_t)stream;
+  Arena A(ws, ws_bytes);
+  const size_t P0 = (size_t)n * H * W;
+  const int H1 = H / 2, W1 = W / 2, H2 = H1 / 2, W2 = W1 / 2;
+  const size_t P1 = (size_t)n * H1 * W1, P2 = (size_t)n * H2 * W2;
+  const int Cm = C > F ? C : F;
+  float* t0 = A.take(P0 * Cm); float* pr0 = A.take(P0 * Cm); float* o0 = A.take(P0 * Cm);
+  float* q1 = A.take(P1 * F); float* t1 = A.take(P1 * F); float* pr1 = A.take(P1 * 2 * F); float* o1 = A.take(P1 * 2 * F);
+  float* q2 = A.take(P2 * 2 * F); float* t2 = A.take(P2 * 4 * F); float* pr2 = A.take(P2 * 4 * F);
+  float* o2 = A.take(P2 * 4 * F); float* o3 = A.take(P2 * 4 * F); float* o4 = A.take(P2 * 4 * F);
+  if (!A.ok()) return SF_ERR_WORKSPACE;
+  SF_TRY(res_block(w->blocks[0], x, o0, t0, pr0, n, H, W, 0, st));            // res_models.py:101-105
+  SF_HIP(launch_maxpool2(o0, q1, n, H, W, F, st));
+  SF_TRY(res_block(w->blocks[1], q1, o1, t1, pr1, n, H1, W1, 0, st));
+  SF_HIP(launch_maxpool2(o1, q2, n, H1, W1, 2 * F, st));
+  SF_TRY(res_block(w->blocks[2], q2, o2, t2, pr2, n, H2, W2, 0, st));
+  SF_TRY(res_block(w->blocks[3], o2, o3, t2, pr2, n, H2, W2, 0, st));
+  SF_TRY(res_block(w->blocks[4], o3, o4, t2, pr2, n, H2, W2, 0, st));
+  return run1(problem(w->last, o4, nullptr, out, n, H2, W2), EPI_AFFINE, st);   // :106 conv+BN+tanh
+}
+
+size_t sf_small_decoder_ws_bytes(int C, int F, int n, int h, int w) {
+  size_t P = (size_t)n * h * w;
+  return (4 * al(P * 4 * F) + 3 * al(4 * P * 2 * F) + 4 * al(16 * P * (size_t)(F > C ? F : C))) * sizeof(float);
+}
+int sf_small_decoder_fwd(const sf_decoder_w* w, const float* z, float* out, int n, int h, int wd, float* ws,
+                         size_t ws_bytes, void* stream) {
+  if (!w || !z || !out) return SF_ERR_INVALID;
+  const int F = w->F, C = w->C;
+  const int Cm = F > C ? F : C;
+  hipStream_t st = (hipStream_t)stream;
+  Arena A(ws, ws_bytes);
+  const size_t P = (size_t)n * h * wd;
+  float* a0 = A.take(P * 4 * F); float* a1 = A.take(P * 4 * F); float* a2 = A.take(P * 4 * F); float* a3 = A.take(P * 4 * F);
+  float* b0 = A.take(4 * P * 2 * F); float* b1 = A.take(4 * P * 2 * F); float* b2 = A.take(4 * P * 2 * F);
+  float* c0 = A.take(16 * P * Cm); float* c1 = A.take(16 * P * Cm); float* c2 = A.take(16 * P * Cm); float* c3 = A.take(16 * P * Cm);
+  if (!A.ok()) return SF_ERR_WORKSPACE;
+  SF_TRY(run1(problem(w->first, z, nullptr, a0, n, h, wd), EPI_AFFINE, st));           // res_models.py:136
+  SF_TRY(res_block(w->blocks[0], a0, a1, a2, a3, n, h, wd, 0, st));                     // 4F -> 2F
+  SF_TRY(res_block(w->blocks[1], a1, a0, a2, a3, n, h, wd, 0, st));                     // 2F -> 2F
+  SF_TRY(res_block(w->blocks[2], a0, a1, a2, a3, n, h, wd, 0, st));                     // 2F -> 2F
+  // upsample(x2) is applied on read by block 3 (conv_1 and projection), :142-143
+  SF_TRY(res_block(w->blocks[3], a1, b0, b1, b2, n, h, wd, 1, st));                     // 2F -> F @2h
+  SF_HIP(launch_upsample2(b0, c0, n, 2 * h, 2 * wd, F, st));
+  SF_TRY(res_block(w->blocks[4], c0, c1, c2, c3, n, 4 * h, 4 * wd, 0, st));             // F -> F @4h
+  SF_TRY(run1(problem(w->last0, c1, nullptr, c2, n, 4 * h, 4 * wd), EPI_AFFINE, st));
+  return run1(problem(w->last1, c2, nullptr, out, n, 4 * h, 4 * wd), EPI_AFFINE, st);
+}
+
+// ---- head blocks ----------------------------------------------------------------------------------
+size_t sf_convnext_block_ws_bytes(int C, int n, int H, int W) {
+  size_t P = (size_t)n * H * W;
+  return (al(P * C) + al(P * 4 * C)) * sizeof(float);
+}
+int sf_convnext_block_fwd(const sf_convnext_w* w, const float* x, float* out, int n, int H, int W, float* ws,
+                          size_t ws_bytes, void* stream) {
+  if (!w || !x || !out) return SF_ERR_INVALID;
+  const int C = w->C;
+  hipStream_t st = (hipStream_t)stream;
+  Arena A(ws, ws_bytes);
+  const size_t P = (size_t)n * H * W;
+  float* t = A.take(P * C);
+  float* u = A.take(P * 4 * C);
+  if (!A.ok()) return SF_ERR_WORKSPACE;
+  if (launch_dwconv7_ln(x, t, w->dw_w, w->dw_b, w->ln_w, w->ln_b, n, H, W, C, 1e-6f, st) != hipSuccess)
+    return SF_ERR_UNSUPPORTED;
+  SF_TRY(run1(problem(w->pw1, t, nullptr, u, n, H, W), EPI_AFFINE, st));
+  ConvProblem p2 = problem(w->pw2, u, nullptr, out, n, H, W);
+  p2.add = x;
+  return run1(p2, EPI_AFFINE, st);
+}
+
+size_t sf_deeplab_head_ws_bytes(int C, int hid, int n, int H, int W) {
+  size_t P = (size_t)n * H * W;
+  return (al(P * 4 * hid) + 2 * al(P * hid) + al((size_t)n * ASPP_SLABS * C) + al((size_t)n * hid)) * sizeof(float);
+}
+int sf_deeplab_head_fwd(const sf_deeplab_w* w, const float* x, float* out, int n, int H, int W, float* ws,
+                        size_t ws_bytes, void* stream) {
+  if (!w || !x || !out) return SF_ERR_INVALID;
+  const int C = w->C, hid = w->hid;
+  hipStream_t st = (hipStream_t)stream;
+  Arena A(ws, ws_bytes);
+  const size_t P = (size_t)n * H * W;
+  float* cat = A.take(P * 4 * hid);
+  float* y = A.take(P * hid);
+  float* z = A.take(P * hid);
+  float* part = A.take((size_t)n * ASPP_SLABS * C);
+  float* bimg = A.take((size_t)n * hid);
+  if (!A.ok()) return SF_ERR_WORKSPACE;
+  SF_HIP(launch_aspp_pool(x, part, bimg, n, H * W, C, hid, w->pool_w, w->pool_scale, w->pool_bias, w->proj_pool_w,
+                          w->project.scale, w->project.bias, ASPP_SLABS, st));
+  ConvProblem ps[4];
+  for (int i = 0; i < 4; ++i) {   // convolutions.py:265-269
+    ps[i] = problem(w->branch[i], x, nullptr, cat, n, H, W);
+    ps[i].out_cs = 4 * hid; ps[i].out_co = i * hid;
+  }
+  SF_TRY(run(ps, 4, EPI_AFFINE, st));
+  ConvProblem pj = problem(w->project, cat, nullptr, y, n, H, W);
+  pj.bias = bimg; pj.bias_per_img = 1;
+  SF_TRY(run1(pj, EPI_AFFINE, st));
+  SF_TRY(run1(problem(w->conv3, y, nullptr, z, n, H, W), EPI_AFFINE, st));
+  return run1(problem(w->cls, z, nullptr, out, n, H, W), EPI_AFFINE, st);
+}
+
+// ---- graphs / events ------------------------------------------------------------------------------
+int sf_graph_begin(void* stream) {
+  SF_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return SF_OK;
+}
+int sf_graph_end(void* stream, void** exec_out) {
+  if (!exec_out) return SF_ERR_INVALID;
+  hipGraph_t g = nullptr;
+  SF_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+  hipGraphExec_t e = nullptr;
+  hipError_t r = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (r != hipSuccess) return SF_ERR_LAUNCH;
+  *exec_out = (void*)e;
+  return SF_OK;
+}
+int sf_graph_launch(void* exec, void* stream) {
+  SF_HIP(hipGraphLaunch((hipGraphExec_t)exec, (hipStream_t)stream));
+  return SF_OK;
+}
+int sf_graph_destroy(void* exec) {
+  SF_HIP(hipGraphExecDestroy((hipGraphExec_t)exec));
+  return SF_OK;
+}
+
+int sf_event_create(void** ev) {
+  hipEvent_t e;
+  SF_HIP(hipEventCreate(&e));
+  *ev = (void*)e;
+  return SF_OK;
+}
+int sf_event_record(void* ev, void* stream) { SF_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return SF_OK; }
+int sf_event_elapsed_ms(void* a, void* b, float* ms) {
+  SF_HIP(hipEventSynchronize((hipEvent_t)b));
+  SF_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+  return SF_OK;
+}
+int sf_event_destroy(void* ev) { SF_HIP(hipEventDestroy((hipEvent_t)ev)); return SF_OK; }
+
+}  // extern "C"

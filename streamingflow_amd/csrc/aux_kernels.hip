@@ -1,0 +1,297 @@
+// Small HBM/LDS-bound helper kernels around the implicit-GEMM conv: layout transposes at the
+// NCHW API boundary, 2x2 max-pool, nearest x2 upsample, SE gate, depthwise 7x7 + LayerNorm
+// (ConvNeXt block head), ASPP global-pool branch.  gfx950 only, NHWC fp32 internally.
+#include "sf_device.h"
+
+namespace sf {
+
+__device__ __forceinline__ float4 ld4a(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4a(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ---- [N][C][HW] <-> [N][HW][C] -------------------------------------------------------------
+// 32x32 tiles through LDS (+1 pad): both the read and the write are 128-B contiguous per row.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        int rows, int cols) {
+  // in: [N][rows][cols] -> out: [N][cols][rows]
+  __shared__ float tile[32][33];
+  const size_t img = (size_t)blockIdx.z * rows * cols;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    int r = r0 + ty + i, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + i][tx] = in[img + (size_t)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    int c = c0 + ty + i, r = r0 + tx;
+    if (r < rows && c < cols) out[img + (size_t)c * rows + r] = tile[tx][ty + i];
+  }
+}
+
+hipError_t launch_transpose(const float* in, float* out, int n, int rows, int cols, hipStream_t s) {
+  if (n <= 0 || rows <= 0 || cols <= 0) return hipSuccess;
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32, n);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols);
+  return hipGetLastError();
+}
+
+// ---- 2x2 max-pool (stride 2, floor) and nearest x2 upsample, NHWC ----------------------------
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                       int n, int Hin, int Win, int C) {
+  const int Ho = Hin >> 1, Wo = Win >> 1, C4 = C >> 2;
+  const size_t total = (size_t)n * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c4 = i % C4;
+    size_t p = i / C4;
+    int ox = p % Wo;
+    size_t q = p / Wo;
+    int oy = q % Ho;
+    int img = q / Ho;
+    const float* b = in + (((size_t)img * Hin + 2 * oy) * Win + 2 * ox) * C + c4 * 4;
+    float4 a0 = ld4a(b), a1 = ld4a(b + C), a2 = ld4a(b + (size_t)Win * C), a3 = ld4a(b + (size_t)Win * C + C);
+    float4 m;
+    m.x = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x));
+    m.y = fmaxf(fmaxf(a0.y, a1.y), fmaxf(a2.y, a3.y));
+    m.z = fmaxf(fmaxf(a0.z, a1.z), fmaxf(a2.z, a3.z));
+    m.w = fmaxf(fmaxf(a0.w, a1.w), fmaxf(a2.w, a3.w));
+    st4a(out + p * C + c4 * 4, m);
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        int n, int Hin, int Win, int C) {
+  const int Ho = Hin * 2, Wo = Win * 2, C4 = C >> 2;
+  const size_t total = (size_t)n * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c4 = i % C4;
+    size_t p = i / C4;
+    int ox = p % Wo;
+    size_t q = p / Wo;
+    int oy = q % Ho;
+    int img = q / Ho;
+    st4a(out + p * C + c4 * 4, ld4a(in + (((size_t)img * Hin + (oy >> 1)) * Win + (ox >> 1)) * C + c4 * 4));
+  }
+}
+
+static int grid_for(size_t total) {
+  size_t b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+hipError_t launch_maxpool2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s) {
+  size_t total = (size_t)n * (Hin / 2) * (Win / 2) * (C / 4);
+  if (!total) return hipSuccess;
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, n, Hin, Win, C);
+  return hipGetLastError();
+}
+hipError_t launch_upsample2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s) {
+  size_t total = (size_t)n * Hin * 2 * Win * 2 * (C / 4);
+  if (!total) return hipSuccess;
+  hipLaunchKernelGGL(upsample2_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, n, Hin, Win, C);
+  return hipGetLastError();
+}
+
+// ---- SE gate (res_models.py:161-165) ---------------------------------------------------------
+// chansum: [ntile16][C] per-16-pixel channel sums written by the producing conv's epilogue.
+// One workgroup: fixed-order sum => mean => fc0 (C/r x C) => ReLU => fc2 (C x C/r) => sigmoid.
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ chansum, int ntile, int C, int Cr,
+                                                    float inv_hw, const float* __restrict__ fc0,
+                                                    const float* __restrict__ fc2, float* __restrict__ scale) {
+  extern __shared__ float sm[];   // mean[C] | hid[Cr]
+  float* mean = sm;
+  float* hid = sm + C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int t = 0; t < ntile; ++t) s += chansum[(size_t)t * C + c];
+    mean[c] = s * inv_hw;
+  }
+  __syncthreads();
+  for (int h = threadIdx.x; h < Cr; h += blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += fc0[h * C + c] * mean[c];
+    hid[h] = s > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int h = 0; h < Cr; ++h) s += fc2[c * Cr + h] * hid[h];
+    scale[c] = 1.f / (1.f + expf(-s));
+  }
+}
+
+hipError_t launch_se_fc(const float* chansum, int ntile, int C, int Cr, int hw, const float* fc0,
+                        const float* fc2, float* scale, hipStream_t s) {
+  hipLaunchKernelGGL(se_fc_kernel, dim3(1), dim3(256), (C + Cr) * sizeof(float), s, chansum, ntile, C, Cr,
+                     1.f / (float)hw, fc0, fc2, scale);
+  return hipGetLastError();
+}
+
+// ---- depthwise 7x7 (+bias) + channels-last LayerNorm (convolutions.py:335-337) ---------------
+// One wave per 8x8 pixel tile, one pixel per lane, all C channels of the pixel in registers
+// (so the LayerNorm is lane-local).  Input patch 14x14xC and weights [49][C] staged in LDS.
+template <int C>
+__global__ __launch_bounds__(64) void dwconv7_ln_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        const float* __restrict__ wdw /*[49][C]*/,
+                                                        const float* __restrict__ bdw, const float* __restrict__ lnw,
+                                                        const float* __restrict__ lnb, int H, int W, float eps) {
+  constexpr int PS = C + 4;   // padded pixel stride (floats)
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* patch = sm;               // [14*14][PS]
+  float* wl = sm + 196 * PS;       // [49][C]
+  const int tiles_x = (W + 7) / 8;
+  const int img = blockIdx.y;
+  const int ty0 = (blockIdx.x / tiles_x) * 8, tx0 = (blockIdx.x % tiles_x) * 8;
+  const float* src = in + (size_t)img * H * W * C;
+  constexpr int C4 = C / 4;
+  for (int i = threadIdx.x; i < 196 * C4; i += 64) {
+    int c4 = i % C4, pp = i / C4;
+    int py = pp / 14, px = pp % 14;
+    int iy = ty0 + py - 3, ix = tx0 + px - 3;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld4a(src + ((size_t)iy * W + ix) * C + c4 * 4);
+    st4a(patch + pp * PS + c4 * 4, v);
+  }
+  for (int i = threadIdx.x; i < 49 * C4; i += 64) st4a(wl + i * 4, ld4a(wdw + i * 4));
+  __syncthreads();
+  const int ly = threadIdx.x >> 3, lx = threadIdx.x & 7;
+  const int oy = ty0 + ly, ox = tx0 + lx;
+  float acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = bdw[c];
+  for (int ky = 0; ky < 7; ++ky)
+    for (int kx = 0; kx < 7; ++kx) {
+      const float* p = patch + ((ly + ky) * 14 + lx + kx) * PS;
+      const float* w = wl + (ky * 7 + kx) * C;
+#pragma unroll
+      for (int c4 = 0; c4 < C4; ++c4) {
+        float4 x = ld4a(p + c4 * 4), ww = ld4a(w + c4 * 4);
+        acc[c4 * 4 + 0] += x.x * ww.x; acc[c4 * 4 + 1] += x.y * ww.y;
+        acc[c4 * 4 + 2] += x.z * ww.z; acc[c4 * 4 + 3] += x.w * ww.w;
+      }
+    }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) s += acc[c];
+  const float mean = s / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { float d = acc[c] - mean; sq += d * d; }
+  const float rstd = 1.f / sqrtf(sq / (float)C + eps);
+  if (oy < H && ox < W) {
+    float* dst = out + ((size_t)img * H * W + (size_t)oy * W + ox) * C;
+#pragma unroll
+    for (int c4 = 0; c4 < C4; ++c4) {
+      float4 w = ld4a(lnw + c4 * 4), b = ld4a(lnb + c4 * 4), o;
+      o.x = (acc[c4 * 4 + 0] - mean) * rstd * w.x + b.x;
+      o.y = (acc[c4 * 4 + 1] - mean) * rstd * w.y + b.y;
+      o.z = (acc[c4 * 4 + 2] - mean) * rstd * w.z + b.z;
+      o.w = (acc[c4 * 4 + 3] - mean) * rstd * w.w + b.w;
+      st4a(dst + c4 * 4, o);
+    }
+  }
+}
+
+template <int C>
+static hipError_t launch_dw_t(const float* in, float* out, const float* wdw, const float* bdw, const float* lnw,
+                              const float* lnb, int n, int H, int W, float eps, hipStream_t s) {
+  int lds = (196 * (C + 4) + 49 * C) * sizeof(float);
+  auto k = dwconv7_ln_kernel<C>;
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    done = true;
+  }
+  dim3 grid(((H + 7) / 8) * ((W + 7) / 8), n);
+  hipLaunchKernelGGL(k, grid, dim3(64), lds, s, in, out, wdw, bdw, lnw, lnb, H, W, eps);
+  return hipGetLastError();
+}
+
+hipError_t launch_dwconv7_ln(const float* in, float* out, const float* wdw, const float* bdw, const float* lnw,
+                             const float* lnb, int n, int H, int W, int C, float eps, hipStream_t s) {
+  switch (C) {
+    case 8:  return launch_dw_t<8>(in, out, wdw, bdw, lnw, lnb, n, H, W, eps, s);
+    case 16: return launch_dw_t<16>(in, out, wdw, bdw, lnw, lnb, n, H, W, eps, s);
+    case 32: return launch_dw_t<32>(in, out, wdw, bdw, lnw, lnb, n, H, W, eps, s);
+    case 64: return launch_dw_t<64>(in, out, wdw, bdw, lnw, lnb, n, H, W, eps, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+// ---- ASPP image-pooling branch (convolutions.py:227-239) -------------------------------------
+// stage 1: per-image, per-slab channel sums (fixed order inside a slab)
+__global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restrict__ in, float* __restrict__ part,
+                                                           int HW, int C, int nslab) {
+  extern __shared__ float sm[];   // [256/C4][C]
+  const int C4 = C >> 2;
+  const int lanes = 256 / C4;     // pixel lanes per block
+  const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
+  const int img = blockIdx.y, slab = blockIdx.x;
+  const int per = (HW + nslab - 1) / nslab;
+  const int p0 = slab * per, p1 = min(HW, p0 + per);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (pl < lanes)
+    for (int p = p0 + pl; p < p1; p += lanes) {
+      float4 v = ld4a(in + ((size_t)img * HW + p) * C + c4 * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  if (pl < lanes) st4a(sm + pl * C + c4 * 4, s);
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int l = 0; l < lanes; ++l) t += sm[l * C + c];
+    part[((size_t)img * nslab + slab) * C + c] = t;
+  }
+}
+
+// stage 2 (one workgroup per image): mean -> 1x1 conv (C->hid) -> BN -> ReLU -> its slice of the
+// ASPP projection (hid->hid) -> folded into the projection's per-image bias:
+//   bias_img[img][co] = proj_scale[co] * (Wp_pool[co][:] . g) + proj_bias[co]
+// (bilinear upsampling of a 1x1 map, align_corners=False, is a constant broadcast.)
+__global__ __launch_bounds__(256) void aspp_pool_kernel(const float* __restrict__ part, int nslab, int C, int hid,
+                                                        float inv_hw, const float* __restrict__ w1 /*[hid][C]*/,
+                                                        const float* __restrict__ s1, const float* __restrict__ b1,
+                                                        const float* __restrict__ wp /*[hid][hid]*/,
+                                                        const float* __restrict__ ps, const float* __restrict__ pb,
+                                                        float* __restrict__ bias_img) {
+  extern __shared__ float sm[];   // mean[C] | g[hid]
+  float* mean = sm;
+  float* gg = sm + C;
+  const int img = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int t = 0; t < nslab; ++t) s += part[((size_t)img * nslab + t) * C + c];
+    mean[c] = s * inv_hw;
+  }
+  __syncthreads();
+  for (int h = threadIdx.x; h < hid; h += blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += w1[h * C + c] * mean[c];
+    s = s * s1[h] + b1[h];
+    gg[h] = s > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  for (int co = threadIdx.x; co < hid; co += blockDim.x) {
+    float s = 0.f;
+    for (int h = 0; h < hid; ++h) s += wp[co * hid + h] * gg[h];
+    bias_img[(size_t)img * hid + co] = ps[co] * s + pb[co];
+  }
+}
+
+hipError_t launch_aspp_pool(const float* in, float* part, float* bias_img, int n, int HW, int C, int hid,
+                            const float* w1, const float* s1, const float* b1, const float* wp, const float* ps,
+                            const float* pb, int nslab, hipStream_t s) {
+  int C4 = C / 4;
+  if (C4 < 1 || C4 > 256) return hipErrorInvalidValue;
+  int lanes = 256 / C4;
+  hipLaunchKernelGGL(chan_partial_kernel, dim3(nslab, n), dim3(256), lanes * C * sizeof(float), s, in, part, HW, C, nslab);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(aspp_pool_kernel, dim3(n), dim3(256), (C + hid) * sizeof(float), s, part, nslab, C, hid,
+                     1.f / (float)HW, w1, s1, b1, wp, ps, pb, bias_img);
+  return hipGetLastError();
+}
+
+}  // namespace sf

@@ -1,0 +1,491 @@
+// Implicit-GEMM convolution on the CDNA4 fp32 matrix cores (v_mfma_f32_16x16x4_f32) with fused
+// conv-GRU / LayerNorm / trusting-gate / Gaussian-sample epilogues.  gfx950 only.
+//
+//   D[cout][pixel] = sum_k  W[cout][k] * X_im2col[k][pixel],   k = (tap, channel)
+//
+// * A operand = packed weights, B operand = activations gathered tap by tap (im2col on the fly,
+//   zero padding, optional channel concat of two tensors, optional reset-gate multiply
+//   (1-r)*s, optional per-channel SE scale, optional nearest x2 upsampling on read).
+// * One wave owns MT x NT tiles of 16(cout) x 16(pixel); a workgroup is WM x WN such waves times
+//   KS "K-groups" that each take every KS-th 32-deep K chunk (in-workgroup split-K, reduced
+//   through LDS in a fixed order => bitwise reproducible).  Small BEV latents (50x50) have far
+//   fewer output tiles than the chip has SIMDs; split-K inside the workgroup is what puts
+//   4-8 waves on every busy CU without a second reduction launch.
+// * Operands are staged global -> registers -> LDS (issue-early / write-late, one barrier per
+//   chunk, double buffered).  LDS rows are 36 floats (32 + 4 pad): a wave's ds_read_b64
+//   fragment reads (row = lane&15, k = 8t + 2*(lane>>4)) then hit 64 distinct banks.
+// * Accumulator layout (16x16x4): lane l holds D[cout = 4*(l>>4)+r][pixel = l&15] in register r,
+//   i.e. four consecutive channels of one pixel => NHWC float4 stores, and per-pixel channel
+//   reductions (LayerNorm, 1x1->2 logits) are in-register sums + two xor-shuffles (16, 32).
+#include "sf_device.h"
+
+namespace sf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case ACT_LRELU:   return v > 0.f ? v : 0.1f * v;
+    case ACT_RELU:    return v > 0.f ? v : 0.f;
+    case ACT_TANH:    return tanhf(v);
+    case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case ACT_GELU:    return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    default:          return v;
+  }
+}
+
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float softplus_f(float v) { return v > 20.f ? v : log1pf(expf(v)); }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// sum over the 4 lanes (l, l^16, l^32, l^48) that hold the other channels of this pixel
+__device__ __forceinline__ float pix_allreduce(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+// sum over the 16 pixels (lanes with equal l>>4) of a wave tile
+__device__ __forceinline__ float tile_px_reduce(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+
+constexpr int LDS_ROW = 36;   // floats per staged row: 32 K values + 4 pad
+constexpr int BK = 32;
+
+template <int MT, int NT, int WM, int WN, int KS, int EPI>
+__global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const ConvLaunch L) {
+  constexpr int BM = 16 * MT * WM;
+  constexpr int BN = 16 * NT * WN;
+  constexpr int TG = 64 * WM * WN;        // threads per K-group
+  constexpr int ROWS_PER_PASS = TG / 8;   // 8 float4 per 32-float row
+  constexpr int A_SLOTS = BM / ROWS_PER_PASS;
+  constexpr int B_SLOTS = BN / ROWS_PER_PASS;
+  static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile/threads mismatch");
+  constexpr int GROUP_FLOATS = 2 * (BM + BN) * LDS_ROW;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const ConvProblem& P = L.p[blockIdx.y];
+  const int Ptot = P.n_img * P.Hout * P.Wout;
+  const int n_mt = (P.cout_pad + BM - 1) / BM;
+  const int m_tile = blockIdx.x % n_mt;
+  const int p_tile = blockIdx.x / n_mt;
+  if (p_tile * BN >= Ptot) return;   // block-uniform
+
+  const int tid = threadIdx.x;
+  const int kg = tid / TG;
+  const int t = tid % TG;
+  const int wave = t >> 6;
+  const int lane = t & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int j = lane & 15, g = lane >> 4;
+
+  float* As = smem + kg * GROUP_FLOATS;          // [2][BM][LDS_ROW]
+  float* Bs = As + 2 * BM * LDS_ROW;             // [2][BN][LDS_ROW]
+
+  // ---- per-thread staging slots ----------------------------------------------------------
+  const int k4 = t & 7;
+  const int row0 = t >> 3;
+  const int HWout = P.Hout * P.Wout;
+  const int Hlog = P.Hin << P.in_up, Wlog = P.Win << P.in_up;
+  int b_iy0[B_SLOTS], b_ix0[B_SLOTS], b_base[B_SLOTS], b_img[B_SLOTS];
+#pragma unroll
+  for (int i = 0; i < B_SLOTS; ++i) {
+    int gp = p_tile * BN + row0 + i * ROWS_PER_PASS;
+    bool v = gp < Ptot;
+    int img = v ? gp / HWout : 0;
+    int rem = gp - img * HWout;
+    int oy = rem / P.Wout, ox = rem - oy * P.Wout;
+    b_iy0[i] = v ? oy * P.stride - P.pad : -(1 << 28);   // invalid pixel: never in range
+    b_ix0[i] = ox * P.stride - P.pad;
+    b_base[i] = img * P.Hin * P.Win;
+    b_img[i] = img;
+  }
+
+  const int kcpt = P.cin_pad / BK;            // chunks per tap
+  const int nchunks = P.KH * P.KW * kcpt;
+  const int niter = (nchunks + KS - 1) / KS;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 ra[A_SLOTS], rb[B_SLOTS];
+
+  auto load_chunk = [&](int chunk) {
+    const int tap = chunk / kcpt;
+    const int kc = chunk - tap * kcpt;
+    const int ty = tap / P.KW, tx = tap - ty * P.KW;
+    // weights
+    const float* wp = P.w + (size_t)chunk * BK + k4 * 4;
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) {
+      int grow = m_tile * BM + row0 + i * ROWS_PER_PASS;
+      ra[i] = (grow < P.cout_pad) ? ld4(wp + (size_t)grow * P.ktot) : zero4();
+    }
+    // activations
+    const int c = kc * BK + k4 * 4;
+#pragma unroll
+    for (int i = 0; i < B_SLOTS; ++i) {
+      int iy = b_iy0[i] + ty * P.dil, ix = b_ix0[i] + tx * P.dil;
+      bool ok = (iy >= 0) & (iy < Hlog) & (ix >= 0) & (ix < Wlog);
+      size_t pix = (size_t)b_base[i] + (size_t)((iy >> P.in_up) * P.Win + (ix >> P.in_up));
+      float4 v = zero4();
+      if (ok) {
+        if (c < P.c0) {
+          v = ld4(P.in0 + pix * P.in0_cs + c);
+          if (P.in_scale) {
+            float4 s = ld4(P.in_scale + (size_t)b_img[i] * P.c0 + c);
+            v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+          }
+        } else if (c < P.c0 + P.c1) {
+          int cc = c - P.c0;
+          v = ld4(P.in1 + pix * P.in1_cs + cc);
+          if (P.gate) {
+            float4 r = ld4(P.gate + pix * P.gate_cs + P.gate_co + cc);
+            v.x *= (1.f - r.x); v.y *= (1.f - r.y); v.z *= (1.f - r.z); v.w *= (1.f - r.w);
+          }
+        }
+      }
+      rb[i] = v;
+    }
+  };
+
+  auto store_chunk = [&](int buf) {
+    float* a = As + buf * BM * LDS_ROW;
+    float* b = Bs + buf * BN * LDS_ROW;
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) st4(a + (row0 + i * ROWS_PER_PASS) * LDS_ROW + k4 * 4, ra[i]);
+#pragma unroll
+    for (int i = 0; i < B_SLOTS; ++i) st4(b + (row0 + i * ROWS_PER_PASS) * LDS_ROW + k4 * 4, rb[i]);
+  };
+
+  auto compute = [&](int buf) {
+    const float* a = As + buf * BM * LDS_ROW + (wm * MT * 16 + j) * LDS_ROW + 2 * g;
+    const float* b = Bs + buf * BN * LDS_ROW + (wn * NT * 16 + j) * LDS_ROW + 2 * g;
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      float2 fa[MT], fb[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const float2*>(a + m * 16 * LDS_ROW + 8 * t4);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const float2*>(b + n * 16 * LDS_ROW + 8 * t4);
+      // all tiles with the even k first, then the odd k: MT*NT independent accumulators between
+      // two MFMAs on the same one (16x16x4 f32: 32-cycle issue, 40-cycle dependent latency)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m].x, fb[n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m].y, fb[n].y, acc[m][n], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop: one barrier per chunk, loads of chunk i+1 in flight under MFMAs of chunk i
+  if (kg < nchunks) {
+    load_chunk(kg);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (int it = 0; it < niter; ++it) {
+    const int nxt = (it + 1) * KS + kg;
+    const bool has_next = nxt < nchunks;
+    if (has_next) load_chunk(nxt);
+    if (it * KS + kg < nchunks) compute(it & 1);
+    if (has_next) store_chunk((it + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- in-workgroup split-K reduction (fixed order) ----------------------------------------
+  if constexpr (KS > 1) {
+    float* red = smem;   // [(KS-1)][WM*WN][MT*NT*4][64]
+    constexpr int PER_WAVE = MT * NT * 4 * 64;
+    if (kg > 0) {
+      float* r = red + ((kg - 1) * (WM * WN) + wave) * PER_WAVE + lane;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) r[((m * NT + n) * 4 + q) * 64] = acc[m][n][q];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int s = 1; s < KS; ++s) {
+      const float* r = red + ((s - 1) * (WM * WN) + wave) * PER_WAVE + lane;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[m][n][q] += r[((m * NT + n) * 4 + q) * 64];
+    }
+  }
+
+  // ---- epilogues ---------------------------------------------------------------------------
+  const int m0 = m_tile * BM + wm * MT * 16;      // first (packed) cout row of this wave
+
+  if constexpr (EPI == EPI_AFFINE || EPI == EPI_BLEND) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int gp = p_tile * BN + (wn * NT + n) * 16 + j;
+      const bool pv = gp < Ptot;
+      const int img = pv ? gp / HWout : 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int c = m0 + m * 16 + 4 * g;
+        const bool cv = c < P.cout;
+        float4 y = zero4();
+        if (pv && cv) {
+          float4 sc = P.scale ? ld4(P.scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+          float4 bi = P.bias ? ld4(P.bias + (P.bias_per_img ? (size_t)img * P.cout : 0) + c) : zero4();
+          float4 v;
+          v.x = acc[m][n][0] * sc.x + bi.x; v.y = acc[m][n][1] * sc.y + bi.y;
+          v.z = acc[m][n][2] * sc.z + bi.z; v.w = acc[m][n][3] * sc.w + bi.w;
+          if constexpr (EPI == EPI_AFFINE) {
+            y.x = act_apply(v.x, P.act); y.y = act_apply(v.y, P.act);
+            y.z = act_apply(v.z, P.act); y.w = act_apply(v.w, P.act);
+            if (P.add) {
+              float4 ad = ld4(P.add + (size_t)gp * P.add_cs + c);
+              if (P.add_scale) {
+                float4 as = ld4(P.add_scale + (size_t)img * P.cout + c);
+                ad.x *= as.x; ad.y *= as.y; ad.z *= as.z; ad.w *= as.w;
+              }
+              y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w;
+            }
+          } else {  // EPI_BLEND  (temporal.py:56, temporal_ode_bayes.py:145,160)
+            float4 u = ld4(P.e0 + (size_t)gp * P.e0_cs + c);
+            float4 s = ld4(P.e1 + (size_t)gp * P.e1_cs + c);
+            y.x = (1.f - u.x) * s.x + u.x * v.x; y.y = (1.f - u.y) * s.y + u.y * v.y;
+            y.z = (1.f - u.z) * s.z + u.z * v.z; y.w = (1.f - u.w) * s.w + u.w * v.w;
+          }
+          st4(P.out + (size_t)gp * P.out_cs + P.out_co + c, y);
+        }
+        if constexpr (EPI == EPI_AFFINE) {
+          if (P.chansum) {   // block-uniform branch; all lanes take part in the shuffles
+            float4 s4;
+            s4.x = tile_px_reduce(y.x); s4.y = tile_px_reduce(y.y);
+            s4.z = tile_px_reduce(y.z); s4.w = tile_px_reduce(y.w);
+            if (j == 0 && cv) {
+              int tile16 = (p_tile * BN) / 16 + wn * NT + n;
+              st4(P.chansum + (size_t)tile16 * P.cout + c, s4);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if constexpr (EPI == EPI_LNG || EPI == EPI_TRUST) {
+    // requires WM == 1 and a single cout tile: the wave holds every channel of its pixels.
+    static_assert(WM == 1, "LayerNorm epilogues need all channels in one wave");
+    const float inv_c = 1.f / (float)P.cout;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int gp = p_tile * BN + (wn * NT + n) * 16 + j;
+      const bool pv = gp < Ptot;
+      float v[MT][4];
+      bool cvm[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        cvm[m] = (m0 + m * 16 + 4 * g) < P.cout;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[m][q] = acc[m][n][q];
+      }
+      const bool do_ln = (EPI == EPI_TRUST) || (P.mode & 1);
+      if (do_ln) {   // convolutions.py:303-308 (channels_first LayerNorm)
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          if (cvm[m]) s += (v[m][0] + v[m][1]) + (v[m][2] + v[m][3]);
+        const float mean = pix_allreduce(s) * inv_c;
+        float sq = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          if (cvm[m]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { float d = v[m][q] - mean; sq += d * d; }
+          }
+        const float var = pix_allreduce(sq) * inv_c;
+        const float rstd = 1.f / sqrtf(var + P.eps);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          if (cvm[m]) {
+            const int c = m0 + m * 16 + 4 * g;
+            float4 w = ld4(P.scale + c), b = ld4(P.bias + c);
+            v[m][0] = w.x * ((v[m][0] - mean) * rstd) + b.x;
+            v[m][1] = w.y * ((v[m][1] - mean) * rstd) + b.y;
+            v[m][2] = w.z * ((v[m][2] - mean) * rstd) + b.z;
+            v[m][3] = w.w * ((v[m][3] - mean) * rstd) + b.w;
+          }
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[m][q] = gelu_f(v[m][q]);
+
+      if constexpr (EPI == EPI_LNG) {
+        if (pv) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            if (cvm[m]) {
+              const int c = m0 + m * 16 + 4 * g;
+              st4(P.out + (size_t)gp * P.out_cs + P.out_co + c, make_float4(v[m][0], v[m][1], v[m][2], v[m][3]));
+            }
+        }
+      } else {
+        // trusting gate tail (temporal_ode_bayes.py:124-131 / :268-275, convolutions.py:375-380):
+        // bb = t3 + skip ; z = W2 bb ; g = softmax(z) ; cur = r2*g0 + r1*g1
+        const size_t po = (size_t)(pv ? gp : 0) * P.cout;
+        float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          if (cvm[m]) {
+            const int c = m0 + m * 16 + 4 * g;
+            float4 sk = ld4(P.e0 + po + c);
+            float4 w0 = ld4(P.e1 + c), w1 = ld4(P.e1 + P.cout + c);
+            float b0 = v[m][0] + sk.x, b1 = v[m][1] + sk.y, b2 = v[m][2] + sk.z, b3 = v[m][3] + sk.w;
+            z0 += (w0.x * b0 + w0.y * b1) + (w0.z * b2 + w0.w * b3);
+            z1 += (w1.x * b0 + w1.y * b1) + (w1.z * b2 + w1.w * b3);
+          }
+        z0 = pix_allreduce(z0);
+        z1 = pix_allreduce(z1);
+        const float zm = fmaxf(z0, z1);
+        const float ez0 = expf(z0 - zm), ez1 = expf(z1 - zm);
+        const float g0 = ez0 / (ez0 + ez1), g1 = ez1 / (ez0 + ez1);
+        if (pv) {
+          const float c0f = P.coef ? P.coef[0] : 0.f;
+          const float c1f = (P.coef && P.out2) ? P.coef[1] : 0.f;
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            if (cvm[m]) {
+              const int c = m0 + m * 16 + 4 * g;
+              float4 r2 = ld4(P.e2 + po + c), r1 = ld4(P.e3 + po + c);
+              float4 cur;
+              cur.x = r2.x * g0 + r1.x * g1; cur.y = r2.y * g0 + r1.y * g1;
+              cur.z = r2.z * g0 + r1.z * g1; cur.w = r2.w * g0 + r1.w * g1;
+              if (P.mode & 1) {   // derivative: d = cur - s ; out = base + coef0*d
+                float4 s = ld4(P.e4 + po + c), base = ld4(P.e5 + po + c);
+                float4 d = make_float4(cur.x - s.x, cur.y - s.y, cur.z - s.z, cur.w - s.w);
+                float4 o;
+                o.x = base.x + c0f * d.x; o.y = base.y + c0f * d.y;
+                o.z = base.z + c0f * d.z; o.w = base.w + c0f * d.w;
+                if (P.out2) {
+                  float4 b2 = (P.mode & 2) ? ld4(P.out2 + po + c) : base;
+                  b2.x += c1f * d.x; b2.y += c1f * d.y; b2.z += c1f * d.z; b2.w += c1f * d.w;
+                  st4(P.out2 + po + c, b2);
+                }
+                st4(P.out + po + c, o);
+              } else {
+                st4(P.out + po + c, cur);
+              }
+            }
+        }
+      }
+    }
+  }
+
+  if constexpr (EPI == EPI_SAMPLE) {
+    // Packed cout rows are interleaved so that a lane holds (loc c, loc c+1, raw c, raw c+1):
+    // row 16*T + 4*g + r  <->  r<2: loc channel 8T+2g+r ; r>=2: raw channel 8T+2g+(r-2).
+    const int Chalf = P.cout >> 1;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int gp = p_tile * BN + (wn * NT + n) * 16 + j;
+      const bool pv = gp < Ptot;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int row = m0 + m * 16 + 4 * g;
+        const int c = (row >> 4) * 8 + 2 * g;   // logical loc channel
+        if (pv && c < Chalf) {
+          float4 bi = P.bias ? ld4(P.bias + row) : zero4();
+          float q0 = act_apply(acc[m][n][0] + bi.x, P.act), q1 = act_apply(acc[m][n][1] + bi.y, P.act);
+          float q2 = act_apply(acc[m][n][2] + bi.z, P.act), q3 = act_apply(acc[m][n][3] + bi.w, P.act);
+          float2 e = *reinterpret_cast<const float2*>(P.e0 + (size_t)gp * Chalf + c);
+          float2 o;
+          o.x = q0 + e.x * (softplus_f(q2) + 1e-8f);     // model_utils.py:84,107-108
+          o.y = q1 + e.y * (softplus_f(q3) + 1e-8f);
+          *reinterpret_cast<float2*>(P.out + (size_t)gp * Chalf + c) = o;
+          if (P.out2) {   // raw q parameters, reference channel order [loc | raw]
+            *reinterpret_cast<float2*>(P.out2 + (size_t)gp * P.cout + c) = make_float2(q0, q1);
+            *reinterpret_cast<float2*>(P.out2 + (size_t)gp * P.cout + Chalf + c) = make_float2(q2, q3);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- host-side launcher --------------------------------------------------------------------
+template <int MT, int NT, int WM, int WN, int KS, int EPI>
+static hipError_t launch_cfg(const ConvLaunch& L, hipStream_t stream) {
+  constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
+  constexpr int stage_bytes = KS * 2 * (BM + BN) * LDS_ROW * 4;
+  constexpr int red_bytes = (KS - 1) * WM * WN * MT * NT * 4 * 64 * 4;
+  constexpr int lds = stage_bytes > red_bytes ? stage_bytes : red_bytes;
+  auto kern = conv_igemm_kernel<MT, NT, WM, WN, KS, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  int maxblocks = 0;
+  for (int i = 0; i < L.nprob; ++i) {
+    const ConvProblem& P = L.p[i];
+    int Ptot = P.n_img * P.Hout * P.Wout;
+    int nb = ((Ptot + BN - 1) / BN) * ((P.cout_pad + BM - 1) / BM);
+    if (nb > maxblocks) maxblocks = nb;
+  }
+  if (maxblocks == 0) return hipSuccess;
+  dim3 grid(maxblocks, L.nprob), block(64 * WM * WN * KS);
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, L);
+  return hipGetLastError();
+}
+
+// Tile configurations.  "S": small pixel counts (BEV latent 50x50): 16 px x 64 cout per
+// workgroup, 4-way in-workgroup split-K.  "L": large pixel counts (200x200 head): 64x64 tile.
+hipError_t launch_conv(const ConvLaunch& L, int epi, int cfg, hipStream_t stream) {
+  switch (cfg) {
+    case 0:   // S: MT4 NT1 1x1 waves, KS 4
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<4, 1, 1, 1, 4, EPI_AFFINE>(L, stream);
+        case EPI_BLEND:  return launch_cfg<4, 1, 1, 1, 4, EPI_BLEND>(L, stream);
+        case EPI_LNG:    return launch_cfg<4, 1, 1, 1, 4, EPI_LNG>(L, stream);
+        case EPI_TRUST:  return launch_cfg<4, 1, 1, 1, 4, EPI_TRUST>(L, stream);
+        case EPI_SAMPLE: return launch_cfg<4, 1, 1, 1, 4, EPI_SAMPLE>(L, stream);
+      }
+      break;
+    case 1:   // L: 2x2 waves of 32x32
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<2, 2, 2, 2, 1, EPI_AFFINE>(L, stream);
+        case EPI_BLEND:  return launch_cfg<2, 2, 2, 2, 1, EPI_BLEND>(L, stream);
+        case EPI_SAMPLE: return launch_cfg<2, 2, 2, 2, 1, EPI_SAMPLE>(L, stream);
+      }
+      break;
+    case 2:   // LN-capable large tile: 4 waves x (64 cout x 32 px)
+      switch (epi) {
+        case EPI_LNG:    return launch_cfg<4, 2, 1, 4, 1, EPI_LNG>(L, stream);
+        case EPI_TRUST:  return launch_cfg<4, 2, 1, 4, 1, EPI_TRUST>(L, stream);
+      }
+      break;
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace sf

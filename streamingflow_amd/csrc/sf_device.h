@@ -1,0 +1,63 @@
+// Device-side problem descriptors shared by the HIP kernels and the host orchestration.
+// gfx950 (MI355X / CDNA4) only.  Activations are NHWC fp32 ("[pixel][channel]"), weights are
+// packed [cout_pad][taps * cin_pad] fp32 (tap-major, channel-minor, zero padded), see
+// include/sfnative.h for the packing contract.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sf {
+
+enum Act : int { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_TANH = 3, ACT_SIGMOID = 4, ACT_GELU = 5 };
+
+// Epilogue families (template parameter of the conv kernel).
+enum Epi : int {
+  EPI_AFFINE = 0,   // y = act(acc*scale + bias) [+ add*add_scale]; optional per-16px channel sums
+  EPI_BLEND  = 1,   // conv-GRU blend: h = acc + bias; y = (1-u)*s + u*h
+  EPI_LNG    = 2,   // [LayerNorm over channels] -> GELU
+  EPI_TRUST  = 3,   // LN -> GELU -> +skip -> 1x1(C->2) -> softmax -> mix -> Euler/RK update
+  EPI_SAMPLE = 4,   // q = lrelu(acc + bias); p = loc + eps*(softplus(raw)+1e-8)
+};
+
+struct ConvProblem {
+  // ---- operands -------------------------------------------------------------------------
+  const float* in0;       // first input, [n_img*Hin*Win][in0_cs]
+  const float* in1;       // optional second input (channel concat), [..][in1_cs]
+  const float* gate;      // optional: in1 is multiplied by (1 - gate[pix][gate_co + c])
+  const float* in_scale;  // optional per-(image, channel) scale on in0 (SE), [n_img][c0]
+  const float* w;         // packed weights [cout_pad][ktot]
+  const float* scale;     // per-cout scale (BN fold / LN weight), may be null (=1)
+  const float* bias;      // per-cout bias (conv bias, BN fold / LN bias), may be null (=0)
+  const float* add;       // optional residual added after the activation, [P][add_cs]
+  const float* add_scale; // optional per-(image, channel) scale on `add` (SE)
+  float* out;             // [P][out_cs], written at channel offset out_co
+  float* out2;            // epilogue specific second output (may be null)
+  float* chansum;         // optional [ceil(P/16)][cout] per-16-pixel channel sums of `out`
+  // epilogue specific read-only tensors
+  const float* e0; const float* e1; const float* e2; const float* e3; const float* e4; const float* e5;
+  const float* coef;      // device scalars (dt coefficients)
+  // ---- geometry --------------------------------------------------------------------------
+  int c0, c1;             // channels taken from in0 / in1
+  int in0_cs, in1_cs, gate_cs, gate_co;
+  int n_img, Hin, Win;    // physical input size per image
+  int in_up;              // 1: input is nearest-upsampled x2 on the fly (logical = 2*Hin x 2*Win)
+  int Hout, Wout;
+  int KH, KW, dil, stride, pad;
+  int cin_pad;            // per-tap padded channel count, multiple of 32
+  int ktot;               // KH*KW*cin_pad
+  int cout, cout_pad;     // real / padded (multiple of 16) output channels
+  int act;
+  int add_cs, out_cs, out_co, out2_cs;
+  int bias_per_img;       // bias indexed [img][cout] (ASPP pooled branch folded into bias)
+  int e0_cs, e1_cs;       // channel strides of e0/e1 where they are not C
+  int mode;               // epilogue specific
+  float eps;              // LayerNorm epsilon
+};
+
+#define SF_MAX_GROUP 4
+struct ConvLaunch {
+  ConvProblem p[SF_MAX_GROUP];
+  int nprob;
+};
+
+}  // namespace sf

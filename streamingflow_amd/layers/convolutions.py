@@ -1,0 +1,149 @@
+"""MI355X-native counterparts of the blocks of streamingflow/layers/convolutions.py that sit on the
+GRU-ODE hot path: channels-first ``LayerNorm`` (:283-308), ConvNeXt ``Block`` (:310-346),
+``Bottleblock`` (:348-380, the trusting-gate body) and ``ASPP``/``DeepLabHead`` (:217-280).
+
+The classes keep the reference constructor signatures and ``state_dict`` keys (torch.nn layers are
+used as parameter containers only); ``forward`` runs on libsfnative (HIP, gfx950).  Inference only.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib, packing, runtime
+from ..runtime import PackedModule, ptr
+
+
+def _seq(*mods):
+    return nn.Sequential(*mods)
+
+
+class LayerNorm(nn.Module):
+    """Parameter container for convolutions.py:283-308; always applied fused into a conv epilogue."""
+
+    def __init__(self, normalized_shape, eps=1e-6, data_format="channels_last"):
+        super().__init__()
+        if data_format not in ("channels_last", "channels_first"):
+            raise NotImplementedError
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+        self.eps, self.data_format, self.normalized_shape = eps, data_format, (normalized_shape,)
+
+
+class Block(PackedModule):
+    """ConvNeXt block: 7x7 depthwise -> LayerNorm -> Linear(4x) -> GELU -> Linear -> gamma -> residual."""
+
+    def __init__(self, dim, drop_path=0., layer_scale_init_value=1e-6):
+        super().__init__()
+        if drop_path > 0.:
+            raise NotImplementedError("inference-only: DropPath is the identity")
+        self.dwconv = nn.Conv2d(dim, dim, kernel_size=7, padding=3, groups=dim)
+        self.norm = LayerNorm(dim, eps=1e-6)
+        self.pwconv1 = nn.Linear(dim, 4 * dim)
+        self.pwconv2 = nn.Linear(4 * dim, dim)
+        self.gamma = nn.Parameter(layer_scale_init_value * torch.ones(dim)) if layer_scale_init_value > 0 else None
+        self.dim = dim
+
+    def _pack(self):
+        pk = packing.Pack(_lib.ConvNextW())
+        s, d = pk.struct, self.dim
+        s.dw_w = pk.hold(self.dwconv.weight.reshape(d, 49).t())          # [49][C]
+        s.dw_b = pk.hold(self.dwconv.bias)
+        s.ln_w, s.ln_b = pk.hold(self.norm.weight), pk.hold(self.norm.bias)
+        s.pw1 = packing.conv_w(pk, self.pwconv1.weight[:, :, None, None], d, bias=self.pwconv1.bias, act="gelu")
+        gamma = self.gamma if self.gamma is not None else torch.ones_like(self.pwconv2.bias)
+        s.pw2 = packing.conv_w(pk, self.pwconv2.weight[:, :, None, None], 4 * d, scale=gamma,
+                               bias=gamma * self.pwconv2.bias)
+        s.C = d
+        return pk
+
+    def forward_nhwc(self, x):
+        n, h, w, c = x.shape
+        L = _lib.lib()
+        ws = runtime.workspace(L.sf_convnext_block_ws_bytes(c, n, h, w), x.device)
+        out = torch.empty_like(x)
+        _lib.check(L.sf_convnext_block_fwd(self.packed().struct, ptr(x), ptr(out), n, h, w, ptr(ws),
+                                           ws.numel() * 4, runtime.stream_ptr(x.device)), "convnext_block")
+        return out
+
+    def forward(self, x):
+        return runtime.to_nchw(self.forward_nhwc(runtime.to_nhwc(x)))
+
+
+class Bottleblock(nn.Module):
+    """Parameter container for the trusting-gate body (convolutions.py:348-380); executed inside
+    the dual GRU cells (layers/temporal_ode_bayes.py)."""
+
+    def __init__(self, in_channels, out_channels=None):
+        super().__init__()
+        mid = int(in_channels / 2)
+        out_channels = out_channels or in_channels
+        cf = dict(eps=1e-6, data_format="channels_first")
+        self.layers = _seq(
+            nn.Conv2d(in_channels, mid, kernel_size=7, bias=False, padding=3), LayerNorm(mid, **cf), nn.GELU(),
+            nn.Conv2d(mid, mid, kernel_size=1, bias=False), LayerNorm(mid, **cf), nn.GELU(),
+            nn.Conv2d(mid, out_channels, kernel_size=3, bias=False, padding=1), LayerNorm(out_channels, **cf), nn.GELU())
+        self.projection = None if out_channels == in_channels else _seq(
+            nn.Conv2d(in_channels, out_channels, kernel_size=1, bias=False), nn.GELU())
+
+
+class ASPP(nn.Module):
+    def __init__(self, in_channels, atrous_rates, out_channels=256):
+        super().__init__()
+        branches = [_seq(nn.Conv2d(in_channels, out_channels, 1, bias=False), nn.BatchNorm2d(out_channels), nn.ReLU())]
+        for rate in tuple(atrous_rates):
+            branches.append(_seq(nn.Conv2d(in_channels, out_channels, 3, padding=rate, dilation=rate, bias=False),
+                                 nn.BatchNorm2d(out_channels), nn.ReLU()))
+        branches.append(_seq(nn.AdaptiveAvgPool2d(1), nn.Conv2d(in_channels, out_channels, 1, bias=False),
+                             nn.BatchNorm2d(out_channels), nn.ReLU()))
+        self.convs = nn.ModuleList(branches)
+        self.project = _seq(nn.Conv2d(len(self.convs) * out_channels, out_channels, 1, bias=False),
+                            nn.BatchNorm2d(out_channels), nn.ReLU(), nn.Dropout(0.5))
+        self.rates = tuple(atrous_rates)
+
+
+class DeepLabHead(nn.Sequential, PackedModule):
+    """ASPP(12,24,36) -> 3x3+BN+ReLU -> 1x1.  The image-pooling branch (global mean -> 1x1 -> BN ->
+    ReLU -> constant broadcast) is folded into a per-image bias of the ASPP projection."""
+
+    def __init__(self, in_channels, num_classes, hidden_channel=256):
+        nn.Sequential.__init__(
+            self, ASPP(in_channels, [12, 24, 36], hidden_channel),
+            nn.Conv2d(hidden_channel, hidden_channel, 3, padding=1, bias=False),
+            nn.BatchNorm2d(hidden_channel), nn.ReLU(), nn.Conv2d(hidden_channel, num_classes, 1))
+        self.in_channels, self.hidden_channel = in_channels, hidden_channel
+
+    def _pack(self):
+        if self.training:
+            raise RuntimeError("streamingflow_amd is inference-only: call .eval() (BatchNorm uses running statistics)")
+        pk = packing.Pack(_lib.DeepLabW())
+        s, aspp, C, hid = pk.struct, self[0], self.in_channels, self.hidden_channel
+        if len(aspp.convs) != 5:
+            raise NotImplementedError
+        for i in range(4):
+            conv, bn = aspp.convs[i][0], aspp.convs[i][1]
+            sc, bi = packing.bn_fold(bn)
+            s.branch[i] = packing.conv_w(pk, conv.weight, C, scale=sc, bias=bi, act="relu", dil=conv.dilation[0])
+        sc, bi = packing.bn_fold(aspp.convs[4][2])
+        s.pool_w = pk.hold(aspp.convs[4][1].weight.reshape(hid, C))
+        s.pool_scale, s.pool_bias = pk.hold(sc), pk.hold(bi)
+        wproj = aspp.project[0].weight                                    # [hid][5*hid][1][1]
+        s.proj_pool_w = pk.hold(wproj[:, 4 * hid:, 0, 0])
+        sc, bi = packing.bn_fold(aspp.project[1])
+        s.project = packing.conv_w(pk, wproj[:, :4 * hid], 4 * hid, scale=sc, bias=bi, act="relu")
+        sc, bi = packing.bn_fold(self[2])
+        s.conv3 = packing.conv_w(pk, self[1].weight, hid, scale=sc, bias=bi, act="relu")
+        s.cls = packing.conv_w(pk, self[4].weight, hid, bias=self[4].bias)
+        s.C, s.hid = C, hid
+        return pk
+
+    def forward_nhwc(self, x):
+        n, h, w, c = x.shape
+        L = _lib.lib()
+        st = self.packed().struct
+        ws = runtime.workspace(L.sf_deeplab_head_ws_bytes(c, self.hidden_channel, n, h, w), x.device)
+        out = torch.empty((n, h, w, st.cls.cout), dtype=torch.float32, device=x.device)
+        _lib.check(L.sf_deeplab_head_fwd(st, ptr(x), ptr(out), n, h, w, ptr(ws), ws.numel() * 4,
+                                         runtime.stream_ptr(x.device)), "deeplab_head")
+        return out
+
+    def forward(self, x):
+        return runtime.to_nchw(self.forward_nhwc(runtime.to_nhwc(x)))

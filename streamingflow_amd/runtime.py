@@ -1,0 +1,83 @@
+"""Device plumbing shared by the modules: current HIP stream handle, a grow-only workspace per
+device, NCHW<->NHWC conversion through the library, cached packed weights."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_WORKSPACES = {}
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("streamingflow_amd runs on MI355X only: got a %s tensor (no CPU fallback)" % t.device)
+
+
+def workspace(nbytes, device):
+    """Grow-only fp32 scratch buffer per device (pointer is stable while it does not grow)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    cur = _WORKSPACES.get(key)
+    need = (int(nbytes) + 3) // 4 + 1024
+    if cur is None or cur.numel() < need:
+        _WORKSPACES[key] = cur = torch.empty(need, dtype=torch.float32, device=torch.device("cuda", key))
+    return cur
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def to_nhwc(x):
+    """(n, C, H, W) fp32 cuda -> (n, H, W, C) contiguous (libsfnative transpose kernel)."""
+    require_cuda(x)
+    x = f32c(x)
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    if out.numel():
+        _lib.check(_lib.lib().sf_nchw_to_nhwc(ptr(x), ptr(out), n, c, h * w, stream_ptr(x.device)), "nchw_to_nhwc")
+    return out
+
+
+def to_nchw(x):
+    """(n, H, W, C) fp32 cuda -> (n, C, H, W) contiguous."""
+    require_cuda(x)
+    n, h, w, c = x.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    if out.numel():
+        _lib.check(_lib.lib().sf_nhwc_to_nchw(ptr(x), ptr(out), n, c, h * w, stream_ptr(x.device)), "nhwc_to_nchw")
+    return out
+
+
+class PackedModule(torch.nn.Module):
+    """Mixin: lazily packs the module's parameters for the HIP library and re-packs when any
+    parameter was replaced, moved or modified in place (load_state_dict, .to(), optimiser)."""
+
+    def _param_signature(self):
+        sig = []
+        for t in list(self.parameters()) + list(self.buffers()):
+            sig.append((t.data_ptr(), t._version, t.device))
+        return tuple(sig)
+
+    def packed(self):
+        sig = self._param_signature()
+        cache = self.__dict__.get("_sf_pack")
+        if cache is None or cache[0] != sig:
+            first = next(self.parameters())
+            require_cuda(first)
+            with torch.no_grad():
+                pk = self._pack()
+            self.__dict__["_sf_pack"] = cache = (sig, pk)
+        return cache[1]
+
+    def _pack(self):
+        raise NotImplementedError

@@ -1,0 +1,102 @@
+"""GPU parity, end to end: FuturePredictionODE.forward on libsfnative against the fixtures
+generated from the real reference (tests/golden/fpode.npz, big_stats.json) and against the oracle
+at BASELINE config 2's full size.  North-star tolerance: <= 1e-3 max-abs on the fp32 BEV output."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import GOLD, cases, hashfill, gold, maxabs, build_pair
+from oracle import ref_torch as R
+
+pytestmark = pytest.mark.gpu
+TOL_E2E = 1e-3
+
+
+def _run(name):
+    C, H, W, ts, solver, impute, variable, eps0 = cases.FPODE_CASES[name]
+    cts, lts, tts, dt = cases.timeset(ts)
+    net, sd = build_pair(C, solver, impute, variable, dt)
+    cam, lid = cases.bev_inputs(C, H, W, cts.shape[1], lts.shape[1])
+    net.gru_ode.noise = hashfill.HashedNoise(cases.EPS_SEED, zero=eps0)
+    y, aux = net(cases.present_input(cam, lid).cuda(), cam.cuda(), lid.cuda(), cts, lts, tts)
+    return y, aux
+
+
+@pytest.mark.parametrize("name", list(cases.FPODE_CASES))
+def test_fpode_golden(name):
+    y, aux = _run(name)
+    assert aux == 0
+    g = gold("fpode.npz")
+    assert maxabs(y, g[name + "/out"]) <= TOL_E2E
+
+
+def test_nnfo_forward_golden():
+    """NNFOwithBayesianJumps.forward alone (state + decoded predictions)."""
+    name = "c8_16_shipped"
+    C, H, W, ts, solver, impute, variable, eps0 = cases.FPODE_CASES[name]
+    cts, lts, tts, dt = cases.timeset(ts)
+    net, sd = build_pair(C, solver, impute, variable, dt)
+    cam, lid = cases.bev_inputs(C, H, W, cts.shape[1], lts.shape[1])
+    times, obs = R.merge_observations(cam, lid, cts, lts, 0)
+    net.gru_ode.noise = hashfill.HashedNoise(cases.EPS_SEED)
+    state, loss, x = net.gru_ode(times, cases.present_input(cam, lid).cuda(), obs.cuda(), dt, tts[0])
+    g = gold("fpode.npz")
+    assert loss == 0
+    assert maxabs(state, g[name + "/nnfo_state"]) <= 1e-4
+    assert maxabs(x, g[name + "/nnfo_x"]) <= TOL_E2E
+
+
+def test_config2_full_size_vs_oracle_and_reference_stats():
+    """BASELINE config 2: C=64, BEV 200x200, 3 camera + 5 LiDAR observations, 7 targets, variable
+    step (10 steps + 8 jumps).  Checked against the oracle (same process, host cores) and against
+    the statistics of the real reference's output (tests/golden/big_stats.json)."""
+    C, H, W = 64, 200, 200
+    cts, lts, tts, dt = cases.timeset("shipped")
+    net, sd = build_pair(C, "euler", True, True, dt)
+    cam, lid = cases.bev_inputs(C, H, W, 3, 5)
+    net.gru_ode.noise = hashfill.HashedNoise(cases.EPS_SEED)
+    y, _ = net(cases.present_input(cam, lid).cuda(), cam.cuda(), lid.cuda(), cts, lts, tts)
+    y = y.cpu()
+    assert y.shape == (1, 7, C, H, W)
+    path = os.path.join(GOLD, "big_stats.json")
+    if os.path.exists(path):
+        st = json.load(open(path))["out"]
+        flat = y.reshape(-1).double()
+        samples = flat[torch.tensor(st["sample_idx"])]
+        assert float((samples - torch.tensor(st["samples"])).abs().max()) <= TOL_E2E
+        assert abs(flat.mean().item() - st["mean"]) <= 1e-4
+        assert abs(flat.abs().max().item() - st["absmax"]) <= TOL_E2E
+    torch.set_num_threads(os.cpu_count() or 8)
+    with torch.no_grad():
+        yr, _ = R.future_prediction_ode_forward(sd, cases.present_input(cam, lid), cam, lid, cts, lts, tts, dt, 2,
+                                                "euler", True, True, hashfill.HashedNoise(cases.EPS_SEED))
+    assert maxabs(y, yr) <= TOL_E2E
+
+
+def test_rollout_properties_long_horizon():
+    """Size-independent properties at full size (46-step streaming schedule, C=64, 50x50 latent):
+    (1) the rollout is deterministic for fixed eps (bitwise: fixed-order reductions, no atomics);
+    (2) targets answered by the same visited state are bitwise equal;
+    (3) with IMPUTE off the result does not depend on eps at all."""
+    from streamingflow_amd import schedule as S
+    C, h, w = 64, 50, 50
+    cts, lts, tts, dt = cases.timeset("stream40")
+    net, _ = build_pair(C, "euler", True, True, dt)
+    ode = net.gru_ode
+    times, _ = S.merge_observations(cts[0].tolist(), lts[0].tolist())
+    sc = S.build_schedule(times, tts[0].tolist() + [tts[0, -1].item()], dt, True)
+    hx = (hashfill.normal("hx", (8, h, w, C), 41) * 0.5).cuda()
+    eps = hashfill.normal("epsL", (sc.n_draws, h, w, C), 42).cuda()
+    a, fa = ode.rollout_nhwc(hx, sc, eps)
+    b, fb = ode.rollout_nhwc(hx, sc, eps)
+    assert torch.equal(a, b) and torch.equal(fa, fb)
+    assert torch.equal(a[-1], a[-2]) and torch.equal(a[-1], fa)
+    assert torch.isfinite(a).all()
+    ode.impute = False
+    c, _ = ode.rollout_nhwc(hx, sc, eps)
+    d, _ = ode.rollout_nhwc(hx, sc, eps * 0 + 3.0)
+    assert torch.equal(c, d)
+    assert not torch.equal(a, c)

@@ -1,0 +1,168 @@
+"""GPU parity, op by op: libsfnative (through the product modules / the C ABI) against
+(a) the fixtures generated from the real reference (tests/golden/ops_c8.npz) and
+(b) the oracle on the same hashed inputs at the shipped channel count (C=64, 50x50 latent).
+Tolerance: 1e-4 max-abs per op, fp32 everywhere."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import cases, hashfill, gold, maxabs, build_pair
+from oracle import ref_torch as R
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def pair8():
+    return build_pair(8)
+
+
+@pytest.fixture(scope="module")
+def pair64():
+    return build_pair(64)
+
+
+def _noise():
+    return hashfill.HashedNoise(cases.EPS_SEED)
+
+
+# ---- generic conv through the C ABI ------------------------------------------------------------
+@pytest.mark.parametrize("cin,cout,k,dil,n,H,W", [
+    (8, 8, 3, 1, 1, 12, 12), (64, 64, 3, 1, 1, 50, 50), (128, 64, 7, 1, 1, 50, 50), (64, 128, 1, 1, 1, 50, 50),
+    (64, 128, 3, 12, 2, 96, 100), (16, 24, 3, 1, 3, 33, 47), (64, 64, 3, 36, 1, 200, 200), (40, 72, 3, 2, 1, 20, 21)])
+def test_conv2d(cin, cout, k, dil, n, H, W):
+    from streamingflow_amd import _lib, packing, runtime
+    x = hashfill.normal("cx", (n, cin, H, W), 5).cuda()
+    w = hashfill.uniform("cw", (cout, cin, k, k), -1, 1, 6) * (3.0 / (cin * k * k)) ** 0.5
+    b = hashfill.uniform("cb", (cout,), -0.5, 0.5, 7)
+    add = hashfill.normal("cadd", (n, cout, H, W), 8)
+    pk = packing.Pack(None)
+    cw = packing.conv_w(pk, w.cuda(), cin, bias=b.cuda(), act="lrelu", dil=dil)
+    xn, an = runtime.to_nhwc(x), runtime.to_nhwc(add.cuda())
+    out = torch.empty((n, H, W, cout), device="cuda")
+    _lib.check(_lib.lib().sf_conv2d_fwd(ctypes.byref(cw), runtime.ptr(xn), None, runtime.ptr(an), runtime.ptr(out),
+                                        n, H, W, 0, runtime.stream_ptr()))
+    ref = F.leaky_relu(F.conv2d(x.cpu(), w, b, padding=dil * (k - 1) // 2, dilation=dil), 0.1) + add
+    assert maxabs(runtime.to_nchw(out), ref) <= TOL
+
+
+def test_layout_roundtrip():
+    from streamingflow_amd import runtime
+    x = hashfill.normal("lay", (3, 24, 17, 29), 1).cuda()
+    y = runtime.to_nhwc(x)
+    assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(runtime.to_nchw(y), x)
+
+
+# ---- golden vectors from the reference (C=8, 12x12 latent / 48x48 BEV) ---------------------------
+def test_golden_cells(pair8):
+    net, _ = pair8
+    g = gold("ops_c8.npz")
+    C, h, w = 8, 12, 12
+    x = hashfill.normal("op_x", (1, C, h, w), 11).cuda()
+    s = (hashfill.normal("op_s", (1, C, h, w), 12) * 0.5).cuda()
+    ode = net.gru_ode
+    assert maxabs(net.spatial_grus[0].gru_cell(x, s), g["spatial_gru_cell"]) <= TOL
+    assert maxabs(ode.gru_c(x, s), g["dual_ode_cell"]) <= TOL
+    assert maxabs(ode.gru_obs(s, None, x)[0], g["dual_obs_cell"]) <= TOL
+    ode.noise = _noise()
+    y, q = ode.infer_state(s)
+    assert maxabs(y, g["infer_state_y"]) <= TOL and maxabs(q, g["infer_state_q"]) <= TOL
+
+
+def test_golden_encoder_decoder(pair8):
+    net, _ = pair8
+    g = gold("ops_c8.npz")
+    C, h, w = 8, 12, 12
+    bev = hashfill.normal("op_bev", (1, 2, C, 4 * h, 4 * w), 13).cuda()
+    assert maxabs(net.gru_ode.srvp_encode(bev)[0], g["srvp_encode"]) <= TOL
+    lat = (hashfill.normal("op_lat", (1, 2, C, h, w), 14) * 0.5).cuda()
+    assert maxabs(net.gru_ode.srvp_decode(lat), g["srvp_decode"]) <= TOL
+
+
+def test_golden_head_blocks(pair8):
+    net, _ = pair8
+    g = gold("ops_c8.npz")
+    C, h, w = 8, 12, 12
+    frames = hashfill.normal("op_frames", (3, C, 4 * h, 4 * w), 15).cuda()
+    assert maxabs(net.res_blocks[0][0](frames), g["convnext_block"]) <= TOL
+    assert maxabs(net.res_blocks[1](frames), g["deeplab_head"]) <= TOL
+    seq = hashfill.normal("op_seq", (1, 3, C, 4 * h, 4 * w), 16).cuda()
+    assert maxabs(net.spatial_grus[1](seq, seq[:, 0]), g["spatial_gru_seq"]) <= TOL
+
+
+@pytest.mark.parametrize("solver", ["euler", "midpoint"])
+@pytest.mark.parametrize("impute", [True, False])
+def test_golden_ode_step(pair8, solver, impute):
+    net, _ = pair8
+    g = gold("ops_c8.npz")
+    C, h, w = 8, 12, 12
+    x = hashfill.normal("op_x", (1, C, h, w), 11).cuda()
+    s = (hashfill.normal("op_s", (1, C, h, w), 12) * 0.5).cuda()
+    ode = net.gru_ode
+    old = ode.solver, ode.impute
+    try:
+        ode.solver, ode.impute = solver, impute
+        for dt in (0.05, torch.tensor(0.37, dtype=torch.float64)):
+            ode.noise = _noise()
+            st, inp, ct, _, _ = ode.ode_step(s, x, dt, 0.0)
+            tag = f"ode_step_{solver}_{'imp' if impute else 'noimp'}_{float(dt):.2f}"
+            assert maxabs(st, g[tag + "_state"]) <= TOL, tag
+            assert maxabs(inp, g[tag + "_input"]) <= TOL, tag
+            assert float(ct) == float(dt)
+    finally:
+        ode.solver, ode.impute = old
+        ode.noise = None
+
+
+# ---- oracle at the shipped size: C=64, latent 50x50 ---------------------------------------------
+def test_c64_cells_vs_oracle(pair64):
+    net, sd = pair64
+    C, h, w = 64, 50, 50
+    x = hashfill.normal("x64", (1, C, h, w), 21)
+    s = hashfill.normal("s64", (1, C, h, w), 22) * 0.5
+    ode = net.gru_ode
+    with torch.no_grad():
+        assert maxabs(ode.gru_c(x.cuda(), s.cuda()), R.dual_cell(sd, "gru_ode.gru_c", x, s, True)) <= TOL
+        assert maxabs(ode.gru_obs(s.cuda(), None, x.cuda())[0], R.dual_cell(sd, "gru_ode.gru_obs.gru_d", x, s, False)) <= TOL
+        ode.noise = _noise()
+        y, q = ode.infer_state(s.cuda())
+        yr, qr = R.infer_state(sd, "gru_ode", s, _noise())
+        assert maxabs(q, qr) <= TOL and maxabs(y, yr) <= TOL
+        for solver in ("euler", "midpoint", "rk4"):
+            ode.solver, ode.noise = solver, _noise()
+            st, inp, *_ = ode.ode_step(s.cuda(), x.cuda(), 0.5, 0.0)
+            sr, ir = R.ode_step(sd, "gru_ode", s, x, 0.5, solver, True, _noise())
+            assert maxabs(st, sr) <= TOL and maxabs(inp, ir) <= TOL, solver
+        ode.solver, ode.noise = "euler", None
+
+
+def test_c64_stress_latent_200(pair64):
+    """ode_step fed a 200x200x64 latent directly (SURVEY §8d stress variant; large-tile kernels)."""
+    net, sd = pair64
+    C, h, w = 64, 200, 200
+    x = hashfill.normal("x64b", (1, C, h, w), 23)
+    s = hashfill.normal("s64b", (1, C, h, w), 24) * 0.5
+    ode = net.gru_ode
+    ode.noise = _noise()
+    st, inp, *_ = ode.ode_step(s.cuda(), x.cuda(), 0.2, 0.0)
+    ode.noise = None
+    with torch.no_grad():
+        sr, ir = R.ode_step(sd, "gru_ode", s, x, 0.2, "euler", True, _noise())
+    assert maxabs(st, sr) <= TOL and maxabs(inp, ir) <= TOL
+
+
+def test_c32_config1_cell(pair8):
+    """BASELINE config 1 state: 50x50x32."""
+    net, sd = build_pair(32)
+    x = hashfill.normal("x32", (1, 32, 50, 50), 31)
+    s = hashfill.normal("s32", (1, 32, 50, 50), 32) * 0.5
+    net.gru_ode.noise = _noise()
+    st, inp, *_ = net.gru_ode.ode_step(s.cuda(), x.cuda(), 0.05, 0.0)
+    with torch.no_grad():
+        sr, ir = R.ode_step(sd, "gru_ode", s, x, 0.05, "euler", True, _noise())
+    assert maxabs(st, sr) <= TOL and maxabs(inp, ir) <= TOL

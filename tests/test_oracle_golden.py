@@ -1,0 +1,61 @@
+"""CPU: the oracle (oracle/ref_torch.py) reproduces the fixtures generated from the real reference
+(tests/golden, made by oracle/gen_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from util import cases, hashfill, gold, maxabs, build_pair
+from oracle import ref_torch as R
+
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def sd8():
+    return build_pair(8, device="cpu")[1]
+
+
+def test_ops_c8(sd8):
+    g = gold("ops_c8.npz")
+    C, h, w = 8, 12, 12
+    x = hashfill.normal("op_x", (1, C, h, w), 11)
+    s = hashfill.normal("op_s", (1, C, h, w), 12) * 0.5
+    eps = lambda: hashfill.HashedNoise(cases.EPS_SEED)
+    with torch.no_grad():
+        assert maxabs(R.gru_cell(sd8, "spatial_grus.0", x, s), g["spatial_gru_cell"]) <= TOL
+        assert maxabs(R.dual_cell(sd8, "gru_ode.gru_c", x, s, True), g["dual_ode_cell"]) <= TOL
+        assert maxabs(R.dual_cell(sd8, "gru_ode.gru_obs.gru_d", x, s, False), g["dual_obs_cell"]) <= TOL
+        y, q = R.infer_state(sd8, "gru_ode", s, eps())
+        assert maxabs(y, g["infer_state_y"]) <= TOL and maxabs(q, g["infer_state_q"]) <= TOL
+        bev = hashfill.normal("op_bev", (1, 2, C, 4 * h, 4 * w), 13)
+        assert maxabs(R.small_encoder(sd8, "gru_ode.srvp_encoder", bev[0]), g["srvp_encode"][0]) <= TOL
+        lat = hashfill.normal("op_lat", (1, 2, C, h, w), 14) * 0.5
+        assert maxabs(R.small_decoder(sd8, "gru_ode.srvp_decoder", lat[0]), g["srvp_decode"][0]) <= TOL
+        frames = hashfill.normal("op_frames", (3, C, 4 * h, 4 * w), 15)
+        assert maxabs(R.convnext_block(sd8, "res_blocks.0.0", frames), g["convnext_block"]) <= TOL
+        assert maxabs(R.deeplab_head(sd8, "res_blocks.1", frames), g["deeplab_head"]) <= TOL
+        seq = hashfill.normal("op_seq", (1, 3, C, 4 * h, 4 * w), 16)
+        assert maxabs(R.spatial_gru(sd8, "spatial_grus.1", seq, seq[:, 0]), g["spatial_gru_seq"]) <= TOL
+        for solver in ("euler", "midpoint"):
+            for impute in (True, False):
+                for dt in (0.05, torch.tensor(0.37, dtype=torch.float64)):
+                    st, inp = R.ode_step(sd8, "gru_ode", s, x, dt, solver, impute, eps())
+                    tag = f"ode_step_{solver}_{'imp' if impute else 'noimp'}_{float(dt):.2f}"
+                    assert maxabs(st, g[tag + "_state"]) <= TOL, tag
+                    assert maxabs(inp, g[tag + "_input"]) <= TOL, tag
+
+
+@pytest.mark.parametrize("name", list(cases.FPODE_CASES))
+def test_fpode_forward(name):
+    C, H, W, ts, solver, impute, variable, eps0 = cases.FPODE_CASES[name]
+    if H >= 48 and C > 8:
+        pytest.skip("kept small for the CPU suite")
+    g = gold("fpode.npz")
+    cts, lts, tts, dt = cases.timeset(ts)
+    _, sd = build_pair(C, solver, impute, variable, dt, device="cpu")
+    cam, lid = cases.bev_inputs(C, H, W, cts.shape[1], lts.shape[1])
+    with torch.no_grad():
+        y, aux = R.future_prediction_ode_forward(sd, cases.present_input(cam, lid), cam, lid, cts, lts, tts, dt, 2,
+                                                 solver, impute, variable, hashfill.HashedNoise(cases.EPS_SEED, zero=eps0))
+    assert aux == 0
+    assert maxabs(y, g[name + "/out"]) <= 1e-5
