@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""bench.py — ODE-steps/s of the MI355X-native GRU-ODE future-state path (BASELINE.json metric).
+
+One "step" of this bench = one pass of the hot path over one synthetic sample: a full
+``FuturePredictionODE.forward`` of BASELINE config 2 (C=64, BEV 200x200, 3 camera + 5 LiDAR
+observations, 7 targets, variable-step Euler: 10 ODE steps + 8 Bayesian jumps, SmallEncoder on 8
+frames, SmallDecoder + 2x(SpatialGRU + res block) head on 7 frames), inputs resident in HBM.
+``value`` = ODE steps integrated per second over all ranks = n_ode_steps * K * N / t.
+
+N > 1: one process per GPU (torchrun), every rank runs its own sample (the reference is batch-1,
+samples shard with no data-path collective: weak scaling); barrier + synchronize on both sides of
+the timed region, max over ranks.
+
+Extra objects on the JSON line: ``roofline`` (dominant kernel, per-launch hipEvent timing in a
+dedicated pass of the same workload through libsfnative's profiler) and ``cpu_baseline`` (the
+oracle — a torch-CPU port of the reference path — on the host cores, rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--timeset", default="shipped", help="oracle.cases.TIMESETS key (default: BASELINE config 2)")
+    ap.add_argument("--solver", default="euler")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import streamingflow_amd as sfa
+    from streamingflow_amd import _lib, schedule as S
+    from oracle import cases, hashfill, refimport
+
+    C, H, W = 64, 200, 200
+    cts, lts, tts, dt = cases.timeset(a.timeset)
+    cfg = refimport.make_cfg(C, impute=True, solver=a.solver, variable=True)
+    net = sfa.FuturePredictionODE(C, C, 4, cfg, n_gru_blocks=2, n_res_layers=1, delta_t=dt).eval()
+    sd = cases.fpode_state_dict(net.state_dict())        # random-init weights (hashed, reproducible)
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    cam, lid = cases.bev_inputs(C, H, W, cts.shape[1], lts.shape[1], seed=rank)     # one sample per rank
+    cam_d, lid_d = cam.to(dev), lid.to(dev)
+    x_in = cases.present_input(cam_d, lid_d)
+    times, _ = S.merge_observations(cts[0].tolist(), lts[0].tolist())
+    sc = S.build_schedule(times, tts[0].tolist(), dt, True, a.solver)
+    n_ode = sc.n_steps
+
+    def forward():
+        return net(x_in, cam_d, lid_d, cts, lts, tts)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        forward()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        y, _ = forward()
+    fence()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ms_per_step = 1e3 * el / a.steps
+    value = n_ode * a.steps * world / el
+
+    # ---- ODE rollout alone (the serial chain the north star names), same stream, hipEvents -------
+    L = _lib.lib()
+    ode = net.gru_ode
+    hx = torch.randn((len(times), H // 4, W // 4, C), device=dev) * 0.5
+    eps = torch.randn((sc.n_draws, H // 4, W // 4, C), device=dev)
+    for _ in range(2):
+        ode.rollout_nhwc(hx, sc, eps)
+    torch.cuda.synchronize()
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    L.sf_event_create(ctypes.byref(e0)); L.sf_event_create(ctypes.byref(e1))
+    from streamingflow_amd import runtime
+    reps = 10
+    L.sf_event_record(e0, runtime.stream_ptr(dev))
+    for _ in range(reps):
+        ode.rollout_nhwc(hx, sc, eps)
+    L.sf_event_record(e1, runtime.stream_ptr(dev))
+    ms = ctypes.c_float()
+    L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+    rollout_ms = ms.value / reps
+    flops_step = 728.0 * C * C * (H // 4) * (W // 4)          # Euler step, algorithmic
+    flops_jump = flops_step
+    rollout = {"ms": rollout_ms, "ode_steps": sc.n_steps, "jumps": sc.n_jumps,
+               "us_per_op": 1e3 * rollout_ms / max(1, len(sc.ops)),
+               "ops_per_s": len(sc.ops) / (rollout_ms * 1e-3),
+               "tflops": (sc.n_steps * flops_step + sc.n_jumps * flops_jump) / (rollout_ms * 1e-3) / 1e12}
+
+    # ---- roofline of the dominant kernel: per-launch hipEvents in a dedicated pass ---------------
+    roof = None
+    if not a.no_roofline:
+        L.sf_prof_enable(1)
+        for _ in range(2):
+            forward()
+        calls = (ctypes.c_int32 * 32)(); pms = (ctypes.c_double * 32)()
+        pfl = (ctypes.c_double * 32)(); pby = (ctypes.c_double * 32)()
+        L.sf_prof_collect(calls, pms, pfl, pby)
+        L.sf_prof_enable(0)
+        tot = sum(pms)
+        k = max(range(32), key=lambda i: pms[i])
+        achieved = pfl[k] / (pms[k] * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                "kernel": _lib.KERNEL_NAMES.get(k, str(k)), "launches_per_forward": calls[k] // 2,
+                "avg_launch_us": 1e3 * pms[k] / max(1, calls[k]),
+                "flops_per_launch": pfl[k] / max(1, calls[k]),
+                "algorithmic_bytes_per_launch": pby[k] / max(1, calls[k]),
+                "hbm_frac_if_bytes_bound": (pby[k] / (pms[k] * 1e-3) / 1e9) / PEAK_HBM_GBS,
+                "share_of_conv_time": pms[k] / tot if tot else None,
+                "all_conv_tflops": sum(pfl) / (tot * 1e-3) / 1e12 if tot else None,
+                "per_kernel": {_lib.KERNEL_NAMES.get(i, str(i)): {
+                    "calls_per_forward": calls[i] // 2, "ms_per_forward": pms[i] / 2,
+                    "tflops": pfl[i] / (pms[i] * 1e-3) / 1e12} for i in range(32) if calls[i]}}
+
+    # ---- CPU baseline: the oracle (torch-CPU port of the reference path) on the host cores --------
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import ref_torch as R
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            R.future_prediction_ode_forward(sd, cases.present_input(cam, lid), cam, lid, cts, lts, tts, dt, 2,
+                                            a.solver, True, True, hashfill.HashedNoise(0))
+            tc = time.perf_counter() - t0
+        cpu = {"value": n_ode / tc, "unit": "ODE-steps/s", "cores": cores, "kind": "port",
+               "sample": f"1 forward of the same workload ({n_ode} ODE steps + {sc.n_jumps} jumps, 8+7 frames at "
+                         f"200x200x64), oracle/ref_torch.py on torch {torch.__version__} CPU, {tc:.1f} s"}
+
+    if rank == 0:
+        out = {"metric": "ODE-steps/s on 200x200x64 BEV (GRU-ODE future-state path, full FuturePredictionODE.forward)",
+               "value": value, "unit": "ODE-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"BASELINE config 2: C=64, BEV 200x200 (latent 50x50), timeset '{a.timeset}' "
+                                      f"({len(times)} observations, {tts.shape[1]} targets), variable-step {a.solver}: "
+                                      f"{n_ode} ODE steps + {sc.n_jumps} jumps per forward, 1 sample per GPU",
+                          "parallelism": f"replicas x{world} (sample sharding, no data-path collective)"},
+               "forwards_per_s": a.steps * world / el,
+               "ode_rollout_only": rollout, "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

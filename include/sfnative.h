@@ -193,6 +193,12 @@ int sf_event_record(void* ev, void* stream);
 int sf_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
 int sf_event_destroy(void* ev);
 
+/* Per-launch profiler for bench.py (off by default): when enabled every implicit-GEMM launch is
+ * bracketed by hipEvents on its own stream.  sf_prof_collect fills 32-entry arrays indexed by
+ * kernel key = tile_config*8 + epilogue (calls, total ms, algorithmic flops, algorithmic bytes). */
+int sf_prof_enable(int on);
+int sf_prof_collect(int32_t* calls, double* ms, double* flops, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -102,7 +102,13 @@ SIGNATURES = {
     "sf_event_record": (_i, [_vp, _vp]),
     "sf_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "sf_event_destroy": (_i, [_vp]),
+    "sf_prof_enable": (_i, [_i]),
+    "sf_prof_collect": (_i, [i32p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
+
+# kernel key = tile_config*8 + epilogue  (csrc/conv_igemm.hip launch_conv)
+KERNEL_NAMES = {c * 8 + e: f"conv_igemm<{cn},{en}>" for c, cn in enumerate(("S16x64k4", "L64x64", "LN64x128"))
+                for e, en in enumerate(("affine", "blend", "ln_gelu", "trust", "sample"))}
 
 _LIB = None
 

@@ -5,6 +5,7 @@
 #include "../../include/sfnative.h"
 
 #include <cstring>
+#include <vector>
 
 namespace sf {
 hipError_t launch_conv(const ConvLaunch& L, int epi, int cfg, hipStream_t stream);
@@ -82,6 +83,20 @@ bool valid_w(const sf_conv_w& w) {
          w.kw > 0 && w.stride > 0 && w.dil > 0;
 }
 
+// ---- optional per-launch profiler (bench.py only; off by default, the only global state) ---------
+struct ProfRec { int key; double flops, bytes; hipEvent_t a, b; };
+struct Profiler {
+  bool on = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+} g_prof;
+
 int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   ConvLaunch L;
   std::memset(&L, 0, sizeof(L));
@@ -95,7 +110,26 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   }
   L.nprob = n;
   if (P <= 0) return SF_OK;
-  SF_HIP(launch_conv(L, epi, pick_cfg(P, epi), st));
+  const int cfg = pick_cfg(P, epi);
+  if (!g_prof.on) {
+    SF_HIP(launch_conv(L, epi, cfg, st));
+    return SF_OK;
+  }
+  ProfRec r;
+  r.key = cfg * 8 + epi; r.flops = 0; r.bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    const ConvProblem& q = ps[i];
+    const double Pi = (double)q.n_img * q.Hout * q.Wout;
+    const double K = (double)q.KH * q.KW * (q.c0 + q.c1);
+    r.flops += 2.0 * Pi * q.cout * K;
+    // algorithmic bytes: each input pixel and each weight once, output once
+    r.bytes += 4.0 * ((double)q.n_img * q.Hin * q.Win * (q.c0 + q.c1) + (double)q.cout * K + Pi * q.cout);
+  }
+  r.a = g_prof.get(); r.b = g_prof.get();
+  SF_HIP(hipEventRecord(r.a, st));
+  SF_HIP(launch_conv(L, epi, cfg, st));
+  SF_HIP(hipEventRecord(r.b, st));
+  g_prof.recs.push_back(r);
   return SF_OK;
 }
 int run1(const ConvProblem& p, int epi, hipStream_t st) { return run(&p, 1, epi, st); }
@@ -223,8 +257,8 @@ int ode_step(const sf_dual_w& gc, const sf_pmodel_w& pm, int solver, int impute,
   if (!A0.ok()) return SF_ERR_WORKSPACE;
   if (solver == SF_SOLVER_MIDPOINT) {
     SF_TRY(cell(x, s_in, k, s_in, coef + 1, nullptr, 0));              // k = s + dt/2 f(p, s)
-    if (impute) SF_TRY(infer(k, 0, pk));
-    SF_TRY(cell(impute ? pk : zeros, k, s_out, s_in, coef + 0, nullptr, 0));   // s' = s + dt f(pk, k)
+    SF_TRY(infer(k, 0, pk));            // :452 — evaluated even when IMPUTE is off (only :443's input is zeroed)
+    SF_TRY(cell(pk, k, s_out, s_in, coef + 0, nullptr, 0));            // s' = s + dt f(pk, k)
     if (!(skip_dead_infer && !impute)) SF_TRY(infer(s_out, 1, p_out));
     return SF_OK;
   }
@@ -237,12 +271,12 @@ int ode_step(const sf_dual_w& gc, const sf_pmodel_w& pm, int solver, int impute,
     // {dt/2, dt/6}, {dt/2, dt/3}, {dt, dt/3}, {dt/6, 0}   (see SF_COEF_STRIDE in sfnative.h)
     const float* rk = coef + 4;
     SF_TRY(cell(x, s_in, s2, s_in, rk + 0, acc, 0));
-    if (impute) SF_TRY(infer(s2, 0, pk));
-    SF_TRY(cell(impute ? pk : zeros, s2, s3, s_in, rk + 2, acc, 1));
-    if (impute) SF_TRY(infer(s3, 1, pk));
-    SF_TRY(cell(impute ? pk : zeros, s3, s2, s_in, rk + 4, acc, 1));   // s4 reuses s2
-    if (impute) SF_TRY(infer(s2, 2, pk));
-    SF_TRY(cell(impute ? pk : zeros, s2, s_out, acc, rk + 6, nullptr, 0));
+    SF_TRY(infer(s2, 0, pk));           // stage inputs always come from infer_state, as in midpoint
+    SF_TRY(cell(pk, s2, s3, s_in, rk + 2, acc, 1));
+    SF_TRY(infer(s3, 1, pk));
+    SF_TRY(cell(pk, s3, s2, s_in, rk + 4, acc, 1));   // s4 reuses s2
+    SF_TRY(infer(s2, 2, pk));
+    SF_TRY(cell(pk, s2, s_out, acc, rk + 6, nullptr, 0));
     if (!(skip_dead_infer && !impute)) SF_TRY(infer(s_out, 3, p_out));
     return SF_OK;
   }
@@ -567,6 +601,27 @@ int sf_graph_launch(void* exec, void* stream) {
 }
 int sf_graph_destroy(void* exec) {
   SF_HIP(hipGraphExecDestroy((hipGraphExec_t)exec));
+  return SF_OK;
+}
+
+int sf_prof_enable(int on) {
+  g_prof.on = on != 0;
+  return SF_OK;
+}
+// Aggregates (and clears) the recorded launches by kernel key = cfg*8 + epi.  Arrays of length 32:
+// calls, total ms, total algorithmic flops, total algorithmic bytes.  Synchronises.
+int sf_prof_collect(int32_t* calls, double* ms, double* flops, double* bytes) {
+  if (!calls || !ms || !flops || !bytes) return SF_ERR_INVALID;
+  for (int i = 0; i < 32; ++i) { calls[i] = 0; ms[i] = 0; flops[i] = 0; bytes[i] = 0; }
+  for (auto& r : g_prof.recs) {
+    float t = 0.f;
+    SF_HIP(hipEventSynchronize(r.b));
+    SF_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    if (r.key >= 0 && r.key < 32) { calls[r.key] += 1; ms[r.key] += t; flops[r.key] += r.flops; bytes[r.key] += r.bytes; }
+    g_prof.pool.push_back(r.a);
+    g_prof.pool.push_back(r.b);
+  }
+  g_prof.recs.clear();
   return SF_OK;
 }
 

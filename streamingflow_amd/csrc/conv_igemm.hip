@@ -80,9 +80,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
   if (p_tile * BN >= Ptot) return;   // block-uniform
 
   const int tid = threadIdx.x;
-  const int kg = tid / TG;
-  const int t = tid % TG;
-  const int wave = t >> 6;
+  // wave-uniform by construction (TG is a multiple of 64): tell the compiler so it can use SALU
+  const int kg = __builtin_amdgcn_readfirstlane(tid / TG);
+  const int t = tid - kg * TG;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lane = t & 63;
   const int wm = wave / WN, wn = wave % WN;
   const int j = lane & 15, g = lane >> 4;
@@ -90,11 +91,22 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
   float* As = smem + kg * GROUP_FLOATS;          // [2][BM][LDS_ROW]
   float* Bs = As + 2 * BM * LDS_ROW;             // [2][BN][LDS_ROW]
 
+  // ---- problem fields used in the K loop, read from the kernarg segment once ------------------
+  const float* const in0 = P.in0;
+  const float* const in1 = P.in1;
+  const float* const gate = P.gate;
+  const float* const in_scale = P.in_scale;
+  const float* const wbase = P.w;
+  const int c0 = P.c0, c01 = P.c0 + P.c1;
+  const int in0_cs = P.in0_cs, in1_cs = P.in1_cs, gate_cs = P.gate_cs, gate_co = P.gate_co;
+  const int Win = P.Win, in_up = P.in_up, dil = P.dil, KW = P.KW;
+  const int Hlog = P.Hin << P.in_up, Wlog = P.Win << P.in_up;
+  const bool has_aux = (gate != nullptr) | (in_scale != nullptr);   // block-uniform
+
   // ---- per-thread staging slots ----------------------------------------------------------
   const int k4 = t & 7;
   const int row0 = t >> 3;
   const int HWout = P.Hout * P.Wout;
-  const int Hlog = P.Hin << P.in_up, Wlog = P.Win << P.in_up;
   int b_iy0[B_SLOTS], b_ix0[B_SLOTS], b_base[B_SLOTS], b_img[B_SLOTS];
 #pragma unroll
   for (int i = 0; i < B_SLOTS; ++i) {
@@ -108,6 +120,14 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
     b_base[i] = img * P.Hin * P.Win;
     b_img[i] = img;
   }
+  // weight rows: clamp instead of predicating (rows >= cout_pad are never stored by any epilogue)
+  size_t a_off[A_SLOTS];
+#pragma unroll
+  for (int i = 0; i < A_SLOTS; ++i) {
+    int grow = m_tile * BM + row0 + i * ROWS_PER_PASS;
+    grow = grow < P.cout_pad ? grow : P.cout_pad - 1;
+    a_off[i] = (size_t)grow * P.ktot + k4 * 4;
+  }
 
   const int kcpt = P.cin_pad / BK;            // chunks per tap
   const int nchunks = P.KH * P.KW * kcpt;
@@ -119,44 +139,46 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
 #pragma unroll
     for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float4 ra[A_SLOTS], rb[B_SLOTS];
+  // Staging registers.  Every load below is UNCONDITIONAL (addresses are selected, never the
+  // loads): a load under a divergent branch makes hipcc wait vmcnt(0) at the join, which would
+  // serialise the whole prefetch.  Masks / gate / SE scale are applied when writing to LDS.
+  float4 ra[A_SLOTS], rb[B_SLOTS], rx[B_SLOTS];
+  int bflag[B_SLOTS];   // bit0: value valid, bit1: multiply by rx, bit2: multiply by (1 - rx)
+
+  // chunk cursor of this K-group: (tap row, tap col, channel chunk), advanced by KS per iteration
+  int cur_kc = kg % kcpt, cur_tap = kg / kcpt;
+  int cur_ty = cur_tap / KW, cur_tx = cur_tap - cur_ty * KW;
 
   auto load_chunk = [&](int chunk) {
-    const int tap = chunk / kcpt;
-    const int kc = chunk - tap * kcpt;
-    const int ty = tap / P.KW, tx = tap - ty * P.KW;
-    // weights
-    const float* wp = P.w + (size_t)chunk * BK + k4 * 4;
+    const float* wp = wbase + (size_t)chunk * BK;
 #pragma unroll
-    for (int i = 0; i < A_SLOTS; ++i) {
-      int grow = m_tile * BM + row0 + i * ROWS_PER_PASS;
-      ra[i] = (grow < P.cout_pad) ? ld4(wp + (size_t)grow * P.ktot) : zero4();
-    }
-    // activations
-    const int c = kc * BK + k4 * 4;
+    for (int i = 0; i < A_SLOTS; ++i) ra[i] = ld4(wp + a_off[i]);
+    const int c = cur_kc * BK + k4 * 4;
+    const bool s0 = c < c0;
+    const bool s1 = (!s0) & (c < c01);
+    const int cc = c - c0;
 #pragma unroll
     for (int i = 0; i < B_SLOTS; ++i) {
-      int iy = b_iy0[i] + ty * P.dil, ix = b_ix0[i] + tx * P.dil;
-      bool ok = (iy >= 0) & (iy < Hlog) & (ix >= 0) & (ix < Wlog);
-      size_t pix = (size_t)b_base[i] + (size_t)((iy >> P.in_up) * P.Win + (ix >> P.in_up));
-      float4 v = zero4();
-      if (ok) {
-        if (c < P.c0) {
-          v = ld4(P.in0 + pix * P.in0_cs + c);
-          if (P.in_scale) {
-            float4 s = ld4(P.in_scale + (size_t)b_img[i] * P.c0 + c);
-            v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
-          }
-        } else if (c < P.c0 + P.c1) {
-          int cc = c - P.c0;
-          v = ld4(P.in1 + pix * P.in1_cs + cc);
-          if (P.gate) {
-            float4 r = ld4(P.gate + pix * P.gate_cs + P.gate_co + cc);
-            v.x *= (1.f - r.x); v.y *= (1.f - r.y); v.z *= (1.f - r.z); v.w *= (1.f - r.w);
-          }
-        }
+      const int iy = b_iy0[i] + cur_ty * dil, ix = b_ix0[i] + cur_tx * dil;
+      const bool ok = (iy >= 0) & (iy < Hlog) & (ix >= 0) & (ix < Wlog) & (s0 | s1);
+      const size_t pix = ok ? (size_t)b_base[i] + (size_t)((iy >> in_up) * Win + (ix >> in_up)) : 0;
+      const float* p = s1 ? in1 + pix * in1_cs + cc : in0 + pix * in0_cs + (s0 ? c : 0);
+      rb[i] = ld4(ok ? p : in0);
+      int fl = ok ? 1 : 0;
+      if (has_aux) {   // block-uniform branch, no dependent use inside
+        const bool m1 = ok & s0 & (in_scale != nullptr);
+        const bool m2 = ok & s1 & (gate != nullptr);
+        const float* q = m1 ? in_scale + (size_t)b_img[i] * c0 + c : (m2 ? gate + pix * gate_cs + gate_co + cc : in0);
+        rx[i] = ld4(q);
+        fl |= (m1 ? 2 : 0) | (m2 ? 4 : 0);
       }
-      rb[i] = v;
+      bflag[i] = fl;
+    }
+    // advance the cursor to this K-group's next chunk
+    cur_kc += KS;
+    while (cur_kc >= kcpt) {
+      cur_kc -= kcpt;
+      if (++cur_tx == KW) { cur_tx = 0; ++cur_ty; }
     }
   };
 
@@ -166,7 +188,19 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
 #pragma unroll
     for (int i = 0; i < A_SLOTS; ++i) st4(a + (row0 + i * ROWS_PER_PASS) * LDS_ROW + k4 * 4, ra[i]);
 #pragma unroll
-    for (int i = 0; i < B_SLOTS; ++i) st4(b + (row0 + i * ROWS_PER_PASS) * LDS_ROW + k4 * 4, rb[i]);
+    for (int i = 0; i < B_SLOTS; ++i) {
+      float4 v = rb[i];
+      const int fl = bflag[i];
+      if (has_aux) {
+        const float4 x = rx[i];
+        // selects, not arithmetic masks: the dummy-address loads may hold anything
+        const bool sc = fl & 2, gt = fl & 4;
+        v.x *= sc ? x.x : (gt ? 1.f - x.x : 1.f); v.y *= sc ? x.y : (gt ? 1.f - x.y : 1.f);
+        v.z *= sc ? x.z : (gt ? 1.f - x.z : 1.f); v.w *= sc ? x.w : (gt ? 1.f - x.w : 1.f);
+      }
+      if (!(fl & 1)) v = zero4();
+      st4(b + (row0 + i * ROWS_PER_PASS) * LDS_ROW + k4 * 4, v);
+    }
   };
 
   auto compute = [&](int buf) {
