@@ -159,7 +159,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import ref_torch as R
-        cores = os.cpu_count() or 1
+        cores = min(os.cpu_count() or 1, 16)   # more threads only thrash on these small convs
         torch.set_num_threads(cores)
         with torch.no_grad():
             t0 = time.perf_counter()

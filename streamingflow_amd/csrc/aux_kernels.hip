@@ -96,34 +96,56 @@ hipError_t launch_upsample2(const float* in, float* out, int n, int Hin, int Win
 // ---- SE gate (res_models.py:161-165) ---------------------------------------------------------
 // chansum: [ntile16][C] per-16-pixel channel sums written by the producing conv's epilogue.
 // One workgroup: fixed-order sum => mean => fc0 (C/r x C) => ReLU => fc2 (C x C/r) => sigmoid.
-__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ chansum, int ntile, int C, int Cr,
-                                                    float inv_hw, const float* __restrict__ fc0,
-                                                    const float* __restrict__ fc2, float* __restrict__ scale) {
-  extern __shared__ float sm[];   // mean[C] | hid[Cr]
-  float* mean = sm;
-  float* hid = sm + C;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f;
-    for (int t = 0; t < ntile; ++t) s += chansum[(size_t)t * C + c];
-    mean[c] = s * inv_hw;
+__global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ chansum, int ntile, int C, int Cr,
+                                                     float inv_hw, const float* __restrict__ fc0,
+                                                     const float* __restrict__ fc2, float* __restrict__ scale) {
+  extern __shared__ float sm[];   // part[G][C] | mean[C] | hid[Cr]
+  const int G = 1024 / C;         // tile groups summed in parallel (C <= 1024)
+  float* part = sm;
+  float* mean = sm + G * C;
+  float* hid = mean + C;
+  const int c = threadIdx.x % C, grp = threadIdx.x / C;
+  if (grp < G) {
+    // fixed assignment tile -> group and fixed order inside a group: bitwise reproducible
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int t = grp;
+    for (; t + 3 * G < ntile; t += 4 * G) {
+      s0 += chansum[(size_t)t * C + c];
+      s1 += chansum[(size_t)(t + G) * C + c];
+      s2 += chansum[(size_t)(t + 2 * G) * C + c];
+      s3 += chansum[(size_t)(t + 3 * G) * C + c];
+    }
+    for (; t < ntile; t += G) s0 += chansum[(size_t)t * C + c];
+    part[grp * C + c] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
-  for (int h = threadIdx.x; h < Cr; h += blockDim.x) {
+  if (threadIdx.x < C) {
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s += fc0[h * C + c] * mean[c];
-    hid[h] = s > 0.f ? s : 0.f;
+    for (int q = 0; q < G; ++q) s += part[q * C + threadIdx.x];
+    mean[threadIdx.x] = s * inv_hw;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  // hidden layer: one wave per output, lanes stride over the C inputs, shuffle reduce
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int h = wave; h < Cr; h += 16) {
     float s = 0.f;
-    for (int h = 0; h < Cr; ++h) s += fc2[c * Cr + h] * hid[h];
-    scale[c] = 1.f / (1.f + expf(-s));
+    for (int k = lane; k < C; k += 64) s += fc0[h * C + k] * mean[k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) hid[h] = s > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float s = 0.f;
+    for (int h = 0; h < Cr; ++h) s += fc2[threadIdx.x * Cr + h] * hid[h];
+    scale[threadIdx.x] = 1.f / (1.f + expf(-s));
   }
 }
 
 hipError_t launch_se_fc(const float* chansum, int ntile, int C, int Cr, int hw, const float* fc0,
                         const float* fc2, float* scale, hipStream_t s) {
-  hipLaunchKernelGGL(se_fc_kernel, dim3(1), dim3(256), (C + Cr) * sizeof(float), s, chansum, ntile, C, Cr,
+  if (C < 1 || C > 1024) return hipErrorInvalidValue;
+  const int G = 1024 / C;
+  hipLaunchKernelGGL(se_fc_kernel, dim3(1), dim3(1024), (G * C + C + Cr) * sizeof(float), s, chansum, ntile, C, Cr,
                      1.f / (float)hw, fc0, fc2, scale);
   return hipGetLastError();
 }

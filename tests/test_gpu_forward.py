@@ -69,7 +69,7 @@ def test_config2_full_size_vs_oracle_and_reference_stats():
         assert float((samples - torch.tensor(st["samples"])).abs().max()) <= TOL_E2E
         assert abs(flat.mean().item() - st["mean"]) <= 1e-4
         assert abs(flat.abs().max().item() - st["absmax"]) <= TOL_E2E
-    torch.set_num_threads(os.cpu_count() or 8)
+    torch.set_num_threads(min(os.cpu_count() or 8, 16))
     with torch.no_grad():
         yr, _ = R.future_prediction_ode_forward(sd, cases.present_input(cam, lid), cam, lid, cts, lts, tts, dt, 2,
                                                 "euler", True, True, hashfill.HashedNoise(cases.EPS_SEED))

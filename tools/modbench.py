@@ -1,0 +1,87 @@
+"""Per-module timing at BASELINE config 2 sizes (C=64, BEV 200x200) + isolated conv shapes.
+Usage (GPU box): python tools/modbench.py > gpurun_out/modbench.txt"""
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from util import build_pair, cases  # noqa: E402
+from streamingflow_amd import _lib, packing, runtime, schedule as S  # noqa: E402
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3   # us
+
+
+def conv_case(cin, cout, k, n, H, W, dil=1, c1=0):
+    x = torch.randn(n, H, W, cin - c1, device="cuda")
+    x1 = torch.randn(n, H, W, c1, device="cuda") if c1 else None
+    w = torch.randn(cout, cin, k, k, device="cuda") * 0.05
+    pk = packing.Pack(None)
+    cw = packing.conv_w(pk, w, cin - c1, c1, act="lrelu", dil=dil)
+    out = torch.empty(n, H, W, cout, device="cuda")
+    L = _lib.lib()
+    fn = lambda: L.sf_conv2d_fwd(ctypes.byref(cw), runtime.ptr(x), runtime.ptr(x1), None, runtime.ptr(out), n, H, W, 0,
+                                 runtime.stream_ptr())
+    us = timeit(fn)
+    fl = 2.0 * n * H * W * cout * cin * k * k
+    print(f"conv {cin:4d}->{cout:4d} k{k} d{dil:2d} n{n} {H}x{W}: {us:9.1f} us  {fl / us / 1e6:7.2f} TFLOP/s")
+
+
+def main():
+    C, H, W = 64, 200, 200
+    net, _ = build_pair(C)
+    ode = net.gru_ode
+    h, w = H // 4, W // 4
+    s = torch.randn(1, h, w, C, device="cuda") * 0.5
+    x = torch.randn(1, h, w, C, device="cuda")
+    out = torch.empty_like(s)
+    one = torch.ones(1, device="cuda")
+    print(f"dual_cell (deriv) 50x50x64      : {timeit(lambda: ode.gru_c.run_nhwc(x, s, out, True, s, one)):9.1f} us  (4.649 GFLOP)")
+    L = _lib.lib()
+    eps = torch.randn(1, h, w, C, device="cuda")
+    p = torch.empty_like(s)
+    ws = runtime.workspace(L.sf_infer_state_ws_bytes(C, h, w), "cuda")
+    pm = ode.p_model.packed().struct
+    f = lambda: L.sf_infer_state_fwd(pm, runtime.ptr(s), runtime.ptr(eps), runtime.ptr(p), None, h, w, runtime.ptr(ws),
+                                     ws.numel() * 4, runtime.stream_ptr())
+    print(f"infer_state 50x50x64            : {timeit(f):9.1f} us  (2.806 GFLOP)")
+    cts, lts, tts, dt = cases.timeset("shipped")
+    times, _ = S.merge_observations(cts[0].tolist(), lts[0].tolist())
+    sc = S.build_schedule(times, tts[0].tolist(), dt, True)
+    hx = torch.randn(8, h, w, C, device="cuda") * 0.5
+    e = torch.randn(sc.n_draws, h, w, C, device="cuda")
+    print(f"rollout 10 steps + 8 jumps      : {timeit(lambda: ode.rollout_nhwc(hx, sc, e), 5, 2):9.1f} us")
+    obs = torch.randn(8, H, W, C, device="cuda")
+    print(f"small_encoder 8 frames          : {timeit(lambda: ode.srvp_encoder.forward_nhwc(obs), 5, 2):9.1f} us  (114 GFLOP)")
+    lat = torch.randn(7, h, w, C, device="cuda")
+    print(f"small_decoder 7 frames          : {timeit(lambda: ode.srvp_decoder.forward_nhwc(lat), 5, 2):9.1f} us  (173 GFLOP)")
+    fr = torch.randn(7, H, W, C, device="cuda")
+    print(f"spatial_gru 7 frames            : {timeit(lambda: net.spatial_grus[0].forward_nhwc(fr, fr[0]), 5, 2):9.1f} us  (126 GFLOP)")
+    print(f"convnext block 7 frames         : {timeit(lambda: net.res_blocks[0][0].forward_nhwc(fr), 5, 2):9.1f} us  (20 GFLOP)")
+    print(f"deeplab head 7 frames           : {timeit(lambda: net.res_blocks[1].forward_nhwc(fr), 5, 2):9.1f} us  (261 GFLOP)")
+    xin = torch.randn(8, C, H, W, device="cuda")
+    print(f"nchw->nhwc 8 frames             : {timeit(lambda: runtime.to_nhwc(xin), 5, 2):9.1f} us")
+    print()
+    for args in [(128, 128, 3, 1, 50, 50, 1, 64), (64, 64, 3, 1, 50, 50), (128, 64, 7, 1, 50, 50, 1, 64), (64, 64, 1, 1, 50, 50),
+                 (64, 128, 3, 1, 50, 50), (128, 128, 3, 1, 50, 50),
+                 (128, 128, 3, 1, 200, 200, 1, 64), (64, 64, 3, 7, 200, 200), (64, 128, 3, 7, 200, 200, 12),
+                 (512, 128, 1, 7, 200, 200), (128, 128, 3, 7, 200, 200), (256, 256, 3, 8, 50, 50), (128, 128, 3, 7, 100, 100)]:
+        conv_case(*args)
+
+
+if __name__ == "__main__":
+    main()
