@@ -107,7 +107,7 @@ SIGNATURES = {
 }
 
 # kernel key = tile_config*8 + epilogue  (csrc/conv_igemm.hip launch_conv)
-KERNEL_NAMES = {c * 8 + e: f"conv_igemm<{cn},{en}>" for c, cn in enumerate(("S16x64k4", "L64x64", "LN64x128"))
+KERNEL_NAMES = {c * 8 + e: f"conv_igemm<{cn},{en}>" for c, cn in enumerate(("S16x64k4", "L64x64", "LN64x128", "direct16px"))
                 for e, en in enumerate(("affine", "blend", "ln_gelu", "trust", "sample"))}
 
 _LIB = None

@@ -4,11 +4,13 @@
 #include "sf_device.h"
 #include "../../include/sfnative.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 namespace sf {
 hipError_t launch_conv(const ConvLaunch& L, int epi, int cfg, hipStream_t stream);
+hipError_t launch_conv_direct(const ConvLaunch& L, int epi, int mt, int ks, hipStream_t stream);
 hipError_t launch_transpose(const float* in, float* out, int n, int rows, int cols, hipStream_t s);
 hipError_t launch_maxpool2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s);
 hipError_t launch_upsample2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s);
@@ -97,6 +99,24 @@ struct Profiler {
   }
 } g_prof;
 
+// Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
+//   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
+//   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
+struct Tune { int direct, mt, ks, chunks_per_wave; };
+const Tune& tune() {
+  static const Tune t = [] {
+    auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
+    Tune x;
+    x.direct = geti("SF_DIRECT", 1);
+    x.mt = geti("SF_DIRECT_MT", 0);
+    x.ks = geti("SF_DIRECT_KS", 0);
+    x.chunks_per_wave = geti("SF_DIRECT_CPW", 5);
+    if (x.chunks_per_wave < 1) x.chunks_per_wave = 1;
+    return x;
+  }();
+  return t;
+}
+
 int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   ConvLaunch L;
   std::memset(&L, 0, sizeof(L));
@@ -110,9 +130,34 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   }
   L.nprob = n;
   if (P <= 0) return SF_OK;
-  const int cfg = pick_cfg(P, epi);
+  int cfg = pick_cfg(P, epi);
+  // small pixel counts: direct-fragment kernel (no LDS staging), see conv_igemm.hip
+  int mt = 0, ks = 1;
+  if (cfg == 0 && tune().direct) {
+    const bool ln = (epi == EPI_LNG || epi == EPI_TRUST);
+    int cp_max = 0, cp_gcd = 0, chunks = 0;
+    bool ok = true;
+    for (int i = 0; i < n; ++i) {
+      const ConvProblem& q = ps[i];
+      ok = ok && (q.c0 % 8 == 0) && (q.c1 % 8 == 0);
+      cp_max = q.cout_pad > cp_max ? q.cout_pad : cp_max;
+      int a = q.cout_pad, b = cp_gcd;
+      while (b) { int t = a % b; a = b; b = t; }
+      cp_gcd = a;
+      int nc = q.KH * q.KW * (q.cin_pad / 32);
+      chunks = nc > chunks ? nc : chunks;
+    }
+    if (ln) mt = (cp_max == 16 || cp_max == 32 || cp_max == 64) ? cp_max / 16 : 0;
+    else mt = tune().mt ? tune().mt : ((cp_gcd % 32 == 0) ? 2 : 1)   /* measured: 32-row tiles (twice the workgroups) beat 64-row ones */;
+    ks = tune().ks ? tune().ks : (chunks + tune().chunks_per_wave - 1) / tune().chunks_per_wave;
+    ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
+    if (ok && mt) cfg = 3;
+  }
+  auto launch = [&]() -> hipError_t {
+    return cfg == 3 ? launch_conv_direct(L, epi, mt, ks, st) : launch_conv(L, epi, cfg, st);
+  };
   if (!g_prof.on) {
-    SF_HIP(launch_conv(L, epi, cfg, st));
+    SF_HIP(launch());
     return SF_OK;
   }
   ProfRec r;
@@ -127,7 +172,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   }
   r.a = g_prof.get(); r.b = g_prof.get();
   SF_HIP(hipEventRecord(r.a, st));
-  SF_HIP(launch_conv(L, epi, cfg, st));
+  SF_HIP(launch());
   SF_HIP(hipEventRecord(r.b, st));
   g_prof.recs.push_back(r);
   return SF_OK;

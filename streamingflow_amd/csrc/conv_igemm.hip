@@ -59,6 +59,204 @@ __device__ __forceinline__ float tile_px_reduce(float v) {
 constexpr int LDS_ROW = 36;   // floats per staged row: 32 K values + 4 pad
 constexpr int BK = 32;
 
+// ---- epilogues (shared by the LDS-staged and the direct-fragment kernels) -------------------
+// acc[m][n]: 16x16 tiles, lane (j = lane&15, g = lane>>4) holds channels m0 + 16m + 4g + (0..3) of
+// pixel p0 + 16n + j.  LayerNorm epilogues need m0 == 0 and 16*MT >= cout (all channels in-wave).
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[MT][NT], const int m0, const int p0,
+                                             const int lane, const int Ptot, const int HWout) {
+  const int j = lane & 15, g = lane >> 4;
+
+  if constexpr (EPI == EPI_AFFINE || EPI == EPI_BLEND) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int gp = p0 + n * 16 + j;
+      const bool pv = gp < Ptot;
+      const int img = pv ? gp / HWout : 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int c = m0 + m * 16 + 4 * g;
+        const bool cv = c < P.cout;
+        float4 y = zero4();
+        if (pv && cv) {
+          float4 sc = P.scale ? ld4(P.scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+          float4 bi = P.bias ? ld4(P.bias + (P.bias_per_img ? (size_t)img * P.cout : 0) + c) : zero4();
+          float4 v;
+          v.x = acc[m][n][0] * sc.x + bi.x; v.y = acc[m][n][1] * sc.y + bi.y;
+          v.z = acc[m][n][2] * sc.z + bi.z; v.w = acc[m][n][3] * sc.w + bi.w;
+          if constexpr (EPI == EPI_AFFINE) {
+            y.x = act_apply(v.x, P.act); y.y = act_apply(v.y, P.act);
+            y.z = act_apply(v.z, P.act); y.w = act_apply(v.w, P.act);
+            if (P.add) {
+              float4 ad = ld4(P.add + (size_t)gp * P.add_cs + c);
+              if (P.add_scale) {
+                float4 as = ld4(P.add_scale + (size_t)img * P.cout + c);
+                ad.x *= as.x; ad.y *= as.y; ad.z *= as.z; ad.w *= as.w;
+              }
+              y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w;
+            }
+          } else {  // EPI_BLEND  (temporal.py:56, temporal_ode_bayes.py:145,160)
+            float4 u = ld4(P.e0 + (size_t)gp * P.e0_cs + c);
+            float4 s = ld4(P.e1 + (size_t)gp * P.e1_cs + c);
+            y.x = (1.f - u.x) * s.x + u.x * v.x; y.y = (1.f - u.y) * s.y + u.y * v.y;
+            y.z = (1.f - u.z) * s.z + u.z * v.z; y.w = (1.f - u.w) * s.w + u.w * v.w;
+          }
+          st4(P.out + (size_t)gp * P.out_cs + P.out_co + c, y);
+        }
+        if constexpr (EPI == EPI_AFFINE) {
+          if (P.chansum) {   // block-uniform branch; all lanes take part in the shuffles
+            float4 s4;
+            s4.x = tile_px_reduce(y.x); s4.y = tile_px_reduce(y.y);
+            s4.z = tile_px_reduce(y.z); s4.w = tile_px_reduce(y.w);
+            if (j == 0 && cv) {
+              int tile16 = p0 / 16 + n;
+              st4(P.chansum + (size_t)tile16 * P.cout + c, s4);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if constexpr (EPI == EPI_LNG || EPI == EPI_TRUST) {
+    // the wave holds every channel of its pixels (m0 == 0, 16*MT >= cout; checked on the host)
+    const float inv_c = 1.f / (float)P.cout;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int gp = p0 + n * 16 + j;
+      const bool pv = gp < Ptot;
+      float v[MT][4];
+      bool cvm[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        cvm[m] = (m0 + m * 16 + 4 * g) < P.cout;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[m][q] = acc[m][n][q];
+      }
+      const bool do_ln = (EPI == EPI_TRUST) || (P.mode & 1);
+      if (do_ln) {   // convolutions.py:303-308 (channels_first LayerNorm)
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          if (cvm[m]) s += (v[m][0] + v[m][1]) + (v[m][2] + v[m][3]);
+        const float mean = pix_allreduce(s) * inv_c;
+        float sq = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          if (cvm[m]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { float d = v[m][q] - mean; sq += d * d; }
+          }
+        const float var = pix_allreduce(sq) * inv_c;
+        const float rstd = 1.f / sqrtf(var + P.eps);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          if (cvm[m]) {
+            const int c = m0 + m * 16 + 4 * g;
+            float4 w = ld4(P.scale + c), b = ld4(P.bias + c);
+            v[m][0] = w.x * ((v[m][0] - mean) * rstd) + b.x;
+            v[m][1] = w.y * ((v[m][1] - mean) * rstd) + b.y;
+            v[m][2] = w.z * ((v[m][2] - mean) * rstd) + b.z;
+            v[m][3] = w.w * ((v[m][3] - mean) * rstd) + b.w;
+          }
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[m][q] = gelu_f(v[m][q]);
+
+      if constexpr (EPI == EPI_LNG) {
+        if (pv) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            if (cvm[m]) {
+              const int c = m0 + m * 16 + 4 * g;
+              st4(P.out + (size_t)gp * P.out_cs + P.out_co + c, make_float4(v[m][0], v[m][1], v[m][2], v[m][3]));
+            }
+        }
+      } else {
+        // trusting gate tail (temporal_ode_bayes.py:124-131 / :268-275, convolutions.py:375-380):
+        // bb = t3 + skip ; z = W2 bb ; g = softmax(z) ; cur = r2*g0 + r1*g1
+        const size_t po = (size_t)(pv ? gp : 0) * P.cout;
+        float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          if (cvm[m]) {
+            const int c = m0 + m * 16 + 4 * g;
+            float4 sk = ld4(P.e0 + po + c);
+            float4 w0 = ld4(P.e1 + c), w1 = ld4(P.e1 + P.cout + c);
+            float b0 = v[m][0] + sk.x, b1 = v[m][1] + sk.y, b2 = v[m][2] + sk.z, b3 = v[m][3] + sk.w;
+            z0 += (w0.x * b0 + w0.y * b1) + (w0.z * b2 + w0.w * b3);
+            z1 += (w1.x * b0 + w1.y * b1) + (w1.z * b2 + w1.w * b3);
+          }
+        z0 = pix_allreduce(z0);
+        z1 = pix_allreduce(z1);
+        const float zm = fmaxf(z0, z1);
+        const float ez0 = expf(z0 - zm), ez1 = expf(z1 - zm);
+        const float g0 = ez0 / (ez0 + ez1), g1 = ez1 / (ez0 + ez1);
+        if (pv) {
+          const float c0f = P.coef ? P.coef[0] : 0.f;
+          const float c1f = (P.coef && P.out2) ? P.coef[1] : 0.f;
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            if (cvm[m]) {
+              const int c = m0 + m * 16 + 4 * g;
+              float4 r2 = ld4(P.e2 + po + c), r1 = ld4(P.e3 + po + c);
+              float4 cur;
+              cur.x = r2.x * g0 + r1.x * g1; cur.y = r2.y * g0 + r1.y * g1;
+              cur.z = r2.z * g0 + r1.z * g1; cur.w = r2.w * g0 + r1.w * g1;
+              if (P.mode & 1) {   // derivative: d = cur - s ; out = base + coef0*d
+                float4 s = ld4(P.e4 + po + c), base = ld4(P.e5 + po + c);
+                float4 d = make_float4(cur.x - s.x, cur.y - s.y, cur.z - s.z, cur.w - s.w);
+                float4 o;
+                o.x = base.x + c0f * d.x; o.y = base.y + c0f * d.y;
+                o.z = base.z + c0f * d.z; o.w = base.w + c0f * d.w;
+                if (P.out2) {
+                  float4 b2 = (P.mode & 2) ? ld4(P.out2 + po + c) : base;
+                  b2.x += c1f * d.x; b2.y += c1f * d.y; b2.z += c1f * d.z; b2.w += c1f * d.w;
+                  st4(P.out2 + po + c, b2);
+                }
+                st4(P.out + po + c, o);
+              } else {
+                st4(P.out + po + c, cur);
+              }
+            }
+        }
+      }
+    }
+  }
+
+  if constexpr (EPI == EPI_SAMPLE) {
+    // Packed cout rows are interleaved so that a lane holds (loc c, loc c+1, raw c, raw c+1):
+    // row 16*T + 4*g + r  <->  r<2: loc channel 8T+2g+r ; r>=2: raw channel 8T+2g+(r-2).
+    const int Chalf = P.cout >> 1;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int gp = p0 + n * 16 + j;
+      const bool pv = gp < Ptot;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int row = m0 + m * 16 + 4 * g;
+        const int c = (row >> 4) * 8 + 2 * g;   // logical loc channel
+        if (pv && c < Chalf) {
+          float4 bi = P.bias ? ld4(P.bias + row) : zero4();
+          float q0 = act_apply(acc[m][n][0] + bi.x, P.act), q1 = act_apply(acc[m][n][1] + bi.y, P.act);
+          float q2 = act_apply(acc[m][n][2] + bi.z, P.act), q3 = act_apply(acc[m][n][3] + bi.w, P.act);
+          float2 e = *reinterpret_cast<const float2*>(P.e0 + (size_t)gp * Chalf + c);
+          float2 o;
+          o.x = q0 + e.x * (softplus_f(q2) + 1e-8f);     // model_utils.py:84,107-108
+          o.y = q1 + e.y * (softplus_f(q3) + 1e-8f);
+          *reinterpret_cast<float2*>(P.out + (size_t)gp * Chalf + c) = o;
+          if (P.out2) {   // raw q parameters, reference channel order [loc | raw]
+            *reinterpret_cast<float2*>(P.out2 + (size_t)gp * P.cout + c) = make_float2(q0, q1);
+            *reinterpret_cast<float2*>(P.out2 + (size_t)gp * P.cout + Chalf + c) = make_float2(q2, q3);
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int MT, int NT, int WM, int WN, int KS, int EPI>
 __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const ConvLaunch L) {
   constexpr int BM = 16 * MT * WM;
@@ -270,198 +468,202 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
     }
   }
 
-  // ---- epilogues ---------------------------------------------------------------------------
-  const int m0 = m_tile * BM + wm * MT * 16;      // first (packed) cout row of this wave
+  // ---- epilogue --------------------------------------------------------------------------------
+  run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
+}
 
-  if constexpr (EPI == EPI_AFFINE || EPI == EPI_BLEND) {
+// ---- direct-fragment kernel (small pixel counts: the 50x50 BEV latent of the GRU-ODE) -------
+// At 2500 pixels a layer has only 157 pixel tiles: nothing is shared between the waves of a
+// workgroup (each K-group has its own K slice), so staging through LDS buys no reuse and only
+// adds a write+read+barrier to every chunk while 92 KB of LDS pin occupancy to one workgroup per CU.
+// Here every wave loads its MFMA fragments straight from global memory (L2-resident): within a
+// 32-deep chunk lane (j, g) owns the 8 consecutive K values 8g..8g+7 of weight row j / pixel j
+// (two 16-B loads, the four g-lanes of a row cover one full 128-B line), and MFMA step e
+// contracts the K slice {8g+e}.  No LDS and no barrier in the K loop, waves run free with one
+// chunk of register prefetch; occupancy is bounded by VGPRs only.  blockDim.x/64 = number of
+// K-groups (in-workgroup split-K, fixed-order LDS reduction at the end).
+template <int MT, int EPI>
+__global__ __launch_bounds__(512) void conv_direct_kernel(const ConvLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const ConvProblem& P = L.p[blockIdx.y];
+  const int Ptot = P.n_img * P.Hout * P.Wout;
+  constexpr int BM = 16 * MT;
+  const int n_mt = (P.cout_pad + BM - 1) / BM;
+  const int m_tile = blockIdx.x % n_mt;
+  const int p_tile = blockIdx.x / n_mt;
+  if (p_tile * 16 >= Ptot) return;   // block-uniform
+
+  const int KS = blockDim.x >> 6;
+  const int kg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15, g = lane >> 4;
+
+  const float* const in0 = P.in0;
+  const float* const in1 = P.in1;
+  const float* const gate = P.gate;
+  const float* const in_scale = P.in_scale;
+  const int c0 = P.c0, c01 = P.c0 + P.c1;
+  const int in0_cs = P.in0_cs, in1_cs = P.in1_cs, gate_cs = P.gate_cs, gate_co = P.gate_co;
+  const int Win = P.Win, in_up = P.in_up, dil = P.dil, KW = P.KW;
+  const int Hlog = P.Hin << P.in_up, Wlog = P.Win << P.in_up;
+  const bool has_aux = (gate != nullptr) | (in_scale != nullptr);
+  const int HWout = P.Hout * P.Wout;
+
+  // this lane's pixel
+  const int gp = p_tile * 16 + j;
+  const bool pvalid = gp < Ptot;
+  const int img = pvalid ? gp / HWout : 0;
+  const int rem = gp - img * HWout;
+  const int oy = rem / P.Wout, ox = rem - oy * P.Wout;
+  const int iy0 = pvalid ? oy * P.stride - P.pad : -(1 << 28);
+  const int ix0 = ox * P.stride - P.pad;
+  const size_t pbase = (size_t)img * P.Hin * P.Win;
+  const float* const sc_row = in_scale ? in_scale + (size_t)img * c0 : in0;
+
+  // this lane's weight rows (clamped: rows >= cout_pad are never stored)
+  const float* a_ptr[MT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int gp = p_tile * BN + (wn * NT + n) * 16 + j;
-      const bool pv = gp < Ptot;
-      const int img = pv ? gp / HWout : 0;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int c = m0 + m * 16 + 4 * g;
-        const bool cv = c < P.cout;
-        float4 y = zero4();
-        if (pv && cv) {
-          float4 sc = P.scale ? ld4(P.scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
-          float4 bi = P.bias ? ld4(P.bias + (P.bias_per_img ? (size_t)img * P.cout : 0) + c) : zero4();
-          float4 v;
-          v.x = acc[m][n][0] * sc.x + bi.x; v.y = acc[m][n][1] * sc.y + bi.y;
-          v.z = acc[m][n][2] * sc.z + bi.z; v.w = acc[m][n][3] * sc.w + bi.w;
-          if constexpr (EPI == EPI_AFFINE) {
-            y.x = act_apply(v.x, P.act); y.y = act_apply(v.y, P.act);
-            y.z = act_apply(v.z, P.act); y.w = act_apply(v.w, P.act);
-            if (P.add) {
-              float4 ad = ld4(P.add + (size_t)gp * P.add_cs + c);
-              if (P.add_scale) {
-                float4 as = ld4(P.add_scale + (size_t)img * P.cout + c);
-                ad.x *= as.x; ad.y *= as.y; ad.z *= as.z; ad.w *= as.w;
-              }
-              y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w;
-            }
-          } else {  // EPI_BLEND  (temporal.py:56, temporal_ode_bayes.py:145,160)
-            float4 u = ld4(P.e0 + (size_t)gp * P.e0_cs + c);
-            float4 s = ld4(P.e1 + (size_t)gp * P.e1_cs + c);
-            y.x = (1.f - u.x) * s.x + u.x * v.x; y.y = (1.f - u.y) * s.y + u.y * v.y;
-            y.z = (1.f - u.z) * s.z + u.z * v.z; y.w = (1.f - u.w) * s.w + u.w * v.w;
-          }
-          st4(P.out + (size_t)gp * P.out_cs + P.out_co + c, y);
-        }
-        if constexpr (EPI == EPI_AFFINE) {
-          if (P.chansum) {   // block-uniform branch; all lanes take part in the shuffles
-            float4 s4;
-            s4.x = tile_px_reduce(y.x); s4.y = tile_px_reduce(y.y);
-            s4.z = tile_px_reduce(y.z); s4.w = tile_px_reduce(y.w);
-            if (j == 0 && cv) {
-              int tile16 = (p_tile * BN) / 16 + wn * NT + n;
-              st4(P.chansum + (size_t)tile16 * P.cout + c, s4);
-            }
-          }
-        }
-      }
-    }
+  for (int m = 0; m < MT; ++m) {
+    int row = m_tile * BM + m * 16 + j;
+    row = row < P.cout_pad ? row : P.cout_pad - 1;
+    a_ptr[m] = P.w + (size_t)row * P.ktot + 8 * g;
   }
 
-  if constexpr (EPI == EPI_LNG || EPI == EPI_TRUST) {
-    // requires WM == 1 and a single cout tile: the wave holds every channel of its pixels.
-    static_assert(WM == 1, "LayerNorm epilogues need all channels in one wave");
-    const float inv_c = 1.f / (float)P.cout;
+  const int kcpt = P.cin_pad / BK;
+  const int nchunks = P.KH * P.KW * kcpt;
+  const int n_my = kg < nchunks ? (nchunks - kg + KS - 1) / KS : 0;
+  int cur_kc = kg % kcpt;
+  int cur_ty = (kg / kcpt) / KW, cur_tx = (kg / kcpt) - cur_ty * KW;
+
+  f32x4 acc[MT][1];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int gp = p_tile * BN + (wn * NT + n) * 16 + j;
-      const bool pv = gp < Ptot;
-      float v[MT][4];
-      bool cvm[MT];
+  for (int m = 0; m < MT; ++m) acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 a0[MT][2], a1[MT][2], b0[2], b1[2], x0[2], x1[2];
+  int f0 = 0, f1 = 0;
+
+  auto load = [&](float4 (&a)[MT][2], float4 (&b)[2], float4 (&x)[2], int& fl, int chunk) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      a[m][0] = ld4(a_ptr[m] + (size_t)chunk * BK);
+      a[m][1] = ld4(a_ptr[m] + (size_t)chunk * BK + 4);
+    }
+    const int c = cur_kc * BK + 8 * g;
+    const bool s0 = c < c0;
+    const bool s1 = (!s0) & (c < c01);
+    const int cc = c - c0;
+    const int iy = iy0 + cur_ty * dil, ix = ix0 + cur_tx * dil;
+    const bool ok = (iy >= 0) & (iy < Hlog) & (ix >= 0) & (ix < Wlog) & (s0 | s1);
+    const size_t pix = ok ? pbase + (size_t)((iy >> in_up) * Win + (ix >> in_up)) : 0;
+    const float* p = s1 ? in1 + pix * in1_cs + cc : in0 + pix * in0_cs + (s0 ? c : 0);
+    b[0] = ld4(p);
+    b[1] = ld4(p + 4);
+    int f = ok ? 1 : 0;
+    if (has_aux) {   // block-uniform
+      const bool m1 = ok & s0 & (in_scale != nullptr);
+      const bool m2 = ok & s1 & (gate != nullptr);
+      const float* q = m1 ? sc_row + c : (m2 ? gate + pix * gate_cs + gate_co + cc : in0);
+      x[0] = ld4(q);
+      x[1] = ld4(q + 4);
+      f |= (m1 ? 2 : 0) | (m2 ? 4 : 0);
+    }
+    fl = f;
+    cur_kc += KS;
+    while (cur_kc >= kcpt) {
+      cur_kc -= kcpt;
+      if (++cur_tx == KW) { cur_tx = 0; ++cur_ty; }
+    }
+  };
+
+  auto compute = [&](float4 (&a)[MT][2], float4 (&b)[2], float4 (&x)[2], int fl) {
+    float bv[8] = {b[0].x, b[0].y, b[0].z, b[0].w, b[1].x, b[1].y, b[1].z, b[1].w};
+    if (has_aux) {
+      const float xv[8] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w};
+      const bool sc = fl & 2, gt = fl & 4;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] *= sc ? xv[e] : (gt ? 1.f - xv[e] : 1.f);
+    }
+    const bool ok = fl & 1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = ok ? bv[e] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        cvm[m] = (m0 + m * 16 + 4 * g) < P.cout;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[m][q] = acc[m][n][q];
+        const float4 av = a[m][e >> 2];
+        const float ae = (e & 3) == 0 ? av.x : ((e & 3) == 1 ? av.y : ((e & 3) == 2 ? av.z : av.w));
+        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae, bv[e], acc[m][0], 0, 0, 0);
       }
-      const bool do_ln = (EPI == EPI_TRUST) || (P.mode & 1);
-      if (do_ln) {   // convolutions.py:303-308 (channels_first LayerNorm)
-        float s = 0.f;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-          if (cvm[m]) s += (v[m][0] + v[m][1]) + (v[m][2] + v[m][3]);
-        const float mean = pix_allreduce(s) * inv_c;
-        float sq = 0.f;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-          if (cvm[m]) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { float d = v[m][q] - mean; sq += d * d; }
-          }
-        const float var = pix_allreduce(sq) * inv_c;
-        const float rstd = 1.f / sqrtf(var + P.eps);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-          if (cvm[m]) {
-            const int c = m0 + m * 16 + 4 * g;
-            float4 w = ld4(P.scale + c), b = ld4(P.bias + c);
-            v[m][0] = w.x * ((v[m][0] - mean) * rstd) + b.x;
-            v[m][1] = w.y * ((v[m][1] - mean) * rstd) + b.y;
-            v[m][2] = w.z * ((v[m][2] - mean) * rstd) + b.z;
-            v[m][3] = w.w * ((v[m][3] - mean) * rstd) + b.w;
-          }
-      }
+    }
+  };
+
+  if (n_my > 0) load(a0, b0, x0, f0, kg);
+  for (int i = 0; i < n_my; i += 2) {
+    if (i + 1 < n_my) load(a1, b1, x1, f1, kg + (i + 1) * KS);
+    compute(a0, b0, x0, f0);
+    if (i + 2 < n_my) load(a0, b0, x0, f0, kg + (i + 2) * KS);
+    if (i + 1 < n_my) compute(a1, b1, x1, f1);
+  }
+
+  // fixed-order split-K reduction through LDS
+  if (KS > 1) {
+    constexpr int PER_WAVE = MT * 4 * 64;
+    if (kg > 0) {
+      float* r = smem + (kg - 1) * PER_WAVE + lane;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[m][q] = gelu_f(v[m][q]);
-
-      if constexpr (EPI == EPI_LNG) {
-        if (pv) {
+        for (int q = 0; q < 4; ++q) r[(m * 4 + q) * 64] = acc[m][0][q];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+    for (int s = 1; s < KS; ++s) {
+      const float* r = smem + (s - 1) * PER_WAVE + lane;
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-            if (cvm[m]) {
-              const int c = m0 + m * 16 + 4 * g;
-              st4(P.out + (size_t)gp * P.out_cs + P.out_co + c, make_float4(v[m][0], v[m][1], v[m][2], v[m][3]));
-            }
-        }
-      } else {
-        // trusting gate tail (temporal_ode_bayes.py:124-131 / :268-275, convolutions.py:375-380):
-        // bb = t3 + skip ; z = W2 bb ; g = softmax(z) ; cur = r2*g0 + r1*g1
-        const size_t po = (size_t)(pv ? gp : 0) * P.cout;
-        float z0 = 0.f, z1 = 0.f;
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-          if (cvm[m]) {
-            const int c = m0 + m * 16 + 4 * g;
-            float4 sk = ld4(P.e0 + po + c);
-            float4 w0 = ld4(P.e1 + c), w1 = ld4(P.e1 + P.cout + c);
-            float b0 = v[m][0] + sk.x, b1 = v[m][1] + sk.y, b2 = v[m][2] + sk.z, b3 = v[m][3] + sk.w;
-            z0 += (w0.x * b0 + w0.y * b1) + (w0.z * b2 + w0.w * b3);
-            z1 += (w1.x * b0 + w1.y * b1) + (w1.z * b2 + w1.w * b3);
-          }
-        z0 = pix_allreduce(z0);
-        z1 = pix_allreduce(z1);
-        const float zm = fmaxf(z0, z1);
-        const float ez0 = expf(z0 - zm), ez1 = expf(z1 - zm);
-        const float g0 = ez0 / (ez0 + ez1), g1 = ez1 / (ez0 + ez1);
-        if (pv) {
-          const float c0f = P.coef ? P.coef[0] : 0.f;
-          const float c1f = (P.coef && P.out2) ? P.coef[1] : 0.f;
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-            if (cvm[m]) {
-              const int c = m0 + m * 16 + 4 * g;
-              float4 r2 = ld4(P.e2 + po + c), r1 = ld4(P.e3 + po + c);
-              float4 cur;
-              cur.x = r2.x * g0 + r1.x * g1; cur.y = r2.y * g0 + r1.y * g1;
-              cur.z = r2.z * g0 + r1.z * g1; cur.w = r2.w * g0 + r1.w * g1;
-              if (P.mode & 1) {   // derivative: d = cur - s ; out = base + coef0*d
-                float4 s = ld4(P.e4 + po + c), base = ld4(P.e5 + po + c);
-                float4 d = make_float4(cur.x - s.x, cur.y - s.y, cur.z - s.z, cur.w - s.w);
-                float4 o;
-                o.x = base.x + c0f * d.x; o.y = base.y + c0f * d.y;
-                o.z = base.z + c0f * d.z; o.w = base.w + c0f * d.w;
-                if (P.out2) {
-                  float4 b2 = (P.mode & 2) ? ld4(P.out2 + po + c) : base;
-                  b2.x += c1f * d.x; b2.y += c1f * d.y; b2.z += c1f * d.z; b2.w += c1f * d.w;
-                  st4(P.out2 + po + c, b2);
-                }
-                st4(P.out + po + c, o);
-              } else {
-                st4(P.out + po + c, cur);
-              }
-            }
-        }
-      }
+        for (int q = 0; q < 4; ++q) acc[m][0][q] += r[(m * 4 + q) * 64];
     }
   }
+  run_epilogue<MT, 1, EPI>(P, acc, m_tile * BM, p_tile * 16, lane, Ptot, HWout);
+}
 
-  if constexpr (EPI == EPI_SAMPLE) {
-    // Packed cout rows are interleaved so that a lane holds (loc c, loc c+1, raw c, raw c+1):
-    // row 16*T + 4*g + r  <->  r<2: loc channel 8T+2g+r ; r>=2: raw channel 8T+2g+(r-2).
-    const int Chalf = P.cout >> 1;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int gp = p_tile * BN + (wn * NT + n) * 16 + j;
-      const bool pv = gp < Ptot;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int row = m0 + m * 16 + 4 * g;
-        const int c = (row >> 4) * 8 + 2 * g;   // logical loc channel
-        if (pv && c < Chalf) {
-          float4 bi = P.bias ? ld4(P.bias + row) : zero4();
-          float q0 = act_apply(acc[m][n][0] + bi.x, P.act), q1 = act_apply(acc[m][n][1] + bi.y, P.act);
-          float q2 = act_apply(acc[m][n][2] + bi.z, P.act), q3 = act_apply(acc[m][n][3] + bi.w, P.act);
-          float2 e = *reinterpret_cast<const float2*>(P.e0 + (size_t)gp * Chalf + c);
-          float2 o;
-          o.x = q0 + e.x * (softplus_f(q2) + 1e-8f);     // model_utils.py:84,107-108
-          o.y = q1 + e.y * (softplus_f(q3) + 1e-8f);
-          *reinterpret_cast<float2*>(P.out + (size_t)gp * Chalf + c) = o;
-          if (P.out2) {   // raw q parameters, reference channel order [loc | raw]
-            *reinterpret_cast<float2*>(P.out2 + (size_t)gp * P.cout + c) = make_float2(q0, q1);
-            *reinterpret_cast<float2*>(P.out2 + (size_t)gp * P.cout + Chalf + c) = make_float2(q2, q3);
-          }
-        }
-      }
-    }
+template <int MT, int EPI>
+static hipError_t launch_direct_t(const ConvLaunch& L, int ks, hipStream_t stream) {
+  int maxblocks = 0;
+  for (int i = 0; i < L.nprob; ++i) {
+    const ConvProblem& P = L.p[i];
+    int Ptot = P.n_img * P.Hout * P.Wout;
+    int nb = ((Ptot + 15) / 16) * ((P.cout_pad + 16 * MT - 1) / (16 * MT));
+    if (nb > maxblocks) maxblocks = nb;
   }
+  if (maxblocks == 0) return hipSuccess;
+  const int lds = (ks - 1) * MT * 4 * 64 * 4;
+  hipLaunchKernelGGL((conv_direct_kernel<MT, EPI>), dim3(maxblocks, L.nprob), dim3(64 * ks), lds, stream, L);
+  return hipGetLastError();
+}
+
+template <int EPI>
+static hipError_t launch_direct_e(const ConvLaunch& L, int mt, int ks, hipStream_t stream) {
+  switch (mt) {
+    case 1: return launch_direct_t<1, EPI>(L, ks, stream);
+    case 2: return launch_direct_t<2, EPI>(L, ks, stream);
+    case 4: return launch_direct_t<4, EPI>(L, ks, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
+// mt: 16-row cout tiles per wave (1, 2, 4); ks: K-groups per workgroup (1..8)
+hipError_t launch_conv_direct(const ConvLaunch& L, int epi, int mt, int ks, hipStream_t stream) {
+  if (ks < 1 || ks > 8) return hipErrorInvalidValue;
+  switch (epi) {
+    case EPI_AFFINE: return launch_direct_e<EPI_AFFINE>(L, mt, ks, stream);
+    case EPI_BLEND:  return launch_direct_e<EPI_BLEND>(L, mt, ks, stream);
+    case EPI_LNG:    return launch_direct_e<EPI_LNG>(L, mt, ks, stream);
+    case EPI_TRUST:  return launch_direct_e<EPI_TRUST>(L, mt, ks, stream);
+    case EPI_SAMPLE: return launch_direct_e<EPI_SAMPLE>(L, mt, ks, stream);
+  }
+  return hipErrorInvalidValue;
 }
 
 // ---- host-side launcher --------------------------------------------------------------------

@@ -65,6 +65,8 @@ def main():
     hx = torch.randn(8, h, w, C, device="cuda") * 0.5
     e = torch.randn(sc.n_draws, h, w, C, device="cuda")
     print(f"rollout 10 steps + 8 jumps      : {timeit(lambda: ode.rollout_nhwc(hx, sc, e), 5, 2):9.1f} us")
+    if "--quick" in sys.argv:
+        return
     obs = torch.randn(8, H, W, C, device="cuda")
     print(f"small_encoder 8 frames          : {timeit(lambda: ode.srvp_encoder.forward_nhwc(obs), 5, 2):9.1f} us  (114 GFLOP)")
     lat = torch.randn(7, h, w, C, device="cuda")
