@@ -128,12 +128,13 @@ def main():
         L.sf_prof_enable(1)
         for _ in range(2):
             forward()
-        calls = (ctypes.c_int32 * 32)(); pms = (ctypes.c_double * 32)()
-        pfl = (ctypes.c_double * 32)(); pby = (ctypes.c_double * 32)()
+        NK = _lib.SF_PROF_KEYS
+        calls = (ctypes.c_int32 * NK)(); pms = (ctypes.c_double * NK)()
+        pfl = (ctypes.c_double * NK)(); pby = (ctypes.c_double * NK)()
         L.sf_prof_collect(calls, pms, pfl, pby)
         L.sf_prof_enable(0)
         tot = sum(pms)
-        k = max(range(32), key=lambda i: pms[i])
+        k = max(range(NK), key=lambda i: pms[i])
         achieved = pfl[k] / (pms[k] * 1e-3) / 1e12
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
@@ -153,7 +154,7 @@ def main():
                 "all_conv_tflops": sum(pfl) / (tot * 1e-3) / 1e12 if tot else None,
                 "per_kernel": {_lib.KERNEL_NAMES.get(i, str(i)): {
                     "calls_per_forward": calls[i] // 2, "ms_per_forward": pms[i] / 2,
-                    "tflops": pfl[i] / (pms[i] * 1e-3) / 1e12} for i in range(32) if calls[i]}}
+                    "tflops": pfl[i] / (pms[i] * 1e-3) / 1e12} for i in range(NK) if calls[i]}}
 
     # ---- CPU baseline: the oracle (torch-CPU port of the reference path) on the host cores --------
     cpu = None

@@ -116,6 +116,10 @@ int sf_nhwc_to_nchw(const float* src, float* dst, int n, int C, int HW, void* st
 int sf_conv2d_fwd(const sf_conv_w* w, const float* in0, const float* in1, const float* add, float* out,
                   int n_img, int Hin, int Win, int in_up, void* stream);
 
+/* benchmarking aid: sf_conv2d_fwd enqueued `reps` times from C++; ws may be NULL */
+int sf_conv2d_repeat(const sf_conv_w* w, const float* in0, const float* in1, const float* add, float* out,
+                     int n_img, int Hin, int Win, int in_up, int reps, float* ws, size_t ws_bytes, void* stream);
+
 /* SpatialGRU.gru_cell — temporal.py:44-57.  x [P][Cx], s [P][C] -> out [P][C] (P = n*H*W) */
 int sf_gru_cell_fwd(const sf_gru_w* w, const float* x, const float* s, float* out, int n_img, int H, int W,
                     float* ws, size_t ws_bytes, void* stream);
@@ -194,8 +198,9 @@ int sf_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on 
 int sf_event_destroy(void* ev);
 
 /* Per-launch profiler for bench.py (off by default): when enabled every implicit-GEMM launch is
- * bracketed by hipEvents on its own stream.  sf_prof_collect fills 32-entry arrays indexed by
+ * bracketed by hipEvents on its own stream.  sf_prof_collect fills SF_PROF_KEYS-entry arrays indexed by
  * kernel key = tile_config*8 + epilogue (calls, total ms, algorithmic flops, algorithmic bytes). */
+#define SF_PROF_KEYS 48
 int sf_prof_enable(int on);
 int sf_prof_collect(int32_t* calls, double* ms, double* flops, double* bytes);
 

@@ -13,6 +13,7 @@ f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
 
 SF_COEF_STRIDE = 12
+SF_PROF_KEYS = 48
 ACT = {"none": 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4, "gelu": 5}
 SOLVER = {"euler": 0, "midpoint": 1, "rk4": 2}
 OP_JUMP, OP_STEP = 0, 1
@@ -72,6 +73,7 @@ SIGNATURES = {
     "sf_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sf_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sf_conv2d_fwd": (_i, [C.POINTER(ConvW), _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sf_conv2d_repeat": (_i, [C.POINTER(ConvW), _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sf_gru_cell_fwd": (_i, [C.POINTER(GruW), _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sf_gru_cell_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "sf_spatial_gru_fwd": (_i, [C.POINTER(GruW), _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
@@ -107,7 +109,7 @@ SIGNATURES = {
 }
 
 # kernel key = tile_config*8 + epilogue  (csrc/conv_igemm.hip launch_conv)
-KERNEL_NAMES = {c * 8 + e: f"conv_igemm<{cn},{en}>" for c, cn in enumerate(("S16x64k4", "L64x64", "LN64x128", "direct16px"))
+KERNEL_NAMES = {c * 8 + e: f"conv_igemm<{cn},{en}>" for c, cn in enumerate(("S16x64k4", "L64x64", "LN64x128", "direct16px", "T64x64splitK"))
                 for e, en in enumerate(("affine", "blend", "ln_gelu", "trust", "sample"))}
 
 _LIB = None

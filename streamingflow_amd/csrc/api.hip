@@ -102,7 +102,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int direct, mt, ks, chunks_per_wave; };
+struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -112,10 +112,22 @@ const Tune& tune() {
     x.ks = geti("SF_DIRECT_KS", 0);
     x.chunks_per_wave = geti("SF_DIRECT_CPW", 5);
     if (x.chunks_per_wave < 1) x.chunks_per_wave = 1;
+    x.split = geti("SF_SPLIT", 1);                 // cross-workgroup split-K on 64x64 tiles (small P)
+    x.split_target = geti("SF_SPLIT_WGS", 512);    // aim for this many workgroups per launch
+    x.split_min_chunks = geti("SF_SPLIT_MINCH", 2);
+    x.split_from = geti("SF_SPLIT_FROM", 100);     // only layers with at least this many K chunks (the 7x7)
     return x;
   }();
   return t;
 }
+
+// Scratch for the cross-workgroup split-K path, carved from the caller's workspace by the
+// top-level entry points (SplitScope) — thread-local pointer, no global allocation.
+struct SplitCtx { float* slab; size_t slab_floats; unsigned* counters; int ncounters; };
+thread_local SplitCtx* g_split = nullptr;
+constexpr size_t SPLIT_SLAB_FLOATS = size_t(4) << 20;   // 16 MB: 1024 (tile, slice) pairs of 64x64 fp32
+constexpr int SPLIT_COUNTERS = 4096;
+constexpr size_t SPLIT_WS_FLOATS = SPLIT_SLAB_FLOATS + SPLIT_COUNTERS + 128;
 
 int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   ConvLaunch L;
@@ -153,6 +165,52 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
     if (ok && mt) cfg = 3;
   }
+  // ... or, preferred: 64x64 tiles with the K range split across workgroups (4x fewer weight
+  // re-reads than 16-pixel tiles, and enough workgroups for all 256 CUs)
+  int chunks_max = 0;
+  for (int i = 0; i < n; ++i) {
+    const int nc = ps[i].KH * ps[i].KW * (ps[i].cin_pad / 32);
+    chunks_max = nc > chunks_max ? nc : chunks_max;
+  }
+  // measured (profiles/r01_d_sweep_convs.txt): the slab publish + ticket + acquire costs ~8 us, so
+  // it only pays for the long-K layers (7x7: 196 chunks, 68 -> 44 us)
+  if ((cfg == 0 || cfg == 3) && tune().split && g_split && chunks_max >= tune().split_from) {
+    int tiles_total = 0;
+    for (int i = 0; i < n; ++i) {
+      const int Pi = ps[i].n_img * ps[i].Hout * ps[i].Wout;
+      tiles_total += ((Pi + 63) / 64) * ((ps[i].cout_pad + 63) / 64);
+    }
+    // workgroup budget shared in proportion to each problem's work (tiles x chunks)
+    double work_total = 0;
+    for (int i = 0; i < n; ++i) {
+      const int Pi = ps[i].n_img * ps[i].Hout * ps[i].Wout;
+      work_total += (double)((Pi + 63) / 64) * ((ps[i].cout_pad + 63) / 64) * ps[i].KH * ps[i].KW * (ps[i].cin_pad / 32);
+    }
+    (void)tiles_total;
+    size_t slab_off = 0;
+    int cnt_off = 0;
+    bool fits = true;
+    for (int i = 0; i < n; ++i) {
+      ConvProblem& q = L.p[i];
+      const int Pi = q.n_img * q.Hout * q.Wout;
+      const int tiles = ((Pi + 63) / 64) * ((q.cout_pad + 63) / 64);
+      const int nc = q.KH * q.KW * (q.cin_pad / 32);
+      int ns = (int)(tune().split_target * (double)nc / work_total + 0.5);
+      if (ns > nc / tune().split_min_chunks) ns = nc / tune().split_min_chunks;
+      if (ns > 16) ns = 16;
+      if (ns < 1) ns = 1;
+      const int cps = (nc + ns - 1) / ns;
+      ns = (nc + cps - 1) / cps;      // every slice non-empty
+      q.nsplit = ns;
+      q.slab = g_split->slab + slab_off;
+      q.counters = g_split->counters + cnt_off;
+      slab_off += (size_t)tiles * ns * 4096;
+      cnt_off += tiles;
+      if (slab_off > g_split->slab_floats || cnt_off > g_split->ncounters) fits = false;
+    }
+    if (fits) cfg = 4;
+    else for (int i = 0; i < n; ++i) { L.p[i].nsplit = 0; L.p[i].slab = nullptr; L.p[i].counters = nullptr; }
+  }
   auto launch = [&]() -> hipError_t {
     return cfg == 3 ? launch_conv_direct(L, epi, mt, ks, st) : launch_conv(L, epi, cfg, st);
   };
@@ -178,6 +236,25 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   return SF_OK;
 }
 int run1(const ConvProblem& p, int epi, hipStream_t st) { return run(&p, 1, epi, st); }
+
+// RAII: carve + zero the split-K scratch for the duration of one top-level call
+struct SplitScope {
+  SplitCtx ctx;
+  SplitCtx* prev;
+  bool active = false;
+  SplitScope(Arena& A, hipStream_t st) : prev(g_split) {
+    if (!tune().split) return;
+    ctx.slab = A.take(SPLIT_SLAB_FLOATS);
+    ctx.counters = reinterpret_cast<unsigned*>(A.take(SPLIT_COUNTERS));
+    ctx.slab_floats = SPLIT_SLAB_FLOATS;
+    ctx.ncounters = SPLIT_COUNTERS;
+    if (!A.ok() || !ctx.slab || !ctx.counters) return;
+    if (hipMemsetAsync(ctx.counters, 0, SPLIT_COUNTERS * sizeof(unsigned), st) != hipSuccess) return;
+    g_split = &ctx;
+    active = true;
+  }
+  ~SplitScope() { g_split = prev; }
+};
 
 // ---- modules ---------------------------------------------------------------------------------
 
@@ -384,6 +461,19 @@ int sf_conv2d_fwd(const sf_conv_w* w, const float* in0, const float* in1, const 
   return run1(p, EPI_AFFINE, (hipStream_t)stream);
 }
 
+// benchmarking aid: the same fused conv enqueued `reps` times back to back from C++ (no per-launch
+// host-language overhead); ws may be NULL (then no cross-workgroup split-K scratch is available)
+int sf_conv2d_repeat(const sf_conv_w* w, const float* in0, const float* in1, const float* add, float* out, int n_img,
+                     int Hin, int Win, int in_up, int reps, float* ws, size_t ws_bytes, void* stream) {
+  if (!w || !valid_w(*w) || !in0 || !out || (w->c1 > 0 && !in1)) return SF_ERR_INVALID;
+  Arena A(ws, ws_bytes);
+  SplitScope sp(A, (hipStream_t)stream);
+  ConvProblem p = problem(*w, in0, in1, out, n_img, Hin, Win, in_up);
+  p.add = add;
+  for (int i = 0; i < reps; ++i) SF_TRY(run1(p, EPI_AFFINE, (hipStream_t)stream));
+  return SF_OK;
+}
+
 size_t sf_gru_cell_ws_bytes(int C, int n_img, int H, int W) { return al((size_t)n_img * H * W * 2 * C) * sizeof(float); }
 int sf_gru_cell_fwd(const sf_gru_w* w, const float* x, const float* s, float* out, int n_img, int H, int W, float* ws,
                     size_t ws_bytes, void* stream) {
@@ -418,40 +508,43 @@ int sf_spatial_gru_fwd(const sf_gru_w* w, const float* x, const float* state0, f
   return SF_OK;
 }
 
-size_t sf_dual_cell_ws_bytes(int C, int H, int W) { return dual_ws_floats(C, H * W) * sizeof(float); }
+size_t sf_dual_cell_ws_bytes(int C, int H, int W) { return (dual_ws_floats(C, H * W) + SPLIT_WS_FLOATS) * sizeof(float); }
 int sf_dual_cell_fwd(const sf_dual_w* w, const float* x, const float* s, float* out, int derivative, const float* base,
                      const float* coef, float* out2, int acc2, int H, int W, float* ws, size_t ws_bytes, void* stream) {
   if (!w || !x || !s || !out || w->C <= 0 || (w->C % 8)) return SF_ERR_INVALID;
   if (w->C > 64) return SF_ERR_UNSUPPORTED;
   Arena A(ws, ws_bytes);
+  SplitScope sp(A, (hipStream_t)stream);
   return dual_cell(*w, x, s, out, derivative, base, coef, out2, acc2, H, W, A, (hipStream_t)stream);
 }
 
-size_t sf_infer_state_ws_bytes(int C, int H, int W) { return infer_ws_floats(C, H * W) * sizeof(float); }
+size_t sf_infer_state_ws_bytes(int C, int H, int W) { return (infer_ws_floats(C, H * W) + SPLIT_WS_FLOATS) * sizeof(float); }
 int sf_infer_state_fwd(const sf_pmodel_w* w, const float* s, const float* eps, float* p_out, float* q_out, int H, int W,
                        float* ws, size_t ws_bytes, void* stream) {
   if (!w || !s || !eps || !p_out || w->C <= 0 || (w->C % 8)) return SF_ERR_INVALID;
   Arena A(ws, ws_bytes);
+  SplitScope sp(A, (hipStream_t)stream);
   return infer_state(*w, s, eps, p_out, q_out, H, W, A, (hipStream_t)stream);
 }
 
-size_t sf_ode_step_ws_bytes(int C, int H, int W) { return (ode_step_ws_floats(C, H * W) + al((size_t)H * W * C)) * sizeof(float); }
+size_t sf_ode_step_ws_bytes(int C, int H, int W) { return (ode_step_ws_floats(C, H * W) + al((size_t)H * W * C) + SPLIT_WS_FLOATS) * sizeof(float); }
 int sf_ode_step_fwd(const sf_dual_w* gru_c, const sf_pmodel_w* pm, int solver, int impute, const float* state_in,
                     const float* p_in, const float* coef, const float* eps, float* state_out, float* p_out, int H, int W,
                     float* ws, size_t ws_bytes, void* stream) {
   if (!gru_c || !pm || !state_in || !p_in || !coef || !eps || !state_out || !p_out) return SF_ERR_INVALID;
   if (gru_c->C > 64 || (gru_c->C % 8)) return SF_ERR_UNSUPPORTED;
   Arena A(ws, ws_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  SplitScope sp(A, st);
   const size_t PC = (size_t)H * W * gru_c->C;
   float* zeros = A.take(PC);
   if (!A.ok()) return SF_ERR_WORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
   if (!impute) SF_HIP(hipMemsetAsync(zeros, 0, PC * sizeof(float), st));
   return ode_step(*gru_c, *pm, solver, impute, state_in, p_in, coef, eps, state_out, p_out, zeros, 0, H, W, A, st);
 }
 
 size_t sf_nnfo_rollout_ws_bytes(int C, int H, int W) {
-  return (ode_step_ws_floats(C, H * W) + 5 * al((size_t)H * W * C)) * sizeof(float);
+  return (ode_step_ws_floats(C, H * W) + 5 * al((size_t)H * W * C) + SPLIT_WS_FLOATS) * sizeof(float);
 }
 int sf_nnfo_rollout_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const sf_pmodel_w* pm, int solver, int impute,
                         const int32_t* ops, int n_ops, const float* hx_obs, const float* eps, const float* coef,
@@ -462,6 +555,7 @@ int sf_nnfo_rollout_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const 
   const int C = gru_c->C;
   const size_t PC = (size_t)H * W * C;
   Arena A(ws, ws_bytes);
+  SplitScope sp(A, (hipStream_t)stream);
   float* zeros = A.take(PC);
   float* sA = A.take(PC);
   float* sB = A.take(PC);
@@ -657,12 +751,12 @@ int sf_prof_enable(int on) {
 // calls, total ms, total algorithmic flops, total algorithmic bytes.  Synchronises.
 int sf_prof_collect(int32_t* calls, double* ms, double* flops, double* bytes) {
   if (!calls || !ms || !flops || !bytes) return SF_ERR_INVALID;
-  for (int i = 0; i < 32; ++i) { calls[i] = 0; ms[i] = 0; flops[i] = 0; bytes[i] = 0; }
+  for (int i = 0; i < SF_PROF_KEYS; ++i) { calls[i] = 0; ms[i] = 0; flops[i] = 0; bytes[i] = 0; }
   for (auto& r : g_prof.recs) {
     float t = 0.f;
     SF_HIP(hipEventSynchronize(r.b));
     SF_HIP(hipEventElapsedTime(&t, r.a, r.b));
-    if (r.key >= 0 && r.key < 32) { calls[r.key] += 1; ms[r.key] += t; flops[r.key] += r.flops; bytes[r.key] += r.bytes; }
+    if (r.key >= 0 && r.key < SF_PROF_KEYS) { calls[r.key] += 1; ms[r.key] += t; flops[r.key] += r.flops; bytes[r.key] += r.bytes; }
     g_prof.pool.push_back(r.a);
     g_prof.pool.push_back(r.b);
   }

@@ -108,7 +108,7 @@ __device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[
             float4 s4;
             s4.x = tile_px_reduce(y.x); s4.y = tile_px_reduce(y.y);
             s4.z = tile_px_reduce(y.z); s4.w = tile_px_reduce(y.w);
-            if (j == 0 && cv) {
+            if (j == 0 && cv && (p0 + n * 16) < Ptot) {   // wave tiles past the last pixel own no slot
               int tile16 = p0 / 16 + n;
               st4(P.chansum + (size_t)tile16 * P.cout + c, s4);
             }
@@ -328,7 +328,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
   }
 
   const int kcpt = P.cin_pad / BK;            // chunks per tap
-  const int nchunks = P.KH * P.KW * kcpt;
+  const int nchunks_all = P.KH * P.KW * kcpt;
+  // cross-workgroup split-K: this workgroup owns chunks [cb, cb + nchunks)
+  const int nsplit = P.nsplit > 1 ? P.nsplit : 1;
+  if ((int)blockIdx.z >= nsplit) return;   // block-uniform
+  const int cps = (nchunks_all + nsplit - 1) / nsplit;
+  const int cb = (int)blockIdx.z * cps;
+  const int nchunks = (nchunks_all - cb) < cps ? (nchunks_all - cb) : cps;
   const int niter = (nchunks + KS - 1) / KS;
 
   f32x4 acc[MT][NT];
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
   int bflag[B_SLOTS];   // bit0: value valid, bit1: multiply by rx, bit2: multiply by (1 - rx)
 
   // chunk cursor of this K-group: (tap row, tap col, channel chunk), advanced by KS per iteration
-  int cur_kc = kg % kcpt, cur_tap = kg / kcpt;
+  int cur_kc = (cb + kg) % kcpt, cur_tap = (cb + kg) / kcpt;
   int cur_ty = cur_tap / KW, cur_tx = cur_tap - cur_ty * KW;
 
   auto load_chunk = [&](int chunk) {
@@ -428,14 +434,14 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
 
   // ---- main loop: one barrier per chunk, loads of chunk i+1 in flight under MFMAs of chunk i
   if (kg < nchunks) {
-    load_chunk(kg);
+    load_chunk(cb + kg);
     store_chunk(0);
   }
   __syncthreads();
   for (int it = 0; it < niter; ++it) {
     const int nxt = (it + 1) * KS + kg;
     const bool has_next = nxt < nchunks;
-    if (has_next) load_chunk(nxt);
+    if (has_next) load_chunk(cb + nxt);
     if (it * KS + kg < nchunks) compute(it & 1);
     if (has_next) store_chunk((it + 1) & 1);
     __syncthreads();
@@ -459,6 +465,56 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
 #pragma unroll
     for (int s = 1; s < KS; ++s) {
       const float* r = red + ((s - 1) * (WM * WN) + wave) * PER_WAVE + lane;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[m][n][q] += r[((m * NT + n) * 4 + q) * 64];
+    }
+  }
+
+  // ---- cross-workgroup split-K: slab publish, ticket, last arriver reduces in slice order ------
+  // (cdna_hip_programming.md "In-launch split-K reduction": plain slab stores, every wave drains,
+  // barrier, ONE agent-scope release + ticket; the last arriver does ONE agent-scope acquire, then
+  // plain loads.  Placement independent; fixed summation order => bitwise reproducible.)
+  if (nsplit > 1) {
+    constexpr int PER_WAVE = MT * NT * 4 * 64;
+    constexpr int NW = WM * WN;
+    float* tile_slab = P.slab + (size_t)blockIdx.x * nsplit * NW * PER_WAVE;
+    {
+      float* my = tile_slab + ((size_t)blockIdx.z * NW + wave) * PER_WAVE + lane;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) my[((m * NT + n) * 4 + q) * 64] = acc[m][n][q];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned* cnt = P.counters + blockIdx.x;
+      const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (t == (unsigned)(nsplit - 1));
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0) return;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < nsplit; ++z) {
+      const float* r = tile_slab + ((size_t)z * NW + wave) * PER_WAVE + lane;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -689,7 +745,9 @@ static hipError_t launch_cfg(const ConvLaunch& L, hipStream_t stream) {
     if (nb > maxblocks) maxblocks = nb;
   }
   if (maxblocks == 0) return hipSuccess;
-  dim3 grid(maxblocks, L.nprob), block(64 * WM * WN * KS);
+  int zs = 1;
+  for (int i = 0; i < L.nprob; ++i) zs = L.p[i].nsplit > zs ? L.p[i].nsplit : zs;
+  dim3 grid(maxblocks, L.nprob, zs), block(64 * WM * WN * KS);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, L);
   return hipGetLastError();
 }
@@ -712,6 +770,15 @@ hipError_t launch_conv(const ConvLaunch& L, int epi, int cfg, hipStream_t stream
         case EPI_AFFINE: return launch_cfg<2, 2, 2, 2, 1, EPI_AFFINE>(L, stream);
         case EPI_BLEND:  return launch_cfg<2, 2, 2, 2, 1, EPI_BLEND>(L, stream);
         case EPI_SAMPLE: return launch_cfg<2, 2, 2, 2, 1, EPI_SAMPLE>(L, stream);
+      }
+      break;
+    case 4:   // T: 4 waves x (64 cout x 16 px) = 64x64 tile, every epilogue; used with cross-WG split-K
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<4, 1, 1, 4, 1, EPI_AFFINE>(L, stream);
+        case EPI_BLEND:  return launch_cfg<4, 1, 1, 4, 1, EPI_BLEND>(L, stream);
+        case EPI_LNG:    return launch_cfg<4, 1, 1, 4, 1, EPI_LNG>(L, stream);
+        case EPI_TRUST:  return launch_cfg<4, 1, 1, 4, 1, EPI_TRUST>(L, stream);
+        case EPI_SAMPLE: return launch_cfg<4, 1, 1, 4, 1, EPI_SAMPLE>(L, stream);
       }
       break;
     case 2:   // LN-capable large tile: 4 waves x (64 cout x 32 px)

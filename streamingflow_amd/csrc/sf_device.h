@@ -52,6 +52,11 @@ struct ConvProblem {
   int e0_cs, e1_cs;       // channel strides of e0/e1 where they are not C
   int mode;               // epilogue specific
   float eps;              // LayerNorm epsilon
+  // cross-workgroup split-K (small pixel counts): blockIdx.z = K slice; partial tiles go to
+  // `slab`, the last slice to arrive (ticket in `counters`) sums them in slice order + epilogue
+  float* slab;            // [tiles][nsplit][waves][MT*NT*4][64]
+  unsigned int* counters; // [tiles], zero before the launch; reset by the last arriver
+  int nsplit;
 };
 
 #define SF_MAX_GROUP 4

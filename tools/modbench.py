@@ -34,9 +34,11 @@ def conv_case(cin, cout, k, n, H, W, dil=1, c1=0):
     cw = packing.conv_w(pk, w, cin - c1, c1, act="lrelu", dil=dil)
     out = torch.empty(n, H, W, cout, device="cuda")
     L = _lib.lib()
-    fn = lambda: L.sf_conv2d_fwd(ctypes.byref(cw), runtime.ptr(x), runtime.ptr(x1), None, runtime.ptr(out), n, H, W, 0,
-                                 runtime.stream_ptr())
-    us = timeit(fn)
+    ws = runtime.workspace(80 << 20, "cuda")
+    reps = 50
+    fn = lambda: L.sf_conv2d_repeat(ctypes.byref(cw), runtime.ptr(x), runtime.ptr(x1), None, runtime.ptr(out), n, H, W, 0,
+                                    reps, runtime.ptr(ws), ws.numel() * 4, runtime.stream_ptr())
+    us = timeit(fn, 4, 1) / reps
     fl = 2.0 * n * H * W * cout * cin * k * k
     print(f"conv {cin:4d}->{cout:4d} k{k} d{dil:2d} n{n} {H}x{W}: {us:9.1f} us  {fl / us / 1e6:7.2f} TFLOP/s")
 
@@ -65,6 +67,12 @@ def main():
     hx = torch.randn(8, h, w, C, device="cuda") * 0.5
     e = torch.randn(sc.n_draws, h, w, C, device="cuda")
     print(f"rollout 10 steps + 8 jumps      : {timeit(lambda: ode.rollout_nhwc(hx, sc, e), 5, 2):9.1f} us")
+    if "--convs" in sys.argv:
+        for args in [(8, 8, 1, 1, 4, 4), (64, 64, 1, 1, 4, 4), (64, 64, 1, 1, 50, 50), (64, 64, 3, 1, 50, 50), (128, 64, 3, 1, 50, 50, 1, 64),
+                     (128, 128, 3, 1, 50, 50, 1, 64), (64, 128, 3, 1, 50, 50), (128, 128, 3, 1, 50, 50), (128, 64, 7, 1, 50, 50, 1, 64),
+                     (64, 64, 3, 1, 200, 200), (128, 128, 3, 1, 200, 200, 1, 64)]:
+            conv_case(*args)
+        return
     if "--quick" in sys.argv:
         return
     obs = torch.randn(8, H, W, C, device="cuda")
