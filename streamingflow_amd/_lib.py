@@ -13,7 +13,7 @@ f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
 
 SF_COEF_STRIDE = 12
-SF_PROF_KEYS = 48
+SF_PROF_KEYS = 80
 ACT = {"none": 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4, "gelu": 5}
 SOLVER = {"euler": 0, "midpoint": 1, "rk4": 2}
 OP_JUMP, OP_STEP = 0, 1
@@ -109,7 +109,7 @@ SIGNATURES = {
 }
 
 # kernel key = tile_config*8 + epilogue  (csrc/conv_igemm.hip launch_conv)
-KERNEL_NAMES = {c * 8 + e: f"conv_igemm<{cn},{en}>" for c, cn in enumerate(("S16x64k4", "L64x64", "LN64x128", "direct16px", "T64x64splitK"))
+KERNEL_NAMES = {c * 8 + e: f"conv_igemm<{cn},{en}>" for c, cn in enumerate(("S16x64k4", "L64x64", "LN64x128", "direct16px", "T64x64splitK", "L128x64", "L64x128", "L128x128w4", "L64x128w8", "L128x128w8"))
                 for e, en in enumerate(("affine", "blend", "ln_gelu", "trust", "sample"))}
 
 _LIB = None

@@ -102,7 +102,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from; };
+struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, l_cfg; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -115,6 +115,7 @@ const Tune& tune() {
     x.split = geti("SF_SPLIT", 1);                 // cross-workgroup split-K on 64x64 tiles (small P)
     x.split_target = geti("SF_SPLIT_WGS", 512);    // aim for this many workgroups per launch
     x.split_min_chunks = geti("SF_SPLIT_MINCH", 2);
+    x.l_cfg = geti("SF_L_CFG", 0);                 // experimental large-P tiling override (5..9)
     x.split_from = geti("SF_SPLIT_FROM", 100);     // only layers with at least this many K chunks (the 7x7)
     return x;
   }();
@@ -143,6 +144,17 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   L.nprob = n;
   if (P <= 0) return SF_OK;
   int cfg = pick_cfg(P, epi);
+  if (cfg == 1 && (epi == EPI_AFFINE || epi == EPI_BLEND)) {
+    if (tune().l_cfg > 0) cfg = tune().l_cfg;
+    else if (tune().l_cfg == 0) {
+      // measured (profiles/r01_e_sweep_large_tiles.txt): 128x128 tiles with 8 waves win 7-10 % once
+      // there are >= ~1000 of them and cout is a multiple of 128; 64x64 wins everywhere else
+      bool big = true;
+      for (int i = 0; i < n; ++i)
+        big = big && (ps[i].cout_pad % 128 == 0) && ((long)ps[i].n_img * ps[i].Hout * ps[i].Wout >= 131072);
+      if (big) cfg = 9;
+    }
+  }
   // small pixel counts: direct-fragment kernel (no LDS staging), see conv_igemm.hip
   int mt = 0, ks = 1;
   if (cfg == 0 && tune().direct) {

@@ -56,6 +56,16 @@ __device__ __forceinline__ float tile_px_reduce(float v) {
   return v;
 }
 
+// One ds_read_b64 per fragment.  The 36-float row pitch is conflict-free for ds_read_b64 (banks
+// (a/4) mod 64 over 32-lane halves) but 2-way conflicting for the ds_read2_b64 hipcc would merge
+// two of these into (banks (a/4) mod 32 over 16-lane groups; measured: SQ_LDS_BANK_CONFLICT = 40 %
+// of SQ_LDS_IDX_ACTIVE) — volatile keeps the loads separate.
+__device__ __forceinline__ float2 lds_read_b64(const float* p) {
+  typedef const volatile __attribute__((address_space(3))) unsigned long long lds_u64;
+  const unsigned long long u = *(lds_u64*)p;   // explicit LDS address space: ds_read_b64, not flat_load
+  return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+}
+
 constexpr int LDS_ROW = 36;   // floats per staged row: 32 K values + 4 pad
 constexpr int BK = 32;
 
@@ -348,6 +358,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
   // serialise the whole prefetch.  Masks / gate / SE scale are applied when writing to LDS.
   float4 ra[A_SLOTS], rb[B_SLOTS], rx[B_SLOTS];
   int bflag[B_SLOTS];   // bit0: value valid, bit1: multiply by rx, bit2: multiply by (1 - rx)
+  // per-tap cache of the gathered pixel (offset in pixels, -1 = outside): with KS == 1 the cursor
+  // walks the channel chunks of one tap before moving on, so the bounds / address arithmetic is
+  // paid once per tap instead of once per chunk (it was 4.7 VALU per MFMA)
+  int tap_pix[B_SLOTS];
+  bool tap_fresh = true;
 
   // chunk cursor of this K-group: (tap row, tap col, channel chunk), advanced by KS per iteration
   int cur_kc = (cb + kg) % kcpt, cur_tap = (cb + kg) / kcpt;
@@ -361,13 +376,20 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
     const bool s0 = c < c0;
     const bool s1 = (!s0) & (c < c01);
     const int cc = c - c0;
+    if (KS > 1 || tap_fresh) {   // wave-uniform
+#pragma unroll
+      for (int i = 0; i < B_SLOTS; ++i) {
+        const int iy = b_iy0[i] + cur_ty * dil, ix = b_ix0[i] + cur_tx * dil;
+        const bool in = (iy >= 0) & (iy < Hlog) & (ix >= 0) & (ix < Wlog);
+        tap_pix[i] = in ? b_base[i] + (iy >> in_up) * Win + (ix >> in_up) : -1;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < B_SLOTS; ++i) {
-      const int iy = b_iy0[i] + cur_ty * dil, ix = b_ix0[i] + cur_tx * dil;
-      const bool ok = (iy >= 0) & (iy < Hlog) & (ix >= 0) & (ix < Wlog) & (s0 | s1);
-      const size_t pix = ok ? (size_t)b_base[i] + (size_t)((iy >> in_up) * Win + (ix >> in_up)) : 0;
+      const bool ok = (tap_pix[i] >= 0) & (s0 | s1);
+      const size_t pix = ok ? (size_t)tap_pix[i] : 0;
       const float* p = s1 ? in1 + pix * in1_cs + cc : in0 + pix * in0_cs + (s0 ? c : 0);
-      rb[i] = ld4(ok ? p : in0);
+      rb[i] = ld4(p);
       int fl = ok ? 1 : 0;
       if (has_aux) {   // block-uniform branch, no dependent use inside
         const bool m1 = ok & s0 & (in_scale != nullptr);
@@ -380,8 +402,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
     }
     // advance the cursor to this K-group's next chunk
     cur_kc += KS;
+    tap_fresh = false;
     while (cur_kc >= kcpt) {
       cur_kc -= kcpt;
+      tap_fresh = true;
       if (++cur_tx == KW) { cur_tx = 0; ++cur_ty; }
     }
   };
@@ -410,25 +434,36 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
   auto compute = [&](int buf) {
     const float* a = As + buf * BM * LDS_ROW + (wm * MT * 16 + j) * LDS_ROW + 2 * g;
     const float* b = Bs + buf * BN * LDS_ROW + (wn * NT * 16 + j) * LDS_ROW + 2 * g;
+    // fragments of k-group t4+1 are read while the MFMAs of k-group t4 run (two register sets,
+    // statically indexed): the LDS latency is hidden inside the wave, not only by other waves
+    float2 fa[2][MT], fb[2][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) fa[0][m] = lds_read_b64(a + m * 16 * LDS_ROW);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) fb[0][n] = lds_read_b64(b + n * 16 * LDS_ROW);
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
-      float2 fa[MT], fb[NT];
+      const int cur = t4 & 1, nxt = cur ^ 1;
+      if (t4 < 3) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const float2*>(a + m * 16 * LDS_ROW + 8 * t4);
+        for (int m = 0; m < MT; ++m) fa[nxt][m] = lds_read_b64(a + m * 16 * LDS_ROW + 8 * (t4 + 1));
 #pragma unroll
-      for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const float2*>(b + n * 16 * LDS_ROW + 8 * t4);
+        for (int n = 0; n < NT; ++n) fb[nxt][n] = lds_read_b64(b + n * 16 * LDS_ROW + 8 * (t4 + 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads above this group's MFMAs
       // all tiles with the even k first, then the odd k: MT*NT independent accumulators between
       // two MFMAs on the same one (16x16x4 f32: 32-cycle issue, 40-cycle dependent latency)
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m].x, fb[n].x, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][m].x, fb[cur][n].x, acc[m][n], 0, 0, 0);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m].y, fb[n].y, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][m].y, fb[cur][n].y, acc[m][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -779,6 +814,37 @@ hipError_t launch_conv(const ConvLaunch& L, int epi, int cfg, hipStream_t stream
         case EPI_LNG:    return launch_cfg<4, 1, 1, 4, 1, EPI_LNG>(L, stream);
         case EPI_TRUST:  return launch_cfg<4, 1, 1, 4, 1, EPI_TRUST>(L, stream);
         case EPI_SAMPLE: return launch_cfg<4, 1, 1, 4, 1, EPI_SAMPLE>(L, stream);
+      }
+      break;
+    // experimental large-P tilings (selected with SF_L_CFG, see api.hip)
+    case 5:   // 128 cout x 64 px, 2x2 waves of 64x32
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<4, 2, 2, 2, 1, EPI_AFFINE>(L, stream);
+        case EPI_BLEND:  return launch_cfg<4, 2, 2, 2, 1, EPI_BLEND>(L, stream);
+      }
+      break;
+    case 6:   // 64 cout x 128 px, 2x2 waves of 32x64
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<2, 4, 2, 2, 1, EPI_AFFINE>(L, stream);
+        case EPI_BLEND:  return launch_cfg<2, 4, 2, 2, 1, EPI_BLEND>(L, stream);
+      }
+      break;
+    case 7:   // 128 x 128, 2x2 waves of 64x64
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<4, 4, 2, 2, 1, EPI_AFFINE>(L, stream);
+        case EPI_BLEND:  return launch_cfg<4, 4, 2, 2, 1, EPI_BLEND>(L, stream);
+      }
+      break;
+    case 8:   // 64 cout x 128 px, 8 waves (2x4) of 32x32
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<2, 2, 2, 4, 1, EPI_AFFINE>(L, stream);
+        case EPI_BLEND:  return launch_cfg<2, 2, 2, 4, 1, EPI_BLEND>(L, stream);
+      }
+      break;
+    case 9:   // 128 x 128, 8 waves (2x4) of 64x32
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<4, 2, 2, 4, 1, EPI_AFFINE>(L, stream);
+        case EPI_BLEND:  return launch_cfg<4, 2, 2, 4, 1, EPI_BLEND>(L, stream);
       }
       break;
     case 2:   // LN-capable large tile: 4 waves x (64 cout x 32 px)

@@ -67,6 +67,11 @@ def main():
     hx = torch.randn(8, h, w, C, device="cuda") * 0.5
     e = torch.randn(sc.n_draws, h, w, C, device="cuda")
     print(f"rollout 10 steps + 8 jumps      : {timeit(lambda: ode.rollout_nhwc(hx, sc, e), 5, 2):9.1f} us")
+    if "--bigconvs" in sys.argv:
+        for args in [(64, 64, 3, 7, 200, 200), (128, 64, 3, 1, 200, 200, 1, 64), (128, 128, 3, 1, 200, 200, 1, 64), (64, 128, 3, 7, 200, 200, 12),
+                     (512, 128, 1, 7, 200, 200), (128, 128, 3, 7, 200, 200), (256, 256, 3, 8, 50, 50), (128, 128, 3, 7, 100, 100), (64, 256, 1, 7, 200, 200)]:
+            conv_case(*args)
+        return
     if "--convs" in sys.argv:
         for args in [(8, 8, 1, 1, 4, 4), (64, 64, 1, 1, 4, 4), (64, 64, 1, 1, 50, 50), (64, 64, 3, 1, 50, 50), (128, 64, 3, 1, 50, 50, 1, 64),
                      (128, 128, 3, 1, 50, 50, 1, 64), (64, 128, 3, 1, 50, 50), (128, 128, 3, 1, 50, 50), (128, 64, 7, 1, 50, 50, 1, 64),
