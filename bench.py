@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--timeset", default="shipped", help="oracle.cases.TIMESETS key (default: BASELINE config 2)")
     ap.add_argument("--solver", default="euler")
+    ap.add_argument("--batch", type=int, default=1, help="samples per forward on each GPU (the reference API "
+                    "takes a batch and loops over it; here same-structure samples run through the kernels together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -66,15 +68,18 @@ def main():
     sd = cases.fpode_state_dict(net.state_dict())        # random-init weights (hashed, reproducible)
     net.load_state_dict(sd)
     net = net.to(dev)
-    cam, lid = cases.bev_inputs(C, H, W, cts.shape[1], lts.shape[1], seed=rank)     # one sample per rank
-    cam_d, lid_d = cam.to(dev), lid.to(dev)
+    B = max(1, a.batch)
+    cams, lids = zip(*[cases.bev_inputs(C, H, W, cts.shape[1], lts.shape[1], seed=rank * 1000 + i) for i in range(B)])
+    cam, lid = cams[0], lids[0]
+    cam_d, lid_d = torch.cat(cams, 0).to(dev), torch.cat(lids, 0).to(dev)     # B samples per rank
+    cts_b, lts_b, tts_b = cts.repeat(B, 1), lts.repeat(B, 1), tts.repeat(B, 1)
     x_in = cases.present_input(cam_d, lid_d)
     times, _ = S.merge_observations(cts[0].tolist(), lts[0].tolist())
     sc = S.build_schedule(times, tts[0].tolist(), dt, True, a.solver)
     n_ode = sc.n_steps
 
     def forward():
-        return net(x_in, cam_d, lid_d, cts, lts, tts)
+        return net(x_in, cam_d, lid_d, cts_b, lts_b, tts_b)
 
     def fence():
         if world > 1:
@@ -94,7 +99,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     ms_per_step = 1e3 * el / a.steps
-    value = n_ode * a.steps * world / el
+    value = n_ode * B * a.steps * world / el
 
     # ---- ODE rollout alone (the serial chain the north star names), same stream, hipEvents -------
     L = _lib.lib()
@@ -115,9 +120,22 @@ def main():
     ms = ctypes.c_float()
     L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
     rollout_ms = ms.value / reps
+    # the same rollout replayed as one captured hipGraph
+    ode.use_graph = True
+    for _ in range(2):
+        ode.rollout_nhwc(hx, sc, eps)
+    torch.cuda.synchronize()
+    L.sf_event_record(e0, runtime.stream_ptr(dev))
+    for _ in range(reps):
+        ode.rollout_nhwc(hx, sc, eps)
+    L.sf_event_record(e1, runtime.stream_ptr(dev))
+    L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+    rollout_graph_ms = ms.value / reps
+    ode.use_graph = False
     flops_step = 728.0 * C * C * (H // 4) * (W // 4)          # Euler step, algorithmic
     flops_jump = flops_step
-    rollout = {"ms": rollout_ms, "ode_steps": sc.n_steps, "jumps": sc.n_jumps,
+    rollout = {"ms": rollout_ms, "hipgraph_replay_ms": rollout_graph_ms, "batch": 1, "ode_steps": sc.n_steps, "jumps": sc.n_jumps,
+               "ode_steps_per_s_single_sample_graph": sc.n_steps / (rollout_graph_ms * 1e-3),
                "us_per_op": 1e3 * rollout_ms / max(1, len(sc.ops)),
                "ops_per_s": len(sc.ops) / (rollout_ms * 1e-3),
                "tflops": (sc.n_steps * flops_step + sc.n_jumps * flops_jump) / (rollout_ms * 1e-3) / 1e12}
@@ -128,6 +146,7 @@ def main():
         L.sf_prof_enable(1)
         for _ in range(2):
             forward()
+        torch.cuda.synchronize()
         NK = _lib.SF_PROF_KEYS
         calls = (ctypes.c_int32 * NK)(); pms = (ctypes.c_double * NK)()
         pfl = (ctypes.c_double * NK)(); pby = (ctypes.c_double * NK)()
@@ -178,9 +197,9 @@ def main():
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"BASELINE config 2: C=64, BEV 200x200 (latent 50x50), timeset '{a.timeset}' "
                                       f"({len(times)} observations, {tts.shape[1]} targets), variable-step {a.solver}: "
-                                      f"{n_ode} ODE steps + {sc.n_jumps} jumps per forward, 1 sample per GPU",
+                                      f"{n_ode} ODE steps + {sc.n_jumps} jumps per sample, {B} sample(s) per forward per GPU",
                           "parallelism": f"replicas x{world} (sample sharding, no data-path collective)"},
-               "forwards_per_s": a.steps * world / el,
+               "samples_per_s": B * a.steps * world / el, "batch_per_gpu": B,
                "ode_rollout_only": rollout, "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -125,46 +125,55 @@ int sf_gru_cell_fwd(const sf_gru_w* w, const float* x, const float* s, float* ou
                     float* ws, size_t ws_bytes, void* stream);
 size_t sf_gru_cell_ws_bytes(int C, int n_img, int H, int W);
 
-/* SpatialGRU.forward — temporal.py:26-42.  x [T][H*W][Cx], state0 [H*W][C] -> out [T][H*W][Cx] */
-int sf_spatial_gru_fwd(const sf_gru_w* w, const float* x, const float* state0, float* out, int T, int H, int W,
-                       float* ws, size_t ws_bytes, void* stream);
-size_t sf_spatial_gru_ws_bytes(int C, int H, int W);
+/* SpatialGRU.forward — temporal.py:26-42 on n_img samples at once.
+ * x [T][n_img][H*W][Cx], state0 [n_img][H*W][C] -> out [T][n_img][H*W][Cx] */
+int sf_spatial_gru_fwd(const sf_gru_w* w, const float* x, const float* state0, float* out, int T, int n_img, int H,
+                       int W, float* ws, size_t ws_bytes, void* stream);
+size_t sf_spatial_gru_ws_bytes(int C, int n_img, int H, int W);
+
+/* The latent-space operators below take n_img >= 1 samples ([n_img][H][W][C] tensors) that are
+ * processed as one pixel space: the reference handles one sample per call (its dual cell is only
+ * well defined at batch 1); batching samples here is what fills the chip at a 50x50 latent. */
 
 /* DualGRUODECell.forward (derivative != 0) / DualGRUCell.forward (derivative == 0) —
  * temporal_ode_bayes.py:92-131 / :239-275, fused with the integrator update:
  *   derivative: out = base + coef[0]*(cur - s); optional out2 = (acc2 ? out2 : base) + coef[1]*(cur - s)
  *   jump:       out = cur
- * coef points at device fp32 scalars.  out may not alias x/s/base. */
+ * coef points at device fp32 scalars (shared by all images).  out may not alias x/s/base. */
 int sf_dual_cell_fwd(const sf_dual_w* w, const float* x, const float* s, float* out, int derivative,
-                     const float* base, const float* coef, float* out2, int acc2, int H, int W,
+                     const float* base, const float* coef, float* out2, int acc2, int n_img, int H, int W,
                      float* ws, size_t ws_bytes, void* stream);
-size_t sf_dual_cell_ws_bytes(int C, int H, int W);
+size_t sf_dual_cell_ws_bytes(int C, int n_img, int H, int W);
 
 /* NNFOwithBayesianJumps.infer_state — temporal_ode_bayes.py:463-477: p = loc + eps*(softplus(raw)+1e-8).
- * q_out (raw p_model output, [P][2C], reference channel order) may be NULL. */
+ * q_out (raw p_model output, [P][2C], reference channel order) may be NULL.  n_img <= 64. */
 int sf_infer_state_fwd(const sf_pmodel_w* w, const float* s, const float* eps, float* p_out, float* q_out,
-                       int H, int W, float* ws, size_t ws_bytes, void* stream);
-size_t sf_infer_state_ws_bytes(int C, int H, int W);
+                       int n_img, int H, int W, float* ws, size_t ws_bytes, void* stream);
+size_t sf_infer_state_ws_bytes(int C, int n_img, int H, int W);
 
 /* NNFOwithBayesianJumps.ode_step — temporal_ode_bayes.py:436-461 (euler, midpoint) and the
- * build-defined classical RK4.  coef: one device coefficient record (SF_COEF_STRIDE floats).  eps: [n_draws][P][C]
- * with n_draws = 1 (euler), 2 (midpoint), 4 (rk4).  If impute == 0 the cell input is zeros
- * (:442-443).  state_out / p_out must not alias state_in / p_in. */
+ * build-defined classical RK4.  coef: one device coefficient record (SF_COEF_STRIDE floats).
+ * eps: [n_draws][n_img][H*W][C] with n_draws = 1 (euler), 2 (midpoint), 4 (rk4).  If impute == 0
+ * the cell input is zeros (:442-443).  state_out / p_out must not alias state_in / p_in. */
 int sf_ode_step_fwd(const sf_dual_w* gru_c, const sf_pmodel_w* pm, int solver, int impute, const float* state_in,
                     const float* p_in, const float* coef, const float* eps, float* state_out, float* p_out,
-                    int H, int W, float* ws, size_t ws_bytes, void* stream);
-size_t sf_ode_step_ws_bytes(int C, int H, int W);
+                    int n_img, int H, int W, float* ws, size_t ws_bytes, void* stream);
+size_t sf_ode_step_ws_bytes(int C, int n_img, int H, int W);
 
 /* The observation/prediction loop of NNFOwithBayesianJumps.forward — temporal_ode_bayes.py:539-604,
- * driven by a schedule computed on the host (streamingflow_amd.schedule).  ops[2*i] = SF_OP_JUMP
- * (ops[2*i+1] = observation index) or SF_OP_STEP (ops[2*i+1] = record index into coef).
- * After op i (1-based count k = i+1) the state is copied to out_states[t] for every target t with
- * sel_nops[t] == k (:606-622).  hx_obs [n_obs][P][C]; eps [n_draws][P][C] in reference draw order. */
+ * driven by a schedule computed on the host (streamingflow_amd.schedule); all n_img samples share
+ * the op sequence.  ops[2*i] = SF_OP_JUMP (ops[2*i+1] = observation index) or SF_OP_STEP
+ * (ops[2*i+1] = step index).  coef: [n_steps][SF_COEF_STRIDE] (coef_per_image == 0) or
+ * [n_steps][n_img][SF_COEF_STRIDE] (per-sample step sizes).  After op i (1-based count k = i+1)
+ * the state is copied to out_states[t] for every target t with sel_nops[t] == k (:606-622).
+ * hx_obs [n_obs][n_img][H*W][C]; eps [n_draws][n_img][H*W][C] in reference draw order;
+ * out_states [n_targets][n_img][H*W][C]; final_state [n_img][H*W][C] (may be NULL). */
 int sf_nnfo_rollout_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const sf_pmodel_w* pm, int solver,
                         int impute, const int32_t* ops, int n_ops, const float* hx_obs, const float* eps,
-                        const float* coef, const int32_t* sel_nops, int n_targets, float* out_states,
-                        float* final_state, int H, int W, float* ws, size_t ws_bytes, void* stream);
-size_t sf_nnfo_rollout_ws_bytes(int C, int H, int W);
+                        const float* coef, int coef_per_image, const int32_t* sel_nops, int n_targets,
+                        float* out_states, float* final_state, int n_img, int H, int W, float* ws,
+                        size_t ws_bytes, void* stream);
+size_t sf_nnfo_rollout_ws_bytes(int C, int n_img, int H, int W);
 
 /* SmallEncoder.forward — res_models.py:98-109: [n][H][W][C] -> [n][H/4][W/4][C] */
 int sf_small_encoder_fwd(const sf_encoder_w* w, const float* x, float* out, int n, int H, int W,

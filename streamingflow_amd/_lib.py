@@ -76,18 +76,18 @@ SIGNATURES = {
     "sf_conv2d_repeat": (_i, [C.POINTER(ConvW), _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sf_gru_cell_fwd": (_i, [C.POINTER(GruW), _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sf_gru_cell_ws_bytes": (_sz, [_i, _i, _i, _i]),
-    "sf_spatial_gru_fwd": (_i, [C.POINTER(GruW), _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
-    "sf_spatial_gru_ws_bytes": (_sz, [_i, _i, _i]),
-    "sf_dual_cell_fwd": (_i, [C.POINTER(DualW), _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
-    "sf_dual_cell_ws_bytes": (_sz, [_i, _i, _i]),
-    "sf_infer_state_fwd": (_i, [C.POINTER(PModelW), _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
-    "sf_infer_state_ws_bytes": (_sz, [_i, _i, _i]),
-    "sf_ode_step_fwd": (_i, [C.POINTER(DualW), C.POINTER(PModelW), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+    "sf_spatial_gru_fwd": (_i, [C.POINTER(GruW), _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_spatial_gru_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "sf_dual_cell_fwd": (_i, [C.POINTER(DualW), _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_dual_cell_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "sf_infer_state_fwd": (_i, [C.POINTER(PModelW), _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_infer_state_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "sf_ode_step_fwd": (_i, [C.POINTER(DualW), C.POINTER(PModelW), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
                              _vp, _sz, _vp]),
-    "sf_ode_step_ws_bytes": (_sz, [_i, _i, _i]),
+    "sf_ode_step_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "sf_nnfo_rollout_fwd": (_i, [C.POINTER(DualW), C.POINTER(DualW), C.POINTER(PModelW), _i, _i, i32p, _i, _vp, _vp,
-                                 _vp, i32p, _i, _vp, _vp, _i, _i, _vp, _sz, _vp]),
-    "sf_nnfo_rollout_ws_bytes": (_sz, [_i, _i, _i]),
+                                 _vp, _i, i32p, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_nnfo_rollout_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "sf_small_encoder_fwd": (_i, [C.POINTER(EncoderW), _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sf_small_encoder_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "sf_small_decoder_fwd": (_i, [C.POINTER(DecoderW), _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),

@@ -15,7 +15,8 @@ hipError_t launch_transpose(const float* in, float* out, int n, int rows, int co
 hipError_t launch_maxpool2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s);
 hipError_t launch_upsample2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s);
 hipError_t launch_se_fc(const float* chansum, int ntile, int C, int Cr, int hw, const float* fc0,
-                        const float* fc2, float* scale, hipStream_t s);
+                        const float* fc2, float* scale, int n_img, hipStream_t s);
+hipError_t launch_chan_partial(const float* in, float* part, int n, int HW, int C, int nslab, hipStream_t s);
 hipError_t launch_dwconv7_ln(const float* in, float* out, const float* wdw, const float* bdw, const float* lnw,
                              const float* lnb, int n, int H, int W, int C, float eps, hipStream_t s);
 hipError_t launch_aspp_pool(const float* in, float* part, float* bias_img, int n, int HW, int C, int hid,
@@ -285,9 +286,11 @@ int gru_cell(const sf_gru_w& w, const float* x, const float* s, float* out, floa
 size_t dual_ws_floats(int C, int P) { return 2 * al((size_t)P * 2 * C) + 6 * al((size_t)P * C); }
 
 // temporal_ode_bayes.py:92-131 / :239-275
+// B images (samples) are processed as one pixel space; coef_stride = floats between the
+// coefficient records of consecutive images (0: one record shared by all)
 int dual_cell(const sf_dual_w& w, const float* x, const float* s, float* out, int derivative, const float* base,
-              const float* coef, float* out2, int acc2, int H, int W, Arena& A, hipStream_t st) {
-  const int C = w.C, P = H * W;
+              const float* coef, int coef_stride, float* out2, int acc2, int B, int H, int W, Arena& A, hipStream_t st) {
+  const int C = w.C, P = B * H * W;
   float* g1 = A.take((size_t)P * 2 * C);
   float* g2 = A.take((size_t)P * 2 * C);
   float* h1 = A.take((size_t)P * C);
@@ -299,66 +302,75 @@ int dual_cell(const sf_dual_w& w, const float* x, const float* s, float* out, in
   if (!A.ok()) return SF_ERR_WORKSPACE;
   ConvProblem ps[2];
   // gates of both cells (cell 2 sees cat[s,s]: duplicate input folded into the packed weights)
-  ps[0] = problem(w.gates1, x, s, g1, 1, H, W);
-  ps[1] = problem(w.gates2, s, nullptr, g2, 1, H, W);
+  ps[0] = problem(w.gates1, x, s, g1, B, H, W);
+  ps[1] = problem(w.gates2, s, nullptr, g2, B, H, W);
   SF_TRY(run(ps, 2, EPI_AFFINE, st));
   // candidates + blend
-  ps[0] = problem(w.cand1, x, s, h1, 1, H, W);
+  ps[0] = problem(w.cand1, x, s, h1, B, H, W);
   ps[0].gate = g1; ps[0].gate_cs = 2 * C; ps[0].gate_co = C; ps[0].e0 = g1; ps[0].e0_cs = 2 * C; ps[0].e1 = s; ps[0].e1_cs = C;
-  ps[1] = problem(w.cand2, s, s, h2, 1, H, W);
+  ps[1] = problem(w.cand2, s, s, h2, B, H, W);
   ps[1].gate = g2; ps[1].gate_cs = 2 * C; ps[1].gate_co = C; ps[1].e0 = g2; ps[1].e0_cs = 2 * C; ps[1].e1 = s; ps[1].e1_cs = C;
   SF_TRY(run(ps, 2, EPI_BLEND, st));
   // rnn_state2 = conv_decoder_2(h2)
-  SF_TRY(run1(problem(w.dec2, h2, nullptr, r2, 1, H, W), EPI_AFFINE, st));
+  SF_TRY(run1(problem(w.dec2, h2, nullptr, r2, B, H, W), EPI_AFFINE, st));
   // trusting gate: 7x7 + LN + GELU  ||  1x1 projection + GELU
-  ps[0] = problem(w.tg7, h1, r2, t1, 1, H, W); ps[0].mode = 1;
-  ps[1] = problem(w.tgproj, h1, r2, sk, 1, H, W); ps[1].mode = 0;
+  ps[0] = problem(w.tg7, h1, r2, t1, B, H, W); ps[0].mode = 1;
+  ps[1] = problem(w.tgproj, h1, r2, sk, B, H, W); ps[1].mode = 0;
   SF_TRY(run(ps, 2, EPI_LNG, st));
-  ConvProblem q = problem(w.tg1, t1, nullptr, t2, 1, H, W); q.mode = 1;
+  ConvProblem q = problem(w.tg1, t1, nullptr, t2, B, H, W); q.mode = 1;
   SF_TRY(run1(q, EPI_LNG, st));
-  ConvProblem f = problem(w.tg3, t2, nullptr, out, 1, H, W);
+  ConvProblem f = problem(w.tg3, t2, nullptr, out, B, H, W);
   f.e0 = sk; f.e1 = w.w_logit; f.e2 = r2; f.e3 = h1; f.e4 = s; f.e5 = base ? base : s;
-  f.coef = coef; f.out2 = out2; f.mode = (derivative ? 1 : 0) | (acc2 ? 2 : 0);
+  f.coef = coef; f.coef_stride = coef_stride; f.out2 = out2; f.mode = (derivative ? 1 : 0) | (acc2 ? 2 : 0);
   if (derivative && !coef) return SF_ERR_INVALID;
   return run1(f, EPI_TRUST, st);
 }
 
+constexpr int SE_SLABS = 64;
 size_t infer_ws_floats(int C, int P) {
   int nt = (P + 15) / 16;
-  return al((size_t)P * C) + 4 * al((size_t)P * 2 * C) + 2 * al((size_t)nt * 2 * C) + 2 * al(2 * C);
+  if (nt < SE_SLABS * 64) nt = SE_SLABS * 64;   // room for [B<=64][SE_SLABS] slab sums as well
+  return al((size_t)P * C) + 4 * al((size_t)P * 2 * C) + 2 * al((size_t)nt * 2 * C) + 2 * al((size_t)64 * 2 * C);
 }
 
-// temporal_ode_bayes.py:463-477
-int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p_out, float* q_out, int H, int W,
+// temporal_ode_bayes.py:463-477 on B images.  SE channel means: B == 1 uses the per-16-pixel sums
+// the producing conv's epilogue writes; B > 1 (16-pixel tiles straddle images) sums per-image
+// slabs with one extra small launch.  Both are fixed-order.
+int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p_out, float* q_out, int B, int H, int W,
                 Arena& A, hipStream_t st) {
-  const int C = w.C, C2 = 2 * C, P = H * W, nt = (P + 15) / 16;
+  const int C = w.C, C2 = 2 * C, HW = H * W, P = B * HW;
+  if (B < 1 || B > 64) return SF_ERR_UNSUPPORTED;
+  const bool tiles = (B == 1);
+  const int nt = tiles ? (P + 15) / 16 : SE_SLABS;
   float* a = A.take((size_t)P * C);
   float* pr = A.take((size_t)P * C2);
   float* y1 = A.take((size_t)P * C2);
   float* b = A.take((size_t)P * C2);
   float* y2 = A.take((size_t)P * C2);
-  float* cs1 = A.take((size_t)nt * C2);
-  float* cs2 = A.take((size_t)nt * C2);
-  float* sc1 = A.take(C2);
-  float* sc2 = A.take(C2);
+  float* cs1 = A.take((size_t)B * nt * C2);
+  float* cs2 = A.take((size_t)B * nt * C2);
+  float* sc1 = A.take((size_t)B * C2);
+  float* sc2 = A.take((size_t)B * C2);
   if (!A.ok()) return SF_ERR_WORKSPACE;
   if (!w.rb0.proj.w || w.rb1.proj.w) return SF_ERR_INVALID;
   ConvProblem ps[2];
-  ps[0] = problem(w.rb0.conv1, s, nullptr, a, 1, H, W);
-  ps[1] = problem(w.rb0.proj, s, nullptr, pr, 1, H, W);
+  ps[0] = problem(w.rb0.conv1, s, nullptr, a, B, H, W);
+  ps[1] = problem(w.rb0.proj, s, nullptr, pr, B, H, W);
   SF_TRY(run(ps, 2, EPI_AFFINE, st));
-  ConvProblem c2 = problem(w.rb0.conv2, a, nullptr, y1, 1, H, W);
-  c2.add = pr; c2.chansum = cs1;
+  ConvProblem c2 = problem(w.rb0.conv2, a, nullptr, y1, B, H, W);
+  c2.add = pr; c2.chansum = tiles ? cs1 : nullptr;
   SF_TRY(run1(c2, EPI_AFFINE, st));
-  SF_HIP(launch_se_fc(cs1, nt, C2, C2 / 8, P, w.se0_fc0, w.se0_fc2, sc1, st));
-  ConvProblem c3 = problem(w.rb1.conv1, y1, nullptr, b, 1, H, W);
+  if (!tiles) SF_HIP(launch_chan_partial(y1, cs1, B, HW, C2, SE_SLABS, st));
+  SF_HIP(launch_se_fc(cs1, nt, C2, C2 / 8, HW, w.se0_fc0, w.se0_fc2, sc1, B, st));
+  ConvProblem c3 = problem(w.rb1.conv1, y1, nullptr, b, B, H, W);
   c3.in_scale = sc1;
   SF_TRY(run1(c3, EPI_AFFINE, st));
-  ConvProblem c4 = problem(w.rb1.conv2, b, nullptr, y2, 1, H, W);
-  c4.add = y1; c4.add_scale = sc1; c4.chansum = cs2;
+  ConvProblem c4 = problem(w.rb1.conv2, b, nullptr, y2, B, H, W);
+  c4.add = y1; c4.add_scale = sc1; c4.chansum = tiles ? cs2 : nullptr;
   SF_TRY(run1(c4, EPI_AFFINE, st));
-  SF_HIP(launch_se_fc(cs2, nt, C2, C2 / 8, P, w.se1_fc0, w.se1_fc2, sc2, st));
-  ConvProblem c5 = problem(w.last, y2, nullptr, p_out, 1, H, W);
+  if (!tiles) SF_HIP(launch_chan_partial(y2, cs2, B, HW, C2, SE_SLABS, st));
+  SF_HIP(launch_se_fc(cs2, nt, C2, C2 / 8, HW, w.se1_fc0, w.se1_fc2, sc2, B, st));
+  ConvProblem c5 = problem(w.last, y2, nullptr, p_out, B, H, W);
   c5.in_scale = sc2; c5.e0 = eps; c5.out2 = q_out;
   return run1(c5, EPI_SAMPLE, st);
 }
@@ -366,19 +378,19 @@ int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p
 // temporal_ode_bayes.py:436-461 (+ build-defined RK4).  `zeros`: [P][C] zero tensor (IMPUTE=False).
 // Scratch: k (P*C), pk (P*C), acc (P*C) + cell/infer workspaces.
 int ode_step(const sf_dual_w& gc, const sf_pmodel_w& pm, int solver, int impute, const float* s_in,
-             const float* p_in, const float* coef, const float* eps, float* s_out, float* p_out, const float* zeros,
-             int skip_dead_infer, int H, int W, Arena& A0, hipStream_t st) {
+             const float* p_in, const float* coef, int coef_stride, const float* eps, float* s_out, float* p_out,
+             const float* zeros, int skip_dead_infer, int B, int H, int W, Arena& A0, hipStream_t st) {
   const int C = gc.C;
-  const size_t PC = (size_t)H * W * C;
+  const size_t PC = (size_t)B * H * W * C;
   const float* x = impute ? p_in : zeros;
   auto cell = [&](const float* xx, const float* ss, float* out, const float* base, const float* cf, float* out2,
                   int acc2) {
     Arena A = A0;
-    return dual_cell(gc, xx, ss, out, 1, base, cf, out2, acc2, H, W, A, st);
+    return dual_cell(gc, xx, ss, out, 1, base, cf, coef_stride, out2, acc2, B, H, W, A, st);
   };
   auto infer = [&](const float* ss, int draw, float* po) {
     Arena A = A0;
-    return infer_state(pm, ss, eps + (size_t)draw * PC, po, nullptr, H, W, A, st);
+    return infer_state(pm, ss, eps + (size_t)draw * PC, po, nullptr, B, H, W, A, st);
   };
   if (solver == SF_SOLVER_EULER) {
     SF_TRY(cell(x, s_in, s_out, s_in, coef + 0, nullptr, 0));
@@ -496,14 +508,14 @@ int sf_gru_cell_fwd(const sf_gru_w* w, const float* x, const float* s, float* ou
   return gru_cell(*w, x, s, out, g, n_img, H, W, (hipStream_t)stream);
 }
 
-size_t sf_spatial_gru_ws_bytes(int C, int H, int W) {
-  return (al((size_t)H * W * 2 * C) + 2 * al((size_t)H * W * C)) * sizeof(float);
+size_t sf_spatial_gru_ws_bytes(int C, int n_img, int H, int W) {
+  return (al((size_t)n_img * H * W * 2 * C) + 2 * al((size_t)n_img * H * W * C)) * sizeof(float);
 }
-int sf_spatial_gru_fwd(const sf_gru_w* w, const float* x, const float* state0, float* out, int T, int H, int W,
-                       float* ws, size_t ws_bytes, void* stream) {
+int sf_spatial_gru_fwd(const sf_gru_w* w, const float* x, const float* state0, float* out, int T, int n_img, int H,
+                       int W, float* ws, size_t ws_bytes, void* stream) {
   if (!w || !x || !state0 || !out || !valid_w(w->gates) || !valid_w(w->cand) || !valid_w(w->decoder)) return SF_ERR_INVALID;
   const int C = w->cand.cout, Cx = w->gates.c0;
-  const size_t P = (size_t)H * W;
+  const size_t P = (size_t)n_img * H * W;
   Arena A(ws, ws_bytes);
   float* g = A.take(P * 2 * C);
   float* sa = A.take(P * C);
@@ -513,59 +525,68 @@ int sf_spatial_gru_fwd(const sf_gru_w* w, const float* x, const float* state0, f
   const float* cur = state0;
   for (int t = 0; t < T; ++t) {   // temporal.py:35-39
     float* nxt = (t & 1) ? sb : sa;
-    SF_TRY(gru_cell(*w, x + t * P * Cx, cur, nxt, g, 1, H, W, st));
-    SF_TRY(run1(problem(w->decoder, nxt, nullptr, out + t * P * w->decoder.cout, 1, H, W), EPI_AFFINE, st));
+    SF_TRY(gru_cell(*w, x + t * P * Cx, cur, nxt, g, n_img, H, W, st));
+    SF_TRY(run1(problem(w->decoder, nxt, nullptr, out + t * P * w->decoder.cout, n_img, H, W), EPI_AFFINE, st));
     cur = nxt;
   }
   return SF_OK;
 }
 
-size_t sf_dual_cell_ws_bytes(int C, int H, int W) { return (dual_ws_floats(C, H * W) + SPLIT_WS_FLOATS) * sizeof(float); }
+size_t sf_dual_cell_ws_bytes(int C, int n_img, int H, int W) {
+  return (dual_ws_floats(C, n_img * H * W) + SPLIT_WS_FLOATS) * sizeof(float);
+}
 int sf_dual_cell_fwd(const sf_dual_w* w, const float* x, const float* s, float* out, int derivative, const float* base,
-                     const float* coef, float* out2, int acc2, int H, int W, float* ws, size_t ws_bytes, void* stream) {
-  if (!w || !x || !s || !out || w->C <= 0 || (w->C % 8)) return SF_ERR_INVALID;
+                     const float* coef, float* out2, int acc2, int n_img, int H, int W, float* ws, size_t ws_bytes,
+                     void* stream) {
+  if (!w || !x || !s || !out || w->C <= 0 || (w->C % 8) || n_img < 1) return SF_ERR_INVALID;
   if (w->C > 64) return SF_ERR_UNSUPPORTED;
   Arena A(ws, ws_bytes);
   SplitScope sp(A, (hipStream_t)stream);
-  return dual_cell(*w, x, s, out, derivative, base, coef, out2, acc2, H, W, A, (hipStream_t)stream);
+  return dual_cell(*w, x, s, out, derivative, base, coef, 0, out2, acc2, n_img, H, W, A, (hipStream_t)stream);
 }
 
-size_t sf_infer_state_ws_bytes(int C, int H, int W) { return (infer_ws_floats(C, H * W) + SPLIT_WS_FLOATS) * sizeof(float); }
-int sf_infer_state_fwd(const sf_pmodel_w* w, const float* s, const float* eps, float* p_out, float* q_out, int H, int W,
-                       float* ws, size_t ws_bytes, void* stream) {
-  if (!w || !s || !eps || !p_out || w->C <= 0 || (w->C % 8)) return SF_ERR_INVALID;
+size_t sf_infer_state_ws_bytes(int C, int n_img, int H, int W) {
+  return (infer_ws_floats(C, n_img * H * W) + SPLIT_WS_FLOATS) * sizeof(float);
+}
+int sf_infer_state_fwd(const sf_pmodel_w* w, const float* s, const float* eps, float* p_out, float* q_out, int n_img,
+                       int H, int W, float* ws, size_t ws_bytes, void* stream) {
+  if (!w || !s || !eps || !p_out || w->C <= 0 || (w->C % 8) || n_img < 1) return SF_ERR_INVALID;
   Arena A(ws, ws_bytes);
   SplitScope sp(A, (hipStream_t)stream);
-  return infer_state(*w, s, eps, p_out, q_out, H, W, A, (hipStream_t)stream);
+  return infer_state(*w, s, eps, p_out, q_out, n_img, H, W, A, (hipStream_t)stream);
 }
 
-size_t sf_ode_step_ws_bytes(int C, int H, int W) { return (ode_step_ws_floats(C, H * W) + al((size_t)H * W * C) + SPLIT_WS_FLOATS) * sizeof(float); }
+size_t sf_ode_step_ws_bytes(int C, int n_img, int H, int W) {
+  const int P = n_img * H * W;
+  return (ode_step_ws_floats(C, P) + al((size_t)P * C) + SPLIT_WS_FLOATS) * sizeof(float);
+}
 int sf_ode_step_fwd(const sf_dual_w* gru_c, const sf_pmodel_w* pm, int solver, int impute, const float* state_in,
-                    const float* p_in, const float* coef, const float* eps, float* state_out, float* p_out, int H, int W,
-                    float* ws, size_t ws_bytes, void* stream) {
-  if (!gru_c || !pm || !state_in || !p_in || !coef || !eps || !state_out || !p_out) return SF_ERR_INVALID;
+                    const float* p_in, const float* coef, const float* eps, float* state_out, float* p_out, int n_img,
+                    int H, int W, float* ws, size_t ws_bytes, void* stream) {
+  if (!gru_c || !pm || !state_in || !p_in || !coef || !eps || !state_out || !p_out || n_img < 1) return SF_ERR_INVALID;
   if (gru_c->C > 64 || (gru_c->C % 8)) return SF_ERR_UNSUPPORTED;
   Arena A(ws, ws_bytes);
   hipStream_t st = (hipStream_t)stream;
   SplitScope sp(A, st);
-  const size_t PC = (size_t)H * W * gru_c->C;
+  const size_t PC = (size_t)n_img * H * W * gru_c->C;
   float* zeros = A.take(PC);
   if (!A.ok()) return SF_ERR_WORKSPACE;
   if (!impute) SF_HIP(hipMemsetAsync(zeros, 0, PC * sizeof(float), st));
-  return ode_step(*gru_c, *pm, solver, impute, state_in, p_in, coef, eps, state_out, p_out, zeros, 0, H, W, A, st);
+  return ode_step(*gru_c, *pm, solver, impute, state_in, p_in, coef, 0, eps, state_out, p_out, zeros, 0, n_img, H, W, A, st);
 }
 
-size_t sf_nnfo_rollout_ws_bytes(int C, int H, int W) {
-  return (ode_step_ws_floats(C, H * W) + 5 * al((size_t)H * W * C) + SPLIT_WS_FLOATS) * sizeof(float);
+size_t sf_nnfo_rollout_ws_bytes(int C, int n_img, int H, int W) {
+  const int P = n_img * H * W;
+  return (ode_step_ws_floats(C, P) + 5 * al((size_t)P * C) + SPLIT_WS_FLOATS) * sizeof(float);
 }
 int sf_nnfo_rollout_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const sf_pmodel_w* pm, int solver, int impute,
                         const int32_t* ops, int n_ops, const float* hx_obs, const float* eps, const float* coef,
-                        const int32_t* sel_nops, int n_targets, float* out_states, float* final_state, int H, int W,
-                        float* ws, size_t ws_bytes, void* stream) {
-  if (!gru_c || !gru_obs || !pm || !ops || !hx_obs || !eps || !sel_nops || !out_states) return SF_ERR_INVALID;
+                        int coef_per_image, const int32_t* sel_nops, int n_targets, float* out_states,
+                        float* final_state, int n_img, int H, int W, float* ws, size_t ws_bytes, void* stream) {
+  if (!gru_c || !gru_obs || !pm || !ops || !hx_obs || !eps || !sel_nops || !out_states || n_img < 1) return SF_ERR_INVALID;
   if (gru_c->C > 64 || (gru_c->C % 8)) return SF_ERR_UNSUPPORTED;
-  const int C = gru_c->C;
-  const size_t PC = (size_t)H * W * C;
+  const int C = gru_c->C, B = n_img;
+  const size_t PC = (size_t)B * H * W * C;
   Arena A(ws, ws_bytes);
   SplitScope sp(A, (hipStream_t)stream);
   float* zeros = A.take(PC);
@@ -581,24 +602,24 @@ int sf_nnfo_rollout_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const 
   float *s = sA, *s2 = sB, *p = pA, *p2 = pB;
   int draw = 0;
   const int draws_per_step = solver == SF_SOLVER_EULER ? 1 : (solver == SF_SOLVER_MIDPOINT ? 2 : 4);
+  const int cstride = coef_per_image ? SF_COEF_STRIDE : 0;
+  const size_t step_stride = (size_t)SF_COEF_STRIDE * (coef_per_image ? B : 1);
   for (int i = 0; i < n_ops; ++i) {
     const int kind = ops[2 * i], arg = ops[2 * i + 1];
     if (kind == SF_OP_JUMP) {   // :562-574
-      Arena B = A;
-      SF_TRY(dual_cell(*gru_obs, hx_obs + (size_t)arg * PC, s, s2, 0, nullptr, nullptr, nullptr, 0, H, W, B, st));
+      Arena Bq = A;
+      SF_TRY(dual_cell(*gru_obs, hx_obs + (size_t)arg * PC, s, s2, 0, nullptr, nullptr, 0, nullptr, 0, B, H, W, Bq, st));
       if (impute) {   // with IMPUTE off the imputed input is never read (:442-443): skip the dead pass
         Arena D = A;
-        SF_TRY(infer_state(*pm, s2, eps + (size_t)draw * PC, p, nullptr, H, W, D, st));
+        SF_TRY(infer_state(*pm, s2, eps + (size_t)draw * PC, p, nullptr, B, H, W, D, st));
       }
       draw += 1;
       float* t = s; s = s2; s2 = t;
     } else if (kind == SF_OP_STEP) {
-      Arena B = A;
-      const int stride = SF_COEF_STRIDE;
-      // the imputed input after the very last op is never consumed -> skip that p_model pass only
-      // when IMPUTE is off (then no later derivative evaluation reads it either)
-      SF_TRY(ode_step(*gru_c, *pm, solver, impute, s, p, coef + (size_t)arg * stride, eps + (size_t)draw * PC, s2, p2,
-                      zeros, 1, H, W, B, st));
+      if (!coef) return SF_ERR_INVALID;
+      Arena Bq = A;
+      SF_TRY(ode_step(*gru_c, *pm, solver, impute, s, p, coef + (size_t)arg * step_stride, cstride,
+                      eps + (size_t)draw * PC, s2, p2, zeros, 1, B, H, W, Bq, st));
       draw += draws_per_step;
       float* t = s; s = s2; s2 = t;
       t = p; p = p2; p2 = t;

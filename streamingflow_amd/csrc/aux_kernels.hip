@@ -100,6 +100,8 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ c
                                                      float inv_hw, const float* __restrict__ fc0,
                                                      const float* __restrict__ fc2, float* __restrict__ scale) {
   extern __shared__ float sm[];   // part[G][C] | mean[C] | hid[Cr]
+  chansum += (size_t)blockIdx.x * ntile * C;   // one workgroup per image
+  scale += (size_t)blockIdx.x * C;
   const int G = 1024 / C;         // tile groups summed in parallel (C <= 1024)
   float* part = sm;
   float* mean = sm + G * C;
@@ -142,10 +144,10 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ c
 }
 
 hipError_t launch_se_fc(const float* chansum, int ntile, int C, int Cr, int hw, const float* fc0,
-                        const float* fc2, float* scale, hipStream_t s) {
-  if (C < 1 || C > 1024) return hipErrorInvalidValue;
+                        const float* fc2, float* scale, int n_img, hipStream_t s) {
+  if (C < 1 || C > 1024 || n_img < 1) return hipErrorInvalidValue;
   const int G = 1024 / C;
-  hipLaunchKernelGGL(se_fc_kernel, dim3(1), dim3(1024), (G * C + C + Cr) * sizeof(float), s, chansum, ntile, C, Cr,
+  hipLaunchKernelGGL(se_fc_kernel, dim3(n_img), dim3(1024), (G * C + C + Cr) * sizeof(float), s, chansum, ntile, C, Cr,
                      1.f / (float)hw, fc0, fc2, scale);
   return hipGetLastError();
 }
@@ -300,6 +302,14 @@ __global__ __launch_bounds__(256) void aspp_pool_kernel(const float* __restrict_
     for (int h = 0; h < hid; ++h) s += wp[co * hid + h] * gg[h];
     bias_img[(size_t)img * hid + co] = ps[co] * s + pb[co];
   }
+}
+
+hipError_t launch_chan_partial(const float* in, float* part, int n, int HW, int C, int nslab, hipStream_t s) {
+  int C4 = C / 4;
+  if (C4 < 1 || C4 > 256) return hipErrorInvalidValue;
+  int lanes = 256 / C4;
+  hipLaunchKernelGGL(chan_partial_kernel, dim3(nslab, n), dim3(256), lanes * C * sizeof(float), s, in, part, HW, C, nslab);
+  return hipGetLastError();
 }
 
 hipError_t launch_aspp_pool(const float* in, float* part, float* bias_img, int n, int HW, int C, int hid,

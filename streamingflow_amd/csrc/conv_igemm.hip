@@ -205,8 +205,9 @@ __device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[
         const float ez0 = expf(z0 - zm), ez1 = expf(z1 - zm);
         const float g0 = ez0 / (ez0 + ez1), g1 = ez1 / (ez0 + ez1);
         if (pv) {
-          const float c0f = P.coef ? P.coef[0] : 0.f;
-          const float c1f = (P.coef && P.out2) ? P.coef[1] : 0.f;
+          const float* cf = P.coef ? P.coef + (size_t)(gp / HWout) * P.coef_stride : nullptr;
+          const float c0f = cf ? cf[0] : 0.f;
+          const float c1f = (cf && P.out2) ? cf[1] : 0.f;
 #pragma unroll
           for (int m = 0; m < MT; ++m)
             if (cvm[m]) {

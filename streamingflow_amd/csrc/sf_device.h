@@ -35,7 +35,7 @@ struct ConvProblem {
   float* chansum;         // optional [ceil(P/16)][cout] per-16-pixel channel sums of `out`
   // epilogue specific read-only tensors
   const float* e0; const float* e1; const float* e2; const float* e3; const float* e4; const float* e5;
-  const float* coef;      // device scalars (dt coefficients)
+  const float* coef;      // device scalars (dt coefficients), record of image i at coef + i*coef_stride
   // ---- geometry --------------------------------------------------------------------------
   int c0, c1;             // channels taken from in0 / in1
   int in0_cs, in1_cs, gate_cs, gate_co;
@@ -57,6 +57,7 @@ struct ConvProblem {
   float* slab;            // [tiles][nsplit][waves][MT*NT*4][64]
   unsigned int* counters; // [tiles], zero before the launch; reset by the last arriver
   int nsplit;
+  int coef_stride;        // floats between per-image coefficient records (0: shared)
 };
 
 #define SF_MAX_GROUP 4

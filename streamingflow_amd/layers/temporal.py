@@ -46,14 +46,18 @@ class SpatialGRU(PackedModule):
         return pk
 
     def forward_nhwc(self, x, state):
-        """x: [T, H, W, Cx], state: [H, W, C] (one sample) -> [T, H, W, Cx]."""
-        T, h, w, _ = x.shape
+        """x: [T, B, H, W, Cx] (or [T, H, W, Cx] for one sample), state: [B, H, W, C] (or [H, W, C]).
+        Returns the decoded outputs with the shape of x."""
+        one = x.dim() == 4
+        if one:
+            x, state = x[:, None], state[None]
+        T, B, h, w, _ = x.shape
         L = _lib.lib()
-        ws = runtime.workspace(L.sf_spatial_gru_ws_bytes(self.hidden_size, h, w), x.device)
-        out = torch.empty((T, h, w, self.input_size), dtype=torch.float32, device=x.device)
-        _lib.check(L.sf_spatial_gru_fwd(self.packed().struct, ptr(x), ptr(state), ptr(out), T, h, w, ptr(ws),
+        ws = runtime.workspace(L.sf_spatial_gru_ws_bytes(self.hidden_size, B, h, w), x.device)
+        out = torch.empty((T, B, h, w, self.input_size), dtype=torch.float32, device=x.device)
+        _lib.check(L.sf_spatial_gru_fwd(self.packed().struct, ptr(x), ptr(state), ptr(out), T, B, h, w, ptr(ws),
                                         ws.numel() * 4, runtime.stream_ptr(x.device)), "spatial_gru")
-        return out
+        return out[:, 0] if one else out
 
     def gru_cell(self, x, state):
         """One cell update on NCHW tensors (temporal.py:44-57)."""
@@ -71,10 +75,8 @@ class SpatialGRU(PackedModule):
         assert len(x.size()) == 5, 'Input tensor must be BxTxCxHxW.'
         runtime.require_cuda(x, state)
         b, T, c, h, w = x.shape
-        outs = []
-        for i in range(b):
-            xn = runtime.to_nhwc(x[i])
-            s0 = (torch.zeros((h, w, self.hidden_size), dtype=torch.float32, device=x.device) if state is None
-                  else runtime.to_nhwc(state[i:i + 1])[0])
-            outs.append(runtime.to_nchw(self.forward_nhwc(xn, s0)))
-        return torch.stack(outs, dim=0)
+        xn = runtime.to_nhwc(x.reshape(b * T, c, h, w)).view(b, T, h, w, c).permute(1, 0, 2, 3, 4).contiguous()
+        s0 = (torch.zeros((b, h, w, self.hidden_size), dtype=torch.float32, device=x.device) if state is None
+              else runtime.to_nhwc(state))
+        out = self.forward_nhwc(xn, s0).permute(1, 0, 2, 3, 4).reshape(b * T, h, w, self.input_size)
+        return runtime.to_nchw(out).view(b, T, self.input_size, h, w)

@@ -64,24 +64,24 @@ class _DualCell(PackedModule):
         return pk
 
     def run_nhwc(self, x, s, out, derivative, base=None, coef=None):
-        h, w, C = s.shape[-3:]
+        """x, s, out: [B, h, w, C] (B samples processed as one pixel space)."""
+        B, h, w, C = s.shape
         L = _lib.lib()
-        ws = runtime.workspace(L.sf_dual_cell_ws_bytes(C, h, w), s.device)
+        ws = runtime.workspace(L.sf_dual_cell_ws_bytes(C, B, h, w), s.device)
         _lib.check(L.sf_dual_cell_fwd(self.packed().struct, ptr(x), ptr(s), ptr(out), int(derivative), ptr(base),
-                                      ptr(coef), None, 0, h, w, ptr(ws), ws.numel() * 4,
+                                      ptr(coef), None, 0, B, h, w, ptr(ws), ws.numel() * 4,
                                       runtime.stream_ptr(s.device)), "dual_cell")
         return out
 
     def forward(self, x, state):
         runtime.require_cuda(x, state)
-        squeeze5 = x.dim() == 5
-        if squeeze5:
+        if x.dim() == 5:
             if x.shape[1] != 1 or state.shape[1] != 1:
                 raise NotImplementedError("n_present > 1 warm-up is unused by the reference forward path")
             x, state = x[:, 0], state[:, 0]
-        if x.shape[0] != 1:
-            raise NotImplementedError("batch 1 only (the reference mis-broadcasts for B > 1, SURVEY.md §0)")
         assert x.shape[1] == self.input_size, f'feature sizes must match, got input {x.shape[1]} for layer with size {self.input_size}'
+        # note: the reference mis-broadcasts for batch > 1 (SURVEY.md §0); here every sample of the
+        # batch gets the batch-1 semantics
         xn, sn = runtime.to_nhwc(x), runtime.to_nhwc(state)
         out = torch.empty_like(sn)
         if self.derivative:   # cur - s  ==  0 + 1*(cur - s)
@@ -145,18 +145,20 @@ class NNFOwithBayesianJumps(nn.Module):
         assert self.solver in ["euler", "midpoint", "rk4"], "Solver must be 'euler', 'midpoint' (reference) or 'rk4' (build-defined)."
         self.input_size, self.hidden_size, self.logvar, self.mixing = input_size, hidden_size, logvar, mixing
         self.noise = None    # None: torch.randn on the device; else callable(shape, dtype, device) -> NCHW eps per draw
+        self.use_graph = False   # capture the rollout of each schedule structure into a hipGraph and replay it
+        self._graphs = {}
         self.apply(init_weights)
 
     # ---- noise --------------------------------------------------------------------------------
-    def _draw_eps(self, n_draws, h, w, device):
-        """[n_draws, h, w, C] fp32 on `device`, one row per infer_state call in reference order."""
+    def _draw_eps(self, n_draws, B, h, w, device):
+        """[n_draws, B, h, w, C] fp32 on `device`, one row per infer_state call in reference order."""
         C = self.hidden_size
         if self.noise is None:
-            return torch.randn((max(1, n_draws), h, w, C), dtype=torch.float32, device=device)
-        rows = [self.noise((1, C, h, w), torch.float32, "cpu") for _ in range(n_draws)]
+            return torch.randn((max(1, n_draws), B, h, w, C), dtype=torch.float32, device=device)
+        rows = [self.noise((B, C, h, w), torch.float32, "cpu") for _ in range(n_draws)]
         if not rows:
-            return torch.zeros((1, h, w, C), dtype=torch.float32, device=device)
-        return torch.cat(rows, 0).permute(0, 2, 3, 1).contiguous().to(device)
+            return torch.zeros((1, B, h, w, C), dtype=torch.float32, device=device)
+        return torch.stack(rows, 0).permute(0, 1, 3, 4, 2).contiguous().to(device)
 
     # ---- reference API on NCHW tensors ------------------------------------------------------------
     def srvp_encode(self, x):
@@ -172,71 +174,123 @@ class NNFOwithBayesianJumps(nn.Module):
     def infer_state(self, x, deterministic=False):
         """(:463-477) returns (sample, raw p_model output).  `deterministic` is ignored as in the reference."""
         runtime.require_cuda(x)
-        if x.shape[0] != 1:
-            raise NotImplementedError("batch 1 only")
         sn = runtime.to_nhwc(x)
-        _, h, w, C = sn.shape
-        eps = self._draw_eps(1, h, w, x.device)
+        B, h, w, C = sn.shape
+        eps = self._draw_eps(1, B, h, w, x.device)
         p = torch.empty_like(sn)
-        q = torch.empty((1, h, w, 2 * C), dtype=torch.float32, device=x.device)
+        q = torch.empty((B, h, w, 2 * C), dtype=torch.float32, device=x.device)
         L = _lib.lib()
-        ws = runtime.workspace(L.sf_infer_state_ws_bytes(C, h, w), x.device)
-        _lib.check(L.sf_infer_state_fwd(self.p_model.packed().struct, ptr(sn), ptr(eps), ptr(p), ptr(q), h, w, ptr(ws),
-                                        ws.numel() * 4, runtime.stream_ptr(x.device)), "infer_state")
+        ws = runtime.workspace(L.sf_infer_state_ws_bytes(C, B, h, w), x.device)
+        _lib.check(L.sf_infer_state_fwd(self.p_model.packed().struct, ptr(sn), ptr(eps), ptr(p), ptr(q), B, h, w,
+                                        ptr(ws), ws.numel() * 4, runtime.stream_ptr(x.device)), "infer_state")
         return runtime.to_nchw(p), runtime.to_nchw(q)
 
     def ode_step(self, state, input, delta_t, current_time):
         """(:436-461) one Euler / midpoint / RK4 step; returns the reference's 5-tuple."""
         runtime.require_cuda(state, input)
-        if state.shape[0] != 1:
-            raise NotImplementedError("batch 1 only")
         dev = state.device
         sn, pn = runtime.to_nhwc(state), runtime.to_nhwc(input)
-        _, h, w, C = sn.shape
+        B, h, w, C = sn.shape
         sc = sched.Schedule(dts=[float(delta_t)])
         coef = torch.from_numpy(sc.coef_array()).to(dev)
-        eps = self._draw_eps(sched.DRAWS_PER_STEP[self.solver], h, w, dev)
+        eps = self._draw_eps(sched.DRAWS_PER_STEP[self.solver], B, h, w, dev)
         s_out, p_out = torch.empty_like(sn), torch.empty_like(pn)
         L = _lib.lib()
-        ws = runtime.workspace(L.sf_ode_step_ws_bytes(C, h, w), dev)
+        ws = runtime.workspace(L.sf_ode_step_ws_bytes(C, B, h, w), dev)
         _lib.check(L.sf_ode_step_fwd(self.gru_c.packed().struct, self.p_model.packed().struct,
                                      _lib.SOLVER[self.solver], int(bool(self.impute)), ptr(sn), ptr(pn), ptr(coef),
-                                     ptr(eps), ptr(s_out), ptr(p_out), h, w, ptr(ws), ws.numel() * 4,
+                                     ptr(eps), ptr(s_out), ptr(p_out), B, h, w, ptr(ws), ws.numel() * 4,
                                      runtime.stream_ptr(dev)), "ode_step")
         current_time = current_time + delta_t
         return (runtime.to_nchw(s_out), runtime.to_nchw(p_out), current_time,
                 torch.tensor([0], device=dev, dtype=torch.float64), torch.tensor([0], device=dev, dtype=torch.float32))
 
     # ---- the rollout ----------------------------------------------------------------------------
-    def rollout_nhwc(self, hx_obs, sc, eps=None):
-        """hx_obs [n_obs, h, w, C] (encoded observations in time order), sc: Schedule.
-        Returns (selected states [n_T, h, w, C], final state [h, w, C])."""
-        n_obs, h, w, C = hx_obs.shape
-        dev = hx_obs.device
-        if eps is None:
-            eps = self._draw_eps(sc.n_draws, h, w, dev)
-        ops = sc.ops_array()
-        sel = np.asarray(sc.sel_nops, dtype=np.int32)
-        coef = torch.from_numpy(sc.coef_array()).to(dev)
-        out = torch.empty((len(sel), h, w, C), dtype=torch.float32, device=dev)
-        final = torch.empty((h, w, C), dtype=torch.float32, device=dev)
+    def _enqueue_rollout(self, s0, per_image, hx_obs, eps, coef, out, final, ws, B, h, w):
+        ops = s0.ops_array()
+        sel = np.asarray(s0.sel_nops, dtype=np.int32)
         L = _lib.lib()
-        ws = runtime.workspace(L.sf_nnfo_rollout_ws_bytes(C, h, w), dev)
         _lib.check(L.sf_nnfo_rollout_fwd(
             self.gru_c.packed().struct, self.gru_obs.gru_d.packed().struct, self.p_model.packed().struct,
-            _lib.SOLVER[self.solver], int(bool(self.impute)), ops.ctypes.data_as(_lib.i32p), len(sc.ops),
-            ptr(hx_obs), ptr(eps), ptr(coef), sel.ctypes.data_as(_lib.i32p), len(sel), ptr(out), ptr(final), h, w,
-            ptr(ws), ws.numel() * 4, runtime.stream_ptr(dev)), "nnfo_rollout")
-        return out, final
+            _lib.SOLVER[self.solver], int(bool(self.impute)), ops.ctypes.data_as(_lib.i32p), len(s0.ops),
+            ptr(hx_obs), ptr(eps), ptr(coef), int(per_image), sel.ctypes.data_as(_lib.i32p), len(sel), ptr(out),
+            ptr(final), B, h, w, ptr(ws), ws.numel() * 4, runtime.stream_ptr(hx_obs.device)), "nnfo_rollout")
 
-    def forward_nhwc(self, times, obs_nhwc, delta_t, T):
-        """obs_nhwc: [n_obs, H, W, C] observations sorted by `times`.  Returns (final latent state
-        [h, w, C], decoded predictions [n_T, H', W', C])."""
-        sc = sched.build_schedule([float(t) for t in times], [float(t) for t in T], delta_t,
-                                  self.use_variable_ode_step, self.solver)
-        hx = self.srvp_encoder.forward_nhwc(obs_nhwc)
-        states, final = self.rollout_nhwc(hx, sc)
-        return final, self.srvp_decoder.forward_nhwc(states), sc
+    def rollout_nhwc(self, hx_obs, sc, eps=None):
+        """hx_obs: [n_obs, B, h, w, C] (or [n_obs, h, w, C] for one sample) encoded observations in
+        time order; sc: one Schedule shared by all samples, or a list of B Schedules with the same
+        structure (``Schedule.key()``) and per-sample step sizes.
+        Returns (selected states [n_T, B, h, w, C], final state [B, h, w, C]); without the B axis
+        when hx_obs had none.  With ``self.use_graph`` the whole rollout (every kernel of every
+        step and jump) is captured once per (schedule structure, shape) into a hipGraph and
+        replayed; step sizes, observations and noise are fed through static device buffers."""
+        one = hx_obs.dim() == 4
+        if one:
+            hx_obs = hx_obs[:, None]
+        n_obs, B, h, w, C = hx_obs.shape
+        dev = hx_obs.device
+        scs = list(sc) if isinstance(sc, (list, tuple)) else [sc]
+        s0 = scs[0]
+        if len(scs) not in (1, B) or any(x.key() != s0.key() for x in scs):
+            raise ValueError("batched rollout needs one schedule, or one per sample with identical structure")
+        per_image = len(scs) > 1 and any(x.dts != s0.dts for x in scs)
+        if eps is None:
+            eps = self._draw_eps(s0.n_draws, B, h, w, dev)
+        elif eps.dim() == 4:
+            eps = eps[:, None]
+        coef_np = np.stack([x.coef_array() for x in scs], axis=1) if per_image else s0.coef_array()
+        coef = torch.from_numpy(np.ascontiguousarray(coef_np)).to(dev)
+        L = _lib.lib()
+        nbytes = L.sf_nnfo_rollout_ws_bytes(C, B, h, w)
+        if not self.use_graph:
+            out = torch.empty((len(s0.sel_nops), B, h, w, C), dtype=torch.float32, device=dev)
+            final = torch.empty((B, h, w, C), dtype=torch.float32, device=dev)
+            ws = runtime.workspace(nbytes, dev)
+            self._enqueue_rollout(s0, per_image, hx_obs, eps, coef, out, final, ws, B, h, w)
+        else:
+            key = (s0.key(), per_image, tuple(hx_obs.shape), tuple(eps.shape), str(dev), self.solver, bool(self.impute),
+                   self.gru_c.packed() is None, id(self.gru_c.packed()), id(self.p_model.packed()),
+                   id(self.gru_obs.gru_d.packed()))
+            g = self._graphs.get(key)
+            if g is None:
+                g = {"hx": torch.empty_like(hx_obs), "eps": torch.empty_like(eps), "coef": torch.empty_like(coef),
+                     "out": torch.empty((len(s0.sel_nops), B, h, w, C), dtype=torch.float32, device=dev),
+                     "final": torch.empty((B, h, w, C), dtype=torch.float32, device=dev),
+                     "ws": torch.empty(nbytes // 4 + 1024, dtype=torch.float32, device=dev)}
+                g["hx"].copy_(hx_obs); g["eps"].copy_(eps); g["coef"].copy_(coef)
+                # eager warm-up (sets kernel attributes, packs weights), then capture on a side stream
+                self._enqueue_rollout(s0, per_image, g["hx"], g["eps"], g["coef"], g["out"], g["final"], g["ws"], B, h, w)
+                torch.cuda.synchronize(dev)
+                side = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(side):
+                    sp = runtime.stream_ptr(dev)
+                    _lib.check(L.sf_graph_begin(sp), "graph_begin")
+                    try:
+                        self._enqueue_rollout(s0, per_image, g["hx"], g["eps"], g["coef"], g["out"], g["final"], g["ws"], B, h, w)
+                    finally:
+                        ex = ctypes.c_void_p()
+                        _lib.check(L.sf_graph_end(sp, ctypes.byref(ex)), "graph_end")
+                g["exec"] = ex
+                self._graphs[key] = g
+            g["hx"].copy_(hx_obs); g["eps"].copy_(eps); g["coef"].copy_(coef)
+            _lib.check(L.sf_graph_launch(g["exec"], runtime.stream_ptr(dev)), "graph_launch")
+            out, final = g["out"], g["final"]      # valid until the next replay of this graph
+        return (out[:, 0], final[0]) if one else (out, final)
+
+    def make_schedule(self, times, delta_t, T):
+        return sched.build_schedule([float(t) for t in times], [float(t) for t in T], delta_t,
+                                    self.use_variable_ode_step, self.solver)
+
+    def forward_nhwc(self, scs, obs_nhwc):
+        """obs_nhwc: [n_obs, B, H, W, C] observations in time order; scs: Schedule or list of B
+        Schedules.  Returns (final latent state [B, h, w, C], decoded predictions [n_T, B, H', W', C])."""
+        n_obs, B, H, W, C = obs_nhwc.shape
+        hx = self.srvp_encoder.forward_nhwc(obs_nhwc.reshape(n_obs * B, H, W, C))
+        hx = hx.view(n_obs, B, *hx.shape[1:])
+        states, final = self.rollout_nhwc(hx, scs)
+        n_T = states.shape[0]
+        x = self.srvp_decoder.forward_nhwc(states.reshape(n_T * B, *states.shape[2:]))
+        return final, x.view(n_T, B, *x.shape[1:])
 
     def forward(self, times, input, obs, delta_t, T, return_path=True):
         """(:479-627) times: 1-D float64 observation times (sorted), input: (1,1,C,H,W) (only its shape
@@ -244,6 +298,7 @@ class NNFOwithBayesianJumps(nn.Module):
         (1,n_obs,C,H,W), T: 1-D float64 target times.  Returns (state, 0, x) as the reference does."""
         runtime.require_cuda(obs)
         if obs.shape[0] != 1:
-            raise NotImplementedError("batch 1 only (as the reference)")
-        final, x, _ = self.forward_nhwc(times, runtime.to_nhwc(obs[0]), delta_t, T)
-        return runtime.to_nchw(final[None]), 0, runtime.to_nchw(x)[None]
+            raise NotImplementedError("one sample per call (as the reference); FuturePredictionODE batches samples")
+        sc = self.make_schedule(times, delta_t, T)
+        final, x = self.forward_nhwc(sc, runtime.to_nhwc(obs[0])[:, None])
+        return runtime.to_nchw(final), 0, runtime.to_nchw(x[:, 0])[None]

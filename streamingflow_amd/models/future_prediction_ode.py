@@ -33,32 +33,57 @@ class FuturePredictionODE(nn.Module):
         self.res_blocks = nn.ModuleList(blocks)
 
     def observations(self, camera_states, lidar_states, camera_timestamp, lidar_timestamp, bs):
-        """Merge + time-sort one sample's observations (:36-49); returns (times, [n_obs,H,W,C])."""
+        """Merge + time-sort one sample's observations (:36-49); returns (times, [frames NCHW])."""
         cam_ts = camera_timestamp[bs].tolist() if camera_states is not None else []
         lid_ts = lidar_timestamp[bs].tolist() if lidar_states is not None else []
         times, order = sched.merge_observations(cam_ts, lid_ts)
-        frames = [(camera_states if src == 0 else lidar_states)[bs, i] for src, i in order]
-        return times, runtime.to_nhwc(torch.stack(frames, dim=0))
+        return times, [(camera_states if src == 0 else lidar_states)[bs, i] for src, i in order]
 
     def head_nhwc(self, x):
-        """x: [T, H, W, C] decoded predictions of one sample -> [T, H, W, C] (:56-62)."""
+        """x: [T, B, H, W, C] decoded predictions -> [T, B, H, W, C] (:56-62)."""
+        T, B, H, W, C = x.shape
         hidden = x[0]
         for gru, blk in zip(self.spatial_grus, self.res_blocks):
-            x = gru.forward_nhwc(x, hidden)
+            x = gru.forward_nhwc(x, hidden).view(T * B, H, W, C)
             if isinstance(blk, DeepLabHead):
                 x = blk.forward_nhwc(x)
             else:
                 for b in blk:
                     x = b.forward_nhwc(x)
+            x = x.view(T, B, H, W, C)
         return x
+
+    def _run_group(self, frames, scs):
+        """frames[b][o]: NCHW observation o of sample b (time order); scs: one Schedule per sample,
+        all with the same structure.  Returns [B, T, C, H, W]."""
+        B, n_obs = len(frames), len(frames[0])
+        stacked = torch.stack([frames[b][o] for o in range(n_obs) for b in range(B)], dim=0)
+        obs = runtime.to_nhwc(stacked)
+        obs = obs.view(n_obs, B, *obs.shape[1:])
+        _, x = self.gru_ode.forward_nhwc(scs if B > 1 else scs[0], obs)
+        y = self.head_nhwc(x)                                   # [T, B, H, W, C]
+        T = y.shape[0]
+        out = runtime.to_nchw(y.view(T * B, *y.shape[2:]))
+        return out.view(T, B, *out.shape[1:]).permute(1, 0, 2, 3, 4)
 
     def forward(self, future_prediction_input, camera_states, lidar_states, camera_timestamp, lidar_timestamp,
                 target_timestamp):
+        """Same contract as the reference.  Samples whose schedules have the same structure (same
+        sequence of jumps / steps and the same target selection — the normal case within a batch)
+        are pushed through the encoder, the rollout and the head together; step sizes may differ
+        per sample.  Samples with a different structure are processed in their own group."""
         some = camera_states if camera_states is not None else lidar_states
         runtime.require_cuda(some)
-        outs = []
-        for bs in range(some.shape[0]):
-            times, obs = self.observations(camera_states, lidar_states, camera_timestamp, lidar_timestamp, bs)
-            _, x, _ = self.gru_ode.forward_nhwc(times, obs, self.delta_t, target_timestamp[bs].tolist())
-            outs.append(runtime.to_nchw(self.head_nhwc(x)))
+        b = some.shape[0]
+        groups, meta = {}, []
+        for bs in range(b):
+            times, frames = self.observations(camera_states, lidar_states, camera_timestamp, lidar_timestamp, bs)
+            sc = self.gru_ode.make_schedule(times, self.delta_t, target_timestamp[bs].tolist())
+            groups.setdefault(sc.key(), []).append(bs)
+            meta.append((frames, sc))
+        outs = [None] * b
+        for members in groups.values():
+            y = self._run_group([meta[i][0] for i in members], [meta[i][1] for i in members])
+            for k, i in enumerate(members):
+                outs[i] = y[k]
         return torch.stack(outs, dim=0), 0

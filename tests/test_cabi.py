@@ -22,7 +22,7 @@ def test_build_and_symbols():
     assert lib.sf_version() >= 100
     assert lib.sf_status_string(-2) == b"workspace too small"
     # workspace sizing is host arithmetic only
-    assert lib.sf_dual_cell_ws_bytes(64, 50, 50) >= 10 * 64 * 2500 * 4
+    assert lib.sf_dual_cell_ws_bytes(64, 1, 50, 50) >= 10 * 64 * 2500 * 4
 
 
 def test_struct_sizes_match_header_layout():

@@ -100,3 +100,87 @@ def test_rollout_properties_long_horizon():
     d, _ = ode.rollout_nhwc(hx, sc, eps * 0 + 3.0)
     assert torch.equal(c, d)
     assert not torch.equal(a, c)
+
+
+class _PerSampleNoise:
+    """eps source for batched calls: draw k of sample b is hashfill.normal(f'eps{k}_s{b}')."""
+
+    def __init__(self, samples):
+        self.samples, self.k = list(samples), 0
+
+    def __call__(self, shape, dtype=torch.float32, device="cpu"):
+        k = self.k
+        self.k += 1
+        assert shape[0] == len(self.samples)
+        return torch.cat([hashfill.normal(f"eps{k}_s{b}", (1,) + tuple(shape[1:]), 7) for b in self.samples], 0)
+
+
+def test_batched_forward_matches_per_sample_oracle():
+    """Three samples with the same schedule structure but different step sizes go through the
+    encoder / rollout / head as ONE batch (per-image dt coefficients, per-image SE gates, per-image
+    ASPP pooling); each must equal the oracle run on that sample alone."""
+    C, H, W = 16, 32, 32
+    cam_ts = torch.tensor([[-1.0, -.5, 0], [-.97, -.52, -.01], [-1.02, -.49, 0]], dtype=torch.float64)
+    lid_ts = torch.tensor([[-.8, -.6, -.4, -.2, 0], [-.83, -.61, -.42, -.17, -.01], [-.79, -.6, -.38, -.2, 0]], dtype=torch.float64)
+    tgt_ts = torch.tensor([[.5, 1, 1.5, 2], [.52, 1.01, 1.49, 2.0], [.5, .98, 1.5, 2.03]], dtype=torch.float64)
+    net, sd = build_pair(C, "euler", True, True, 0.05)
+    cam = hashfill.normal("bcam", (3, 3, C, H, W), 9)
+    lid = hashfill.normal("blid", (3, 5, C, H, W), 10)
+    net.gru_ode.noise = _PerSampleNoise([0, 1, 2])
+    y, aux = net(cam[:, -1:].cuda(), cam.cuda(), lid.cuda(), cam_ts, lid_ts, tgt_ts)
+    assert aux == 0 and y.shape == (3, 4, C, H, W)
+    for b in range(3):
+        k = [0]
+
+        def eps_fn(shape, dtype, device, b=b, k=k):
+            k[0] += 1
+            return hashfill.normal(f"eps{k[0] - 1}_s{b}", tuple(shape), 7)
+
+        with torch.no_grad():
+            yr, _ = R.future_prediction_ode_forward(sd, cam[b:b + 1, -1:], cam[b:b + 1], lid[b:b + 1], cam_ts[b:b + 1],
+                                                    lid_ts[b:b + 1], tgt_ts[b:b + 1], 0.05, 2, "euler", True, True, eps_fn)
+        assert maxabs(y[b:b + 1], yr) <= TOL_E2E, b
+
+
+def test_mixed_schedule_structures_in_one_batch():
+    """Samples with different schedule structures are split into groups transparently."""
+    C, H, W = 8, 16, 16
+    cam_ts = torch.tensor([[-1.0, -.5, 0], [-1.0, -.5, 0]], dtype=torch.float64)
+    lid_ts = torch.tensor([[-.8, -.6, -.4, -.2, 0], [-.8, -.6, -.45, -.2, 0]], dtype=torch.float64)   # -.45: extra step
+    tgt_ts = torch.tensor([[.5, 1.0], [.5, 1.0]], dtype=torch.float64)
+    net, sd = build_pair(C, "euler", True, True, 0.05)
+    cam = hashfill.normal("mcam", (2, 3, C, H, W), 9)
+    lid = hashfill.normal("mlid", (2, 5, C, H, W), 10)
+    net.gru_ode.noise = hashfill.HashedNoise(0, zero=True)
+    y, _ = net(cam[:, -1:].cuda(), cam.cuda(), lid.cuda(), cam_ts, lid_ts, tgt_ts)
+    for b in range(2):
+        with torch.no_grad():
+            yr, _ = R.future_prediction_ode_forward(sd, cam[b:b + 1, -1:], cam[b:b + 1], lid[b:b + 1], cam_ts[b:b + 1],
+                                                    lid_ts[b:b + 1], tgt_ts[b:b + 1], 0.05, 2, "euler", True, True,
+                                                    hashfill.HashedNoise(0, zero=True))
+        assert maxabs(y[b:b + 1], yr) <= TOL_E2E, b
+
+
+def test_hipgraph_rollout_replay_matches_eager():
+    """The captured hipGraph of a rollout gives bitwise the eager result, also when replayed with
+    new observations / noise / step sizes of the same schedule structure."""
+    from streamingflow_amd import schedule as S
+    C, h, w = 64, 50, 50
+    cts, lts, tts, dt = cases.timeset("shipped")
+    net, _ = build_pair(C, "euler", True, True, dt)
+    ode = net.gru_ode
+    times, _ = S.merge_observations(cts[0].tolist(), lts[0].tolist())
+    sc1 = S.build_schedule(times, tts[0].tolist(), dt, True)
+    sc2 = S.build_schedule([t * 1.01 for t in times], [t * 1.01 for t in tts[0].tolist()], dt, True)
+    assert sc1.key() == sc2.key() and sc1.dts != sc2.dts
+    for k, sc in enumerate((sc1, sc2, sc1)):
+        hx = (hashfill.normal(f"ghx{k}", (8, h, w, C), 51) * 0.5).cuda()
+        eps = hashfill.normal(f"geps{k}", (sc.n_draws, h, w, C), 52).cuda()
+        ode.use_graph = False
+        a, fa = ode.rollout_nhwc(hx, sc, eps)
+        a, fa = a.clone(), fa.clone()
+        ode.use_graph = True
+        b, fb = ode.rollout_nhwc(hx, sc, eps)
+        assert torch.equal(a, b) and torch.equal(fa, fb), k
+    assert len(ode._graphs) == 1
+    ode.use_graph = False

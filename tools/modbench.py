@@ -56,9 +56,9 @@ def main():
     L = _lib.lib()
     eps = torch.randn(1, h, w, C, device="cuda")
     p = torch.empty_like(s)
-    ws = runtime.workspace(L.sf_infer_state_ws_bytes(C, h, w), "cuda")
+    ws = runtime.workspace(L.sf_infer_state_ws_bytes(C, 1, h, w), "cuda")
     pm = ode.p_model.packed().struct
-    f = lambda: L.sf_infer_state_fwd(pm, runtime.ptr(s), runtime.ptr(eps), runtime.ptr(p), None, h, w, runtime.ptr(ws),
+    f = lambda: L.sf_infer_state_fwd(pm, runtime.ptr(s), runtime.ptr(eps), runtime.ptr(p), None, 1, h, w, runtime.ptr(ws),
                                      ws.numel() * 4, runtime.stream_ptr())
     print(f"infer_state 50x50x64            : {timeit(f):9.1f} us  (2.806 GFLOP)")
     cts, lts, tts, dt = cases.timeset("shipped")
@@ -78,6 +78,11 @@ def main():
                      (64, 64, 3, 1, 200, 200), (128, 128, 3, 1, 200, 200, 1, 64)]:
             conv_case(*args)
         return
+    for B in (2, 4, 8):
+        hxb = torch.randn(8, B, h, w, C, device="cuda") * 0.5
+        eb = torch.randn(sc.n_draws, B, h, w, C, device="cuda")
+        t = timeit(lambda: ode.rollout_nhwc(hxb, sc, eb), 3, 1)
+        print(f"rollout batch {B}                 : {t:9.1f} us  = {t / B:8.1f} us / sample")
     if "--quick" in sys.argv:
         return
     obs = torch.randn(8, H, W, C, device="cuda")
