@@ -105,6 +105,12 @@ typedef struct sf_deeplab_w {
   int32_t C, hid;
 } sf_deeplab_w;
 
+/* Bottleneck (streamingflow/layers/convolutions.py:65-172 == beverse basic_modules.py:68-178) */
+typedef struct sf_bottleneck_w {
+  sf_conv_w down, conv, up, proj; /* BN folded; proj.w == NULL for the identity skip */
+  int32_t downsample;
+} sf_bottleneck_w;
+
 int sf_version(void);
 const char* sf_status_string(int status);
 
@@ -192,6 +198,17 @@ size_t sf_convnext_block_ws_bytes(int C, int n, int H, int W);
 int sf_deeplab_head_fwd(const sf_deeplab_w* w, const float* x, float* out, int n, int H, int W,
                         float* ws, size_t ws_bytes, void* stream);
 size_t sf_deeplab_head_ws_bytes(int C, int hid, int n, int H, int W);
+
+/* Bottleneck.forward — convolutions.py:164-172: [n][H][W][Cin] -> [n][Ho][Wo][Cout] */
+int sf_bottleneck_fwd(const sf_bottleneck_w* w, const float* x, float* out, int n, int H, int W, float* ws,
+                      size_t ws_bytes, void* stream);
+size_t sf_bottleneck_ws_bytes(int Cin, int Cout, int n, int H, int W);
+/* last_conv of DistributionModule / SpatialDistributionModule — beverse motion_modules.py:34-46,74-88
+ * (and streamingflow/models/distributions.py:35-49 with clamp == 0): [global avg-pool +] 1x1 conv + bias,
+ * second half of the channels clamped to [lo, hi] */
+int sf_dist_head_fwd(const sf_conv_w* w, const float* enc, float* out, int n, int H, int W, int global_pool,
+                     int clamp, float lo, float hi, float* ws, size_t ws_bytes, void* stream);
+size_t sf_dist_head_ws_bytes(int C, int n);
 
 /* hipGraph capture of whatever the caller enqueues between begin and end on `stream` (must not be
  * the legacy default stream). */

@@ -89,3 +89,10 @@ FPODE_CASES = {
     "c16_24_irregular":     (16, 24, 24, "irregular", "euler", True, True, False),
     "c8_16_lidar_only":     (8, 16, 16, "lidar_only", "euler", True, True, False),
 }
+
+
+# BEVerse-named secondary classes: tag -> (in_channels, latent_dim, h, w, n_future)
+BEVERSE_CASES = {
+    "config1_c32": (32, 16, 50, 50, 4),     # BASELINE config 1: FuturePrediction(32, 16, 3, 3) at 50x50
+    "odd_c16": (16, 8, 13, 21, 2),          # odd sizes: zero-pad + ceil pooling of the skip path
+}

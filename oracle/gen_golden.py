@@ -153,6 +153,36 @@ def gen_schedules(m):
         json.dump(out, f, indent=0)
 
 
+def gen_beverse(m):
+    """G6: BEVerse FuturePrediction / SpatialDistributionModule / DistributionModule and the unused
+    streamingflow DistributionModule; incl. BASELINE config 1's FuturePrediction(32, 16, 3, 3) case."""
+    refimport.install()
+    from mmdet3d.models.beverse.models import motion_modules as RM
+    from streamingflow.models import distributions as RD
+    out = {}
+    for tag, (C, lat, h, w, T) in cases.BEVERSE_CASES.items():
+        fp = RM.FuturePrediction(C, lat, 3, 3).eval()
+        fp.load_state_dict(hashfill.fill_state_dict(fp.state_dict(), seed=2))
+        x = hashfill.normal("bv_x", (1, T, lat, h, w), 21)
+        hid = hashfill.normal("bv_h", (1, C, h, w), 22)
+        s_t = hashfill.normal("bv_s", (1, 1, C, h, w), 23)
+        sdm = RM.SpatialDistributionModule(C, lat, -5.0, 5.0).eval()
+        sdm.load_state_dict(hashfill.fill_state_dict(sdm.state_dict(), seed=2, gain=3.0))
+        dm = RM.DistributionModule(C, lat, -0.05, 0.05).eval()
+        dm.load_state_dict(hashfill.fill_state_dict(dm.state_dict(), seed=2, gain=3.0))
+        sfd = RD.DistributionModule(C, lat).eval()
+        sfd.load_state_dict(hashfill.fill_state_dict(sfd.state_dict(), seed=2, gain=2.0))
+        with torch.no_grad():
+            out[tag + "/future_prediction"] = _np(fp(x, hid))
+            mu, ls = sdm(s_t)
+            out[tag + "/spatial_mu"], out[tag + "/spatial_log_sigma"] = _np(mu), _np(ls)
+            mu, ls = dm(s_t)
+            out[tag + "/dist_mu"], out[tag + "/dist_log_sigma"] = _np(mu), _np(ls)
+            out[tag + "/sf_dist"] = _np(sfd(s_t))
+        print(tag, {k.split("/")[1]: v.shape for k, v in out.items() if k.startswith(tag)})
+    np.savez_compressed(os.path.join(OUT, "beverse.npz"), **out)
+
+
 def gen_big(m):
     """G7: C=64, BEV 200x200, shipped schedule — statistics only."""
     C, H, W = 64, 200, 200
@@ -184,13 +214,15 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     m = refimport.modules()
-    todo = a.only.split(",") if a.only else ["ops", "fpode", "schedules"]
+    todo = a.only.split(",") if a.only else ["ops", "fpode", "schedules", "beverse"]
     if "ops" in todo:
         gen_ops(m)
     if "fpode" in todo:
         gen_fpode(m)
     if "schedules" in todo:
         gen_schedules(m)
+    if "beverse" in todo:
+        gen_beverse(m)
     if a.big or "big" in todo:
         gen_big(m)
 

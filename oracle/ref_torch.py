@@ -330,3 +330,76 @@ def future_prediction_ode_forward(sd, x_in, camera_states, lidar_states, camera_
             x = deeplab_head(sd, rb, x)
         x = x.view(b, s, c, h, w)
     return x, 0
+
+
+# --------------------------------------------------------------------------------------------
+# secondary: BEVerse-named classes (mmdet3d/models/beverse/models/*.py) and the unused
+# streamingflow/models/distributions.py — signature-compat rows a8 / a17 of SURVEY.md §8
+# --------------------------------------------------------------------------------------------
+def bottleneck(sd, p, x, downsample=False):
+    """streamingflow/layers/convolutions.py:164-172 == beverse basic_modules.py:168-178."""
+    L = p + ".layers"
+    r = F.relu(_bn(sd, L + ".abn_down_project.0", _conv(sd, L + ".conv_down_project", x)))
+    r = F.relu(_bn(sd, L + ".abn.0", _conv(sd, L + ".conv", r, padding=1, stride=2 if downsample else 1)))
+    r = F.relu(_bn(sd, L + ".abn_up_project.0", _conv(sd, L + ".conv_up_project", r)))
+    if (p + ".projection.conv_skip_proj.weight") in sd:
+        if downsample:
+            x = F.pad(x, (0, x.shape[-1] % 2, 0, x.shape[-2] % 2), value=0)
+            x = F.max_pool2d(x, 2, 2)
+        return r + _bn(sd, p + ".projection.bn_skip_proj", _conv(sd, p + ".projection.conv_skip_proj", x))
+    return r + x
+
+
+def beverse_spatial_gru(sd, p, x, state):
+    """beverse basic_modules.py:241-284 (flow=None): candidate = conv+BN+ReLU, returns the states."""
+    b, T, c, h, w = x.shape
+    out = []
+    for t in range(T):
+        xs = torch.cat([x[:, t], state], dim=1)
+        u = torch.sigmoid(_conv(sd, p + ".conv_update", xs, padding=1))
+        r = torch.sigmoid(_conv(sd, p + ".conv_reset", xs, padding=1))
+        cand = torch.cat([x[:, t], (1.0 - r) * state], dim=1)
+        cand = F.relu(_bn(sd, p + ".conv_state_tilde.norm", _conv(sd, p + ".conv_state_tilde.conv", cand, padding=1)))
+        state = (1.0 - u) * state + u * cand
+        out.append(state)
+    return torch.stack(out, dim=1)
+
+
+def beverse_future_prediction(sd, x, hidden, n_gru_blocks=3, n_res_layers=3, p=""):
+    """beverse motion_modules.py:132-146."""
+    for i in range(n_gru_blocks):
+        x = beverse_spatial_gru(sd, f"{p}spatial_grus.{i}", x, hidden)
+        b, n, c, h, w = x.shape
+        y = x.reshape(b * n, c, h, w)
+        for j in range(n_res_layers):
+            y = bottleneck(sd, f"{p}res_blocks.{i}.{j}", y)
+        x = y.view(b, n, c, h, w)
+    return x
+
+
+def _dist_encoder(sd, p, x, n):
+    for i in range(n):
+        x = bottleneck(sd, f"{p}.model.{i}", x, downsample=True)
+    return x
+
+
+def beverse_spatial_distribution(sd, s_t, latent_dim, lo, hi, p=""):
+    """beverse motion_modules.py:74-88."""
+    e = _dist_encoder(sd, p + "encoder", s_t[:, 0], 2)
+    o = _conv(sd, p + "last_conv.0", e)
+    return o[:, :latent_dim], torch.clamp(o[:, latent_dim:], lo, hi)
+
+
+def beverse_distribution(sd, s_t, latent_dim, lo, hi, p=""):
+    """beverse motion_modules.py:34-46."""
+    b = s_t.shape[0]
+    e = _dist_encoder(sd, p + "encoder", s_t[:, 0], 2)
+    o = _conv(sd, p + "last_conv.1", e.mean(dim=(2, 3), keepdim=True)).view(b, 1, 2 * latent_dim)
+    return o[:, :, :latent_dim], torch.clamp(o[:, :, latent_dim:], lo, hi)
+
+
+def sf_distribution(sd, s_t, latent_dim, p=""):
+    """streamingflow/models/distributions.py:35-51, method GAUSSIAN."""
+    b = s_t.shape[0]
+    e = _dist_encoder(sd, p + "encoder", s_t[:, 0], 4)
+    return _conv(sd, p + "decoder.1", e.mean(dim=(2, 3), keepdim=True)).view(b, 1, 2 * latent_dim)

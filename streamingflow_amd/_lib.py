@@ -65,6 +65,10 @@ class DeepLabW(C.Structure):
                 ("conv3", ConvW), ("cls", ConvW), ("C", C.c_int32), ("hid", C.c_int32)]
 
 
+class BottleneckW(C.Structure):
+    _fields_ = [("down", ConvW), ("conv", ConvW), ("up", ConvW), ("proj", ConvW), ("downsample", C.c_int32)]
+
+
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 # name -> (restype, argtypes); every symbol declared in include/sfnative.h
 SIGNATURES = {
@@ -96,6 +100,10 @@ SIGNATURES = {
     "sf_convnext_block_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "sf_deeplab_head_fwd": (_i, [C.POINTER(DeepLabW), _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sf_deeplab_head_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "sf_bottleneck_fwd": (_i, [C.POINTER(BottleneckW), _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_bottleneck_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "sf_dist_head_fwd": (_i, [C.POINTER(ConvW), _vp, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float, _vp, _sz, _vp]),
+    "sf_dist_head_ws_bytes": (_sz, [_i, _i]),
     "sf_graph_begin": (_i, [_vp]),
     "sf_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "sf_graph_launch": (_i, [_vp, _vp]),

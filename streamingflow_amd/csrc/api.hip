@@ -12,7 +12,8 @@ namespace sf {
 hipError_t launch_conv(const ConvLaunch& L, int epi, int cfg, hipStream_t stream);
 hipError_t launch_conv_direct(const ConvLaunch& L, int epi, int mt, int ks, hipStream_t stream);
 hipError_t launch_transpose(const float* in, float* out, int n, int rows, int cols, hipStream_t s);
-hipError_t launch_maxpool2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s);
+hipError_t launch_maxpool2(const float* in, float* out, int n, int Hin, int Win, int C, int ceil_pad, hipStream_t s);
+hipError_t launch_mean_from_partials(const float* part, float* out, int n, int nslab, int C, int hw, hipStream_t s);
 hipError_t launch_upsample2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s);
 hipError_t launch_se_fc(const float* chansum, int ntile, int C, int Cr, int hw, const float* fc0,
                         const float* fc2, float* scale, int n_img, hipStream_t s);
@@ -77,6 +78,7 @@ ConvProblem problem(const sf_conv_w& w, const float* in0, const float* in1, floa
   p.cout = w.cout; p.cout_pad = w.cout_pad; p.act = w.act;
   p.add_cs = w.cout; p.out_cs = w.cout; p.out_co = 0; p.out2_cs = w.cout;
   p.eps = 1e-6f;
+  p.clamp_from = -1;
   return p;
 }
 
@@ -513,7 +515,9 @@ size_t sf_spatial_gru_ws_bytes(int C, int n_img, int H, int W) {
 }
 int sf_spatial_gru_fwd(const sf_gru_w* w, const float* x, const float* state0, float* out, int T, int n_img, int H,
                        int W, float* ws, size_t ws_bytes, void* stream) {
-  if (!w || !x || !state0 || !out || !valid_w(w->gates) || !valid_w(w->cand) || !valid_w(w->decoder)) return SF_ERR_INVALID;
+  if (!w || !x || !state0 || !out || !valid_w(w->gates) || !valid_w(w->cand)) return SF_ERR_INVALID;
+  const bool has_dec = w->decoder.w != nullptr;
+  if (has_dec && !valid_w(w->decoder)) return SF_ERR_INVALID;
   const int C = w->cand.cout, Cx = w->gates.c0;
   const size_t P = (size_t)n_img * H * W;
   Arena A(ws, ws_bytes);
@@ -524,9 +528,11 @@ int sf_spatial_gru_fwd(const sf_gru_w* w, const float* x, const float* state0, f
   hipStream_t st = (hipStream_t)stream;
   const float* cur = state0;
   for (int t = 0; t < T; ++t) {   // temporal.py:35-39
-    float* nxt = (t & 1) ? sb : sa;
+    // without a decoder (BEVerse SpatialGRU, basic_modules.py:225-284) the states ARE the output
+    float* nxt = has_dec ? ((t & 1) ? sb : sa) : out + t * P * C;
     SF_TRY(gru_cell(*w, x + t * P * Cx, cur, nxt, g, n_img, H, W, st));
-    SF_TRY(run1(problem(w->decoder, nxt, nullptr, out + t * P * w->decoder.cout, n_img, H, W), EPI_AFFINE, st));
+    if (has_dec)
+      SF_TRY(run1(problem(w->decoder, nxt, nullptr, out + t * P * w->decoder.cout, n_img, H, W), EPI_AFFINE, st));
     cur = nxt;
   }
   return SF_OK;
@@ -659,9 +665,9 @@ int sf_small_encoder_fwd(const sf_encoder_w* w, const float* x, float* out, int 
   float* o2 = A.take(P2 * 4 * F); float* o3 = A.take(P2 * 4 * F); float* o4 = A.take(P2 * 4 * F);
   if (!A.ok()) return SF_ERR_WORKSPACE;
   SF_TRY(res_block(w->blocks[0], x, o0, t0, pr0, n, H, W, 0, st));            // res_models.py:101-105
-  SF_HIP(launch_maxpool2(o0, q1, n, H, W, F, st));
+  SF_HIP(launch_maxpool2(o0, q1, n, H, W, F, 0, st));
   SF_TRY(res_block(w->blocks[1], q1, o1, t1, pr1, n, H1, W1, 0, st));
-  SF_HIP(launch_maxpool2(o1, q2, n, H1, W1, 2 * F, st));
+  SF_HIP(launch_maxpool2(o1, q2, n, H1, W1, 2 * F, 0, st));
   SF_TRY(res_block(w->blocks[2], q2, o2, t2, pr2, n, H2, W2, 0, st));
   SF_TRY(res_block(w->blocks[3], o2, o3, t2, pr2, n, H2, W2, 0, st));
   SF_TRY(res_block(w->blocks[4], o3, o4, t2, pr2, n, H2, W2, 0, st));
@@ -694,6 +700,71 @@ int sf_small_decoder_fwd(const sf_decoder_w* w, const float* z, float* out, int 
   SF_TRY(res_block(w->blocks[4], c0, c1, c2, c3, n, 4 * h, 4 * wd, 0, st));             // F -> F @4h
   SF_TRY(run1(problem(w->last0, c1, nullptr, c2, n, 4 * h, 4 * wd), EPI_AFFINE, st));
   return run1(problem(w->last1, c2, nullptr, out, n, 4 * h, 4 * wd), EPI_AFFINE, st);
+}
+
+// ---- Bottleneck / distribution heads (secondary, BEVerse-compatible classes) ------------------------
+size_t sf_bottleneck_ws_bytes(int Cin, int Cout, int n, int H, int W) {
+  size_t P = (size_t)n * H * W;
+  return (2 * al(P * (Cin / 2)) + al(P * Cin) + al(P * Cout)) * sizeof(float);
+}
+// Bottleneck.forward (streamingflow/layers/convolutions.py:65-172, beverse basic_modules.py:68-178):
+// 1x1 -> BN,ReLU -> 3x3 (stride 2 if downsample) -> BN,ReLU -> 1x1 -> BN,ReLU, + skip (identity, or
+// [zero-pad + 2x2 max-pool] + 1x1 + BN).  out: [n][Ho][Wo][Cout], Ho = ceil(H/2) when downsampling.
+int sf_bottleneck_fwd(const sf_bottleneck_w* w, const float* x, float* out, int n, int H, int W, float* ws,
+                      size_t ws_bytes, void* stream) {
+  if (!w || !x || !out || !valid_w(w->down) || !valid_w(w->conv) || !valid_w(w->up)) return SF_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  Arena A(ws, ws_bytes);
+  const int Cin = w->down.c0, Cm = w->down.cout, Cout = w->up.cout;
+  const int Ho = w->downsample ? (H + 1) / 2 : H, Wo = w->downsample ? (W + 1) / 2 : W;
+  const size_t P = (size_t)n * H * W, Po = (size_t)n * Ho * Wo;
+  float* t1 = A.take(P * Cm);
+  float* t2 = A.take(Po * Cm);
+  float* xp = A.take(Po * Cin);
+  float* pr = A.take(Po * Cout);
+  if (!A.ok()) return SF_ERR_WORKSPACE;
+  SF_TRY(run1(problem(w->down, x, nullptr, t1, n, H, W), EPI_AFFINE, st));
+  ConvProblem c = problem(w->conv, t1, nullptr, t2, n, H, W);
+  if (c.Hout != Ho || c.Wout != Wo) return SF_ERR_INVALID;
+  SF_TRY(run1(c, EPI_AFFINE, st));
+  ConvProblem u = problem(w->up, t2, nullptr, out, n, Ho, Wo);
+  if (w->proj.w) {
+    const float* src = x;
+    if (w->downsample) {
+      SF_HIP(launch_maxpool2(x, xp, n, H, W, Cin, 1, st));
+      src = xp;
+    }
+    SF_TRY(run1(problem(w->proj, src, nullptr, pr, n, Ho, Wo), EPI_AFFINE, st));
+    u.add = pr;
+  } else {
+    if (w->downsample || Cin != Cout) return SF_ERR_INVALID;
+    u.add = x;
+  }
+  return run1(u, EPI_AFFINE, st);
+}
+
+// 1x1 head of the (Spatial)DistributionModule (beverse motion_modules.py:34-46, 74-88): optional
+// global average pool, 1x1 conv with bias, log-sigma half clamped to [lo, hi] when clamp != 0.
+size_t sf_dist_head_ws_bytes(int C, int n) { return (al((size_t)n * 64 * C) + al((size_t)n * C)) * sizeof(float); }
+int sf_dist_head_fwd(const sf_conv_w* w, const float* enc, float* out, int n, int H, int W, int global_pool, int clamp,
+                     float lo, float hi, float* ws, size_t ws_bytes, void* stream) {
+  if (!w || !enc || !out || !valid_w(*w)) return SF_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const int C = w->c0;
+  const float* src = enc;
+  int Hh = H, Wh = W;
+  if (global_pool) {
+    Arena A(ws, ws_bytes);
+    float* part = A.take((size_t)n * 64 * C);
+    float* mean = A.take((size_t)n * C);
+    if (!A.ok()) return SF_ERR_WORKSPACE;
+    SF_HIP(launch_chan_partial(enc, part, n, H * W, C, 64, st));
+    SF_HIP(launch_mean_from_partials(part, mean, n, 64, C, H * W, st));
+    src = mean; Hh = 1; Wh = 1;
+  }
+  ConvProblem p = problem(*w, src, nullptr, out, n, Hh, Wh);
+  if (clamp) { p.clamp_from = w->cout / 2; p.clamp_lo = lo; p.clamp_hi = hi; }
+  return run1(p, EPI_AFFINE, st);
 }
 
 // ---- head blocks ----------------------------------------------------------------------------------

@@ -38,9 +38,11 @@ hipError_t launch_transpose(const float* in, float* out, int n, int rows, int co
 }
 
 // ---- 2x2 max-pool (stride 2, floor) and nearest x2 upsample, NHWC ----------------------------
+// ceil_pad != 0: output is ceil(H/2) x ceil(W/2) and the missing row/column of an odd input counts
+// as zeros (F.pad(value=0) + MaxPool2d(2,2), BEVerse Bottleneck skip path)
 __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                       int n, int Hin, int Win, int C) {
-  const int Ho = Hin >> 1, Wo = Win >> 1, C4 = C >> 2;
+                                                       int n, int Hin, int Win, int C, int ceil_pad) {
+  const int Ho = (Hin + ceil_pad) >> 1, Wo = (Win + ceil_pad) >> 1, C4 = C >> 2;
   const size_t total = (size_t)n * Ho * Wo * C4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     int c4 = i % C4;
@@ -50,7 +52,10 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__
     int oy = q % Ho;
     int img = q / Ho;
     const float* b = in + (((size_t)img * Hin + 2 * oy) * Win + 2 * ox) * C + c4 * 4;
-    float4 a0 = ld4a(b), a1 = ld4a(b + C), a2 = ld4a(b + (size_t)Win * C), a3 = ld4a(b + (size_t)Win * C + C);
+    const bool xr = 2 * ox + 1 < Win, yb = 2 * oy + 1 < Hin;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a0 = ld4a(b), a1 = xr ? ld4a(b + C) : z, a2 = yb ? ld4a(b + (size_t)Win * C) : z,
+           a3 = (xr && yb) ? ld4a(b + (size_t)Win * C + C) : z;
     float4 m;
     m.x = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x));
     m.y = fmaxf(fmaxf(a0.y, a1.y), fmaxf(a2.y, a3.y));
@@ -80,10 +85,10 @@ static int grid_for(size_t total) {
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
-hipError_t launch_maxpool2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s) {
-  size_t total = (size_t)n * (Hin / 2) * (Win / 2) * (C / 4);
+hipError_t launch_maxpool2(const float* in, float* out, int n, int Hin, int Win, int C, int ceil_pad, hipStream_t s) {
+  size_t total = (size_t)n * ((Hin + ceil_pad) / 2) * ((Win + ceil_pad) / 2) * (C / 4);
   if (!total) return hipSuccess;
-  hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, n, Hin, Win, C);
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, n, Hin, Win, C, ceil_pad);
   return hipGetLastError();
 }
 hipError_t launch_upsample2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s) {
@@ -302,6 +307,21 @@ __global__ __launch_bounds__(256) void aspp_pool_kernel(const float* __restrict_
     for (int h = 0; h < hid; ++h) s += wp[co * hid + h] * gg[h];
     bias_img[(size_t)img * hid + co] = ps[co] * s + pb[co];
   }
+}
+
+// mean over pixels from per-slab sums: out[img][c] = inv_hw * sum_slab part[img][slab][c]
+__global__ void mean_from_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int nslab, int C,
+                                          float inv_hw) {
+  const int img = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int t = 0; t < nslab; ++t) s += part[((size_t)img * nslab + t) * C + c];
+    out[(size_t)img * C + c] = s * inv_hw;
+  }
+}
+hipError_t launch_mean_from_partials(const float* part, float* out, int n, int nslab, int C, int hw, hipStream_t s) {
+  hipLaunchKernelGGL(mean_from_partials_kernel, dim3(n), dim3(256), 0, s, part, out, nslab, C, 1.f / (float)hw);
+  return hipGetLastError();
 }
 
 hipError_t launch_chan_partial(const float* in, float* part, int n, int HW, int C, int nslab, hipStream_t s) {

@@ -97,6 +97,12 @@ __device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[
           if constexpr (EPI == EPI_AFFINE) {
             y.x = act_apply(v.x, P.act); y.y = act_apply(v.y, P.act);
             y.z = act_apply(v.z, P.act); y.w = act_apply(v.w, P.act);
+            if (P.clamp_from >= 0) {   // clamp(log_sigma) of the distribution heads (motion_modules.py:44,85)
+              if (c + 0 >= P.clamp_from) y.x = fminf(fmaxf(y.x, P.clamp_lo), P.clamp_hi);
+              if (c + 1 >= P.clamp_from) y.y = fminf(fmaxf(y.y, P.clamp_lo), P.clamp_hi);
+              if (c + 2 >= P.clamp_from) y.z = fminf(fmaxf(y.z, P.clamp_lo), P.clamp_hi);
+              if (c + 3 >= P.clamp_from) y.w = fminf(fmaxf(y.w, P.clamp_lo), P.clamp_hi);
+            }
             if (P.add) {
               float4 ad = ld4(P.add + (size_t)gp * P.add_cs + c);
               if (P.add_scale) {
@@ -105,7 +111,9 @@ __device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[
               }
               y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w;
             }
-          } else {  // EPI_BLEND  (temporal.py:56, temporal_ode_bayes.py:145,160)
+          } else {  // EPI_BLEND  (temporal.py:56, temporal_ode_bayes.py:145,160; BEVerse cells apply BN+ReLU first)
+            v.x = act_apply(v.x, P.act); v.y = act_apply(v.y, P.act);
+            v.z = act_apply(v.z, P.act); v.w = act_apply(v.w, P.act);
             float4 u = ld4(P.e0 + (size_t)gp * P.e0_cs + c);
             float4 s = ld4(P.e1 + (size_t)gp * P.e1_cs + c);
             y.x = (1.f - u.x) * s.x + u.x * v.x; y.y = (1.f - u.y) * s.y + u.y * v.y;

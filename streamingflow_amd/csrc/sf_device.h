@@ -58,6 +58,8 @@ struct ConvProblem {
   unsigned int* counters; // [tiles], zero before the launch; reset by the last arriver
   int nsplit;
   int coef_stride;        // floats between per-image coefficient records (0: shared)
+  int clamp_from;         // AFFINE: output channels >= clamp_from are clamped to [clamp_lo, clamp_hi] (<0: off)
+  float clamp_lo, clamp_hi;
 };
 
 #define SF_MAX_GROUP 4

@@ -16,6 +16,72 @@ def _seq(*mods):
     return nn.Sequential(*mods)
 
 
+class Bottleneck(PackedModule):
+    """1x1 -> 3x3 (optionally stride 2) -> 1x1 bottleneck with a residual connection
+    (convolutions.py:65-172; identical to BEVerse's basic_modules.Bottleneck)."""
+
+    def __init__(self, in_channels, out_channels=None, kernel_size=3, dilation=1, groups=1, upsample=False,
+                 downsample=False, dropout=0.0):
+        super().__init__()
+        if upsample or dilation != 1 or groups != 1 or kernel_size != 3:
+            raise NotImplementedError("Bottleneck: only the k3 / dilation 1 / groups 1, non-upsampling form is on the path")
+        from collections import OrderedDict
+        self._downsample = downsample
+        mid = int(in_channels / 2)
+        out_channels = out_channels or in_channels
+
+        def abn(c):
+            return nn.Sequential(nn.BatchNorm2d(c), nn.ReLU(inplace=True))
+        self.layers = nn.Sequential(OrderedDict([
+            ('conv_down_project', nn.Conv2d(in_channels, mid, kernel_size=1, bias=False)), ('abn_down_project', abn(mid)),
+            ('conv', nn.Conv2d(mid, mid, kernel_size=3, bias=False, stride=2 if downsample else 1, padding=1)),
+            ('abn', abn(mid)),
+            ('conv_up_project', nn.Conv2d(mid, out_channels, kernel_size=1, bias=False)), ('abn_up_project', abn(out_channels)),
+            ('dropout', nn.Dropout2d(p=dropout))]))
+        if out_channels == in_channels and not downsample:
+            self.projection = None
+        else:
+            proj = OrderedDict()
+            if downsample:
+                proj['upsample_skip_proj'] = nn.MaxPool2d(kernel_size=2, stride=2)
+            proj['conv_skip_proj'] = nn.Conv2d(in_channels, out_channels, kernel_size=1, bias=False)
+            proj['bn_skip_proj'] = nn.BatchNorm2d(out_channels)
+            self.projection = nn.Sequential(proj)
+        self.cin, self.cout = in_channels, out_channels
+
+    def _pack(self):
+        if self.training:
+            raise RuntimeError("streamingflow_amd is inference-only: call .eval() (BatchNorm uses running statistics)")
+        pk = packing.Pack(_lib.BottleneckW())
+        s, L = pk.struct, self.layers
+        sc, bi = packing.bn_fold(L.abn_down_project[0])
+        s.down = packing.conv_w(pk, L.conv_down_project.weight, self.cin, scale=sc, bias=bi, act="relu")
+        sc, bi = packing.bn_fold(L.abn[0])
+        s.conv = packing.conv_w(pk, L.conv.weight, self.cin // 2, scale=sc, bias=bi, act="relu",
+                                stride=2 if self._downsample else 1, pad=1)
+        sc, bi = packing.bn_fold(L.abn_up_project[0])
+        s.up = packing.conv_w(pk, L.conv_up_project.weight, self.cin // 2, scale=sc, bias=bi, act="relu")
+        if self.projection is not None:
+            sc, bi = packing.bn_fold(self.projection.bn_skip_proj)
+            s.proj = packing.conv_w(pk, self.projection.conv_skip_proj.weight, self.cin, scale=sc, bias=bi)
+        s.downsample = int(bool(self._downsample))
+        return pk
+
+    def forward_nhwc(self, x):
+        n, h, w, c = x.shape
+        L = _lib.lib()
+        ho, wo = ((h + 1) // 2, (w + 1) // 2) if self._downsample else (h, w)
+        ws = runtime.workspace(L.sf_bottleneck_ws_bytes(self.cin, self.cout, n, h, w), x.device)
+        out = torch.empty((n, ho, wo, self.cout), dtype=torch.float32, device=x.device)
+        _lib.check(L.sf_bottleneck_fwd(self.packed().struct, ptr(x), ptr(out), n, h, w, ptr(ws), ws.numel() * 4,
+                                       runtime.stream_ptr(x.device)), "bottleneck")
+        return out
+
+    def forward(self, *args):
+        (x,) = args
+        return runtime.to_nchw(self.forward_nhwc(runtime.to_nhwc(x)))
+
+
 class LayerNorm(nn.Module):
     """Parameter container for convolutions.py:283-308; always applied fused into a conv epilogue."""
 

@@ -1,0 +1,72 @@
+"""Secondary, signature-compatible classes: BEVerse FuturePrediction,
+SpatialDistributionModule, DistributionModule and streamingflow's (unused) DistributionModule.
+CPU: the oracle against fixtures generated from the reference classes (tests/golden/beverse.npz);
+GPU: the product classes against the same fixtures."""
+import pytest
+import torch
+
+from util import cases, hashfill, gold, maxabs
+from oracle import ref_torch as R
+
+
+def _inputs(tag):
+    C, lat, h, w, T = cases.BEVERSE_CASES[tag]
+    x = hashfill.normal("bv_x", (1, T, lat, h, w), 21)
+    hid = hashfill.normal("bv_h", (1, C, h, w), 22)
+    s_t = hashfill.normal("bv_s", (1, 1, C, h, w), 23)
+    return C, lat, x, hid, s_t
+
+
+def _build(device):
+    from streamingflow_amd.beverse import motion_modules as M
+    from streamingflow_amd.models import distributions as D
+
+    def mk(tag):
+        C, lat, *_ = cases.BEVERSE_CASES[tag]
+        mods = {"fp": (M.FuturePrediction(C, lat, 3, 3), 1.0), "sdm": (M.SpatialDistributionModule(C, lat, -5.0, 5.0), 3.0),
+                "dm": (M.DistributionModule(C, lat, -0.05, 0.05), 3.0), "sfd": (D.DistributionModule(C, lat), 2.0)}
+        out = {}
+        for k, (mod, gain) in mods.items():
+            sd = hashfill.fill_state_dict(mod.state_dict(), seed=2, gain=gain)
+            mod.load_state_dict(sd)
+            out[k] = (mod.eval().to(device), sd)
+        return out
+    return mk
+
+
+@pytest.mark.parametrize("tag", list(cases.BEVERSE_CASES))
+def test_oracle_matches_reference_fixture(tag):
+    g = gold("beverse.npz")
+    C, lat, x, hid, s_t = _inputs(tag)
+    mods = _build("cpu")(tag)
+    with torch.no_grad():
+        assert maxabs(R.beverse_future_prediction(mods["fp"][1], x, hid), g[tag + "/future_prediction"]) <= 1e-5
+        mu, ls = R.beverse_spatial_distribution(mods["sdm"][1], s_t, lat, -5.0, 5.0)
+        assert maxabs(mu, g[tag + "/spatial_mu"]) <= 1e-5 and maxabs(ls, g[tag + "/spatial_log_sigma"]) <= 1e-5
+        mu, ls = R.beverse_distribution(mods["dm"][1], s_t, lat, -0.05, 0.05)
+        assert maxabs(mu, g[tag + "/dist_mu"]) <= 1e-5 and maxabs(ls, g[tag + "/dist_log_sigma"]) <= 1e-5
+        assert maxabs(R.sf_distribution(mods["sfd"][1], s_t, lat), g[tag + "/sf_dist"]) <= 1e-5
+
+
+def _close(a, ref, rel=2e-5, scale_ref=None):
+    """fp32 summation-order differences only: relative to the tensor's magnitude (the hashed
+    distribution heads deliberately produce |values| of a few hundred so that the clamp bites)."""
+    import numpy as np
+    scale = ref if scale_ref is None else scale_ref      # clamped outputs: judge by the unclamped magnitude
+    return maxabs(a, ref) <= rel * max(1.0, float(np.abs(scale).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(cases.BEVERSE_CASES))
+def test_gpu_matches_reference_fixture(tag):
+    g = gold("beverse.npz")
+    C, lat, x, hid, s_t = _inputs(tag)
+    mods = _build("cuda")(tag)
+    y = mods["fp"][0](x.cuda(), hid.cuda())
+    assert maxabs(y, g[tag + "/future_prediction"]) <= 1e-3
+    mu, ls = mods["sdm"][0](s_t.cuda())
+    assert _close(mu, g[tag + "/spatial_mu"]) and _close(ls, g[tag + "/spatial_log_sigma"], scale_ref=g[tag + "/spatial_mu"])
+    mu, ls = mods["dm"][0](s_t.cuda())
+    assert _close(mu, g[tag + "/dist_mu"]) and _close(ls, g[tag + "/dist_log_sigma"], scale_ref=g[tag + "/dist_mu"])
+    assert float(ls.abs().max()) <= 0.05 + 1e-7            # the clamp is exercised
+    assert _close(mods["sfd"][0](s_t.cuda()), g[tag + "/sf_dist"])
