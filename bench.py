@@ -1,11 +1,14 @@
 #!/usr/bin/env python
 """bench.py — ODE-steps/s of the MI355X-native GRU-ODE future-state path (BASELINE.json metric).
 
-One "step" of this bench = one pass of the hot path over one synthetic sample: a full
-``FuturePredictionODE.forward`` of BASELINE config 2 (C=64, BEV 200x200, 3 camera + 5 LiDAR
-observations, 7 targets, variable-step Euler: 10 ODE steps + 8 Bayesian jumps, SmallEncoder on 8
-frames, SmallDecoder + 2x(SpatialGRU + res block) head on 7 frames), inputs resident in HBM.
-``value`` = ODE steps integrated per second over all ranks = n_ode_steps * K * N / t.
+One "step" of this bench = one pass of the hot path over one batch of synthetic input: a full
+``FuturePredictionODE.forward`` on ``--batch`` samples (default 8) of BASELINE config 2 (C=64, BEV
+200x200, 3 camera + 5 LiDAR observations, 7 targets, variable-step Euler: 10 ODE steps + 8
+Bayesian jumps, SmallEncoder on 8 frames, SmallDecoder + 2x(SpatialGRU + res block) head on 7 frames
+per sample), inputs resident in HBM.  The reference's forward takes a batch and loops over it one
+sample at a time; here samples with the same schedule structure go through the kernels together.
+``value`` = ODE steps integrated per second over all ranks = n_ode_steps * batch * K * N / t;
+the single-sample (batch 1) latency of the same forward is reported next to it.
 
 N > 1: one process per GPU (torchrun), every rank runs its own sample (the reference is batch-1,
 samples shard with no data-path collective: weak scaling); barrier + synchronize on both sides of
@@ -36,7 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--timeset", default="shipped", help="oracle.cases.TIMESETS key (default: BASELINE config 2)")
     ap.add_argument("--solver", default="euler")
-    ap.add_argument("--batch", type=int, default=1, help="samples per forward on each GPU (the reference API "
+    ap.add_argument("--batch", type=int, default=8, help="samples per forward on each GPU (the reference API "
                     "takes a batch and loops over it; here same-structure samples run through the kernels together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -100,6 +103,17 @@ def main():
         el = float(t.item())
     ms_per_step = 1e3 * el / a.steps
     value = n_ode * B * a.steps * world / el
+
+    # ---- single-sample latency of the same forward (batch 1) -----------------------------------------
+    def forward1():
+        return net(x_in[:1], cam_d[:1], lid_d[:1], cts, lts, tts)
+    forward1()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        forward1()
+    torch.cuda.synchronize()
+    single_ms = 1e3 * (time.perf_counter() - t0) / 3
 
     # ---- ODE rollout alone (the serial chain the north star names), same stream, hipEvents -------
     L = _lib.lib()
@@ -199,7 +213,8 @@ def main():
                                       f"({len(times)} observations, {tts.shape[1]} targets), variable-step {a.solver}: "
                                       f"{n_ode} ODE steps + {sc.n_jumps} jumps per sample, {B} sample(s) per forward per GPU",
                           "parallelism": f"replicas x{world} (sample sharding, no data-path collective)"},
-               "samples_per_s": B * a.steps * world / el, "batch_per_gpu": B,
+               "samples_per_s": B * a.steps * world / el, "batch_per_gpu": B, "ms_per_sample": ms_per_step / B,
+               "single_sample_forward_ms": single_ms, "single_sample_ode_steps_per_s": n_ode / (single_ms * 1e-3),
                "ode_rollout_only": rollout, "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:

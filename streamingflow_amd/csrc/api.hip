@@ -105,7 +105,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, l_cfg; };
+struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, l_cfg, mid_tiles; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -118,6 +118,7 @@ const Tune& tune() {
     x.split = geti("SF_SPLIT", 1);                 // cross-workgroup split-K on 64x64 tiles (small P)
     x.split_target = geti("SF_SPLIT_WGS", 512);    // aim for this many workgroups per launch
     x.split_min_chunks = geti("SF_SPLIT_MINCH", 2);
+    x.mid_tiles = geti("SF_MID_TILES", 640);
     x.l_cfg = geti("SF_L_CFG", 0);                 // experimental large-P tiling override (5..9)
     x.split_from = geti("SF_SPLIT_FROM", 100);     // only layers with at least this many K chunks (the 7x7)
     return x;
@@ -129,7 +130,7 @@ const Tune& tune() {
 // top-level entry points (SplitScope) — thread-local pointer, no global allocation.
 struct SplitCtx { float* slab; size_t slab_floats; unsigned* counters; int ncounters; };
 thread_local SplitCtx* g_split = nullptr;
-constexpr size_t SPLIT_SLAB_FLOATS = size_t(4) << 20;   // 16 MB: 1024 (tile, slice) pairs of 64x64 fp32
+constexpr size_t SPLIT_SLAB_FLOATS = size_t(8) << 20;   // 32 MB: 2048 (tile, slice) pairs of 64x64 fp32
 constexpr int SPLIT_COUNTERS = 4096;
 constexpr size_t SPLIT_WS_FLOATS = SPLIT_SLAB_FLOATS + SPLIT_COUNTERS + 128;
 
@@ -189,12 +190,16 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   }
   // measured (profiles/r01_d_sweep_convs.txt): the slab publish + ticket + acquire costs ~8 us, so
   // it only pays for the long-K layers (7x7: 196 chunks, 68 -> 44 us)
-  if ((cfg == 0 || cfg == 3) && tune().split && g_split && chunks_max >= tune().split_from) {
-    int tiles_total = 0;
-    for (int i = 0; i < n; ++i) {
-      const int Pi = ps[i].n_img * ps[i].Hout * ps[i].Wout;
-      tiles_total += ((Pi + 63) / 64) * ((ps[i].cout_pad + 63) / 64);
-    }
+  int tiles_total = 0;
+  for (int i = 0; i < n; ++i) {
+    const int Pi = ps[i].n_img * ps[i].Hout * ps[i].Wout;
+    tiles_total += ((Pi + 63) / 64) * ((ps[i].cout_pad + 63) / 64);
+  }
+  const bool split_small = (cfg == 0 || cfg == 3) && chunks_max >= tune().split_from;
+  // a few batched samples (P = 8k..40k pixels): the large-tile kernels would have too few tiles,
+  // each walking the whole K range; split the K range instead (also keeps LayerNorm layers on 64x64)
+  const bool split_mid = (cfg == 1 || cfg == 2) && tiles_total < tune().mid_tiles && chunks_max >= 8;
+  if ((split_small || split_mid) && tune().split && g_split) {
     // workgroup budget shared in proportion to each problem's work (tiles x chunks)
     double work_total = 0;
     for (int i = 0; i < n; ++i) {

@@ -158,23 +158,27 @@ hipError_t launch_se_fc(const float* chansum, int ntile, int C, int Cr, int hw, 
 }
 
 // ---- depthwise 7x7 (+bias) + channels-last LayerNorm (convolutions.py:335-337) ---------------
-// One wave per 8x8 pixel tile, one pixel per lane, all C channels of the pixel in registers
-// (so the LayerNorm is lane-local).  Input patch 14x14xC and weights [49][C] staged in LDS.
-template <int C>
-__global__ __launch_bounds__(64) void dwconv7_ln_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                        const float* __restrict__ wdw /*[49][C]*/,
-                                                        const float* __restrict__ bdw, const float* __restrict__ lnw,
-                                                        const float* __restrict__ lnb, int H, int W, float eps) {
-  constexpr int PS = C + 4;   // padded pixel stride (floats)
+// One workgroup per 8x8 pixel tile; the 14x14xC input patch and the [49][C] weights are staged in
+// LDS once and shared by NW waves, each of which owns C/NW channels of every pixel (one pixel per
+// lane).  LayerNorm statistics are combined across the waves through LDS in a fixed order.
+template <int C, int NW>
+__global__ __launch_bounds__(64 * NW) void dwconv7_ln_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             const float* __restrict__ wdw /*[49][C]*/,
+                                                             const float* __restrict__ bdw, const float* __restrict__ lnw,
+                                                             const float* __restrict__ lnb, int H, int W, float eps) {
+  constexpr int PS = C + 4;        // padded pixel stride (floats)
+  constexpr int CW = C / NW;       // channels per wave
+  constexpr int C4 = C / 4, CW4 = CW / 4;
+  static_assert(CW % 4 == 0, "channels per wave must be a multiple of 4");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* patch = sm;               // [14*14][PS]
   float* wl = sm + 196 * PS;       // [49][C]
+  float* red = wl + 49 * C;        // [2][NW][64] partial sums / sums of squares
   const int tiles_x = (W + 7) / 8;
   const int img = blockIdx.y;
   const int ty0 = (blockIdx.x / tiles_x) * 8, tx0 = (blockIdx.x % tiles_x) * 8;
   const float* src = in + (size_t)img * H * W * C;
-  constexpr int C4 = C / 4;
-  for (int i = threadIdx.x; i < 196 * C4; i += 64) {
+  for (int i = threadIdx.x; i < 196 * C4; i += 64 * NW) {
     int c4 = i % C4, pp = i / C4;
     int py = pp / 14, px = pp % 14;
     int iy = ty0 + py - 3, ix = tx0 + px - 3;
@@ -182,37 +186,50 @@ __global__ __launch_bounds__(64) void dwconv7_ln_kernel(const float* __restrict_
     if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld4a(src + ((size_t)iy * W + ix) * C + c4 * 4);
     st4a(patch + pp * PS + c4 * 4, v);
   }
-  for (int i = threadIdx.x; i < 49 * C4; i += 64) st4a(wl + i * 4, ld4a(wdw + i * 4));
+  for (int i = threadIdx.x; i < 49 * C4; i += 64 * NW) st4a(wl + i * 4, ld4a(wdw + i * 4));
   __syncthreads();
-  const int ly = threadIdx.x >> 3, lx = threadIdx.x & 7;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ly = lane >> 3, lx = lane & 7;
   const int oy = ty0 + ly, ox = tx0 + lx;
-  float acc[C];
+  const int cb = wave * CW;
+  float acc[CW];
 #pragma unroll
-  for (int c = 0; c < C; ++c) acc[c] = bdw[c];
+  for (int c = 0; c < CW; ++c) acc[c] = bdw[cb + c];
   for (int ky = 0; ky < 7; ++ky)
     for (int kx = 0; kx < 7; ++kx) {
-      const float* p = patch + ((ly + ky) * 14 + lx + kx) * PS;
-      const float* w = wl + (ky * 7 + kx) * C;
+      const float* p = patch + ((ly + ky) * 14 + lx + kx) * PS + cb;
+      const float* w = wl + (ky * 7 + kx) * C + cb;
 #pragma unroll
-      for (int c4 = 0; c4 < C4; ++c4) {
+      for (int c4 = 0; c4 < CW4; ++c4) {
         float4 x = ld4a(p + c4 * 4), ww = ld4a(w + c4 * 4);
         acc[c4 * 4 + 0] += x.x * ww.x; acc[c4 * 4 + 1] += x.y * ww.y;
         acc[c4 * 4 + 2] += x.z * ww.z; acc[c4 * 4 + 3] += x.w * ww.w;
       }
     }
+  // mean over all C channels of the pixel (fixed wave order)
   float s = 0.f;
 #pragma unroll
-  for (int c = 0; c < C; ++c) s += acc[c];
-  const float mean = s / (float)C;
+  for (int c = 0; c < CW; ++c) s += acc[c];
+  red[wave * 64 + lane] = s;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int q = 0; q < NW; ++q) tot += red[q * 64 + lane];
+  const float mean = tot / (float)C;
   float sq = 0.f;
 #pragma unroll
-  for (int c = 0; c < C; ++c) { float d = acc[c] - mean; sq += d * d; }
-  const float rstd = 1.f / sqrtf(sq / (float)C + eps);
-  if (oy < H && ox < W) {
-    float* dst = out + ((size_t)img * H * W + (size_t)oy * W + ox) * C;
+  for (int c = 0; c < CW; ++c) { float d = acc[c] - mean; sq += d * d; }
+  red[(NW + wave) * 64 + lane] = sq;
+  __syncthreads();
+  float tsq = 0.f;
 #pragma unroll
-    for (int c4 = 0; c4 < C4; ++c4) {
-      float4 w = ld4a(lnw + c4 * 4), b = ld4a(lnb + c4 * 4), o;
+  for (int q = 0; q < NW; ++q) tsq += red[(NW + q) * 64 + lane];
+  const float rstd = 1.f / sqrtf(tsq / (float)C + eps);
+  if (oy < H && ox < W) {
+    float* dst = out + ((size_t)img * H * W + (size_t)oy * W + ox) * C + cb;
+#pragma unroll
+    for (int c4 = 0; c4 < CW4; ++c4) {
+      float4 w = ld4a(lnw + cb + c4 * 4), b = ld4a(lnb + cb + c4 * 4), o;
       o.x = (acc[c4 * 4 + 0] - mean) * rstd * w.x + b.x;
       o.y = (acc[c4 * 4 + 1] - mean) * rstd * w.y + b.y;
       o.z = (acc[c4 * 4 + 2] - mean) * rstd * w.z + b.z;
@@ -222,11 +239,11 @@ __global__ __launch_bounds__(64) void dwconv7_ln_kernel(const float* __restrict_
   }
 }
 
-template <int C>
+template <int C, int NW>
 static hipError_t launch_dw_t(const float* in, float* out, const float* wdw, const float* bdw, const float* lnw,
                               const float* lnb, int n, int H, int W, float eps, hipStream_t s) {
-  int lds = (196 * (C + 4) + 49 * C) * sizeof(float);
-  auto k = dwconv7_ln_kernel<C>;
+  int lds = (196 * (C + 4) + 49 * C + 2 * NW * 64) * sizeof(float);
+  auto k = dwconv7_ln_kernel<C, NW>;
   static bool done = false;
   if (!done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -234,17 +251,17 @@ static hipError_t launch_dw_t(const float* in, float* out, const float* wdw, con
     done = true;
   }
   dim3 grid(((H + 7) / 8) * ((W + 7) / 8), n);
-  hipLaunchKernelGGL(k, grid, dim3(64), lds, s, in, out, wdw, bdw, lnw, lnb, H, W, eps);
+  hipLaunchKernelGGL(k, grid, dim3(64 * NW), lds, s, in, out, wdw, bdw, lnw, lnb, H, W, eps);
   return hipGetLastError();
 }
 
 hipError_t launch_dwconv7_ln(const float* in, float* out, const float* wdw, const float* bdw, const float* lnw,
                              const float* lnb, int n, int H, int W, int C, float eps, hipStream_t s) {
   switch (C) {
-    case 8:  return launch_dw_t<8>(in, out, wdw, bdw, lnw, lnb, n, H, W, eps, s);
-    case 16: return launch_dw_t<16>(in, out, wdw, bdw, lnw, lnb, n, H, W, eps, s);
-    case 32: return launch_dw_t<32>(in, out, wdw, bdw, lnw, lnb, n, H, W, eps, s);
-    case 64: return launch_dw_t<64>(in, out, wdw, bdw, lnw, lnb, n, H, W, eps, s);
+    case 8:  return launch_dw_t<8, 1>(in, out, wdw, bdw, lnw, lnb, n, H, W, eps, s);
+    case 16: return launch_dw_t<16, 2>(in, out, wdw, bdw, lnw, lnb, n, H, W, eps, s);
+    case 32: return launch_dw_t<32, 4>(in, out, wdw, bdw, lnw, lnb, n, H, W, eps, s);
+    case 64: return launch_dw_t<64, 4>(in, out, wdw, bdw, lnw, lnb, n, H, W, eps, s);
   }
   return hipErrorInvalidValue;
 }

@@ -78,7 +78,7 @@ def main():
                      (64, 64, 3, 1, 200, 200), (128, 128, 3, 1, 200, 200, 1, 64)]:
             conv_case(*args)
         return
-    for B in (2, 4, 8):
+    for B in (2, 4, 8, 16):
         hxb = torch.randn(8, B, h, w, C, device="cuda") * 0.5
         eb = torch.randn(sc.n_draws, B, h, w, C, device="cuda")
         t = timeit(lambda: ode.rollout_nhwc(hxb, sc, eb), 3, 1)
