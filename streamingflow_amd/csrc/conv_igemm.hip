@@ -66,6 +66,10 @@ __device__ __forceinline__ float2 lds_read_b64(const float* p) {
   return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
 }
 
+#ifndef SF_SETPRIO
+#define SF_SETPRIO 1
+#endif
+constexpr bool SETPRIO = SF_SETPRIO;
 constexpr int LDS_ROW = 36;   // floats per staged row: 32 K values + 4 pad
 constexpr int BK = 32;
 
@@ -460,6 +464,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
         for (int n = 0; n < NT; ++n) fb[nxt][n] = lds_read_b64(b + n * 16 * LDS_ROW + 8 * (t4 + 1));
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads above this group's MFMAs
+      if (SETPRIO) __builtin_amdgcn_s_setprio(1);
       // all tiles with the even k first, then the odd k: MT*NT independent accumulators between
       // two MFMAs on the same one (16x16x4 f32: 32-cycle issue, 40-cycle dependent latency)
 #pragma unroll
@@ -472,6 +477,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
 #pragma unroll
         for (int n = 0; n < NT; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][m].y, fb[cur][n].y, acc[m][n], 0, 0, 0);
+      if (SETPRIO) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -854,6 +860,24 @@ hipError_t launch_conv(const ConvLaunch& L, int epi, int cfg, hipStream_t stream
       switch (epi) {
         case EPI_AFFINE: return launch_cfg<4, 2, 2, 4, 1, EPI_AFFINE>(L, stream);
         case EPI_BLEND:  return launch_cfg<4, 2, 2, 4, 1, EPI_BLEND>(L, stream);
+      }
+      break;
+    case 10:  // 64 cout x 128 px, 4 waves (1x4) of 64x32
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<4, 2, 1, 4, 1, EPI_AFFINE>(L, stream);
+        case EPI_BLEND:  return launch_cfg<4, 2, 1, 4, 1, EPI_BLEND>(L, stream);
+      }
+      break;
+    case 11:  // 64 cout x 256 px, 4 waves (1x4) of 64x64
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<4, 4, 1, 4, 1, EPI_AFFINE>(L, stream);
+        case EPI_BLEND:  return launch_cfg<4, 4, 1, 4, 1, EPI_BLEND>(L, stream);
+      }
+      break;
+    case 12:  // 64 cout x 256 px, 8 waves (1x8) of 64x32
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<4, 2, 1, 8, 1, EPI_AFFINE>(L, stream);
+        case EPI_BLEND:  return launch_cfg<4, 2, 1, 8, 1, EPI_BLEND>(L, stream);
       }
       break;
     case 2:   // LN-capable large tile: 4 waves x (64 cout x 32 px)
