@@ -53,12 +53,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import streamingflow_amd as sfa
     from streamingflow_amd import _lib, schedule as S

@@ -280,16 +280,19 @@ __device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[
   }
 }
 
-template <int MT, int NT, int WM, int WN, int KS, int EPI>
+template <int MT, int NT, int WM, int WN, int KS, int EPI, int KB = 32>
 __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const ConvLaunch L) {
+  constexpr int BKc = KB;          // K depth of one staged chunk (32, or 64 when cin_pad % 64 == 0)
+  constexpr int ROW = KB + 4;      // padded LDS row: (KB+4)/4 is odd => ds_read_b64 fragments stay conflict-free
+  constexpr int F4 = KB / 4;       // float4 slots per staged row
   constexpr int BM = 16 * MT * WM;
   constexpr int BN = 16 * NT * WN;
   constexpr int TG = 64 * WM * WN;        // threads per K-group
-  constexpr int ROWS_PER_PASS = TG / 8;   // 8 float4 per 32-float row
+  constexpr int ROWS_PER_PASS = TG / F4;
   constexpr int A_SLOTS = BM / ROWS_PER_PASS;
   constexpr int B_SLOTS = BN / ROWS_PER_PASS;
   static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile/threads mismatch");
-  constexpr int GROUP_FLOATS = 2 * (BM + BN) * LDS_ROW;
+  constexpr int GROUP_FLOATS = 2 * (BM + BN) * ROW;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -309,8 +312,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
   const int wm = wave / WN, wn = wave % WN;
   const int j = lane & 15, g = lane >> 4;
 
-  float* As = smem + kg * GROUP_FLOATS;          // [2][BM][LDS_ROW]
-  float* Bs = As + 2 * BM * LDS_ROW;             // [2][BN][LDS_ROW]
+  float* As = smem + kg * GROUP_FLOATS;          // [2][BM][ROW]
+  float* Bs = As + 2 * BM * ROW;             // [2][BN][ROW]
 
   // ---- problem fields used in the K loop, read from the kernarg segment once ------------------
   const float* const in0 = P.in0;
@@ -325,8 +328,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
   const bool has_aux = (gate != nullptr) | (in_scale != nullptr);   // block-uniform
 
   // ---- per-thread staging slots ----------------------------------------------------------
-  const int k4 = t & 7;
-  const int row0 = t >> 3;
+  const int k4 = t % F4;
+  const int row0 = t / F4;
   const int HWout = P.Hout * P.Wout;
   int b_iy0[B_SLOTS], b_ix0[B_SLOTS], b_base[B_SLOTS], b_img[B_SLOTS];
 #pragma unroll
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
     a_off[i] = (size_t)grow * P.ktot + k4 * 4;
   }
 
-  const int kcpt = P.cin_pad / BK;            // chunks per tap
+  const int kcpt = P.cin_pad / BKc;            // chunks per tap
   const int nchunks_all = P.KH * P.KW * kcpt;
   // cross-workgroup split-K: this workgroup owns chunks [cb, cb + nchunks)
   const int nsplit = P.nsplit > 1 ? P.nsplit : 1;
@@ -382,10 +385,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
   int cur_ty = cur_tap / KW, cur_tx = cur_tap - cur_ty * KW;
 
   auto load_chunk = [&](int chunk) {
-    const float* wp = wbase + (size_t)chunk * BK;
+    const float* wp = wbase + (size_t)chunk * BKc;
 #pragma unroll
     for (int i = 0; i < A_SLOTS; ++i) ra[i] = ld4(wp + a_off[i]);
-    const int c = cur_kc * BK + k4 * 4;
+    const int c = cur_kc * BKc + k4 * 4;
     const bool s0 = c < c0;
     const bool s1 = (!s0) & (c < c01);
     const int cc = c - c0;
@@ -424,10 +427,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
   };
 
   auto store_chunk = [&](int buf) {
-    float* a = As + buf * BM * LDS_ROW;
-    float* b = Bs + buf * BN * LDS_ROW;
+    float* a = As + buf * BM * ROW;
+    float* b = Bs + buf * BN * ROW;
 #pragma unroll
-    for (int i = 0; i < A_SLOTS; ++i) st4(a + (row0 + i * ROWS_PER_PASS) * LDS_ROW + k4 * 4, ra[i]);
+    for (int i = 0; i < A_SLOTS; ++i) st4(a + (row0 + i * ROWS_PER_PASS) * ROW + k4 * 4, ra[i]);
 #pragma unroll
     for (int i = 0; i < B_SLOTS; ++i) {
       float4 v = rb[i];
@@ -440,28 +443,28 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
         v.z *= sc ? x.z : (gt ? 1.f - x.z : 1.f); v.w *= sc ? x.w : (gt ? 1.f - x.w : 1.f);
       }
       if (!(fl & 1)) v = zero4();
-      st4(b + (row0 + i * ROWS_PER_PASS) * LDS_ROW + k4 * 4, v);
+      st4(b + (row0 + i * ROWS_PER_PASS) * ROW + k4 * 4, v);
     }
   };
 
   auto compute = [&](int buf) {
-    const float* a = As + buf * BM * LDS_ROW + (wm * MT * 16 + j) * LDS_ROW + 2 * g;
-    const float* b = Bs + buf * BN * LDS_ROW + (wn * NT * 16 + j) * LDS_ROW + 2 * g;
+    const float* a = As + buf * BM * ROW + (wm * MT * 16 + j) * ROW + 2 * g;
+    const float* b = Bs + buf * BN * ROW + (wn * NT * 16 + j) * ROW + 2 * g;
     // fragments of k-group t4+1 are read while the MFMAs of k-group t4 run (two register sets,
     // statically indexed): the LDS latency is hidden inside the wave, not only by other waves
     float2 fa[2][MT], fb[2][NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) fa[0][m] = lds_read_b64(a + m * 16 * LDS_ROW);
+    for (int m = 0; m < MT; ++m) fa[0][m] = lds_read_b64(a + m * 16 * ROW);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) fb[0][n] = lds_read_b64(b + n * 16 * LDS_ROW);
+    for (int n = 0; n < NT; ++n) fb[0][n] = lds_read_b64(b + n * 16 * ROW);
 #pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) {
+    for (int t4 = 0; t4 < BKc / 8; ++t4) {
       const int cur = t4 & 1, nxt = cur ^ 1;
-      if (t4 < 3) {
+      if (t4 < BKc / 8 - 1) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) fa[nxt][m] = lds_read_b64(a + m * 16 * LDS_ROW + 8 * (t4 + 1));
+        for (int m = 0; m < MT; ++m) fa[nxt][m] = lds_read_b64(a + m * 16 * ROW + 8 * (t4 + 1));
 #pragma unroll
-        for (int n = 0; n < NT; ++n) fb[nxt][n] = lds_read_b64(b + n * 16 * LDS_ROW + 8 * (t4 + 1));
+        for (int n = 0; n < NT; ++n) fb[nxt][n] = lds_read_b64(b + n * 16 * ROW + 8 * (t4 + 1));
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads above this group's MFMAs
       if (SETPRIO) __builtin_amdgcn_s_setprio(1);
@@ -773,13 +776,13 @@ hipError_t launch_conv_direct(const ConvLaunch& L, int epi, int mt, int ks, hipS
 }
 
 // ---- host-side launcher --------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, int KS, int EPI>
+template <int MT, int NT, int WM, int WN, int KS, int EPI, int KB = 32>
 static hipError_t launch_cfg(const ConvLaunch& L, hipStream_t stream) {
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
-  constexpr int stage_bytes = KS * 2 * (BM + BN) * LDS_ROW * 4;
+  constexpr int stage_bytes = KS * 2 * (BM + BN) * (KB + 4) * 4;
   constexpr int red_bytes = (KS - 1) * WM * WN * MT * NT * 4 * 64 * 4;
   constexpr int lds = stage_bytes > red_bytes ? stage_bytes : red_bytes;
-  auto kern = conv_igemm_kernel<MT, NT, WM, WN, KS, EPI>;
+  auto kern = conv_igemm_kernel<MT, NT, WM, WN, KS, EPI, KB>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -860,6 +863,30 @@ hipError_t launch_conv(const ConvLaunch& L, int epi, int cfg, hipStream_t stream
       switch (epi) {
         case EPI_AFFINE: return launch_cfg<4, 2, 2, 4, 1, EPI_AFFINE>(L, stream);
         case EPI_BLEND:  return launch_cfg<4, 2, 2, 4, 1, EPI_BLEND>(L, stream);
+      }
+      break;
+    case 15:  // 64x64 tile, 16-deep chunks (20 KB of LDS: up to 8 workgroups per CU)
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<2, 2, 2, 2, 1, EPI_AFFINE, 16>(L, stream);
+        case EPI_BLEND:  return launch_cfg<2, 2, 2, 2, 1, EPI_BLEND, 16>(L, stream);
+      }
+      break;
+    case 16:  // 128x128 tile, 8 waves, 16-deep chunks
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<4, 2, 2, 4, 1, EPI_AFFINE, 16>(L, stream);
+        case EPI_BLEND:  return launch_cfg<4, 2, 2, 4, 1, EPI_BLEND, 16>(L, stream);
+      }
+      break;
+    case 13:  // 64x64 tile, 64-deep chunks (half the barriers; needs cin_pad % 64 == 0)
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<2, 2, 2, 2, 1, EPI_AFFINE, 64>(L, stream);
+        case EPI_BLEND:  return launch_cfg<2, 2, 2, 2, 1, EPI_BLEND, 64>(L, stream);
+      }
+      break;
+    case 14:  // 128x128 tile, 8 waves, 64-deep chunks
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<4, 2, 2, 4, 1, EPI_AFFINE, 64>(L, stream);
+        case EPI_BLEND:  return launch_cfg<4, 2, 2, 4, 1, EPI_BLEND, 64>(L, stream);
       }
       break;
     case 10:  // 64 cout x 128 px, 4 waves (1x4) of 64x32

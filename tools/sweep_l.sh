@@ -2,5 +2,7 @@
 out=gpurun_out/sweep_l.txt
 : > $out
 run() { echo "== $*" >> $out; env "$@" python tools/modbench.py --bigconvs 2>/dev/null | grep conv >> $out; }
-run SF_L_CFG=-1
-for c in 10 11 12; do run SF_L_CFG=$c; done
+run SF_L_CFG=1
+run SF_L_CFG=15
+run SF_L_CFG=9
+run SF_L_CFG=16
