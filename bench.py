@@ -53,12 +53,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # SF_BENCH_BACKEND=gloo + SF_BENCH_ONE_DEVICE=1: exercise the multi-rank path on a 1-GPU box
+    backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
+    if os.environ.get("SF_BENCH_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     import streamingflow_amd as sfa
     from streamingflow_amd import _lib, schedule as S
@@ -98,7 +102,7 @@ def main():
     fence()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     ms_per_step = 1e3 * el / a.steps
