@@ -166,3 +166,23 @@ def test_c32_config1_cell(pair8):
     with torch.no_grad():
         sr, ir = R.ode_step(sd, "gru_ode", s, x, 0.05, "euler", True, _noise())
     assert maxabs(st, sr) <= TOL and maxabs(inp, ir) <= TOL
+
+
+def test_split_k_handoff_is_stable_under_repetition(pair64):
+    """The 7x7 trusting-gate conv runs with its K range split over workgroups (slab publish +
+    ticket + last-arriver reduce).  A stale read would show up as a run-to-run difference: 150
+    back-to-back evaluations at 1 and 4 batched samples must be bitwise identical."""
+    net, _ = pair64
+    cell = net.gru_ode.gru_c
+    one = torch.ones(1, device="cuda")
+    for B in (1, 4):
+        x = hashfill.normal("rx", (B, 50, 50, 64), 61).cuda()
+        s = (hashfill.normal("rs", (B, 50, 50, 64), 62) * 0.5).cuda()
+        ref = torch.empty_like(s)
+        cell.run_nhwc(x, s, ref, True, s, one)
+        ref = ref.clone()
+        out = torch.empty_like(s)
+        for i in range(150):
+            cell.run_nhwc(x, s, out, True, s, one)
+            if i % 10 == 9:
+                assert torch.equal(out, ref), (B, i)
