@@ -130,6 +130,10 @@ int sf_conv2d_repeat(const sf_conv_w* w, const float* in0, const float* in1, con
 int sf_gru_cell_fwd(const sf_gru_w* w, const float* x, const float* s, float* out, int n_img, int H, int W,
                     float* ws, size_t ws_bytes, void* stream);
 size_t sf_gru_cell_ws_bytes(int C, int n_img, int H, int W);
+/* SpatialGRUODECell.forward — temporal_ode_bayes.py:35-61 (defined, unused by the shipped model):
+ * dh = u * (h~ - s), candidate = conv + BN + ReLU.  Same workspace as sf_gru_cell_fwd. */
+int sf_gru_ode_cell_fwd(const sf_gru_w* w, const float* x, const float* s, float* out, int n_img, int H, int W,
+                        float* ws, size_t ws_bytes, void* stream);
 
 /* SpatialGRU.forward — temporal.py:26-42 on n_img samples at once.
  * x [T][n_img][H*W][Cx], state0 [n_img][H*W][C] -> out [T][n_img][H*W][Cx] */

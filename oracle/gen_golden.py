@@ -180,6 +180,15 @@ def gen_beverse(m):
             out[tag + "/dist_mu"], out[tag + "/dist_log_sigma"] = _np(mu), _np(ls)
             out[tag + "/sf_dist"] = _np(sfd(s_t))
         print(tag, {k.split("/")[1]: v.shape for k, v in out.items() if k.startswith(tag)})
+    # a16: single-branch cells defined (unused) in temporal_ode_bayes.py
+    tob = m.tob
+    x = hashfill.normal("sg_x", (2, 16, 12, 10), 31)
+    st = hashfill.normal("sg_s", (2, 16, 12, 10), 32) * 0.5
+    for name, cls in (("gru_ode_cell", tob.SpatialGRUODECell), ("gru_cell", tob.SpatialGRUCell)):
+        mod = cls(16, 16).eval()
+        mod.load_state_dict(hashfill.fill_state_dict(mod.state_dict(), seed=4))
+        with torch.no_grad():
+            out["single/" + name] = _np(mod(x, st))
     np.savez_compressed(os.path.join(OUT, "beverse.npz"), **out)
 
 

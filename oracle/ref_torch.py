@@ -403,3 +403,14 @@ def sf_distribution(sd, s_t, latent_dim, p=""):
     b = s_t.shape[0]
     e = _dist_encoder(sd, p + "encoder", s_t[:, 0], 4)
     return _conv(sd, p + "decoder.1", e.mean(dim=(2, 3), keepdim=True)).view(b, 1, 2 * latent_dim)
+
+
+def single_gru_cell(sd, x, state, ode, p=""):
+    """temporal_ode_bayes.py:35-61 (``SpatialGRUODECell``, ode=True: u*(h~ - s)) and :184-208
+    (``SpatialGRUCell``): candidate = ConvBlock (conv, BatchNorm, ReLU)."""
+    xs = torch.cat([x, state], dim=1)
+    u = torch.sigmoid(_conv(sd, p + "conv_update", xs, padding=1))
+    r = torch.sigmoid(_conv(sd, p + "conv_reset", xs, padding=1))
+    cand = torch.cat([x, (1.0 - r) * state], dim=1)
+    cand = F.relu(_bn(sd, p + "conv_state_tilde.norm", _conv(sd, p + "conv_state_tilde.conv", cand, padding=1)))
+    return u * (cand - state) if ode else (1.0 - u) * state + u * cand

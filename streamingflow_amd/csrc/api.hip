@@ -280,13 +280,14 @@ struct SplitScope {
 
 // conv-GRU cell (temporal.py:44-57): gates -> blend.  gates buffer g: [P][2C] = [u | r]
 int gru_cell(const sf_gru_w& w, const float* x, const float* s, float* out, float* g, int n, int H, int W,
-             hipStream_t st) {
+             hipStream_t st, int ode_derivative = 0) {
   const int C = w.cand.cout;
   ConvProblem a = problem(w.gates, x, s, g, n, H, W);
   SF_TRY(run1(a, EPI_AFFINE, st));
   ConvProblem b = problem(w.cand, x, s, out, n, H, W);
   b.gate = g; b.gate_cs = 2 * C; b.gate_co = C;
   b.e0 = g; b.e0_cs = 2 * C; b.e1 = s; b.e1_cs = C;
+  b.mode = ode_derivative ? 1 : 0;
   return run1(b, EPI_BLEND, st);
 }
 
@@ -512,7 +513,16 @@ int sf_gru_cell_fwd(const sf_gru_w* w, const float* x, const float* s, float* ou
   Arena A(ws, ws_bytes);
   float* g = A.take((size_t)n_img * H * W * 2 * w->cand.cout);
   if (!A.ok()) return SF_ERR_WORKSPACE;
-  return gru_cell(*w, x, s, out, g, n_img, H, W, (hipStream_t)stream);
+  return gru_cell(*w, x, s, out, g, n_img, H, W, (hipStream_t)stream, 0);
+}
+// SpatialGRUODECell.forward — temporal_ode_bayes.py:35-61: dh = u * (h~ - s)
+int sf_gru_ode_cell_fwd(const sf_gru_w* w, const float* x, const float* s, float* out, int n_img, int H, int W, float* ws,
+                        size_t ws_bytes, void* stream) {
+  if (!w || !x || !s || !out || !valid_w(w->gates) || !valid_w(w->cand)) return SF_ERR_INVALID;
+  Arena A(ws, ws_bytes);
+  float* g = A.take((size_t)n_img * H * W * 2 * w->cand.cout);
+  if (!A.ok()) return SF_ERR_WORKSPACE;
+  return gru_cell(*w, x, s, out, g, n_img, H, W, (hipStream_t)stream, 1);
 }
 
 size_t sf_spatial_gru_ws_bytes(int C, int n_img, int H, int W) {

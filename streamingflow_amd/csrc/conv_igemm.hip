@@ -120,8 +120,12 @@ __device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[
             v.z = act_apply(v.z, P.act); v.w = act_apply(v.w, P.act);
             float4 u = ld4(P.e0 + (size_t)gp * P.e0_cs + c);
             float4 s = ld4(P.e1 + (size_t)gp * P.e1_cs + c);
-            y.x = (1.f - u.x) * s.x + u.x * v.x; y.y = (1.f - u.y) * s.y + u.y * v.y;
-            y.z = (1.f - u.z) * s.z + u.z * v.z; y.w = (1.f - u.w) * s.w + u.w * v.w;
+            if (P.mode & 1) {   // SpatialGRUODECell (temporal_ode_bayes.py:60): dh = u * (h~ - s)
+              y.x = u.x * (v.x - s.x); y.y = u.y * (v.y - s.y); y.z = u.z * (v.z - s.z); y.w = u.w * (v.w - s.w);
+            } else {
+              y.x = (1.f - u.x) * s.x + u.x * v.x; y.y = (1.f - u.y) * s.y + u.y * v.y;
+              y.z = (1.f - u.z) * s.z + u.z * v.z; y.w = (1.f - u.w) * s.w + u.w * v.w;
+            }
           }
           st4(P.out + (size_t)gp * P.out_cs + P.out_co + c, y);
         }

@@ -25,6 +25,61 @@ from .res_models import ConvNet, SmallDecoder, SmallEncoder
 from .temporal import pack_gru
 
 
+class _SingleGRU(PackedModule):
+    """Single-branch conv-GRU cells of temporal_ode_bayes.py (``SpatialGRUODECell`` :14-61,
+    ``SpatialGRUCell`` :165-208): gates = conv3x3 + bias + sigmoid, candidate = ConvBlock (conv3x3,
+    BatchNorm, ReLU).  Defined by the reference but not instantiated on the shipped path."""
+    ode = False
+
+    def __init__(self, input_size, hidden_size, gru_bias_init=0.0, norm='bn', activation='relu', bias=True):
+        super().__init__()
+        if norm != 'bn' or activation != 'relu':
+            raise NotImplementedError("conv + BatchNorm + ReLU candidate only")
+        from ..beverse.basic_modules import ConvBlock
+        self.input_size, self.hidden_size, self.bias, self.gru_bias_init = input_size, hidden_size, bias, gru_bias_init
+        cat = input_size + hidden_size
+        self.conv_update = nn.Conv2d(cat, hidden_size, kernel_size=3, bias=True, padding=1)
+        self.conv_reset = nn.Conv2d(cat, hidden_size, kernel_size=3, bias=True, padding=1)
+        self.conv_state_tilde = ConvBlock(cat, hidden_size, kernel_size=3, bias=False, norm=norm, activation=activation)
+
+    def _pack(self):
+        if self.training:
+            raise RuntimeError("streamingflow_amd is inference-only: call .eval()")
+        if self.gru_bias_init != 0.0:
+            raise NotImplementedError("gru_bias_init != 0")
+        pk = packing.Pack(_lib.GruW())
+        s = pk.struct
+        wg = torch.cat([self.conv_update.weight, self.conv_reset.weight], 0)
+        bg = torch.cat([self.conv_update.bias, self.conv_reset.bias], 0)
+        s.gates = packing.conv_w(pk, wg, self.input_size, self.hidden_size, bias=bg, act="sigmoid")
+        sc, bi = packing.bn_fold(self.conv_state_tilde.norm)
+        s.cand = packing.conv_w(pk, self.conv_state_tilde.conv.weight, self.input_size, self.hidden_size, scale=sc,
+                                bias=bi, act="relu")
+        return pk
+
+    def forward(self, x, state):
+        runtime.require_cuda(x, state)
+        xn, sn = runtime.to_nhwc(x), runtime.to_nhwc(state)
+        n, h, w, _ = xn.shape
+        L = _lib.lib()
+        ws = runtime.workspace(L.sf_gru_cell_ws_bytes(self.hidden_size, n, h, w), x.device)
+        out = torch.empty_like(sn)
+        fn = L.sf_gru_ode_cell_fwd if self.ode else L.sf_gru_cell_fwd
+        _lib.check(fn(self.packed().struct, ptr(xn), ptr(sn), ptr(out), n, h, w, ptr(ws), ws.numel() * 4,
+                      runtime.stream_ptr(x.device)), "single_gru_cell")
+        return runtime.to_nchw(out)
+
+
+class SpatialGRUODECell(_SingleGRU):
+    """dh = u * (h~ - s) (temporal_ode_bayes.py:35-61)."""
+    ode = True
+
+
+class SpatialGRUCell(_SingleGRU):
+    """(1 - u) * s + u * h~ (temporal_ode_bayes.py:184-208)."""
+    ode = False
+
+
 class _DualCell(PackedModule):
     """Two conv-GRU branches mixed by a soft 'trusting gate'; 6 fused launches per evaluation."""
     derivative = False

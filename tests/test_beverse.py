@@ -70,3 +70,33 @@ def test_gpu_matches_reference_fixture(tag):
     assert _close(mu, g[tag + "/dist_mu"]) and _close(ls, g[tag + "/dist_log_sigma"], scale_ref=g[tag + "/dist_mu"])
     assert float(ls.abs().max()) <= 0.05 + 1e-7            # the clamp is exercised
     assert _close(mods["sfd"][0](s_t.cuda()), g[tag + "/sf_dist"])
+
+
+def _single(device):
+    from streamingflow_amd.layers import temporal_ode_bayes as T
+    x = hashfill.normal("sg_x", (2, 16, 12, 10), 31)
+    st = hashfill.normal("sg_s", (2, 16, 12, 10), 32) * 0.5
+    mods = {}
+    for name, cls in (("gru_ode_cell", T.SpatialGRUODECell), ("gru_cell", T.SpatialGRUCell)):
+        mod = cls(16, 16)
+        sd = hashfill.fill_state_dict(mod.state_dict(), seed=4)
+        mod.load_state_dict(sd)
+        mods[name] = (mod.eval().to(device), sd)
+    return x, st, mods
+
+
+def test_single_branch_cells_oracle():
+    """SpatialGRUODECell / SpatialGRUCell (defined, unused by the shipped model)."""
+    g = gold("beverse.npz")
+    x, st, mods = _single("cpu")
+    with torch.no_grad():
+        assert maxabs(R.single_gru_cell(mods["gru_ode_cell"][1], x, st, True), g["single/gru_ode_cell"]) <= 1e-6
+        assert maxabs(R.single_gru_cell(mods["gru_cell"][1], x, st, False), g["single/gru_cell"]) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_single_branch_cells_gpu():
+    g = gold("beverse.npz")
+    x, st, mods = _single("cuda")
+    assert maxabs(mods["gru_ode_cell"][0](x.cuda(), st.cuda()), g["single/gru_ode_cell"]) <= 1e-4
+    assert maxabs(mods["gru_cell"][0](x.cuda(), st.cuda()), g["single/gru_cell"]) <= 1e-4
