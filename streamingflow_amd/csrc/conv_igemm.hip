@@ -284,10 +284,14 @@ __device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[
   }
 }
 
-template <int MT, int NT, int WM, int WN, int KS, int EPI, int KB = 32>
+template <int MT, int NT, int WM, int WN, int KS, int EPI, int KB = 32, bool SWZ = false>
 __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const ConvLaunch L) {
   constexpr int BKc = KB;          // K depth of one staged chunk (32, or 64 when cin_pad % 64 == 0)
-  constexpr int ROW = KB + 4;      // padded LDS row: (KB+4)/4 is odd => ds_read_b64 fragments stay conflict-free
+  // LDS row pitch: KB+4 floats ((KB+4)/4 odd => conflict-free ds_read_b64 fragments), or — SWZ, KB = 32
+  // only — unpadded 128-B rows whose eight 16-B slots are XOR-swizzled with (row>>1)&7: equally
+  // conflict-free, 32 KB instead of 36 KB per 64x64 workgroup => 5 instead of 4 workgroups per CU
+  constexpr int ROW = SWZ ? KB : KB + 4;
+  static_assert(!SWZ || KB == 32, "slot swizzle is defined for 32-deep chunks");
   constexpr int F4 = KB / 4;       // float4 slots per staged row
   constexpr int BM = 16 * MT * WM;
   constexpr int BN = 16 * NT * WN;
@@ -433,8 +437,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
   auto store_chunk = [&](int buf) {
     float* a = As + buf * BM * ROW;
     float* b = Bs + buf * BN * ROW;
+    const int k4s = SWZ ? (k4 ^ ((row0 >> 1) & 7)) : k4;   // ROWS_PER_PASS is a multiple of 16: row bits 1-3 = row0's
 #pragma unroll
-    for (int i = 0; i < A_SLOTS; ++i) st4(a + (row0 + i * ROWS_PER_PASS) * ROW + k4 * 4, ra[i]);
+    for (int i = 0; i < A_SLOTS; ++i) st4(a + (row0 + i * ROWS_PER_PASS) * ROW + k4s * 4, ra[i]);
 #pragma unroll
     for (int i = 0; i < B_SLOTS; ++i) {
       float4 v = rb[i];
@@ -447,28 +452,30 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
         v.z *= sc ? x.z : (gt ? 1.f - x.z : 1.f); v.w *= sc ? x.w : (gt ? 1.f - x.w : 1.f);
       }
       if (!(fl & 1)) v = zero4();
-      st4(b + (row0 + i * ROWS_PER_PASS) * ROW + k4 * 4, v);
+      st4(b + (row0 + i * ROWS_PER_PASS) * ROW + k4s * 4, v);
     }
   };
 
   auto compute = [&](int buf) {
-    const float* a = As + buf * BM * ROW + (wm * MT * 16 + j) * ROW + 2 * g;
-    const float* b = Bs + buf * BN * ROW + (wn * NT * 16 + j) * ROW + 2 * g;
+    const int sx = (j >> 1) & 7;   // swizzle key of this lane's rows (tile rows are multiples of 16 apart)
+    auto koff = [&](int t4) { return SWZ ? 4 * ((2 * t4 + (g >> 1)) ^ sx) + ((2 * g) & 3) : 8 * t4 + 2 * g; };
+    const float* a = As + buf * BM * ROW + (wm * MT * 16 + j) * ROW;
+    const float* b = Bs + buf * BN * ROW + (wn * NT * 16 + j) * ROW;
     // fragments of k-group t4+1 are read while the MFMAs of k-group t4 run (two register sets,
     // statically indexed): the LDS latency is hidden inside the wave, not only by other waves
     float2 fa[2][MT], fb[2][NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) fa[0][m] = lds_read_b64(a + m * 16 * ROW);
+    for (int m = 0; m < MT; ++m) fa[0][m] = lds_read_b64(a + m * 16 * ROW + koff(0));
 #pragma unroll
-    for (int n = 0; n < NT; ++n) fb[0][n] = lds_read_b64(b + n * 16 * ROW);
+    for (int n = 0; n < NT; ++n) fb[0][n] = lds_read_b64(b + n * 16 * ROW + koff(0));
 #pragma unroll
     for (int t4 = 0; t4 < BKc / 8; ++t4) {
       const int cur = t4 & 1, nxt = cur ^ 1;
       if (t4 < BKc / 8 - 1) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) fa[nxt][m] = lds_read_b64(a + m * 16 * ROW + 8 * (t4 + 1));
+        for (int m = 0; m < MT; ++m) fa[nxt][m] = lds_read_b64(a + m * 16 * ROW + koff(t4 + 1));
 #pragma unroll
-        for (int n = 0; n < NT; ++n) fb[nxt][n] = lds_read_b64(b + n * 16 * ROW + 8 * (t4 + 1));
+        for (int n = 0; n < NT; ++n) fb[nxt][n] = lds_read_b64(b + n * 16 * ROW + koff(t4 + 1));
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads above this group's MFMAs
       if (SETPRIO) __builtin_amdgcn_s_setprio(1);
@@ -780,13 +787,13 @@ hipError_t launch_conv_direct(const ConvLaunch& L, int epi, int mt, int ks, hipS
 }
 
 // ---- host-side launcher --------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, int KS, int EPI, int KB = 32>
+template <int MT, int NT, int WM, int WN, int KS, int EPI, int KB = 32, bool SWZ = false>
 static hipError_t launch_cfg(const ConvLaunch& L, hipStream_t stream) {
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
-  constexpr int stage_bytes = KS * 2 * (BM + BN) * (KB + 4) * 4;
+  constexpr int stage_bytes = KS * 2 * (BM + BN) * (SWZ ? KB : KB + 4) * 4;
   constexpr int red_bytes = (KS - 1) * WM * WN * MT * NT * 4 * 64 * 4;
   constexpr int lds = stage_bytes > red_bytes ? stage_bytes : red_bytes;
-  auto kern = conv_igemm_kernel<MT, NT, WM, WN, KS, EPI, KB>;
+  auto kern = conv_igemm_kernel<MT, NT, WM, WN, KS, EPI, KB, SWZ>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -867,6 +874,18 @@ hipError_t launch_conv(const ConvLaunch& L, int epi, int cfg, hipStream_t stream
       switch (epi) {
         case EPI_AFFINE: return launch_cfg<4, 2, 2, 4, 1, EPI_AFFINE>(L, stream);
         case EPI_BLEND:  return launch_cfg<4, 2, 2, 4, 1, EPI_BLEND>(L, stream);
+      }
+      break;
+    case 17:  // 64x64 tile, unpadded swizzled LDS rows (32 KB: 5 workgroups per CU)
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<2, 2, 2, 2, 1, EPI_AFFINE, 32, true>(L, stream);
+        case EPI_BLEND:  return launch_cfg<2, 2, 2, 2, 1, EPI_BLEND, 32, true>(L, stream);
+      }
+      break;
+    case 18:  // 128x128 tile, 8 waves, swizzled rows (64 KB: 2 workgroups per CU)
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<4, 2, 2, 4, 1, EPI_AFFINE, 32, true>(L, stream);
+        case EPI_BLEND:  return launch_cfg<4, 2, 2, 4, 1, EPI_BLEND, 32, true>(L, stream);
       }
       break;
     case 15:  // 64x64 tile, 16-deep chunks (20 KB of LDS: up to 8 workgroups per CU)

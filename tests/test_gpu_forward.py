@@ -184,3 +184,20 @@ def test_hipgraph_rollout_replay_matches_eager():
         assert torch.equal(a, b) and torch.equal(fa, fb), k
     assert len(ode._graphs) == 1
     ode.use_graph = False
+
+
+def test_bev_size_not_divisible_by_four():
+    """The reference silently shrinks the output when H, W are not multiples of 4 (two floor
+    max-pools, then x4 nearest upsampling: 50x50 BEV -> 12x12 latent -> 48x48 out, SURVEY.md §0);
+    rectangular 50x38 here.  Same behaviour, same numbers as the oracle."""
+    C, H, W = 8, 50, 38
+    cts, lts, tts, dt = cases.timeset("camera_only")
+    net, sd = build_pair(C, "euler", True, True, dt)
+    cam, _ = cases.bev_inputs(C, H, W, cts.shape[1], 0)
+    net.gru_ode.noise = hashfill.HashedNoise(cases.EPS_SEED)
+    y, _ = net(cam[:, -1:].cuda(), cam.cuda(), None, cts, None, tts)
+    with torch.no_grad():
+        yr, _ = R.future_prediction_ode_forward(sd, cam[:, -1:], cam, None, cts, None, tts, dt, 2, "euler", True, True,
+                                                hashfill.HashedNoise(cases.EPS_SEED))
+    assert y.shape == yr.shape == (1, 3, C, 48, 36)
+    assert maxabs(y, yr) <= TOL_E2E
