@@ -72,6 +72,15 @@ def main():
                      (512, 128, 1, 7, 200, 200), (128, 128, 3, 7, 200, 200), (256, 256, 3, 8, 50, 50), (128, 128, 3, 7, 100, 100), (64, 256, 1, 7, 200, 200)]:
             conv_case(*args)
         return
+    if "--tail" in sys.argv:
+        # tail-quantisation probe: 256x256 images = 1024 64-pixel-row tiles each
+        for n in (1, 2, 3, 4, 5, 8, 16):
+            conv_case(64, 64, 3, n, 256, 256)
+        for n in (1, 2, 4, 8, 16):
+            conv_case(128, 128, 3, n, 256, 256)
+        for hw in (232, 240, 248, 256, 264, 272):
+            conv_case(128, 128, 3, 4, hw, hw)
+        return
     if "--convs" in sys.argv:
         for args in [(8, 8, 1, 1, 4, 4), (64, 64, 1, 1, 4, 4), (64, 64, 1, 1, 50, 50), (64, 64, 3, 1, 50, 50), (128, 64, 3, 1, 50, 50, 1, 64),
                      (128, 128, 3, 1, 50, 50, 1, 64), (64, 128, 3, 1, 50, 50), (128, 128, 3, 1, 50, 50), (128, 64, 7, 1, 50, 50, 1, 64),
