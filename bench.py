@@ -158,6 +158,48 @@ def main():
                "ops_per_s": len(sc.ops) / (rollout_ms * 1e-3),
                "tflops": (sc.n_steps * flops_step + sc.n_jumps * flops_jump) / (rollout_ms * 1e-3) / 1e12}
 
+    # ---- one fused GRU-ODE step alone (SURVEY §8d unit of work), hipEvents on the launch stream -----
+    def time_step(Bs, h, w, reps):
+        s_in = torch.randn((Bs, h, w, C), device=dev) * 0.5
+        p_in = torch.randn((Bs, h, w, C), device=dev) * 0.5
+        e_in = torch.randn((S.DRAWS_PER_STEP[a.solver], Bs, h, w, C), device=dev)
+        s_o, p_o = torch.empty_like(s_in), torch.empty_like(p_in)
+        coef = torch.from_numpy(S.Schedule(dts=[float(dt)]).coef_array()).to(dev)
+        wsb = L.sf_ode_step_ws_bytes(C, Bs, h, w)
+        ws = runtime.workspace(wsb, dev)
+        pr = runtime.ptr
+
+        def one():
+            _lib.check(L.sf_ode_step_fwd(ode.gru_c.packed().struct, ode.p_model.packed().struct, _lib.SOLVER[a.solver], 1,
+                                         pr(s_in), pr(p_in), pr(coef), pr(e_in), pr(s_o), pr(p_o), Bs, h, w, pr(ws),
+                                         ws.numel() * 4, runtime.stream_ptr(dev)), "ode_step")
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        L.sf_event_record(e0, runtime.stream_ptr(dev))
+        for _ in range(reps):
+            one()
+        L.sf_event_record(e1, runtime.stream_ptr(dev))
+        L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+        t = ms.value / reps * 1e-3
+        mult = {"euler": 1, "midpoint": 2, "rk4": 4}[a.solver]
+        fl = mult * 728.0 * C * C * h * w * Bs
+        nparam = sum(v.numel() for k, v in sd.items() if k.startswith(("gru_ode.gru_c.", "gru_ode.p_model."))
+                     and "num_batches" not in k)
+        by = (16.0 + 4.0 * S.DRAWS_PER_STEP[a.solver]) * C * h * w * Bs + 4.0 * nparam
+        return {"batch": Bs, "latent": f"{h}x{w}x{C}", "us_per_step": t * 1e6, "steps_per_s": Bs / t,
+                "tflops": fl / t / 1e12, "mfma_frac": fl / t / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "algorithmic_bytes_per_step": by / Bs, "algorithmic_gbs": by / t / 1e9,
+                "hbm_frac": by / t / 1e9 / PEAK_HBM_GBS}
+    step_only = {"single_sample": time_step(1, H // 4, W // 4, 50), "batch8": time_step(8, H // 4, W // 4, 20),
+                 "stress_latent_200x200": time_step(1, H, W, 5)}
+    pmc_step = os.path.join(ROOT, "profiles", "pmc_ode_step.json")
+    if os.path.exists(pmc_step):
+        try:
+            step_only["rocprof_hbm"] = json.load(open(pmc_step))
+        except Exception:
+            pass
+
     # ---- roofline of the dominant kernel: per-launch hipEvents in a dedicated pass ---------------
     roof = None
     if not a.no_roofline:
@@ -219,7 +261,7 @@ def main():
                           "parallelism": f"replicas x{world} (sample sharding, no data-path collective)"},
                "samples_per_s": B * a.steps * world / el, "batch_per_gpu": B, "ms_per_sample": ms_per_step / B,
                "single_sample_forward_ms": single_ms, "single_sample_ode_steps_per_s": n_ode / (single_ms * 1e-3),
-               "ode_rollout_only": rollout, "roofline": roof, "cpu_baseline": cpu}
+               "ode_rollout_only": rollout, "ode_step_only": step_only, "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -214,6 +214,54 @@ int sf_dist_head_fwd(const sf_conv_w* w, const float* enc, float* out, int n, in
                      int clamp, float lo, float hi, float* ws, size_t ws_bytes, void* stream);
 size_t sf_dist_head_ws_bytes(int C, int n);
 
+/* ---- N1: camera lift-splat voxel pooling ---------------------------------------
+ * Layouts: frustum point p = ((cam*D + d)*fH + h)*fW + w of batch element b, points of a call are
+ * numbered b-major; BEV cell id = ((b*Z + z)*X + x)*Y + y; pooled output [n_cells][C] = [B][Z][X][Y][C]
+ * (the reference kernel's own output layout, NHWC for Z == 1).  `lo`, `res` (3 floats) and `dim`
+ * (X, Y, Z) are HOST arrays; lo = bev_start_position - bev_resolution / 2 evaluated in fp32. */
+
+/* bev_pool_forward — mmdet3d/ops/bev_pool/src/bev_pool.cpp:26-49 + bev_pool_cuda.cu:20-42: x [n][c]
+ * already in sorted order, geom_feats [n][4] = (x, y, z, b) int32, one interval per occupied cell;
+ * out [b][d][h][w][c] is zero-filled, each interval is summed in the given order (fp32, sequential:
+ * bit-identical to the reference kernel). */
+int sf_bev_pool_fwd(const float* x, const int32_t* geom_feats, const int32_t* interval_lengths,
+                    const int32_t* interval_starts, int n, int c, int n_intervals, int b, int d, int h, int w,
+                    float* out, void* stream);
+
+/* Quantise + filter + rank + sort of streamingflow.bev_pool (streamingflow.py:353-368) and
+ * bev_pool() (bev_pool.py:85-93), without host round trips: geom [n_points][3] float ->
+ * order [n_points] (point ids, points of a cell contiguous, ascending inside a cell; points outside
+ * the grid last), cell_start [n_cells + 1] (CSR row starts; cell_start[n_cells] = number of kept
+ * points), optional coords [n_points][4] = (x, y, z, b) per point in input order, -1 when outside. */
+size_t sf_lift_index_ws_bytes(int n_points, int n_cells);
+int sf_lift_index_fwd(const float* geom, int n_points, int n_batch, const float* lo, const float* res,
+                      const int32_t* dim, int32_t* coords, int32_t* order, int32_t* cell_start, void* ws,
+                      size_t ws_bytes, void* stream);
+/* Same index from integer coordinates [n_points][4] = (x, y, z, b) — the input of mmdet3d's
+ * bev_pool(feats, coords, B, D, H, W) (bev_pool.py:85-93; its D, H, W are Z, X, Y here). */
+int sf_lift_index_coords_fwd(const int32_t* coords, int n_points, int B, int Z, int X, int Y, int32_t* order,
+                             int32_t* cell_start, void* ws, size_t ws_bytes, void* stream);
+/* Same index, geometry computed in the kernel from the camera rig instead of being read:
+ * position = affine[b*n_cam + cam] (3x4 row major, device) applied to (us[w]*ds[d], vs[h]*ds[d], ds[d], 1)
+ * — create_frustum (streamingflow.py:149-168), get_geometry (:277-292) and the ego-motion warps of
+ * projection_to_birds_eye_view (:386-396) composed by the host into one affine per (frame, camera). */
+int sf_lift_index_rig_fwd(const float* affine, const float* us, const float* vs, const float* ds, int n_batch,
+                          int n_cam, int D, int fH, int fW, const float* lo, const float* res, const int32_t* dim,
+                          int32_t* order, int32_t* cell_start, void* ws, size_t ws_bytes, void* stream);
+
+/* Pooling proper (bev_pool_cuda.cu:20-42 over every cell, empty ones included) fused with the temporal
+ * blend of projection_to_birds_eye_view (streamingflow.py:419): out = prev*discount + sum (prev NULL:
+ * plain sum).  x [n_points][C] is the materialised depth (x) feature tensor in point order. */
+int sf_lift_pool_fwd(const float* x, const int32_t* order, const int32_t* cell_start, int n_cells, int C,
+                     const float* prev, float discount, float* out, void* stream);
+/* Same with the outer product of encoder_forward (streamingflow.py:304-307) folded in:
+ * x[p][c] = depth_prob[p] * feat[ray(p)][c]; feat [n_batch*n_cam*fHW][C], depth_prob [n_points]. */
+int sf_lift_pool_fused_fwd(const float* feat, const float* depth_prob, int D, int fHW, const int32_t* order,
+                           const int32_t* cell_start, int n_cells, int C, const float* prev, float discount,
+                           float* out, void* stream);
+/* depth.softmax(dim=1) of streamingflow.py:304 on [rows][D][fHW] */
+int sf_depth_softmax_fwd(const float* logits, float* prob, int rows, int D, int fHW, void* stream);
+
 /* hipGraph capture of whatever the caller enqueues between begin and end on `stream` (must not be
  * the legacy default stream). */
 int sf_graph_begin(void* stream);

@@ -96,3 +96,123 @@ BEVERSE_CASES = {
     "config1_c32": (32, 16, 50, 50, 4),     # BASELINE config 1: FuturePrediction(32, 16, 3, 3) at 50x50
     "odd_c16": (16, 8, 13, 21, 2),          # odd sizes: zero-pad + ceil pooling of the skip path
 }
+
+
+# ---- camera lift-splat ------------------------------------------------------------
+# tag -> b, s, n_cam, D, fH, fW, C, X_BOUND, Y_BOUND, Z_BOUND, discount
+LIFT_CASES = {
+    "tiny":     (2, 3, 2, 5, 3, 4, 8, (-4.0, 4.0, 0.5), (-4.0, 4.0, 0.5), (-10.0, 10.0, 20.0), 0.5),
+    "wide_c64": (1, 3, 3, 6, 4, 7, 64, (-6.0, 6.0, 0.5), (-5.0, 5.0, 0.5), (-10.0, 10.0, 20.0), 0.5),
+    "one_frame_c20": (1, 1, 2, 4, 3, 5, 20, (-3.0, 3.0, 0.25), (-2.0, 2.0, 0.5), (-10.0, 10.0, 20.0), 0.9),
+}
+# bev_pool alone also with several height slices (projection_to_birds_eye_view needs Z == 1)
+LIFT_POOL_CASES = {
+    "z4_b2": (2, 2, 4, 3, 5, 16, (-3.0, 3.0, 0.5), (-2.0, 2.0, 0.25), (-2.0, 2.0, 1.0)),   # B, N, D, fH, fW, C, bounds
+    "z1_b1": (1, 3, 5, 4, 4, 8, (-4.0, 4.0, 0.5), (-4.0, 4.0, 0.5), (-10.0, 10.0, 20.0)),
+    "empty": (1, 1, 2, 2, 2, 8, (-1.0, 1.0, 0.5), (-1.0, 1.0, 0.5), (-10.0, 10.0, 20.0)),     # every point outside
+}
+LIFT_MARGIN = 2e-3      # in cells: no test point closer than this to a cell boundary (see safe_geometry)
+
+
+def lift_bounds(xb, yb, zb):
+    from . import lift_splat as LS
+    return LS.calculate_birds_eye_view_parameters(list(xb), list(yb), list(zb))
+
+
+def safe_geometry(geo, final_of, lo, res):
+    """Nudge points whose *final* (float64-evaluated) cell coordinate lies within LIFT_MARGIN of a cell
+    boundary, so that fp32 rounding differences between devices in the ego-motion matmul cannot move
+    a test point into a neighbouring cell.  ``final_of(geo64) -> final positions`` (same shape)."""
+    geo = geo.clone()
+    for _ in range(50):
+        q = (final_of(geo.double()) - lo.double()) / res.double()
+        bad = (q - q.round()).abs() < LIFT_MARGIN
+        if not bool(bad.any()):
+            return geo
+        geo = torch.where(bad, geo + 0.037 * res, geo)
+    raise RuntimeError("could not move the test geometry off the cell boundaries")
+
+
+def lift_pool_inputs(tag):
+    """Inputs of ``streamingflow.bev_pool``: (geom_feats [B,N,D,H,W,3], x [B,N,D,H,W,C], start, res, dim)."""
+    B, N, D, fH, fW, C, xb, yb, zb = LIFT_POOL_CASES[tag]
+    res, start, dim = lift_bounds(xb, yb, zb)
+    lo = start - res / 2.0
+    span = torch.tensor([xb[1] - xb[0], yb[1] - yb[0], zb[1] - zb[0]])
+    u = hashfill.uniform("lift_pool_geo_" + tag, (B, N, D, fH, fW, 3), 0.0, 1.0, seed=21)
+    if tag == "empty":
+        geo = lo + span * (1.5 + u)                     # all beyond the far corner
+    else:
+        geo = lo + span * (u * 1.3 - 0.15)              # ~23 % outside, some in (-1, 0) cells (truncate to 0)
+    geo = safe_geometry(geo, lambda g: g, lo, res)
+    x = hashfill.normal("lift_pool_x_" + tag, (B, N, D, fH, fW, C), seed=22)
+    return geo, x, start, res, dim
+
+
+def lift_inputs(tag):
+    """Inputs of the camera branch after the image encoder: feat [b,s,n,C,fH,fW], depth logits
+    [b,s,n,D,fH,fW], geometry [b,s,n,D,fH,fW,3], future_egomotion [b,s,6], (start, res, dim), discount."""
+    from . import lift_splat as LS
+    b, s, n, D, fH, fW, C, xb, yb, zb, discount = LIFT_CASES[tag]
+    res, start, dim = lift_bounds(xb, yb, zb)
+    lo = start - res / 2.0
+    span = torch.tensor([xb[1] - xb[0], yb[1] - yb[0], zb[1] - zb[0]])
+    u = hashfill.uniform("lift_geo_" + tag, (b, s, n, D, fH, fW, 3), 0.0, 1.0, seed=23)
+    geo = lo + span * (u * 1.3 - 0.15)
+    ego = torch.cat([hashfill.uniform("lift_ego_t_" + tag, (b, s, 3), -0.8, 0.8, seed=24),
+                     hashfill.uniform("lift_ego_r_" + tag, (b, s, 3), -0.08, 0.08, seed=25)], -1)
+    mat = LS.pose_vec2mat(ego.double())
+
+    def final_of(g):
+        return torch.stack([LS.warp_geometry(g[i], mat[i, :, :3, :3], mat[i, :, :3, 3]) for i in range(b)])
+    geo = safe_geometry(geo, final_of, lo, res)
+    feat = hashfill.normal("lift_feat_" + tag, (b, s, n, C, fH, fW), seed=26)
+    depth = hashfill.normal("lift_depth_" + tag, (b, s, n, D, fH, fW), seed=27, std=2.0)
+    return feat, depth, geo, ego, (start, res, dim), discount
+
+
+# fused path: the camera rig itself is the input.  tag -> b, s, n_cam, C, final_dim, downsample, D_BOUND, bounds, discount
+LIFT_RIG_CASES = {
+    "rig_small": (2, 3, 2, 8, (32, 48), 8, (2.0, 8.0, 1.0), (-6.0, 6.0, 0.5), (-6.0, 6.0, 0.5), (-10.0, 10.0, 20.0), 0.5),
+    "rig_c64":   (1, 2, 3, 64, (24, 40), 8, (1.0, 7.0, 0.5), (-5.0, 5.0, 0.25), (-5.0, 5.0, 0.5), (-10.0, 10.0, 20.0), 0.7),
+}
+
+
+def lift_rig_inputs(tag):
+    """feat [b,s,n,C,fH,fW], depth logits [b,s,n,D,fH,fW], intrinsics [b,s,n,3,3], extrinsics [b,s,n,4,4],
+    future_egomotion [b,s,6], frustum [D,fH,fW,3], (start, res, dim), discount.  The rig is shifted
+    (deterministically) until no frustum point ends within LIFT_MARGIN/4 cells of a cell boundary, so
+    the fp32 rounding of the composed transform cannot change a cell."""
+    from . import lift_splat as LS
+    b, s, n, C, final_dim, down, d_bound, xb, yb, zb, discount = LIFT_RIG_CASES[tag]
+    res, start, dim = lift_bounds(xb, yb, zb)
+    lo = start - res / 2.0
+    fr = LS.create_frustum(final_dim, down, list(d_bound))
+    D, fH, fW, _ = fr.shape
+    H, W = final_dim
+    f = 0.9 * W
+    intr = torch.tensor([[f, 0.0, W / 2.0], [0.0, f, H / 2.0], [0.0, 0.0, 1.0]]).repeat(b, s, n, 1, 1)
+    intr = intr * (1.0 + 0.05 * hashfill.uniform("rig_intr_" + tag, (b, s, n, 1, 1), -1.0, 1.0, seed=41))
+    intr[..., 2, 2] = 1.0
+    # cameras look along +x / -x / +y ... : camera z (depth) -> ego x, camera x -> ego -y, camera y -> ego -z
+    base = torch.tensor([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])
+    ego = torch.cat([hashfill.uniform("rig_ego_t_" + tag, (b, s, 3), -0.6, 0.6, seed=44),
+                     hashfill.uniform("rig_ego_r_" + tag, (b, s, 3), -0.06, 0.06, seed=45)], -1)
+    for attempt in range(200):
+        yaw = hashfill.uniform("rig_yaw_%s_%d" % (tag, attempt), (b, s, n), -3.1, 3.1, seed=42)
+        ang = torch.stack([torch.zeros_like(yaw), torch.zeros_like(yaw), yaw], -1)
+        rot = LS.euler2mat(ang).matmul(base)
+        trans = hashfill.uniform("rig_t_%s_%d" % (tag, attempt), (b, s, n, 3), -0.5, 0.5, seed=43)
+        extr = torch.zeros(b, s, n, 4, 4)
+        extr[..., :3, :3], extr[..., :3, 3], extr[..., 3, 3] = rot, trans, 1.0
+        g = LS.get_geometry(fr.double(), intr.double().view(b * s, n, 3, 3), extr.double().view(b * s, n, 4, 4)).view(b, s, n, D, fH, fW, 3)
+        mat = LS.pose_vec2mat(ego.double())
+        fin = torch.stack([LS.warp_geometry(g[i], mat[i, :, :3, :3], mat[i, :, :3, 3]) for i in range(b)])
+        q = (fin - lo.double()) / res.double()
+        if float((q - q.round()).abs().min()) >= LIFT_MARGIN / 4:
+            break
+    else:
+        raise RuntimeError("no safe rig found")
+    feat = hashfill.normal("rig_feat_" + tag, (b, s, n, C, fH, fW), seed=46)
+    depth = hashfill.normal("rig_depth_" + tag, (b, s, n, D, fH, fW), seed=47, std=2.0)
+    return feat, depth, intr, extr, ego, fr, (start, res, dim), discount

@@ -10,6 +10,8 @@ Only outputs (data) are stored; weights / inputs / eps are regenerated from thei
   schedules.json  G4: (kind, dt) op lists + selection indices produced by the reference's own
                   control flow (temporal_ode_bayes.py:508-620) with its numerics stubbed out
   big_stats.json  G7: statistics of the C=64, 200x200 forward (tensors are 72 MB)
+  lift_splat.npz  N1: streamingflow.bev_pool / projection_to_birds_eye_view / get_geometry /
+                  create_frustum / pose_vec2mat / mmdet3d bev_pool (+ QuickCumsum) outputs
 """
 import argparse
 import json
@@ -215,6 +217,78 @@ def gen_big(m):
         json.dump(stats, f)
 
 
+def gen_lift():
+    """N1: camera lift-splat.  The reference's own Python runs (bev_pool.py, streamingflow.bev_pool,
+    projection_to_birds_eye_view, get_geometry, create_frustum, pose_vec2mat); only the CUDA kernel
+    behind ``bev_pool_ext.bev_pool_forward`` is the oracle's restatement (no nvcc here)."""
+    from types import SimpleNamespace as NS
+    from . import lift_splat as LS
+    R = refimport.lift_splat_reference(LS.bev_pool_kernel)
+    out = {}
+
+    def fake_self(start, res, dim, discount=0.5):
+        me = NS(bev_start_position=start, bev_resolution=res, bev_dimension=dim, discount=discount)
+        me.bev_pool = lambda g, x: R.model.bev_pool(me, g, x)
+        return me
+    with torch.no_grad():
+        for tag in cases.LIFT_POOL_CASES:
+            geo, x, start, res, dim = cases.lift_pool_inputs(tag)
+            if tag == "empty":      # no point inside the grid: the reference fails (bev_pool.py:45)
+                try:
+                    R.model.bev_pool(fake_self(start, res, dim), geo.clone(), x.clone())
+                    raise AssertionError("expected the reference to raise on an empty frame")
+                except IndexError:
+                    continue
+            pooled, kept = R.model.bev_pool(fake_self(start, res, dim), geo.clone(), x.clone())
+            out["pool_" + tag] = _np(pooled)
+            out["pool_kept_" + tag] = kept.numpy().astype(np.int32)
+            mine, kept2 = LS.sf_bev_pool(geo, x, start, res, dim, stable=False)
+            assert torch.equal(kept, kept2) and torch.equal(pooled, mine), tag    # same argsort => same bits
+            print("pool", tag, tuple(pooled.shape), int(kept.shape[0]), "kept of", x.numel() // x.shape[-1])
+        for tag in cases.LIFT_CASES:
+            feat, depth, geo, ego, (start, res, dim), discount = cases.lift_inputs(tag)
+            b, s, n, C, fH, fW = feat.shape
+            x = LS.depth_outer(feat.reshape(b * s * n, C, fH, fW), depth.reshape(b * s * n, -1, fH, fW))
+            x = x.reshape(b, s, n, *x.shape[1:])
+            ref = R.model.projection_to_birds_eye_view(fake_self(start, res, dim, discount), x.clone(), geo.clone(), ego.clone())
+            out["proj_" + tag] = _np(ref)
+            mine = LS.projection_to_birds_eye_view(x, geo, ego, start, res, dim, discount, stable=False)
+            assert torch.equal(ref, mine), tag
+            print("proj", tag, tuple(ref.shape), float(ref.abs().max()))
+        # frustum + geometry of a small rig through the reference's create_frustum / get_geometry
+        cfg = NS(IMAGE=NS(FINAL_DIM=(32, 48)), LIFT=NS(D_BOUND=[2.0, 10.0, 1.0]))
+        me = NS(cfg=cfg, encoder_downsample=8)
+        fr = R.model.create_frustum(me).data
+        assert torch.equal(fr, LS.create_frustum((32, 48), 8, [2.0, 10.0, 1.0]))
+        out["frustum"] = _np(fr)
+        intr = torch.tensor([[20.0, 0.0, 24.0], [0.0, 20.0, 16.0], [0.0, 0.0, 1.0]]).repeat(1, 2, 1, 1)
+        ang = hashfill.uniform("lift_extr_r", (1, 2, 3), -1.0, 1.0, seed=31)
+        extr = R.geometry.pose_vec2mat(torch.cat([hashfill.uniform("lift_extr_t", (1, 2, 3), -1.0, 1.0, seed=32), ang], -1))
+        assert torch.equal(extr, LS.pose_vec2mat(torch.cat([hashfill.uniform("lift_extr_t", (1, 2, 3), -1.0, 1.0, seed=32), ang], -1)))
+        me.frustum = fr
+        g = R.model.get_geometry(me, intr, extr)
+        assert torch.equal(g, LS.get_geometry(fr, intr, extr))
+        out["geometry"] = _np(g)
+        out["pose_vec2mat"] = _np(extr)
+        # the pooling op itself, with duplicated coordinates, vs the reference's QuickCumsum implementation
+        n, c = 3000, 8
+        coords = (hashfill.uniform("lift_op_coords", (n, 4), 0.0, 1.0, seed=33) * torch.tensor([7.0, 6.0, 2.0, 2.0])).long()
+        feats = hashfill.normal("lift_op_feats", (n, c), seed=34)
+        a = R.bev_pool_py.bev_pool(feats, coords, 2, 2, 7, 6)
+        assert torch.equal(a, LS.bev_pool_op(feats, coords, 2, 2, 7, 6, stable=False))
+        ranks = coords[:, 0] * (6 * 2 * 2) + coords[:, 1] * (2 * 2) + coords[:, 2] * 2 + coords[:, 3]
+        idx = ranks.argsort()
+        xq, gq = R.bev_pool_py.QuickCumsum.apply(feats[idx], coords[idx], ranks[idx])
+        o = torch.zeros(2, 2, 7, 6, c)
+        o[gq[:, 3], gq[:, 2], gq[:, 0], gq[:, 1]] = xq
+        print("bev_pool op vs QuickCumsum:", float((o.permute(0, 4, 1, 2, 3) - a).abs().max()))
+        assert float((o.permute(0, 4, 1, 2, 3) - a).abs().max()) < 1e-4
+        out["op_bev_pool"] = _np(a)
+        out["op_quickcumsum"] = _np(o.permute(0, 4, 1, 2, 3))
+    np.savez_compressed(os.path.join(OUT, "lift_splat.npz"), **out)
+    print("lift_splat.npz", sum(v.nbytes for v in out.values()), "bytes raw")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also generate the C=64 200x200 statistics (slow)")
@@ -222,8 +296,12 @@ def main():
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    todo = a.only.split(",") if a.only else ["ops", "fpode", "schedules", "beverse", "lift"]
+    if "lift" in todo:
+        gen_lift()
+        if todo == ["lift"]:
+            return
     m = refimport.modules()
-    todo = a.only.split(",") if a.only else ["ops", "fpode", "schedules", "beverse"]
     if "ops" in todo:
         gen_ops(m)
     if "fpode" in todo:

@@ -7,5 +7,7 @@ Host side: Python modules mirroring the reference's nn.Module interface for this
 from .models.future_prediction_ode import FuturePredictionODE  # noqa: F401
 from .layers.temporal_ode_bayes import NNFOwithBayesianJumps, DualGRUODECell, DualGRUCell, GRUObservationCell  # noqa: F401
 from .layers.temporal import SpatialGRU  # noqa: F401
+from .models.lift_splat import LiftSplat  # noqa: F401
+from .bev_pool import bev_pool  # noqa: F401
 
 __version__ = "0.1.0"

@@ -71,6 +71,8 @@ class BottleneckW(C.Structure):
 
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 # name -> (restype, argtypes); every symbol declared in include/sfnative.h
+_f3 = C.POINTER(C.c_float * 3)
+_i3 = C.POINTER(C.c_int32 * 3)
 SIGNATURES = {
     "sf_version": (_i, []),
     "sf_status_string": (C.c_char_p, [_i]),
@@ -105,6 +107,14 @@ SIGNATURES = {
     "sf_bottleneck_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "sf_dist_head_fwd": (_i, [C.POINTER(ConvW), _vp, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float, _vp, _sz, _vp]),
     "sf_dist_head_ws_bytes": (_sz, [_i, _i]),
+    "sf_bev_pool_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sf_lift_index_ws_bytes": (_sz, [_i, _i]),
+    "sf_lift_index_fwd": (_i, [_vp, _i, _i, _f3, _f3, _i3, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sf_lift_index_coords_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "sf_lift_index_rig_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f3, _f3, _i3, _vp, _vp, _vp, _sz, _vp]),
+    "sf_lift_pool_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, C.c_float, _vp, _vp]),
+    "sf_lift_pool_fused_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, C.c_float, _vp, _vp]),
+    "sf_depth_softmax_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sf_graph_begin": (_i, [_vp]),
     "sf_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "sf_graph_launch": (_i, [_vp, _vp]),
