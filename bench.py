@@ -235,6 +235,19 @@ def main():
                     "calls_per_forward": calls[i] // 2, "ms_per_forward": pms[i] / 2,
                     "tflops": pfl[i] / (pms[i] * 1e-3) / 1e12} for i in range(NK) if calls[i]}}
 
+    # ---- camera lift-splat voxel pooling feeding the BEV tensor (HBM-bound gather) ----
+    lift = None
+    if rank == 0:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import liftbench
+            lift = liftbench.run(reps=10, cpu=(world == 1 and not a.no_cpu_baseline), dev=dev)
+            pl = os.path.join(ROOT, "profiles", "pmc_lift_pool.json")
+            if os.path.exists(pl):
+                lift["roofline"]["traffic"] = json.load(open(pl)).get("hbm_bytes_per_launch")
+        except Exception as ex:      # secondary figure: never lose the headline line over it
+            lift = {"error": repr(ex)}
+
     # ---- CPU baseline: the oracle (torch-CPU port of the reference path) on the host cores --------
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -261,7 +274,7 @@ def main():
                           "parallelism": f"replicas x{world} (sample sharding, no data-path collective)"},
                "samples_per_s": B * a.steps * world / el, "batch_per_gpu": B, "ms_per_sample": ms_per_step / B,
                "single_sample_forward_ms": single_ms, "single_sample_ode_steps_per_s": n_ode / (single_ms * 1e-3),
-               "ode_rollout_only": rollout, "ode_step_only": step_only, "roofline": roof, "cpu_baseline": cpu}
+               "ode_rollout_only": rollout, "ode_step_only": step_only, "lift_splat": lift, "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -112,36 +112,64 @@ __global__ void lift_cell_start_kernel(const unsigned* __restrict__ keys, int n,
   cell_start[c] = lo;
 }
 
-// MODE 0: v = x[p][c].  MODE 1: v = depth[p] * feat[ray(p)][c], ray(p) = (p / (D*fHW))*fHW + p % fHW.
+// One wave per (cell, 64-channel chunk); lane = channel.  The cell's point list is read 64 entries at a
+// time, one entry per lane (coalesced), together with everything that depends on the point only
+// (MODE 1: its depth probability and its ray index — two integer divisions done once per point
+// instead of once per (point, channel)); the entries are then broadcast one by one with
+// v_readlane and every lane gathers its channel of that point's feature row (one 256-B line per
+// wave).  Adds are sequential in list order: the sum is reproducible and bit-identical to a scalar
+// loop.  MODE 0: v = x[p][c].  MODE 1: v = depth[p] * feat[ray(p)][c], ray(p) = (p / (D*fHW))*fHW + p % fHW.
+#ifndef LIFT_INFLIGHT
+#define LIFT_INFLIGHT 16
+#endif
 template <int MODE>
-__global__ void lift_pool_kernel(const int* __restrict__ order, const int* __restrict__ cell_start, int ncells, int C,
-                                 const float* __restrict__ x, const float* __restrict__ depth, const float* __restrict__ feat,
-                                 int D, int fHW, const float* __restrict__ prev, float discount, float* __restrict__ out) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int cell = (int)(idx / C);
-  const int c = (int)(idx - (long)cell * C);
-  if (cell >= ncells) return;
+__global__ __launch_bounds__(256) void lift_pool_kernel(const int* __restrict__ order, const int* __restrict__ cell_start, int ncells,
+                                                        int C, const float* __restrict__ x, const float* __restrict__ depth,
+                                                        const float* __restrict__ feat, int D, int fHW,
+                                                        const float* __restrict__ prev, float discount, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int chunks = (C + 63) >> 6;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int cell = (int)(wave / chunks);
+  if (cell >= ncells) return;                       // wave-uniform
+  const int c = (int)(wave - (long)cell * chunks) * 64 + lane;
+  const bool act = c < C;
+  const int cc = act ? c : 0;
   const int s = cell_start[cell], e = cell_start[cell + 1];
   const int DF = D * fHW;
-  auto value = [&](int p) -> float {
-    if (MODE == 0) return x[(size_t)p * C + c];
-    const int cam = p / DF;
-    const int hw = p % fHW;
-    return __fmul_rn(depth[p], feat[((size_t)cam * fHW + hw) * C + c]);
-  };
+  const float* __restrict__ table = (MODE == 0) ? x : feat;
   float acc = 0.f;
-  int k = s;
-  for (; k + 4 <= e; k += 4) {          // 4 independent gathers in flight, sequential adds (fixed order)
-    const int p0 = order[k], p1 = order[k + 1], p2 = order[k + 2], p3 = order[k + 3];
-    const float v0 = value(p0), v1 = value(p1), v2 = value(p2), v3 = value(p3);
-    acc = __fadd_rn(acc, v0);
-    acc = __fadd_rn(acc, v1);
-    acc = __fadd_rn(acc, v2);
-    acc = __fadd_rn(acc, v3);
+  for (int base = s; base < e; base += 64) {
+    const int m = (e - base) < 64 ? (e - base) : 64;
+    int row = 0;
+    float dv = 0.f;
+    if (lane < m) {
+      const int p = order[base + lane];
+      if (MODE == 0) row = p;
+      else {
+        dv = depth[p];
+        row = (p / DF) * fHW + (p % fHW);
+      }
+    }
+    for (int j = 0; j < m; j += LIFT_INFLIGHT) {    // gathers in flight; padded slots contribute +0 (identity)
+      float v[LIFT_INFLIGHT];
+#pragma unroll
+      for (int i = 0; i < LIFT_INFLIGHT; ++i) {
+        const int jj = (j + i) < m ? (j + i) : j;
+        const int r = __builtin_amdgcn_readlane(row, jj);
+        const float t = table[(size_t)r * C + cc];
+        if (MODE == 0) v[i] = t;
+        else v[i] = __fmul_rn(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), jj)), t);
+        if ((j + i) >= m) v[i] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < LIFT_INFLIGHT; ++i) acc = __fadd_rn(acc, v[i]);
+    }
   }
-  for (; k < e; ++k) acc = __fadd_rn(acc, value(order[k]));
-  if (prev) acc = __fadd_rn(__fmul_rn(prev[idx], discount), acc);      // streamingflow.py:419
-  out[idx] = acc;
+  if (!act) return;
+  const size_t o = (size_t)cell * C + c;
+  if (prev) acc = __fadd_rn(__fmul_rn(prev[o], discount), acc);      // streamingflow.py:419
+  out[o] = acc;
 }
 
 // mmdet3d/ops/bev_pool/src/bev_pool_cuda.cu:20-42, coalesced the same way (adjacent lanes = channels)
@@ -165,13 +193,32 @@ __global__ void bev_pool_intervals_kernel(int d, int h, int w, int c, int n_inte
   out[((((size_t)g[3] * d + g[2]) * h + g[0]) * w + g[1]) * c + cc] = acc;
 }
 
-// softmax over the depth axis of [rows][D][fHW] (streamingflow.py:304): one thread per (row, hw)
+// softmax over the depth axis of [rows][D][fHW] (streamingflow.py:304): one thread per (row, hw); the
+// D <= 64 logits of a ray are read once (all loads in flight together) and kept in registers.
 __global__ void depth_softmax_kernel(const float* __restrict__ logits, float* __restrict__ prob, int rows, int D, int fHW) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * fHW) return;
   const int r = i / fHW, hw = i - r * fHW;
   const float* in = logits + (size_t)r * D * fHW + hw;
   float* o = prob + (size_t)r * D * fHW + hw;
+  if (D <= 64) {
+    float v[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) v[d] = d < D ? in[(size_t)d * fHW] : -INFINITY;
+    float m = -INFINITY;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) m = fmaxf(m, v[d]);
+    float sum = 0.f;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) {
+      v[d] = d < D ? expf(v[d] - m) : 0.f;
+      sum += v[d];
+    }
+#pragma unroll
+    for (int d = 0; d < 64; ++d)
+      if (d < D) o[(size_t)d * fHW] = v[d] / sum;
+    return;
+  }
   float m = -INFINITY;
   for (int d = 0; d < D; ++d) m = fmaxf(m, in[(size_t)d * fHW]);
   float sum = 0.f;
@@ -306,8 +353,8 @@ int sf_lift_index_rig_fwd(const float* affine, const float* us, const float* vs,
 int sf_lift_pool_fwd(const float* x, const int32_t* order, const int32_t* cell_start, int n_cells, int C, const float* prev,
                      float discount, float* out, void* stream) {
   if (!x || !order || !cell_start || !out || n_cells < 1 || C < 1) return SF_ERR_INVALID;
-  const long total = (long)n_cells * C;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(lift_pool_kernel<0>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+  const long waves = (long)n_cells * ((C + 63) / 64);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(lift_pool_kernel<0>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), order, cell_start, n_cells, C, x, nullptr, nullptr, 1, 1, prev, discount, out);
   return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
 }
@@ -316,8 +363,8 @@ int sf_lift_pool_fused_fwd(const float* feat, const float* depth_prob, int D, in
                            const int32_t* cell_start, int n_cells, int C, const float* prev, float discount, float* out,
                            void* stream) {
   if (!feat || !depth_prob || !order || !cell_start || !out || n_cells < 1 || C < 1 || D < 1 || fHW < 1) return SF_ERR_INVALID;
-  const long total = (long)n_cells * C;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(lift_pool_kernel<1>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+  const long waves = (long)n_cells * ((C + 63) / 64);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(lift_pool_kernel<1>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), order, cell_start, n_cells, C, nullptr, depth_prob, feat, D, fHW, prev, discount,
                      out);
   return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
@@ -326,7 +373,7 @@ int sf_lift_pool_fused_fwd(const float* feat, const float* depth_prob, int D, in
 int sf_depth_softmax_fwd(const float* logits, float* prob, int rows, int D, int fHW, void* stream) {
   if (!logits || !prob || rows < 1 || D < 1 || fHW < 1) return SF_ERR_INVALID;
   const long total = (long)rows * fHW;
-  hipLaunchKernelGGL(depth_softmax_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), logits,
+  hipLaunchKernelGGL(depth_softmax_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), logits,
                      prob, rows, D, fHW);
   return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
 }
