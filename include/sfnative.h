@@ -262,6 +262,20 @@ int sf_lift_pool_fused_fwd(const float* feat, const float* depth_prob, int D, in
 /* depth.softmax(dim=1) of streamingflow.py:304 on [rows][D][fHW] */
 int sf_depth_softmax_fwd(const float* logits, float* prob, int rows, int D, int fHW, void* stream);
 
+/* ---- N2 (first half): LiDAR hard voxelisation ------------------------------------------------------
+ * hard_voxelize — mmdet3d/ops/voxel/src/voxelization.h:63-85, deterministic GPU path
+ * voxelization_cuda.cu:262-420 (same result as voxelization_cpu.cpp:45-102): points [num_points][F]
+ * (x, y, z first), voxel_size / coors_range HOST arrays of 3 / 6 floats.  Outputs sized for
+ * max_voxels and zero-filled as in voxelize.py:52-54: voxels [max_voxels][max_points][F] (may be NULL),
+ * coors [max_voxels][3] = (x, y, z), num_points_per_voxel [max_voxels]; voxel_num: device int = the
+ * reference's return value.  mean_feats (may be NULL) [max_voxels][F] = sum over the voxel's points /
+ * their number — the reduction streamingflow.voxelize applies right after (streamingflow.py:190-195). */
+size_t sf_hard_voxelize_ws_bytes(int num_points);
+int sf_hard_voxelize_fwd(const float* points, int num_points, int num_features, const float* voxel_size,
+                         const float* coors_range, int max_points, int max_voxels, float* voxels, int32_t* coors,
+                         int32_t* num_points_per_voxel, float* mean_feats, int32_t* voxel_num, void* ws,
+                         size_t ws_bytes, void* stream);
+
 /* hipGraph capture of whatever the caller enqueues between begin and end on `stream` (must not be
  * the legacy default stream). */
 int sf_graph_begin(void* stream);

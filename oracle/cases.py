@@ -216,3 +216,27 @@ def lift_rig_inputs(tag):
     feat = hashfill.normal("rig_feat_" + tag, (b, s, n, C, fH, fW), seed=46)
     depth = hashfill.normal("rig_depth_" + tag, (b, s, n, D, fH, fW), seed=47, std=2.0)
     return feat, depth, intr, extr, ego, fr, (start, res, dim), discount
+
+
+# ---- LiDAR hard voxelisation --------------------------------------------------------
+# tag -> n_points, F, voxel_size, point_cloud_range, max_points, max_voxels.  Cubic grids: the reference's
+# CPU kernel (the fixture generator) is only memory-safe there (see oracle/voxelize.py).
+VOXEL_CASES = {
+    "cube16":      (3000, 5, (0.5, 0.5, 0.5), (-4.0, -4.0, -4.0, 4.0, 4.0, 4.0), 3, 200),
+    "cube8_dense": (5000, 4, (1.0, 1.0, 1.0), (-4.0, -4.0, -4.0, 4.0, 4.0, 4.0), 10, 5000),
+    "cap50":       (2000, 5, (0.5, 0.5, 0.5), (-4.0, -4.0, -4.0, 4.0, 4.0, 4.0), 2, 50),
+    "one_point":   (1, 3, (0.5, 0.5, 0.5), (-4.0, -4.0, -4.0, 4.0, 4.0, 4.0), 4, 10),
+}
+# the shipped configuration (streamingflow.py:111): 1600 x 1600 x 40 voxels, <= 10 points, <= 160000 voxels (eval)
+VOXEL_SHIPPED = ((0.0625, 0.0625, 0.2), (-50.0, -50.0, -5.0, 50.0, 50.0, 3.0), 10, 160000)
+
+
+def voxel_points(tag):
+    n, F, vs, rng, mp, mv = VOXEL_CASES[tag]
+    p = hashfill.uniform("voxel_pts_" + tag, (n, F), -5.0, 5.0, seed=51)
+    if n >= 16:      # points exactly on cell / range boundaries: floor() and the open upper bound
+        edge = torch.tensor([-4.0, 4.0, 0.0, 0.5, -0.5, 3.5, 3.9999998, -4.0000005])
+        p[:8, 0] = edge
+        p[8:16, 1] = edge
+        p[4:12, 2] = edge
+    return p

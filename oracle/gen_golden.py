@@ -10,6 +10,7 @@ Only outputs (data) are stored; weights / inputs / eps are regenerated from thei
   schedules.json  G4: (kind, dt) op lists + selection indices produced by the reference's own
                   control flow (temporal_ode_bayes.py:508-620) with its numerics stubbed out
   big_stats.json  G7: statistics of the C=64, 200x200 forward (tensors are 72 MB)
+  voxelize.npz    N2: mmdet3d Voxelization (hard voxelisation) outputs from the reference's C++ CPU kernel
   lift_splat.npz  N1: streamingflow.bev_pool / projection_to_birds_eye_view / get_geometry /
                   create_frustum / pose_vec2mat / mmdet3d bev_pool (+ QuickCumsum) outputs
 """
@@ -289,6 +290,23 @@ def gen_lift():
     print("lift_splat.npz", sum(v.nbytes for v in out.values()), "bytes raw")
 
 
+def gen_voxel():
+    """N2 (voxelise half): the reference's Voxelization module on the reference's own C++ CPU kernel
+    (oracle/build_ref.py compiles mmdet3d/ops/voxel/src/voxelization{,_cpu}.cpp in place)."""
+    from . import voxelize as VZ
+    R = refimport.voxel_reference()
+    out = {}
+    for tag, (n, F, vs, rng, mp, mv) in cases.VOXEL_CASES.items():
+        pts = cases.voxel_points(tag)
+        m = R.Voxelization(list(vs), list(rng), mp, (mv, mv)).eval()
+        v, c, k = m(pts)
+        out["voxels_" + tag], out["coors_" + tag], out["num_" + tag] = _np(v), c.numpy().astype(np.int32), k.numpy().astype(np.int32)
+        v2, c2, k2 = VZ.hard_voxelize(pts.numpy(), vs, rng, mp, mv)
+        assert np.array_equal(v.numpy(), v2) and np.array_equal(c.numpy(), c2) and np.array_equal(k.numpy(), k2), tag
+        print("voxel", tag, tuple(v.shape), int(k.sum()), "points kept of", n)
+    np.savez_compressed(os.path.join(OUT, "voxelize.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also generate the C=64 200x200 statistics (slow)")
@@ -296,11 +314,13 @@ def main():
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["ops", "fpode", "schedules", "beverse", "lift"]
+    todo = a.only.split(",") if a.only else ["ops", "fpode", "schedules", "beverse", "lift", "voxel"]
     if "lift" in todo:
         gen_lift()
-        if todo == ["lift"]:
-            return
+    if "voxel" in todo:
+        gen_voxel()
+    if not set(todo) - {"lift", "voxel"}:
+        return
     m = refimport.modules()
     if "ops" in todo:
         gen_ops(m)

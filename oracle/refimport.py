@@ -147,3 +147,28 @@ def lift_splat_reference(kernel_forward):
     sfm = importlib.import_module("streamingflow.models.streamingflow")
     from streamingflow.utils import geometry
     return SimpleNamespace(bev_pool_py=bp, model=sfm.streamingflow, geometry=geometry)
+
+
+def voxel_reference():
+    """The reference's ``Voxelization`` module (mmdet3d/ops/voxel/voxelize.py) running on the reference's
+    own C++ CPU kernel, compiled from its sources by ``oracle/build_ref.py`` into oracle/_ref/.
+    Returns a namespace with ``Voxelization`` and the raw extension, or None when the extension was
+    never built (GPU box without the prebuilt file)."""
+    import importlib
+    from . import build_ref
+    if available():
+        build_ref.build()
+    ext = build_ref.load_voxel_layer()
+    if ext is None or not available():
+        return SimpleNamespace(ext=ext, Voxelization=None) if ext is not None else None
+    install()
+    if "mmdet3d.ops" not in sys.modules:
+        ops = types.ModuleType("mmdet3d.ops")
+        ops.__path__ = []
+        sys.modules["mmdet3d.ops"] = ops
+    pkg = types.ModuleType("mmdet3d.ops.voxel")
+    pkg.__path__ = [os.path.join(REF_ROOT, "mmdet3d", "ops", "voxel")]
+    sys.modules["mmdet3d.ops.voxel"] = pkg
+    sys.modules["mmdet3d.ops.voxel.voxel_layer"] = ext
+    vz = importlib.import_module("mmdet3d.ops.voxel.voxelize")
+    return SimpleNamespace(ext=ext, Voxelization=vz.Voxelization, voxelization=vz.voxelization)

@@ -73,6 +73,7 @@ _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 # name -> (restype, argtypes); every symbol declared in include/sfnative.h
 _f3 = C.POINTER(C.c_float * 3)
 _i3 = C.POINTER(C.c_int32 * 3)
+_f6 = C.POINTER(C.c_float * 6)
 SIGNATURES = {
     "sf_version": (_i, []),
     "sf_status_string": (C.c_char_p, [_i]),
@@ -115,6 +116,8 @@ SIGNATURES = {
     "sf_lift_pool_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, C.c_float, _vp, _vp]),
     "sf_lift_pool_fused_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, C.c_float, _vp, _vp]),
     "sf_depth_softmax_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sf_hard_voxelize_ws_bytes": (_sz, [_i]),
+    "sf_hard_voxelize_fwd": (_i, [_vp, _i, _i, _f3, _f6, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sf_graph_begin": (_i, [_vp]),
     "sf_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "sf_graph_launch": (_i, [_vp, _vp]),

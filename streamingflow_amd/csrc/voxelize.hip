@@ -1,0 +1,208 @@
+// LiDAR hard voxelisation for gfx950 (SURVEY.md §8f, row N2 — the voxelise half) + its C ABI.
+//
+// Reference: mmdet3d/ops/voxel/src/voxelization_cuda.cu:262-420 (hard_voxelize_gpu, deterministic):
+//   1. dynamic_voxelize_kernel        point -> (x, y, z) voxel coordinate or -1              (:25-60)
+//   2. point_to_voxelidx_kernel       every point scans ALL earlier points for the same
+//                                     coordinate: O(N^2) global loads, N = 350 000            (:101-146)
+//   3. determin_voxel_num<<<1,1>>>    one thread walks all points to number the voxels in
+//                                     first-appearance order                                   (:148-178)
+//   4. assign_point_to_voxel / assign_voxel_coors                                             (:62-99)
+//   with cudaDeviceSynchronize() between the steps.
+//
+// Same result (bit-exact: integer + copy work), O(N log N), no host sync, no serial kernel:
+//   vox_key_kernel      cell key (z*gy + y)*gx + x, or a sentinel for points outside the range
+//   stable radix sort   of (key, point index): the points of a voxel become contiguous, in
+//                       ascending point index; the head of a run is the voxel's first point
+//   vox_head_kernel     flag[first point of every run] = 1   (flags live in point order)
+//   exclusive scan      of the flags over the points: scan[first point] = number of voxels that
+//                       appeared earlier = the reference's voxel number
+//   vox_assign_kernel   per sorted position: run head by binary search -> voxel number and the
+//                       point's slot; copy the feature row, coordinates, count; optionally the
+//                       per-voxel mean that streamingflow.voxelize computes right after
+//                       (streamingflow.py:190-195), so the [max_voxels][max_points][F] tensor need
+//                       not exist at all.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "../../include/sfnative.h"
+
+namespace sf {
+
+struct VoxGrid {
+  float vs[3], lo[3];
+  int g[3];
+};
+
+// voxelization_cuda.cu:37-58: c = floor((p - min) / size) in fp32; 0 <= c < grid on every axis
+__global__ void vox_key_kernel(const float* __restrict__ points, int n, int F, VoxGrid G, unsigned sentinel,
+                               unsigned* __restrict__ key, unsigned* __restrict__ val) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = points + (size_t)i * F;
+  bool ok = true;
+  int c[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float f = floorf(__fdiv_rn(__fsub_rn(p[a], G.lo[a]), G.vs[a]));
+    ok = ok && (f >= 0.f) && (f < (float)G.g[a]);
+    c[a] = ok ? (int)f : 0;
+  }
+  key[i] = ok ? (unsigned)((c[2] * G.g[1] + c[1]) * G.g[0] + c[0]) : sentinel;
+  val[i] = (unsigned)i;
+}
+
+__global__ void vox_head_kernel(const unsigned* __restrict__ keys, const unsigned* __restrict__ order, int n, unsigned sentinel,
+                                int* __restrict__ flag) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const unsigned k = keys[j];
+  if (k == sentinel) return;
+  if (j == 0 || keys[j - 1] != k) flag[order[j]] = 1;
+}
+
+__device__ __forceinline__ int lower_bound_u(const unsigned* __restrict__ a, int n, unsigned v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void vox_assign_kernel(const float* __restrict__ points, int n, int F, const unsigned* __restrict__ keys,
+                                  const unsigned* __restrict__ order, const int* __restrict__ scan, const int* __restrict__ flag,
+                                  VoxGrid G, unsigned sentinel, int max_points, int max_voxels, float* __restrict__ voxels,
+                                  int* __restrict__ coors, int* __restrict__ num, float* __restrict__ mean, int* __restrict__ voxel_num) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0 && voxel_num) {
+    const int total = n > 0 ? scan[n - 1] + flag[n - 1] : 0;
+    voxel_num[0] = total < max_voxels ? total : max_voxels;
+  }
+  if (j >= n) return;
+  const unsigned k = keys[j];
+  if (k == sentinel) return;
+  const int h = (j == 0 || keys[j - 1] != k) ? j : lower_bound_u(keys, j, k);
+  const int vid = scan[order[h]];
+  if (vid >= max_voxels) return;                    // voxel appeared after the cap: dropped with its points (:160)
+  const int r = j - h;
+  if (voxels && r < max_points) {
+    const float* src = points + (size_t)order[j] * F;
+    float* dst = voxels + ((size_t)vid * max_points + r) * F;
+    for (int f = 0; f < F; ++f) dst[f] = src[f];
+  }
+  if (r != 0) return;
+  int e = j + 1;                                    // run length, capped: only the first max_points matter
+  while (e < n && e - j < max_points && keys[e] == k) ++e;
+  const int cnt = e - j;
+  num[vid] = cnt;
+  const int x = (int)(k % (unsigned)G.g[0]);
+  const unsigned t = k / (unsigned)G.g[0];
+  coors[3 * vid] = x;
+  coors[3 * vid + 1] = (int)(t % (unsigned)G.g[1]);
+  coors[3 * vid + 2] = (int)(t / (unsigned)G.g[1]);
+  if (mean) {                                       // feats.sum(dim=1) / sizes   (streamingflow.py:190-193)
+    for (int f = 0; f < F; ++f) {
+      float s = 0.f;
+      for (int q = 0; q < cnt; ++q) s = __fadd_rn(s, points[(size_t)order[j + q] * F + f]);
+      mean[(size_t)vid * F + f] = __fdiv_rn(s, (float)cnt);
+    }
+  }
+}
+
+inline size_t a256(size_t n) { return (n + 255) & ~size_t(255); }
+inline int bits_for(unsigned sentinel) {
+  int b = 1;
+  while (b < 32 && (sentinel >> b)) ++b;
+  return b;
+}
+inline size_t vox_sort_tmp(int n, int bits, hipStream_t st) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr,
+                                  (unsigned*)nullptr, (size_t)n, 0u, (unsigned)bits, st);
+  return bytes;
+}
+inline size_t vox_scan_tmp(int n, hipStream_t st) {
+  size_t bytes = 0;
+  (void)rocprim::exclusive_scan(nullptr, bytes, (const int*)nullptr, (int*)nullptr, 0, (size_t)n, rocprim::plus<int>(), st);
+  return bytes;
+}
+
+}  // namespace sf
+
+using namespace sf;
+
+extern "C" {
+
+size_t sf_hard_voxelize_ws_bytes(int num_points) {
+  if (num_points < 1) return 0;
+  const size_t a = a256((size_t)num_points * 4);
+  return 6 * a + a256(vox_sort_tmp(num_points, 32, nullptr)) + a256(vox_scan_tmp(num_points, nullptr)) + 256;
+}
+
+int sf_hard_voxelize_fwd(const float* points, int num_points, int num_features, const float* voxel_size, const float* coors_range,
+                         int max_points, int max_voxels, float* voxels, int32_t* coors, int32_t* num_points_per_voxel,
+                         float* mean_feats, int32_t* voxel_num, void* ws, size_t ws_bytes, void* stream) {
+  if (!voxel_size || !coors_range || !coors || !num_points_per_voxel || num_points < 0 || num_features < 3 || max_points < 1 ||
+      max_voxels < 1)
+    return SF_ERR_INVALID;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  VoxGrid G;
+  double cells = 1.0;
+  for (int a = 0; a < 3; ++a) {
+    G.vs[a] = voxel_size[a];
+    G.lo[a] = coors_range[a];
+    if (!(voxel_size[a] > 0.f)) return SF_ERR_INVALID;
+    G.g[a] = (int)roundf((coors_range[3 + a] - coors_range[a]) / voxel_size[a]);       // voxelization_cuda.cu:283-285
+    if (G.g[a] < 1) return SF_ERR_INVALID;
+    cells *= G.g[a];
+  }
+  if (cells >= 4294967295.0) return SF_ERR_UNSUPPORTED;
+  const unsigned sentinel = (unsigned)cells;
+  // the reference hands back zero-initialised outputs (voxelize.py:52-54)
+  if (voxels && hipMemsetAsync(voxels, 0, (size_t)max_voxels * max_points * num_features * sizeof(float), st) != hipSuccess)
+    return SF_ERR_LAUNCH;
+  if (hipMemsetAsync(coors, 0, (size_t)max_voxels * 3 * sizeof(int), st) != hipSuccess) return SF_ERR_LAUNCH;
+  if (hipMemsetAsync(num_points_per_voxel, 0, (size_t)max_voxels * sizeof(int), st) != hipSuccess) return SF_ERR_LAUNCH;
+  if (mean_feats && hipMemsetAsync(mean_feats, 0, (size_t)max_voxels * num_features * sizeof(float), st) != hipSuccess)
+    return SF_ERR_LAUNCH;
+  if (num_points == 0) {
+    if (voxel_num && hipMemsetAsync(voxel_num, 0, sizeof(int), st) != hipSuccess) return SF_ERR_LAUNCH;
+    return SF_OK;
+  }
+  if (!points) return SF_ERR_INVALID;
+  const int n = num_points;
+  const int bits = bits_for(sentinel);
+  const size_t a = a256((size_t)n * 4);
+  const size_t tb_sort = vox_sort_tmp(n, bits, st), tb_scan = vox_scan_tmp(n, st);
+  if (!ws || ws_bytes < 6 * a + a256(tb_sort) + a256(tb_scan)) return SF_ERR_WORKSPACE;
+  char* p = static_cast<char*>(ws);
+  unsigned* key = reinterpret_cast<unsigned*>(p);
+  unsigned* val = reinterpret_cast<unsigned*>(p + a);
+  unsigned* key_s = reinterpret_cast<unsigned*>(p + 2 * a);
+  unsigned* order = reinterpret_cast<unsigned*>(p + 3 * a);
+  int* flag = reinterpret_cast<int*>(p + 4 * a);
+  int* scan = reinterpret_cast<int*>(p + 5 * a);
+  void* tmp_sort = p + 6 * a;
+  void* tmp_scan = p + 6 * a + a256(tb_sort);
+  const dim3 grid((n + 255) / 256), block(256);
+  hipLaunchKernelGGL(vox_key_kernel, grid, block, 0, st, points, n, num_features, G, sentinel, key, val);
+  size_t tb = tb_sort;
+  if (rocprim::radix_sort_pairs(tmp_sort, tb, (const unsigned*)key, key_s, (const unsigned*)val, order, (size_t)n, 0u, (unsigned)bits,
+                                st) != hipSuccess)
+    return SF_ERR_LAUNCH;
+  if (hipMemsetAsync(flag, 0, (size_t)n * sizeof(int), st) != hipSuccess) return SF_ERR_LAUNCH;
+  hipLaunchKernelGGL(vox_head_kernel, grid, block, 0, st, key_s, order, n, sentinel, flag);
+  tb = tb_scan;
+  if (rocprim::exclusive_scan(tmp_scan, tb, (const int*)flag, scan, 0, (size_t)n, rocprim::plus<int>(), st) != hipSuccess)
+    return SF_ERR_LAUNCH;
+  hipLaunchKernelGGL(vox_assign_kernel, grid, block, 0, st, points, n, num_features, key_s, order, scan, flag, G, sentinel, max_points,
+                     max_voxels, voxels, coors, num_points_per_voxel, mean_feats, voxel_num);
+  return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
+}
+
+}  // extern "C"
