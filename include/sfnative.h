@@ -214,6 +214,23 @@ int sf_dist_head_fwd(const sf_conv_w* w, const float* enc, float* out, int n, in
                      int clamp, float lo, float hi, float* ws, size_t ws_bytes, void* stream);
 size_t sf_dist_head_ws_bytes(int C, int n);
 
+/* ---- N3 building blocks: BEV Decoder (streamingflow/models/decoder.py:8-140) ---------------------------
+ * The decoder is a ResNet-18 U-Net of plain convolutions; its host mirror
+ * (streamingflow_amd/models/decoder.py) drives these two entry points layer by layer.
+ * sf_conv2d_ex_fwd: sf_conv2d_fwd with channel-sliced operands (in0/in1/add/out may be channel ranges
+ * of wider NHWC tensors: *_cs = channel stride of the tensor, out_co = first output channel) and
+ * `act_after_add` (torchvision BasicBlock: relu(bn2(conv2(.)) + identity)); ws/ws_bytes: optional
+ * split-K scratch (sf_conv2d_ex_ws_bytes()), may be NULL. */
+int sf_conv2d_ex_fwd(const sf_conv_w* w, const float* in0, int in0_cs, const float* in1, int in1_cs, const float* add,
+                     int add_cs, int act_after_add, float* out, int out_cs, int out_co, int n_img, int Hin, int Win,
+                     int in_up, float* ws, size_t ws_bytes, void* stream);
+size_t sf_conv2d_ex_ws_bytes(void);
+/* UpsamplingAdd — convolutions.py:204-215: out [n][2H][2W][C] = bilinear_x2(in, align_corners=False) + skip.
+ * (The 1x1 conv + BatchNorm of the module commute with the interpolation and run before it, at the
+ * low resolution: a quarter of the MACs.) */
+int sf_upsample_bilinear2_add_fwd(const float* in, const float* skip, float* out, int n, int Hin, int Win, int C,
+                                  void* stream);
+
 /* ---- N1: camera lift-splat voxel pooling ---------------------------------------
  * Layouts: frustum point p = ((cam*D + d)*fH + h)*fW + w of batch element b, points of a call are
  * numbered b-major; BEV cell id = ((b*Z + z)*X + x)*Y + y; pooled output [n_cells][C] = [B][Z][X][Y][C]

@@ -240,3 +240,20 @@ def voxel_points(tag):
         p[8:16, 1] = edge
         p[4:12, 2] = edge
     return p
+
+
+# ---- BEV Decoder --------------------------------------------------------------------------
+# tag -> in_channels, n_classes, n_present, n_hdmap, predict_gate, (b, s, h, w)
+DECODER_CASES = {
+    "shipped_gates_small": (64, 2, 3, 2, dict(perceive_hdmap=False, predict_pedestrian=False, predict_instance=True,
+                                               predict_future_flow=True, planning=False), (1, 3, 24, 32)),
+    "all_heads_c32": (32, 2, 2, 2, dict(perceive_hdmap=True, predict_pedestrian=True, predict_instance=True,
+                                         predict_future_flow=True, planning=True), (2, 2, 16, 16)),
+}
+
+
+def decoder_state_dict(shapes_sd, seed=61):
+    """Hashed weights; BatchNorm statistics randomised so that the folding is exercised (bn2.weight is NOT
+    left at its zero init: that would silence the residual branches)."""
+    sd = hashfill.fill_state_dict(shapes_sd, seed=seed, gain=0.9)
+    return sd

@@ -307,6 +307,32 @@ def gen_voxel():
     np.savez_compressed(os.path.join(OUT, "voxelize.npz"), **out)
 
 
+def gen_decoder():
+    """N3 (Decoder): the reference's Decoder class on the oracle's restatement of torchvision's resnet18 trunk."""
+    from . import decoder_ref as DR
+    D = refimport.decoder_reference()
+    out, keys = {}, {}
+    for tag, (cin, ncls, npres, nhd, gate, (b, s, h, w)) in cases.DECODER_CASES.items():
+        m = D(cin, ncls, npres, nhd, gate).eval()
+        sd = cases.decoder_state_dict(m.state_dict())
+        m.load_state_dict(sd)
+        x = hashfill.normal("dec_x_" + tag, (b, s, cin, h, w), seed=62)
+        with torch.no_grad():
+            ref = m(x)
+            mine = DR.decoder_forward(sd, x, npres)
+        for k, v in ref.items():
+            if v is None:
+                assert mine[k] is None
+                continue
+            assert torch.equal(v, mine[k]), (tag, k)
+            out[f"{tag}.{k}"] = _np(v)
+        keys[tag] = {k: list(v.shape) for k, v in m.state_dict().items()}
+        print("decoder", tag, {k: tuple(v.shape) for k, v in ref.items() if v is not None})
+    np.savez_compressed(os.path.join(OUT, "decoder.npz"), **out)
+    with open(os.path.join(OUT, "decoder_state_dict_keys.json"), "w") as f:
+        json.dump(keys, f)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also generate the C=64 200x200 statistics (slow)")
@@ -314,12 +340,14 @@ def main():
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["ops", "fpode", "schedules", "beverse", "lift", "voxel"]
+    todo = a.only.split(",") if a.only else ["ops", "fpode", "schedules", "beverse", "lift", "voxel", "decoder"]
     if "lift" in todo:
         gen_lift()
     if "voxel" in todo:
         gen_voxel()
-    if not set(todo) - {"lift", "voxel"}:
+    if "decoder" in todo:
+        gen_decoder()
+    if not set(todo) - {"lift", "voxel", "decoder"}:
         return
     m = refimport.modules()
     if "ops" in todo:

@@ -172,3 +172,22 @@ def voxel_reference():
     sys.modules["mmdet3d.ops.voxel.voxel_layer"] = ext
     vz = importlib.import_module("mmdet3d.ops.voxel.voxelize")
     return SimpleNamespace(ext=ext, Voxelization=vz.Voxelization, voxelization=vz.voxelization)
+
+
+def decoder_reference():
+    """The reference's ``Decoder`` class (streamingflow/models/decoder.py) with the absent third-party
+    ``torchvision.models.resnet.resnet18`` supplied by the oracle's restatement of torchvision's
+    BasicBlock trunk (oracle/decoder_ref.py:tv_resnet18)."""
+    import importlib
+    install()
+    from . import decoder_ref
+    tv = _stub("torchvision")
+    if not hasattr(tv, "transforms"):
+        tv.transforms = _stub("torchvision.transforms", Normalize=object)
+    models = _stub("torchvision.models")
+    tv.models = models
+    models.resnet = _stub("torchvision.models.resnet", resnet18=decoder_ref.tv_resnet18)
+    sys.modules["torchvision.models.resnet"].resnet18 = decoder_ref.tv_resnet18
+    sys.modules.pop("streamingflow.models.decoder", None)      # lift_splat_reference() may have stubbed it
+    mod = importlib.import_module("streamingflow.models.decoder")
+    return mod.Decoder

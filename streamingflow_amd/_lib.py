@@ -108,6 +108,9 @@ SIGNATURES = {
     "sf_bottleneck_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "sf_dist_head_fwd": (_i, [C.POINTER(ConvW), _vp, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float, _vp, _sz, _vp]),
     "sf_dist_head_ws_bytes": (_sz, [_i, _i]),
+    "sf_conv2d_ex_fwd": (_i, [C.POINTER(ConvW), _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_conv2d_ex_ws_bytes": (_sz, []),
+    "sf_upsample_bilinear2_add_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sf_bev_pool_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sf_lift_index_ws_bytes": (_sz, [_i, _i]),
     "sf_lift_index_fwd": (_i, [_vp, _i, _i, _f3, _f3, _i3, _vp, _vp, _vp, _vp, _sz, _vp]),

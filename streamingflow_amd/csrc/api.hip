@@ -15,6 +15,8 @@ hipError_t launch_transpose(const float* in, float* out, int n, int rows, int co
 hipError_t launch_maxpool2(const float* in, float* out, int n, int Hin, int Win, int C, int ceil_pad, hipStream_t s);
 hipError_t launch_mean_from_partials(const float* part, float* out, int n, int nslab, int C, int hw, hipStream_t s);
 hipError_t launch_upsample2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s);
+hipError_t launch_upsample_bilinear2_add(const float* in, const float* skip, float* out, int n, int Hin, int Win, int C,
+                                         hipStream_t s);
 hipError_t launch_se_fc(const float* chansum, int ntile, int C, int Cr, int hw, const float* fc0,
                         const float* fc2, float* scale, int n_img, hipStream_t s);
 hipError_t launch_chan_partial(const float* in, float* part, int n, int HW, int C, int nslab, hipStream_t s);
@@ -105,7 +107,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, l_cfg, mid_tiles; };
+struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, l_cfg, mid_tiles, split_cfg; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -120,6 +122,7 @@ const Tune& tune() {
     x.split_min_chunks = geti("SF_SPLIT_MINCH", 2);
     x.mid_tiles = geti("SF_MID_TILES", 640);
     x.l_cfg = geti("SF_L_CFG", 0);                 // experimental large-P tiling override (5..9)
+    x.split_cfg = geti("SF_SPLIT_CFG", 4);         // tile config of the mid-P split-K launches without a LayerNorm epilogue (4 | 1)
     x.split_from = geti("SF_SPLIT_FROM", 100);     // only layers with at least this many K chunks (the 7x7)
     return x;
   }();
@@ -228,7 +231,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       cnt_off += tiles;
       if (slab_off > g_split->slab_floats || cnt_off > g_split->ncounters) fits = false;
     }
-    if (fits) cfg = 4;
+    if (fits) cfg = (split_mid && tune().split_cfg == 1 && (epi == EPI_AFFINE || epi == EPI_BLEND || epi == EPI_SAMPLE)) ? 1 : 4;
     else for (int i = 0; i < n; ++i) { L.p[i].nsplit = 0; L.p[i].slab = nullptr; L.p[i].counters = nullptr; }
   }
   auto launch = [&]() -> hipError_t {
@@ -491,6 +494,37 @@ int sf_conv2d_fwd(const sf_conv_w* w, const float* in0, const float* in1, const 
   ConvProblem p = problem(*w, in0, in1, out, n_img, Hin, Win, in_up);
   p.add = add;
   return run1(p, EPI_AFFINE, (hipStream_t)stream);
+}
+
+// The same with channel-sliced operands (a layer reading / writing a channel range of a wider NHWC
+// tensor, e.g. the stacked heads of the BEV decoder), the residual added before the activation
+// (ResNet BasicBlock) and optional split-K scratch for mid-sized pixel counts.
+int sf_conv2d_ex_fwd(const sf_conv_w* w, const float* in0, int in0_cs, const float* in1, int in1_cs, const float* add, int add_cs,
+                     int act_after_add, float* out, int out_cs, int out_co, int n_img, int Hin, int Win, int in_up, float* ws,
+                     size_t ws_bytes, void* stream) {
+  if (!w || !valid_w(*w) || !in0 || !out || (w->c1 > 0 && !in1)) return SF_ERR_INVALID;
+  if (in0_cs < w->c0 || (w->c1 > 0 && in1_cs < w->c1) || out_cs < out_co + w->cout || (in0_cs % 4) || (out_cs % 4) || (out_co % 4) ||
+      (add && (add_cs < w->cout || (add_cs % 4))))
+    return SF_ERR_INVALID;
+  Arena A(ws, ws_bytes);
+  SplitScope sp(A, (hipStream_t)stream);
+  ConvProblem p = problem(*w, in0, in1, out, n_img, Hin, Win, in_up);
+  p.in0_cs = in0_cs;
+  if (w->c1 > 0) p.in1_cs = in1_cs;
+  p.add = add;
+  if (add) p.add_cs = add_cs;
+  p.out_cs = out_cs;
+  p.out_co = out_co;
+  if (act_after_add) p.mode |= 2;
+  return run1(p, EPI_AFFINE, (hipStream_t)stream);
+}
+size_t sf_conv2d_ex_ws_bytes(void) { return SPLIT_WS_FLOATS * sizeof(float); }
+
+/* UpsamplingAdd tail — convolutions.py:208,215: out = bilinear_x2(in) + skip (skip may be NULL) */
+int sf_upsample_bilinear2_add_fwd(const float* in, const float* skip, float* out, int n, int Hin, int Win, int C, void* stream) {
+  if (!in || !out || n < 1 || Hin < 1 || Win < 1 || C < 4 || (C % 4)) return SF_ERR_INVALID;
+  SF_HIP(launch_upsample_bilinear2_add(in, skip, out, n, Hin, Win, C, (hipStream_t)stream));
+  return SF_OK;
 }
 
 // benchmarking aid: the same fused conv enqueued `reps` times back to back from C++ (no per-launch

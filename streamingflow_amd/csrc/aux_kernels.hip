@@ -80,6 +80,38 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict_
   }
 }
 
+// UpsamplingAdd (convolutions.py:204-215): bilinear x2 (align_corners=False) of `in`, plus the skip tensor.
+// source index as ATen's area_pixel_compute_source_index: src = 0.5*(dst + 0.5) - 0.5, clamped at 0.
+__global__ __launch_bounds__(256) void upsample_bilinear2_add_kernel(const float* __restrict__ in, const float* __restrict__ skip,
+                                                                     float* __restrict__ out, int n, int Hin, int Win, int C) {
+  const int Ho = Hin * 2, Wo = Win * 2, C4 = C >> 2;
+  const size_t total = (size_t)n * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = i % C4;
+    const size_t p = i / C4;
+    const int ox = p % Wo;
+    const size_t q = p / Wo;
+    const int oy = q % Ho;
+    const int img = q / Ho;
+    float sy = 0.5f * ((float)oy + 0.5f) - 0.5f, sx = 0.5f * ((float)ox + 0.5f) - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* base = in + (size_t)img * Hin * Win * C + c4 * 4;
+    const float4 a = ld4a(base + ((size_t)y0 * Win + x0) * C), b = ld4a(base + ((size_t)y0 * Win + x1) * C);
+    const float4 c = ld4a(base + ((size_t)y1 * Win + x0) * C), d = ld4a(base + ((size_t)y1 * Win + x1) * C);
+    float4 r = skip ? ld4a(skip + p * C + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    r.x += hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
+    r.y += hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
+    r.z += hy * (hx * a.z + lx * b.z) + ly * (hx * c.z + lx * d.z);
+    r.w += hy * (hx * a.w + lx * b.w) + ly * (hx * c.w + lx * d.w);
+    st4a(out + p * C + c4 * 4, r);
+  }
+}
+
 static int grid_for(size_t total) {
   size_t b = (total + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -89,6 +121,13 @@ hipError_t launch_maxpool2(const float* in, float* out, int n, int Hin, int Win,
   size_t total = (size_t)n * ((Hin + ceil_pad) / 2) * ((Win + ceil_pad) / 2) * (C / 4);
   if (!total) return hipSuccess;
   hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, n, Hin, Win, C, ceil_pad);
+  return hipGetLastError();
+}
+hipError_t launch_upsample_bilinear2_add(const float* in, const float* skip, float* out, int n, int Hin, int Win, int C,
+                                         hipStream_t s) {
+  size_t total = (size_t)n * Hin * 2 * Win * 2 * (C / 4);
+  if (!total) return hipSuccess;
+  hipLaunchKernelGGL(upsample_bilinear2_add_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, skip, out, n, Hin, Win, C);
   return hipGetLastError();
 }
 hipError_t launch_upsample2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s) {

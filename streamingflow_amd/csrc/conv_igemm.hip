@@ -99,8 +99,12 @@ __device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[
           v.x = acc[m][n][0] * sc.x + bi.x; v.y = acc[m][n][1] * sc.y + bi.y;
           v.z = acc[m][n][2] * sc.z + bi.z; v.w = acc[m][n][3] * sc.w + bi.w;
           if constexpr (EPI == EPI_AFFINE) {
-            y.x = act_apply(v.x, P.act); y.y = act_apply(v.y, P.act);
-            y.z = act_apply(v.z, P.act); y.w = act_apply(v.w, P.act);
+            const bool act_last = (P.mode & 2) != 0;   // ResNet BasicBlock: relu(bn(conv) + identity)
+            y = v;
+            if (!act_last) {
+              y.x = act_apply(v.x, P.act); y.y = act_apply(v.y, P.act);
+              y.z = act_apply(v.z, P.act); y.w = act_apply(v.w, P.act);
+            }
             if (P.clamp_from >= 0) {   // clamp(log_sigma) of the distribution heads (motion_modules.py:44,85)
               if (c + 0 >= P.clamp_from) y.x = fminf(fmaxf(y.x, P.clamp_lo), P.clamp_hi);
               if (c + 1 >= P.clamp_from) y.y = fminf(fmaxf(y.y, P.clamp_lo), P.clamp_hi);
@@ -114,6 +118,10 @@ __device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[
                 ad.x *= as.x; ad.y *= as.y; ad.z *= as.z; ad.w *= as.w;
               }
               y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w;
+            }
+            if (act_last) {
+              y.x = act_apply(y.x, P.act); y.y = act_apply(y.y, P.act);
+              y.z = act_apply(y.z, P.act); y.w = act_apply(y.w, P.act);
             }
           } else {  // EPI_BLEND  (temporal.py:56, temporal_ode_bayes.py:145,160; BEVerse cells apply BN+ReLU first)
             v.x = act_apply(v.x, P.act); v.y = act_apply(v.y, P.act);
