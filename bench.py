@@ -256,6 +256,14 @@ def main():
         except Exception as ex:
             vox = {"error": repr(ex)}
 
+    dec = None
+    if rank == 0:
+        try:
+            import decoderbench
+            dec = decoderbench.run(reps=5, cpu=(world == 1 and not a.no_cpu_baseline), dev=dev)
+        except Exception as ex:
+            dec = {"error": repr(ex)}
+
     # ---- CPU baseline: the oracle (torch-CPU port of the reference path) on the host cores --------
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -282,7 +290,7 @@ def main():
                           "parallelism": f"replicas x{world} (sample sharding, no data-path collective)"},
                "samples_per_s": B * a.steps * world / el, "batch_per_gpu": B, "ms_per_sample": ms_per_step / B,
                "single_sample_forward_ms": single_ms, "single_sample_ode_steps_per_s": n_ode / (single_ms * 1e-3),
-               "ode_rollout_only": rollout, "ode_step_only": step_only, "lift_splat": lift, "lidar_voxelize": vox, "roofline": roof, "cpu_baseline": cpu}
+               "ode_rollout_only": rollout, "ode_step_only": step_only, "lift_splat": lift, "lidar_voxelize": vox, "bev_decoder": dec, "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,72 @@
+"""BEV Decoder (N3) at the shipped size: 7 frames of 200 x 200 x 64, heads segmentation + instance
+(center / offset / flow).  One JSON object.  Usage: python3 tools/decoderbench.py [--cpu]"""
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PEAK = 157.3
+
+
+def flops_per_frame(C=64, H=200, W=200, head_couts=(2, 2, 1, 2)):
+    f = 0.0
+    h, w = H // 2, W // 2
+    f += 2.0 * h * w * 64 * C * 49                                   # first 7x7 s2
+    f += 4 * 2.0 * h * w * 64 * 64 * 9                               # layer1
+    h2, w2 = h // 2, w // 2
+    f += 2.0 * h2 * w2 * 128 * (64 * 9 + 64) + 3 * 2.0 * h2 * w2 * 128 * 128 * 9      # layer2 (+1x1 shortcut)
+    h3, w3 = h2 // 2, w2 // 2
+    f += 2.0 * h3 * w3 * 256 * (128 * 9 + 128) + 3 * 2.0 * h3 * w3 * 256 * 256 * 9    # layer3
+    # UpsamplingAdd 1x1 convs as the reference runs them (after the interpolation, at the high resolution)
+    f += 2.0 * h2 * w2 * 256 * 128 + 2.0 * h * w * 128 * 64 + 2.0 * H * W * 64 * C
+    f += len(head_couts) * 2.0 * H * W * C * C * 9 + sum(2.0 * H * W * C * k for k in head_couts)
+    return f
+
+
+def run(reps=10, cpu=False, dev=None, frames=7):
+    from streamingflow_amd import _lib, runtime
+    from streamingflow_amd.models.decoder import Decoder
+    from oracle import cases, decoder_ref as DR
+    dev = dev or torch.device("cuda", 0)
+    cin, ncls, npres, nhd, gate, _ = cases.DECODER_CASES["shipped_gates_small"]
+    m = Decoder(cin, ncls, npres, nhd, gate).eval()
+    sd = cases.decoder_state_dict(m.state_dict())
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    x = torch.randn((1, frames, cin, 200, 200), generator=torch.Generator().manual_seed(1)).to(dev)
+    L = _lib.lib()
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    L.sf_event_create(ctypes.byref(e0)); L.sf_event_create(ctypes.byref(e1))
+    ms = ctypes.c_float()
+    for _ in range(3):
+        m(x)
+    torch.cuda.synchronize()
+    L.sf_event_record(e0, runtime.stream_ptr(dev))
+    for _ in range(reps):
+        m(x)
+    L.sf_event_record(e1, runtime.stream_ptr(dev))
+    L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+    t = ms.value / reps * 1e-3
+    fl = flops_per_frame() * frames
+    out = {"workload": f"{frames} frames of 200x200x{cin}, heads segmentation/instance_center/offset/flow",
+           "ms_per_call": t * 1e3, "frames_per_s": frames / t, "gflop_per_frame_reference_order": flops_per_frame() / 1e9,
+           "tflops_reference_flops": fl / t / 1e12, "mfma_frac": fl / t / 1e12 / PEAK}
+    if cpu:
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        xc = x[:, :1].cpu()
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            DR.decoder_forward(sd, xc, 1)
+            tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "frames/s", "cores": min(os.cpu_count() or 1, 16), "kind": "port",
+                               "sample": f"1 frame, oracle/decoder_ref.py on torch CPU, {tc:.2f} s"}
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps(run(cpu="--cpu" in sys.argv)))
