@@ -261,6 +261,8 @@ def main():
         try:
             import decoderbench
             dec = decoderbench.run(reps=5, cpu=(world == 1 and not a.no_cpu_baseline), dev=dev)
+            import temporalbench
+            dec["temporal_model"] = temporalbench.run(reps=5, cpu=(world == 1 and not a.no_cpu_baseline), dev=dev)
         except Exception as ex:
             dec = {"error": repr(ex)}
 

@@ -231,6 +231,13 @@ size_t sf_conv2d_ex_ws_bytes(void);
 int sf_upsample_bilinear2_add_fwd(const float* in, const float* skip, float* out, int n, int Hin, int Win, int C,
                                   void* stream);
 
+/* TemporalBlock helpers (streamingflow/layers/temporal.py:394-432, :435-490): per-image channel means of
+ * an NHWC tensor (the spatial part of PyramidSpatioTemporalPooling's AvgPool3d) and the broadcast of a
+ * per-image channel vector over a channel slice (its bilinear upsampling of a 1x1 map is a constant). */
+size_t sf_channel_mean_ws_bytes(int C, int n);
+int sf_channel_mean_fwd(const float* x, float* out, int n, int HW, int C, float* ws, size_t ws_bytes, void* stream);
+int sf_broadcast_channels_fwd(const float* vec, float* out, int n, int HW, int k, int out_cs, int out_co, void* stream);
+
 /* ---- N1: camera lift-splat voxel pooling ---------------------------------------
  * Layouts: frustum point p = ((cam*D + d)*fH + h)*fW + w of batch element b, points of a call are
  * numbered b-major; BEV cell id = ((b*Z + z)*X + x)*Y + y; pooled output [n_cells][C] = [B][Z][X][Y][C]

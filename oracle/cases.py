@@ -257,3 +257,12 @@ def decoder_state_dict(shapes_sd, seed=61):
     left at its zero init: that would silence the residual branches)."""
     sd = hashfill.fill_state_dict(shapes_sd, seed=seed, gain=0.9)
     return sd
+
+
+# ---- TemporalModel (SURVEY.md §8f N3) --------------------------------------------------------------------------
+# tag -> in_channels, receptive_field, start_out_channels, extra_in_channels, inbetween, pyramid, (b, s, h, w)
+TEMPORAL_CASES = {
+    "camera_c70": (70, 3, 64, 0, 0, True, (1, 3, 24, 16)),        # 64 + 6 ego-pose channels (config.py:141)
+    "lidar_c256_b2": (256, 3, 64, 0, 0, True, (2, 3, 16, 16)),
+    "rf2_nopool_c16": (16, 2, 16, 0, 0, False, (1, 2, 12, 20)),
+}

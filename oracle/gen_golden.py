@@ -333,6 +333,29 @@ def gen_decoder():
         json.dump(keys, f)
 
 
+def gen_temporal():
+    """N3 (TemporalModel): the reference class itself."""
+    from . import temporal_model_ref as TR
+    T = refimport.temporal_model_reference()
+    out, keys = {}, {}
+    for tag, (cin, rf, start, extra, inb, pyr, (b, s, h, w)) in cases.TEMPORAL_CASES.items():
+        m = T(cin, rf, (h, w), start_out_channels=start, extra_in_channels=extra, n_spatial_layers_between_temporal_layers=inb,
+              use_pyramid_pooling=pyr).eval()
+        sd = cases.decoder_state_dict(m.state_dict(), seed=71)
+        m.load_state_dict(sd)
+        x = hashfill.normal("tm_x_" + tag, (b, s, cin, h, w), seed=72)
+        with torch.no_grad():
+            ref = m(x)
+            mine = TR.temporal_model_forward(sd, x, (h, w))
+        assert torch.equal(ref, mine), tag
+        out[tag] = _np(ref)
+        keys[tag] = {k: list(v.shape) for k, v in m.state_dict().items()}
+        print("temporal", tag, tuple(ref.shape), float(ref.abs().max()))
+    np.savez_compressed(os.path.join(OUT, "temporal_model.npz"), **out)
+    with open(os.path.join(OUT, "temporal_model_state_dict_keys.json"), "w") as f:
+        json.dump(keys, f)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also generate the C=64 200x200 statistics (slow)")
@@ -340,14 +363,16 @@ def main():
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["ops", "fpode", "schedules", "beverse", "lift", "voxel", "decoder"]
+    todo = a.only.split(",") if a.only else ["ops", "fpode", "schedules", "beverse", "lift", "voxel", "decoder", "temporal"]
     if "lift" in todo:
         gen_lift()
     if "voxel" in todo:
         gen_voxel()
     if "decoder" in todo:
         gen_decoder()
-    if not set(todo) - {"lift", "voxel", "decoder"}:
+    if "temporal" in todo:
+        gen_temporal()
+    if not set(todo) - {"lift", "voxel", "decoder", "temporal"}:
         return
     m = refimport.modules()
     if "ops" in todo:

@@ -191,3 +191,11 @@ def decoder_reference():
     sys.modules.pop("streamingflow.models.decoder", None)      # lift_splat_reference() may have stubbed it
     mod = importlib.import_module("streamingflow.models.decoder")
     return mod.Decoder
+
+
+def temporal_model_reference():
+    """The reference's ``TemporalModel`` (streamingflow/models/temporal_model.py) — importable as is."""
+    import importlib
+    install()
+    sys.modules.pop("streamingflow.models.temporal_model", None)   # lift_splat_reference() may have stubbed it
+    return importlib.import_module("streamingflow.models.temporal_model").TemporalModel

@@ -111,6 +111,9 @@ SIGNATURES = {
     "sf_conv2d_ex_fwd": (_i, [C.POINTER(ConvW), _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sf_conv2d_ex_ws_bytes": (_sz, []),
     "sf_upsample_bilinear2_add_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sf_channel_mean_ws_bytes": (_sz, [_i, _i]),
+    "sf_channel_mean_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_broadcast_channels_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sf_bev_pool_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sf_lift_index_ws_bytes": (_sz, [_i, _i]),
     "sf_lift_index_fwd": (_i, [_vp, _i, _i, _f3, _f3, _i3, _vp, _vp, _vp, _vp, _sz, _vp]),

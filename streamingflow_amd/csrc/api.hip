@@ -15,6 +15,7 @@ hipError_t launch_transpose(const float* in, float* out, int n, int rows, int co
 hipError_t launch_maxpool2(const float* in, float* out, int n, int Hin, int Win, int C, int ceil_pad, hipStream_t s);
 hipError_t launch_mean_from_partials(const float* part, float* out, int n, int nslab, int C, int hw, hipStream_t s);
 hipError_t launch_upsample2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s);
+hipError_t launch_broadcast_channels(const float* vec, float* out, int n, int HW, int k, int out_cs, int out_co, hipStream_t s);
 hipError_t launch_upsample_bilinear2_add(const float* in, const float* skip, float* out, int n, int Hin, int Win, int C,
                                          hipStream_t s);
 hipError_t launch_se_fc(const float* chansum, int ntile, int C, int Cr, int hw, const float* fc0,
@@ -524,6 +525,24 @@ size_t sf_conv2d_ex_ws_bytes(void) { return SPLIT_WS_FLOATS * sizeof(float); }
 int sf_upsample_bilinear2_add_fwd(const float* in, const float* skip, float* out, int n, int Hin, int Win, int C, void* stream) {
   if (!in || !out || n < 1 || Hin < 1 || Win < 1 || C < 4 || (C % 4)) return SF_ERR_INVALID;
   SF_HIP(launch_upsample_bilinear2_add(in, skip, out, n, Hin, Win, C, (hipStream_t)stream));
+  return SF_OK;
+}
+
+/* per-image channel means of an NHWC tensor (fixed-order two-level sum: reproducible) */
+size_t sf_channel_mean_ws_bytes(int C, int n) { return al((size_t)n * 64 * C) * sizeof(float); }
+int sf_channel_mean_fwd(const float* x, float* out, int n, int HW, int C, float* ws, size_t ws_bytes, void* stream) {
+  if (!x || !out || n < 1 || HW < 1 || C < 4 || (C % 4) || C > 1024) return SF_ERR_INVALID;
+  Arena A(ws, ws_bytes);
+  float* part = A.take((size_t)n * 64 * C);
+  if (!A.ok() || !part) return SF_ERR_WORKSPACE;
+  SF_HIP(launch_chan_partial(x, part, n, HW, C, 64, (hipStream_t)stream));
+  SF_HIP(launch_mean_from_partials(part, out, n, 64, C, HW, (hipStream_t)stream));
+  return SF_OK;
+}
+/* out[img][pixel][out_co .. out_co+k) = vec[img][0..k) for every pixel (k, out_cs, out_co multiples of 4) */
+int sf_broadcast_channels_fwd(const float* vec, float* out, int n, int HW, int k, int out_cs, int out_co, void* stream) {
+  if (!vec || !out || n < 1 || HW < 1 || k < 4 || (k % 4) || (out_cs % 4) || (out_co % 4) || out_co + k > out_cs) return SF_ERR_INVALID;
+  SF_HIP(launch_broadcast_channels(vec, out, n, HW, k, out_cs, out_co, (hipStream_t)stream));
   return SF_OK;
 }
 

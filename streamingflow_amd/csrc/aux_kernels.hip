@@ -380,6 +380,24 @@ hipError_t launch_mean_from_partials(const float* part, float* out, int n, int n
   return hipGetLastError();
 }
 
+// out[img][p][co + c] = vec[img][c]: a per-image channel vector broadcast over the pixels of a channel slice
+__global__ __launch_bounds__(256) void broadcast_channels_kernel(const float* __restrict__ vec, float* __restrict__ out, int HW, int k,
+                                                                 int out_cs, int out_co, size_t total) {
+  const int k4 = k >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = i % k4;
+    const size_t p = i / k4;                 // global pixel = img*HW + pixel
+    const size_t img = p / HW;
+    st4a(out + p * out_cs + out_co + c4 * 4, ld4a(vec + img * k + c4 * 4));
+  }
+}
+hipError_t launch_broadcast_channels(const float* vec, float* out, int n, int HW, int k, int out_cs, int out_co, hipStream_t s) {
+  size_t total = (size_t)n * HW * (k / 4);
+  if (!total) return hipSuccess;
+  hipLaunchKernelGGL(broadcast_channels_kernel, dim3(grid_for(total)), dim3(256), 0, s, vec, out, HW, k, out_cs, out_co, total);
+  return hipGetLastError();
+}
+
 hipError_t launch_chan_partial(const float* in, float* part, int n, int HW, int C, int nslab, hipStream_t s) {
   int C4 = C / 4;
   if (C4 < 1 || C4 > 256) return hipErrorInvalidValue;
