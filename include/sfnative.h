@@ -300,6 +300,32 @@ int sf_hard_voxelize_fwd(const float* points, int num_points, int num_features, 
                          int32_t* num_points_per_voxel, float* mean_feats, int32_t* voxel_num, void* ws,
                          size_t ws_bytes, void* stream);
 
+/* ---- N2 (second half): LiDAR SparseEncoder — sparse 3-D convolutions (mmdet3d/ops/spconv, spconv 1.x) ---------
+ * Sites are rows of coords [n][4] = (batch, x, y, z) int32 in a grid `shape` = (X, Y, Z); ksize / stride /
+ * padding are HOST arrays of 3 ints; kernel tap t = (kx*KY + ky)*KZ + kz.
+ * sf_sparse_out_sites_fwd — output sites of a strided SparseConv3d (spconv/ops.py:19-33 output size; a
+ *   site is active when some active input p and tap k satisfy p = o*stride - padding + k): sorted unique
+ *   coordinates into out_coords (capacity `cap` rows), their number into the device int n_out.
+ * sf_sparse_table_fwd — neighbour table nbr [n_out][ntaps]: input row read by output site j through tap t,
+ *   or -1 (subm != 0: submanifold conv, out_coords == in_coords, offsets centred, stride/padding ignored).
+ * sf_sparse_conv_fwd — the convolution (spconv/conv.py:114-214 + BatchNorm1d + ReLU of
+ *   make_sparse_convmodule / SparseBasicBlock, sparse_block.py:88-107, :110-176):
+ *   out[j] = act(scale * sum_t W_t^T . feats[nbr[j][t]] + bias) + add   (act_after_add: act(... + add));
+ *   w packs [Cout][Cin][ntaps][1] (kh = ntaps, kw = 1); feats rows have feats_cs floats.
+ * sf_sparse_to_dense_fwd — SparseConvTensor.dense() + permute/view of sparse_encoder.py:131-137 as NHWC:
+ *   out [batch][X][Y][C*D], channel c*D + z (zero where no site is active). */
+size_t sf_sparse_index_ws_bytes(int n_in, int ntaps);
+int sf_sparse_out_sites_fwd(const int32_t* in_coords, int n_in, int batch, const int32_t* shape, const int32_t* ksize,
+                            const int32_t* stride, const int32_t* padding, int32_t* out_coords, int cap, int32_t* n_out,
+                            void* ws, size_t ws_bytes, void* stream);
+int sf_sparse_table_fwd(const int32_t* in_coords, int n_in, const int32_t* out_coords, int n_out, int batch,
+                        const int32_t* shape, const int32_t* ksize, const int32_t* stride, const int32_t* padding, int subm,
+                        int32_t* nbr, void* ws, size_t ws_bytes, void* stream);
+int sf_sparse_conv_fwd(const sf_conv_w* w, const float* feats, int feats_cs, const int32_t* nbr, int n_out, const float* add,
+                       int act_after_add, float* out, float* ws, size_t ws_bytes, void* stream);
+int sf_sparse_to_dense_fwd(const float* feats, const int32_t* coords, int n, int C, int batch, int X, int Y, int D, float* out,
+                           void* stream);
+
 /* hipGraph capture of whatever the caller enqueues between begin and end on `stream` (must not be
  * the legacy default stream). */
 int sf_graph_begin(void* stream);

@@ -266,3 +266,49 @@ TEMPORAL_CASES = {
     "lidar_c256_b2": (256, 3, 64, 0, 0, True, (2, 3, 16, 16)),
     "rf2_nopool_c16": (16, 2, 16, 0, 0, False, (1, 2, 12, 20)),
 }
+
+
+# ---- LiDAR SparseEncoder (second half) -------------------------------------------------------
+# tag -> cfg overrides, n_voxels per sample, batch.  Small grids so that the dense formulation fits.
+SPARSE_CASES = {
+    "grid32x24x27": (dict(sparse_shape=[32, 24, 27]), 260, 2),
+    "thin_c8": (dict(sparse_shape=[24, 24, 41], base_channels=8, output_channels=16,
+                     encoder_channels=[[8, 8, 16], [16, 16, 16], [16, 16, 32], [32, 32]]), 150, 1),
+}
+
+
+def sparse_cfg(tag):
+    from . import sparse_encoder_ref as SR
+    cfg = SR.default_cfg()
+    cfg.update(SPARSE_CASES[tag][0])
+    return cfg
+
+
+def sparse_inputs(tag):
+    """(voxel_features [N, Cin] f32, coors [N, 4] int32 (batch, x, y, z), batch_size): unique random sites,
+    clustered so that neighbourhoods are populated."""
+    cfg = sparse_cfg(tag)
+    _, n, B = SPARSE_CASES[tag]
+    X, Y, Z = cfg["sparse_shape"]
+    feats, coords = [], []
+    for b in range(B):
+        u = hashfill.uniform(f"sp_sites_{tag}_{b}", (4 * n, 3), 0.0, 1.0, seed=81)
+        c = (u * torch.tensor([X * 0.6, Y * 0.6, Z * 0.8])).long() + torch.tensor([int(X * 0.2), int(Y * 0.2), 0])
+        key = (c[:, 0] * Y + c[:, 1]) * Z + c[:, 2]
+        seen, keep = set(), []
+        for i, k in enumerate(key.tolist()):
+            if k not in seen:
+                seen.add(k)
+                keep.append(i)
+            if len(keep) == n:
+                break
+        c = c[keep]
+        coords.append(torch.cat([torch.full((c.shape[0], 1), b, dtype=torch.long), c], 1))
+        feats.append(hashfill.normal(f"sp_feats_{tag}_{b}", (c.shape[0], cfg["in_channels"]), seed=82))
+    return torch.cat(feats, 0), torch.cat(coords, 0).int(), B
+
+
+def sparse_state_dict(tag, seed=83):
+    from . import sparse_encoder_ref as SR
+    shapes = SR.state_dict_shapes(sparse_cfg(tag))
+    return hashfill.fill_state_dict({k: torch.empty(v) if v else torch.tensor(0) for k, v in shapes.items()}, seed=seed, gain=1.6)

@@ -124,6 +124,11 @@ SIGNATURES = {
     "sf_depth_softmax_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sf_hard_voxelize_ws_bytes": (_sz, [_i]),
     "sf_hard_voxelize_fwd": (_i, [_vp, _i, _i, _f3, _f6, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sf_sparse_index_ws_bytes": (_sz, [_i, _i]),
+    "sf_sparse_out_sites_fwd": (_i, [_vp, _i, _i, _i3, _i3, _i3, _i3, _vp, _i, _vp, _vp, _sz, _vp]),
+    "sf_sparse_table_fwd": (_i, [_vp, _i, _vp, _i, _i, _i3, _i3, _i3, _i3, _i, _vp, _vp, _sz, _vp]),
+    "sf_sparse_conv_fwd": (_i, [C.POINTER(ConvW), _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "sf_sparse_to_dense_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sf_graph_begin": (_i, [_vp]),
     "sf_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "sf_graph_launch": (_i, [_vp, _vp]),

@@ -152,6 +152,12 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   L.nprob = n;
   if (P <= 0) return SF_OK;
   int cfg = pick_cfg(P, epi);
+  bool gathered = false;
+  for (int i = 0; i < n; ++i) gathered = gathered || (ps[i].gather != nullptr);
+  if (gathered) {            // sparse convolution: only the LDS-staged kernels read the neighbour table
+    if (epi != EPI_AFFINE) return SF_ERR_UNSUPPORTED;
+    if (cfg == 0) cfg = 1;
+  }
   if (cfg == 1 && (epi == EPI_AFFINE || epi == EPI_BLEND)) {
     if (tune().l_cfg > 0) cfg = tune().l_cfg;
     else if (tune().l_cfg == 0) {
@@ -165,7 +171,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   }
   // small pixel counts: direct-fragment kernel (no LDS staging), see conv_igemm.hip
   int mt = 0, ks = 1;
-  if (cfg == 0 && tune().direct) {
+  if (cfg == 0 && tune().direct && !gathered) {
     const bool ln = (epi == EPI_LNG || epi == EPI_TRUST);
     int cp_max = 0, cp_gcd = 0, chunks = 0;
     bool ok = true;
@@ -526,6 +532,23 @@ int sf_upsample_bilinear2_add_fwd(const float* in, const float* skip, float* out
   if (!in || !out || n < 1 || Hin < 1 || Win < 1 || C < 4 || (C % 4)) return SF_ERR_INVALID;
   SF_HIP(launch_upsample_bilinear2_add(in, skip, out, n, Hin, Win, C, (hipStream_t)stream));
   return SF_OK;
+}
+
+/* sparse (gather) convolution: out[j] = act(scale * sum_t W_t . feats[nbr[j][t]] + bias) (+ add), see sfnative.h */
+int sf_sparse_conv_fwd(const sf_conv_w* w, const float* feats, int feats_cs, const int32_t* nbr, int n_out, const float* add,
+                       int act_after_add, float* out, float* ws, size_t ws_bytes, void* stream) {
+  if (!w || !valid_w(*w) || !feats || !nbr || !out || n_out < 0 || w->kw != 1 || w->c1 != 0 || feats_cs < w->c0 || (feats_cs % 4))
+    return SF_ERR_INVALID;
+  if (n_out == 0) return SF_OK;
+  Arena A(ws, ws_bytes);
+  SplitScope sp(A, (hipStream_t)stream);
+  ConvProblem p = problem(*w, feats, nullptr, out, 1, 1, 1, 0);
+  p.in0_cs = feats_cs;
+  p.Hout = 1; p.Wout = n_out;
+  p.gather = nbr;
+  p.add = add;
+  if (act_after_add) p.mode |= 2;
+  return run1(p, EPI_AFFINE, (hipStream_t)stream);
 }
 
 /* per-image channel means of an NHWC tensor (fixed-order two-level sum: reproducible) */

@@ -342,6 +342,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
   const int Win = P.Win, in_up = P.in_up, dil = P.dil, KW = P.KW;
   const int Hlog = P.Hin << P.in_up, Wlog = P.Win << P.in_up;
   const bool has_aux = (gate != nullptr) | (in_scale != nullptr);   // block-uniform
+  const int* const gather = P.gather;
+  const int KHg = P.KH;
 
   // ---- per-thread staging slots ----------------------------------------------------------
   const int k4 = t % F4;
@@ -409,11 +411,20 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
     const bool s1 = (!s0) & (c < c01);
     const int cc = c - c0;
     if (KS > 1 || tap_fresh) {   // wave-uniform
+      if (gather) {              // block-uniform: sparse convolution, the neighbour table replaces the arithmetic
 #pragma unroll
-      for (int i = 0; i < B_SLOTS; ++i) {
-        const int iy = b_iy0[i] + cur_ty * dil, ix = b_ix0[i] + cur_tx * dil;
-        const bool in = (iy >= 0) & (iy < Hlog) & (ix >= 0) & (ix < Wlog);
-        tap_pix[i] = in ? b_base[i] + (iy >> in_up) * Win + (ix >> in_up) : -1;
+        for (int i = 0; i < B_SLOTS; ++i) {
+          const int gp = p_tile * BN + row0 + i * ROWS_PER_PASS;
+          tap_pix[i] = gather[(size_t)(gp < Ptot ? gp : 0) * KHg + cur_ty];
+          if (gp >= Ptot) tap_pix[i] = -1;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < B_SLOTS; ++i) {
+          const int iy = b_iy0[i] + cur_ty * dil, ix = b_ix0[i] + cur_tx * dil;
+          const bool in = (iy >= 0) & (iy < Hlog) & (ix >= 0) & (ix < Wlog);
+          tap_pix[i] = in ? b_base[i] + (iy >> in_up) * Win + (ix >> in_up) : -1;
+        }
       }
     }
 #pragma unroll
@@ -1164,6 +1175,18 @@ hipError_t launch_conv(const ConvLaunch& L, int epi, int cfg, hipStream_t stream
       switch (epi) {
         case EPI_AFFINE: return launch_cfg<4, 2, 2, 4, 1, EPI_AFFINE, 64>(L, stream);
         case EPI_BLEND:  return launch_cfg<4, 2, 2, 4, 1, EPI_BLEND, 64>(L, stream);
+      }
+      break;
+    case 23:  // 64 cout x 128 px, 4 waves (1x4) of 64x32, 16-deep chunks (30 KB of LDS: 5 workgroups per CU)
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<4, 2, 1, 4, 1, EPI_AFFINE, 16>(L, stream);
+        case EPI_BLEND:  return launch_cfg<4, 2, 1, 4, 1, EPI_BLEND, 16>(L, stream);
+      }
+      break;
+    case 25:  // 128 x 128, 8 waves (2x4) of 64x32, 16-deep chunks (40 KB: 4 workgroups per CU)  [= cfg 16]
+      switch (epi) {
+        case EPI_AFFINE: return launch_cfg<4, 2, 2, 4, 1, EPI_AFFINE, 16>(L, stream);
+        case EPI_BLEND:  return launch_cfg<4, 2, 2, 4, 1, EPI_BLEND, 16>(L, stream);
       }
       break;
     case 10:  // 64 cout x 128 px, 4 waves (1x4) of 64x32

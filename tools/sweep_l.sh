@@ -2,8 +2,5 @@
 out=gpurun_out/sweep_l.txt
 : > $out
 run() { echo "== $*" >> $out; env "$@" python tools/modbench.py --bigconvs 2>/dev/null | grep conv >> $out; }
-run SF_L_CFG=1
-run SF_L_CFG=20
-run SF_L_CFG=9
-run SF_L_CFG=21
-run SF_L_CFG=22
+run SF_L_CFG=23
+run SF_L_CFG=15
