@@ -326,6 +326,25 @@ int sf_sparse_conv_fwd(const sf_conv_w* w, const float* feats, int feats_cs, con
 int sf_sparse_to_dense_fwd(const float* feats, const int32_t* coords, int n, int C, int batch, int X, int Y, int D, float* out,
                            void* stream);
 
+/* ---- N4: evaluation harness kernels (streamingflow/metrics.py, streamingflow/utils/instance.py) ------------
+ * sf_confusion_fwd — out[b[i]*K + a[i]] += 1 over n int64 labels in [0, K) (zero-filled here); *bad != 0 when
+ *   a label was outside the range.  IntersectionOverUnion.update (metrics.py:37: tp/fp/fn/support are sums of
+ *   this matrix) and PanopticMetric.panoptic_metrics (:171-176: bincount of prediction + K * target).
+ * sf_instance_centers_fwd — find_instance_centers (instance.py:80-92) on one [H][W] heat map: (row, col) of
+ *   the thresholded 3x3 local maxima in row-major order (as torch.nonzero), count in the device int.
+ * sf_group_pixels_fwd — group_pixels * foreground (instance.py:95-116, :136-137): offsets [2][H][W],
+ *   foreground [H][W] bytes, instance [H][W] int64 = 1 + index of the nearest centre of (pixel + offset), 0 on background.
+ * sf_instance_sums_fwd — per instance id (1..max_id): sum of (row + flow[0], col + flow[1]) in float64 and
+ *   pixel count (flow may be NULL): the masked means of instance.py:213-236. */
+int sf_confusion_fwd(const int64_t* a, const int64_t* b, long n, int K, int64_t* out, int32_t* bad, void* stream);
+size_t sf_instance_centers_ws_bytes(int H, int W);
+int sf_instance_centers_fwd(const float* center, int H, int W, float conf_threshold, int32_t* centers, int cap,
+                            int32_t* n_centers, void* ws, size_t ws_bytes, void* stream);
+int sf_group_pixels_fwd(const int32_t* centers, int n_centers, const float* offsets, const uint8_t* foreground, int H,
+                        int W, int64_t* instance, void* stream);
+int sf_instance_sums_fwd(const int64_t* instance, const float* flow, int H, int W, int max_id, double* sums,
+                         int32_t* counts, void* stream);
+
 /* hipGraph capture of whatever the caller enqueues between begin and end on `stream` (must not be
  * the legacy default stream). */
 int sf_graph_begin(void* stream);

@@ -312,3 +312,37 @@ def sparse_state_dict(tag, seed=83):
     from . import sparse_encoder_ref as SR
     shapes = SR.state_dict_shapes(sparse_cfg(tag))
     return hashfill.fill_state_dict({k: torch.empty(v) if v else torch.tensor(0) for k, v in shapes.items()}, seed=seed, gain=1.6)
+
+
+# ---- evaluation harness: synthetic decoder outputs with a few moving blobs -------------------
+def eval_scene(seed=0, b=1, s=4, h=48, w=40, n_obj=5):
+    """(output dict like Decoder.forward's, labels dict): Gaussian centre heat maps, offsets pointing at the
+    centres, a small constant flow, ground-truth instance ids / segmentation slightly perturbed."""
+    g = torch.Generator().manual_seed(100 + seed)
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float), torch.arange(w, dtype=torch.float), indexing="ij")
+    seg = torch.zeros(b, s, 2, h, w)
+    center = torch.zeros(b, s, 1, h, w)
+    offset = torch.zeros(b, s, 2, h, w)
+    flow = torch.zeros(b, s, 2, h, w)
+    gt_inst = torch.zeros(b, s, h, w, dtype=torch.long)
+    for bi in range(b):
+        pos = torch.stack([torch.rand(n_obj, generator=g) * (h - 16) + 8, torch.rand(n_obj, generator=g) * (w - 16) + 8], 1)
+        vel = (torch.rand(n_obj, 2, generator=g) - 0.5) * 3.0
+        for t in range(s):
+            fg = torch.zeros(h, w, dtype=torch.bool)
+            for k in range(n_obj):
+                cy, cx = pos[k] + vel[k] * t
+                m = ((yy - cy).abs() <= 2.5) & ((xx - cx).abs() <= 1.5)
+                fg |= m
+                gt_inst[bi, t][((yy - cy - 0.4).abs() <= 2.5) & ((xx - cx + 0.3).abs() <= 1.5)] = k + 1
+                center[bi, t, 0] = torch.maximum(center[bi, t, 0], torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / 6.0))
+                offset[bi, t, 0][m] = (cy.round() - yy)[m]
+                offset[bi, t, 1][m] = (cx.round() - xx)[m]
+                flow[bi, t, 0][m] = vel[k, 0]
+                flow[bi, t, 1][m] = vel[k, 1]
+            seg[bi, t, 1][fg] = 4.0
+            seg[bi, t, 0][~fg] = 4.0
+    noise = torch.randn(center.shape, generator=g) * 0.01
+    out = {"segmentation": seg, "instance_center": (center + noise).clamp(0, 1), "instance_offset": offset, "instance_flow": flow}
+    labels = {"segmentation": (gt_inst > 0).long().unsqueeze(2), "instance": gt_inst}
+    return out, labels

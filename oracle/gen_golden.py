@@ -356,6 +356,39 @@ def gen_temporal():
         json.dump(keys, f)
 
 
+def gen_eval():
+    """N4: the reference's instance post-processing (utils/instance.py, as is) and metrics (metrics.py on a restated
+    pytorch-lightning Metric base) on synthetic decoder outputs."""
+    R = refimport.eval_reference()
+    I, M = R.instance, R.metrics
+    out = {}
+    for seed in (0, 1, 2):
+        o, labels = cases.eval_scene(seed)
+        centers = I.find_instance_centers(o["instance_center"][0, 0].clone(), conf_threshold=0.1)
+        out[f"centers_{seed}"] = centers.numpy()
+        fg = torch.argmax(o["segmentation"][0, 0], 0) == 1
+        inst0, _ = I.get_instance_segmentation_and_centers(o["instance_center"][0, 0].clone(), o["instance_offset"][0, 0], fg)
+        out[f"inst0_{seed}"] = inst0.numpy()
+        cons, traj = I.predict_instance_segmentation_and_trajectories({k: v.clone() for k, v in o.items()}, compute_matched_centers=True)
+        out[f"consistent_{seed}"] = cons.numpy()
+        for k, v in traj.items():
+            out[f"traj_{seed}_{k}"] = np.ascontiguousarray(v)
+        iou = M.IntersectionOverUnion(2)
+        seg_pred = torch.argmax(o["segmentation"], dim=2, keepdim=True)
+        iou(seg_pred, labels["segmentation"])
+        iou(seg_pred[:, 1:], labels["segmentation"][:, 1:])
+        out[f"iou_tp_{seed}"], out[f"iou_fp_{seed}"] = iou.true_positive.numpy(), iou.false_positive.numpy()
+        out[f"iou_fn_{seed}"], out[f"iou_{seed}"] = iou.false_negative.numpy(), iou.compute().numpy()
+        pq = M.PanopticMetric(2)
+        pq(cons, labels["instance"])
+        res = pq.compute()
+        for k in ("true_positive", "false_positive", "false_negative"):
+            out[f"pq_{k}_{seed}"] = getattr(pq, k).numpy()
+        out[f"pq_iou_{seed}"], out[f"pq_{seed}"] = pq.iou.numpy(), res["pq"].numpy()
+        print("eval", seed, "centers", len(centers), "ids", int(cons.max()), "iou", iou.compute().tolist(), "pq", res["pq"].tolist())
+    np.savez_compressed(os.path.join(OUT, "eval.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also generate the C=64 200x200 statistics (slow)")
@@ -363,7 +396,7 @@ def main():
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["ops", "fpode", "schedules", "beverse", "lift", "voxel", "decoder", "temporal"]
+    todo = a.only.split(",") if a.only else ["ops", "fpode", "schedules", "beverse", "lift", "voxel", "decoder", "temporal", "eval"]
     if "lift" in todo:
         gen_lift()
     if "voxel" in todo:
@@ -372,7 +405,9 @@ def main():
         gen_decoder()
     if "temporal" in todo:
         gen_temporal()
-    if not set(todo) - {"lift", "voxel", "decoder", "temporal"}:
+    if "eval" in todo:
+        gen_eval()
+    if not set(todo) - {"lift", "voxel", "decoder", "temporal", "eval"}:
         return
     m = refimport.modules()
     if "ops" in todo:

@@ -199,3 +199,69 @@ def temporal_model_reference():
     install()
     sys.modules.pop("streamingflow.models.temporal_model", None)   # lift_splat_reference() may have stubbed it
     return importlib.import_module("streamingflow.models.temporal_model").TemporalModel
+
+
+def eval_reference():
+    """The reference's evaluation code: ``streamingflow/utils/instance.py`` (pure torch + scipy,
+    imported as is) and ``IntersectionOverUnion`` / ``PanopticMetric`` of ``streamingflow/metrics.py``.  metrics.py
+    needs ``pytorch_lightning.metrics`` (an API removed upstream; absent here): its ``Metric`` base class,
+    ``stat_scores_multiple_classes`` and ``reduce`` are restated below from their published behaviour
+    (pytorch-lightning 1.1 ``metrics/metric.py``, ``functional/classification.py``, ``functional/reduction.py``);
+    ``skimage`` and ``streamingflow.utils.tools`` (plotting deps) are stubbed — these classes never call them."""
+    import importlib
+    import torch
+    install()
+
+    class Metric(torch.nn.Module):
+        def __init__(self, compute_on_step=True, **kw):
+            super().__init__()
+            self._defaults = {}
+
+        def add_state(self, name, default, dist_reduce_fx=None, persistent=False):
+            self._defaults[name] = default.clone()
+            setattr(self, name, default.clone())
+
+        def forward(self, *a, **k):
+            self.update(*a, **k)
+
+        def reset(self):
+            for k, v in self._defaults.items():
+                setattr(self, k, v.clone())
+
+    def stat_scores_multiple_classes(pred, target, num_classes=None, argmax_dim=1, reduction="none"):
+        if pred.ndim == target.ndim + 1:
+            pred = torch.argmax(pred, dim=argmax_dim)
+        pred, target = pred.reshape(-1).long(), target.reshape(-1).long()
+        tps = torch.zeros((num_classes + 1,), device=pred.device)
+        fps, fns, sups = torch.zeros_like(tps), torch.zeros_like(tps), torch.zeros_like(tps)
+        match_true = (pred == target).float()
+        match_false = 1 - match_true
+        tps.scatter_add_(0, pred, match_true)
+        fps.scatter_add_(0, pred, match_false)
+        fns.scatter_add_(0, target, match_false)
+        tns = pred.size(0) - (tps + fps + fns)
+        sups.scatter_add_(0, target, torch.ones_like(match_true))
+        return (tps[:num_classes].float(), fps[:num_classes].float(), tns[:num_classes].float(), fns[:num_classes].float(),
+                sups[:num_classes].float())
+
+    def reduce(to_reduce, reduction):
+        if reduction == "elementwise_mean":
+            return torch.mean(to_reduce)
+        if reduction == "none":
+            return to_reduce
+        if reduction == "sum":
+            return torch.sum(to_reduce)
+        raise ValueError("Reduction parameter unknown.")
+
+    _stub("pytorch_lightning")
+    _stub("pytorch_lightning.metrics")
+    _stub("pytorch_lightning.metrics.metric", Metric=Metric)
+    _stub("pytorch_lightning.metrics.functional")
+    _stub("pytorch_lightning.metrics.functional.classification", stat_scores_multiple_classes=stat_scores_multiple_classes)
+    _stub("pytorch_lightning.metrics.functional.reduction", reduce=reduce)
+    _stub("skimage")
+    _stub("skimage.draw", polygon=None)
+    _stub("streamingflow.utils.tools", gen_dx_bx=None)
+    inst = importlib.import_module("streamingflow.utils.instance")
+    met = importlib.import_module("streamingflow.metrics")
+    return SimpleNamespace(instance=inst, metrics=met)

@@ -129,6 +129,11 @@ SIGNATURES = {
     "sf_sparse_table_fwd": (_i, [_vp, _i, _vp, _i, _i, _i3, _i3, _i3, _i3, _i, _vp, _vp, _sz, _vp]),
     "sf_sparse_conv_fwd": (_i, [C.POINTER(ConvW), _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "sf_sparse_to_dense_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sf_confusion_fwd": (_i, [_vp, _vp, C.c_long, _i, _vp, _vp, _vp]),
+    "sf_instance_centers_ws_bytes": (_sz, [_i, _i]),
+    "sf_instance_centers_fwd": (_i, [_vp, _i, _i, C.c_float, _vp, _i, _vp, _vp, _sz, _vp]),
+    "sf_group_pixels_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "sf_instance_sums_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "sf_graph_begin": (_i, [_vp]),
     "sf_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "sf_graph_launch": (_i, [_vp, _vp]),

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsfnative.so")
-SOURCES = ["conv_igemm.hip", "aux_kernels.hip", "api.hip", "lift_splat.hip", "voxelize.hip", "sparse_index.hip"]
+SOURCES = ["conv_igemm.hip", "aux_kernels.hip", "api.hip", "lift_splat.hip", "voxelize.hip", "sparse_index.hip", "eval_kernels.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
@@ -42,7 +42,7 @@ def build(force=False, verbose=False):
         return r.stderr
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=6) as ex:
+        with ThreadPoolExecutor(max_workers=7) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)

@@ -1,0 +1,159 @@
+// Evaluation-side kernels for gfx950 + C ABI: the per-pixel parts of
+// streamingflow/metrics.py and streamingflow/utils/instance.py.  Integer / index work: results are exact.
+//   sf_confusion_fwd          joint histogram of two label maps (IntersectionOverUnion's stat scores,
+//                             PanopticMetric's bincount of prediction + K * target, metrics.py:37, :171-176)
+//   sf_instance_centers_fwd   find_instance_centers (instance.py:80-92): threshold, 3x3 max-pool NMS, and the
+//                             row-major list torch.nonzero returns (flags + exclusive scan + compaction)
+//   sf_group_pixels_fwd       group_pixels + foreground mask (instance.py:95-116, :136-137): nearest centre of
+//                             (pixel + offset), first minimum on ties
+//   sf_instance_sums_fwd      per-instance sums of (pixel position + flow) and pixel counts — the masked means of
+//                             make_instance_id_temporally_consistent (instance.py:213-236)
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include <rocprim/device/device_scan.hpp>
+
+#include "../../include/sfnative.h"
+
+namespace sf {
+
+__global__ void confusion_kernel(const long long* __restrict__ a, const long long* __restrict__ b, long n, int K,
+                                 unsigned long long* __restrict__ out, int* __restrict__ bad) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long long x = a[i], y = b[i];
+    if (x < 0 || x >= K || y < 0 || y >= K) { *bad = 1; continue; }
+    atomicAdd(out + (size_t)y * K + x, 1ULL);
+  }
+}
+
+// keep[i][j] = thresholded value is a strict-positive local maximum of its 3x3 neighbourhood
+__global__ void center_flag_kernel(const float* __restrict__ c, int H, int W, float thr, int* __restrict__ flag) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= H * W) return;
+  const int i = idx / W, j = idx - i * W;
+  auto val = [&](int y, int x) -> float {
+    if (y < 0 || y >= H || x < 0 || x >= W) return -INFINITY;       // max_pool2d pads with -inf
+    const float v = c[y * W + x];
+    return v > thr ? v : -1.f;                                       // F.threshold(x, thr, -1)
+  };
+  const float v = val(i, j);
+  float m = v;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) m = fmaxf(m, val(i + dy, j + dx));
+  flag[idx] = (v == m && v > 0.f) ? 1 : 0;
+}
+
+__global__ void center_compact_kernel(const int* __restrict__ flag, const int* __restrict__ scan, int H, int W, int cap,
+                                      int* __restrict__ centers, int* __restrict__ n_out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = H * W;
+  if (idx == 0) n_out[0] = scan[n - 1] + flag[n - 1];
+  if (idx >= n || !flag[idx]) return;
+  const int r = scan[idx];
+  if (r >= cap) return;
+  centers[2 * r] = idx / W;
+  centers[2 * r + 1] = idx % W;
+}
+
+__global__ void group_pixels_kernel(const int* __restrict__ centers, int nc, const float* __restrict__ off, const unsigned char* __restrict__ fg,
+                                    int H, int W, long long* __restrict__ inst) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= H * W) return;
+  const int i = idx / W, j = idx - i * W;
+  const float lx = __fadd_rn((float)i, off[idx]), ly = __fadd_rn((float)j, off[H * W + idx]);
+  float best = INFINITY;
+  int arg = 0;
+  for (int k = 0; k < nc; ++k) {
+    const float dx = __fsub_rn((float)centers[2 * k], lx), dy = __fsub_rn((float)centers[2 * k + 1], ly);
+    const float d = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    if (d < best) { best = d; arg = k; }
+  }
+  inst[idx] = fg[idx] ? (long long)(arg + 1) : 0LL;
+}
+
+__global__ void instance_sums_kernel(const long long* __restrict__ inst, const float* __restrict__ flow, int H, int W, int max_id,
+                                     double* __restrict__ sums, int* __restrict__ cnt) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= H * W) return;
+  const long long id = inst[idx];
+  if (id <= 0 || id > max_id) return;
+  const int i = idx / W, j = idx - i * W;
+  float x = (float)i, y = (float)j;
+  if (flow) { x = __fadd_rn(x, flow[idx]); y = __fadd_rn(y, flow[H * W + idx]); }
+  atomicAdd(sums + 2 * id, (double)x);
+  atomicAdd(sums + 2 * id + 1, (double)y);
+  atomicAdd(cnt + id, 1);
+}
+
+inline size_t a256e(size_t n) { return (n + 255) & ~size_t(255); }
+
+}  // namespace sf
+
+using namespace sf;
+
+extern "C" {
+
+int sf_confusion_fwd(const int64_t* a, const int64_t* b, long n, int K, int64_t* out, int32_t* bad, void* stream) {
+  if (!out || !bad || K < 1 || n < 0) return SF_ERR_INVALID;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(out, 0, (size_t)K * K * sizeof(int64_t), st) != hipSuccess) return SF_ERR_LAUNCH;
+  if (hipMemsetAsync(bad, 0, sizeof(int32_t), st) != hipSuccess) return SF_ERR_LAUNCH;
+  if (n == 0) return SF_OK;
+  if (!a || !b) return SF_ERR_INVALID;
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const long long*>(a),
+                     reinterpret_cast<const long long*>(b), n, K, reinterpret_cast<unsigned long long*>(out), bad);
+  return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
+}
+
+size_t sf_instance_centers_ws_bytes(int H, int W) {
+  if (H < 1 || W < 1) return 0;
+  size_t tb = 0;
+  (void)rocprim::exclusive_scan(nullptr, tb, (const int*)nullptr, (int*)nullptr, 0, (size_t)H * W, rocprim::plus<int>(), nullptr);
+  return 2 * a256e((size_t)H * W * 4) + a256e(tb) + 256;
+}
+
+int sf_instance_centers_fwd(const float* center, int H, int W, float conf_threshold, int32_t* centers, int cap, int32_t* n_centers,
+                            void* ws, size_t ws_bytes, void* stream) {
+  if (!center || !centers || !n_centers || H < 1 || W < 1 || cap < 1 || !ws) return SF_ERR_INVALID;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t n = (size_t)H * W, a = a256e(n * 4);
+  size_t tb = 0;
+  (void)rocprim::exclusive_scan(nullptr, tb, (const int*)nullptr, (int*)nullptr, 0, n, rocprim::plus<int>(), st);
+  if (ws_bytes < 2 * a + a256e(tb)) return SF_ERR_WORKSPACE;
+  char* p = static_cast<char*>(ws);
+  int* flag = reinterpret_cast<int*>(p);
+  int* scan = reinterpret_cast<int*>(p + a);
+  void* tmp = p + 2 * a;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipLaunchKernelGGL(center_flag_kernel, grid, block, 0, st, center, H, W, conf_threshold, flag);
+  if (rocprim::exclusive_scan(tmp, tb, (const int*)flag, scan, 0, n, rocprim::plus<int>(), st) != hipSuccess) return SF_ERR_LAUNCH;
+  hipLaunchKernelGGL(center_compact_kernel, grid, block, 0, st, flag, scan, H, W, cap, centers, n_centers);
+  return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
+}
+
+int sf_group_pixels_fwd(const int32_t* centers, int n_centers, const float* offsets, const uint8_t* foreground, int H, int W,
+                        int64_t* instance, void* stream) {
+  if (!centers || !offsets || !foreground || !instance || n_centers < 1 || H < 1 || W < 1) return SF_ERR_INVALID;
+  hipLaunchKernelGGL(group_pixels_kernel, dim3((H * W + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), centers, n_centers,
+                     offsets, foreground, H, W, reinterpret_cast<long long*>(instance));
+  return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
+}
+
+int sf_instance_sums_fwd(const int64_t* instance, const float* flow, int H, int W, int max_id, double* sums, int32_t* counts,
+                         void* stream) {
+  if (!instance || !sums || !counts || H < 1 || W < 1 || max_id < 0) return SF_ERR_INVALID;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(sums, 0, (size_t)(max_id + 1) * 2 * sizeof(double), st) != hipSuccess) return SF_ERR_LAUNCH;
+  if (hipMemsetAsync(counts, 0, (size_t)(max_id + 1) * sizeof(int32_t), st) != hipSuccess) return SF_ERR_LAUNCH;
+  hipLaunchKernelGGL(instance_sums_kernel, dim3((H * W + 255) / 256), dim3(256), 0, st, reinterpret_cast<const long long*>(instance),
+                     flow, H, W, max_id, sums, counts);
+  return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
+}
+
+}  // extern "C"
