@@ -265,6 +265,8 @@ def main():
             dec = decoderbench.run(reps=5, cpu=(world == 1 and not a.no_cpu_baseline), dev=dev)
             import temporalbench
             dec["temporal_model"] = temporalbench.run(reps=5, cpu=(world == 1 and not a.no_cpu_baseline), dev=dev)
+            import e2ebench
+            dec["end_to_end_after_image_backbone"] = e2ebench.run(reps=2, dev=dev)
         except Exception as ex:
             dec = {"error": repr(ex)}
 

@@ -175,6 +175,7 @@ def lift_inputs(tag):
 LIFT_RIG_CASES = {
     "rig_small": (2, 3, 2, 8, (32, 48), 8, (2.0, 8.0, 1.0), (-6.0, 6.0, 0.5), (-6.0, 6.0, 0.5), (-10.0, 10.0, 20.0), 0.5),
     "rig_c64":   (1, 2, 3, 64, (24, 40), 8, (1.0, 7.0, 0.5), (-5.0, 5.0, 0.25), (-5.0, 5.0, 0.5), (-10.0, 10.0, 20.0), 0.7),
+    "e2e_c16":   (1, 3, 2, 16, (32, 48), 8, (2.0, 8.0, 1.0), (-4.0, 4.0, 0.5), (-4.0, 4.0, 0.5), (-10.0, 10.0, 20.0), 0.5),
 }
 
 
