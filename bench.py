@@ -237,7 +237,7 @@ def main():
 
     # ---- camera lift-splat voxel pooling feeding the BEV tensor (HBM-bound gather) ----
     lift = None
-    if rank == 0:
+    if rank == 0 and world == 1:     # secondary figures: single-GPU runs only (no rank may lag behind the others at N > 1)
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import liftbench
@@ -249,7 +249,7 @@ def main():
             lift = {"error": repr(ex)}
 
     vox = None
-    if rank == 0:
+    if rank == 0 and world == 1:
         try:
             import voxelbench
             vox = voxelbench.run(reps=10, cpu=(world == 1 and not a.no_cpu_baseline), dev=dev)
@@ -259,7 +259,7 @@ def main():
             vox = {"error": repr(ex)}
 
     dec = None
-    if rank == 0:
+    if rank == 0 and world == 1:
         try:
             import decoderbench
             dec = decoderbench.run(reps=5, cpu=(world == 1 and not a.no_cpu_baseline), dev=dev)
