@@ -396,6 +396,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
   // walks the channel chunks of one tap before moving on, so the bounds / address arithmetic is
   // paid once per tap instead of once per chunk (it was 4.7 VALU per MFMA)
   int tap_pix[B_SLOTS];
+  int tap_off0[B_SLOTS], tap_off1[B_SLOTS];
   bool tap_fresh = true;
 
   // chunk cursor of this K-group: (tap row, tap col, channel chunk), advanced by KS per iteration
@@ -426,12 +427,20 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
           tap_pix[i] = in ? b_base[i] + (iy >> in_up) * Win + (ix >> in_up) : -1;
         }
       }
+      // element offsets of the gathered pixel in both sources, once per tap (< 2^31 elements: host check)
+#pragma unroll
+      for (int i = 0; i < B_SLOTS; ++i) {
+        const int px = tap_pix[i] >= 0 ? tap_pix[i] : 0;
+        tap_off0[i] = px * in0_cs;
+        tap_off1[i] = px * in1_cs - c0;
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_SLOTS; ++i) {
       const bool ok = (tap_pix[i] >= 0) & (s0 | s1);
       const size_t pix = ok ? (size_t)tap_pix[i] : 0;
-      const float* p = s1 ? in1 + pix * in1_cs + cc : in0 + pix * in0_cs + (s0 ? c : 0);
+      const int eoff = s1 ? tap_off1[i] + c : tap_off0[i] + (s0 ? c : 0);
+      const float* p = (s1 ? in1 : in0) + eoff;
       rb[i] = ld4(p);
       int fl = ok ? 1 : 0;
       if (has_aux) {   // block-uniform branch, no dependent use inside
