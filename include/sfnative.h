@@ -336,6 +336,10 @@ int sf_sparse_to_dense_fwd(const float* feats, const int32_t* coords, int n, int
  *   foreground [H][W] bytes, instance [H][W] int64 = 1 + index of the nearest centre of (pixel + offset), 0 on background.
  * sf_instance_sums_fwd — per instance id (1..max_id): sum of (row + flow[0], col + flow[1]) in float64 and
  *   pixel count (flow may be NULL): the masked means of instance.py:213-236. */
+/* sf_warp_affine_fwd — warp_features (utils/geometry.py:196-236): F.affine_grid(theta [B][2][3], align_corners=False)
+ *   + F.grid_sample(mode nearest | bilinear, padding zeros, align_corners=False) on NCHW maps x [B][C][H][W]. */
+int sf_warp_affine_fwd(const float* x, const float* theta, int B, int C, int H, int W, int bilinear, float* out,
+                       void* stream);
 int sf_confusion_fwd(const int64_t* a, const int64_t* b, long n, int K, int64_t* out, int32_t* bad, void* stream);
 size_t sf_instance_centers_ws_bytes(int H, int W);
 int sf_instance_centers_fwd(const float* center, int H, int W, float conf_threshold, int32_t* centers, int cap,

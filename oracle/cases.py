@@ -347,3 +347,14 @@ def eval_scene(seed=0, b=1, s=4, h=48, w=40, n_obj=5):
     out = {"segmentation": seg, "instance_center": (center + noise).clamp(0, 1), "instance_offset": offset, "instance_flow": flow}
     labels = {"segmentation": (gt_inst > 0).long().unsqueeze(2), "instance": gt_inst}
     return out, labels
+
+
+def label_batch(seed=0, b=2, T=7, h=64, w=64):
+    """A dataset-like batch: label sequences of the eval_scene kind + ego-motion + depth maps."""
+    g = torch.Generator().manual_seed(300 + seed)
+    out, labels = eval_scene(seed, b=b, s=T, h=h, w=w, n_obj=6)
+    ego = torch.cat([(torch.rand((b, T, 3), generator=g) - 0.5) * torch.tensor([6.0, 4.0, 0.0]),
+                     (torch.rand((b, T, 3), generator=g) - 0.5) * torch.tensor([0.0, 0.0, 0.12])], -1)
+    return {"segmentation": labels["segmentation"], "instance": labels["instance"], "centerness": out["instance_center"],
+            "offset": out["instance_offset"], "flow": out["instance_flow"], "future_egomotion": ego,
+            "depths": torch.rand((b, T, 2, 32, 48), generator=g) * 60.0}

@@ -389,6 +389,28 @@ def gen_eval():
     np.savez_compressed(os.path.join(OUT, "eval.npz"), **out)
 
 
+def gen_labels():
+    """N4 (label warping): the reference's geometry helpers themselves (utils/geometry.py) under the restated
+    dictionary plumbing of TrainingModule.prepare_future_labels."""
+    from types import SimpleNamespace as NS
+    from . import labels_ref as LR
+    refimport.install()
+    import importlib
+    G = importlib.import_module("streamingflow.utils.geometry")
+    cfg = NS(LIFT=NS(GT_DEPTH=True, D_BOUND=[2.0, 50.0, 1.0]), SEMANTIC_SEG=NS(PEDESTRIAN=NS(ENABLED=False)),
+             INSTANCE_SEG=NS(ENABLED=True), INSTANCE_FLOW=NS(ENABLED=True))
+    out = {}
+    for seed in (0, 1):
+        batch = cases.label_batch(seed)
+        lab = LR.prepare_future_labels(G, batch, cfg, 3, (50.0, 50.0), 8)
+        for k, v in lab.items():
+            out[f"{seed}.{k}"] = v.numpy()
+        x = batch["centerness"][:, 0]
+        out[f"{seed}.warp_bilinear"] = G.warp_features(x, batch["future_egomotion"][:, 0], mode="bilinear", spatial_extent=(50.0, 50.0)).numpy()
+        print("labels", seed, {k: tuple(v.shape) for k, v in lab.items()})
+    np.savez_compressed(os.path.join(OUT, "labels.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also generate the C=64 200x200 statistics (slow)")
@@ -396,7 +418,7 @@ def main():
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["ops", "fpode", "schedules", "beverse", "lift", "voxel", "decoder", "temporal", "eval"]
+    todo = a.only.split(",") if a.only else ["ops", "fpode", "schedules", "beverse", "lift", "voxel", "decoder", "temporal", "eval", "labels"]
     if "lift" in todo:
         gen_lift()
     if "voxel" in todo:
@@ -407,7 +429,9 @@ def main():
         gen_temporal()
     if "eval" in todo:
         gen_eval()
-    if not set(todo) - {"lift", "voxel", "decoder", "temporal", "eval"}:
+    if "labels" in todo:
+        gen_labels()
+    if not set(todo) - {"lift", "voxel", "decoder", "temporal", "eval", "labels"}:
         return
     m = refimport.modules()
     if "ops" in todo:

@@ -89,6 +89,48 @@ __global__ void instance_sums_kernel(const long long* __restrict__ inst, const f
   atomicAdd(cnt + id, 1);
 }
 
+// warp_features (utils/geometry.py:196-236): affine_grid(theta, align_corners=False) + grid_sample(mode, zeros
+// padding, align_corners=False) on NCHW maps.  theta [b][6] row major (2 x 3).
+//   base grid   x_j = (2j + 1)/W - 1,  y_i = (2i + 1)/H - 1
+//   source      gx = t0*x + t1*y + t2, gy = t3*x + t4*y + t5;  ix = ((gx + 1)*W - 1)/2, iy likewise
+//   nearest     index = nearbyint(ix) (ties to even), zero when outside; bilinear: 4 taps, zeros outside
+__global__ void warp_affine_kernel(const float* __restrict__ x, const float* __restrict__ theta, int B, int C, int H, int W, int bilinear,
+                                   float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * H * W) return;
+  const int j = (int)(idx % W);
+  const long r = idx / W;
+  const int i = (int)(r % H), b = (int)(r / H);
+  const float* t = theta + 6 * b;
+  const float xs = (2.f * j + 1.f) / (float)W - 1.f, ys = (2.f * i + 1.f) / (float)H - 1.f;
+  const float gx = __fadd_rn(__fadd_rn(__fmul_rn(t[0], xs), __fmul_rn(t[1], ys)), t[2]);
+  const float gy = __fadd_rn(__fadd_rn(__fmul_rn(t[3], xs), __fmul_rn(t[4], ys)), t[5]);
+  const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+  const size_t plane = (size_t)H * W;
+  const float* xb = x + (size_t)b * C * plane;
+  float* ob = out + (size_t)b * C * plane + (size_t)i * W + j;
+  if (!bilinear) {
+    const float fx = nearbyintf(ix), fy = nearbyintf(iy);
+    const bool ok = fx >= 0.f && fx < (float)W && fy >= 0.f && fy < (float)H;
+    const size_t src = ok ? (size_t)((int)fy) * W + (int)fx : 0;
+    for (int c = 0; c < C; ++c) ob[c * plane] = ok ? xb[c * plane + src] : 0.f;
+    return;
+  }
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+  const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+  auto in = [&](int yy, int xx) { return yy >= 0 && yy < H && xx >= 0 && xx < W; };
+  for (int c = 0; c < C; ++c) {
+    const float* pc = xb + c * plane;
+    float v = 0.f;
+    if (in(y0, x0)) v += pc[(size_t)y0 * W + x0] * (wx0 * wy0);
+    if (in(y0, x1)) v += pc[(size_t)y0 * W + x1] * (wx1 * wy0);
+    if (in(y1, x0)) v += pc[(size_t)y1 * W + x0] * (wx0 * wy1);
+    if (in(y1, x1)) v += pc[(size_t)y1 * W + x1] * (wx1 * wy1);
+    ob[c * plane] = v;
+  }
+}
+
 inline size_t a256e(size_t n) { return (n + 255) & ~size_t(255); }
 
 }  // namespace sf
@@ -153,6 +195,14 @@ int sf_instance_sums_fwd(const int64_t* instance, const float* flow, int H, int 
   if (hipMemsetAsync(counts, 0, (size_t)(max_id + 1) * sizeof(int32_t), st) != hipSuccess) return SF_ERR_LAUNCH;
   hipLaunchKernelGGL(instance_sums_kernel, dim3((H * W + 255) / 256), dim3(256), 0, st, reinterpret_cast<const long long*>(instance),
                      flow, H, W, max_id, sums, counts);
+  return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
+}
+
+int sf_warp_affine_fwd(const float* x, const float* theta, int B, int C, int H, int W, int bilinear, float* out, void* stream) {
+  if (!x || !theta || !out || B < 1 || C < 1 || H < 1 || W < 1) return SF_ERR_INVALID;
+  const long total = (long)B * H * W;
+  hipLaunchKernelGGL(warp_affine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, theta, B,
+                     C, H, W, bilinear, out);
   return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
 }
 
