@@ -1,0 +1,77 @@
+"""GPU: randomised parity sweep of the fused convolution entry points (sf_conv2d_ex_fwd) against torch CPU fp32:
+random channel splits (two concatenated inputs), kernel sizes, strides, dilations, paddings, batch sizes, odd
+spatial sizes, channel-sliced inputs / outputs, residual before or after the activation.  The seeds are fixed:
+the same 48 configurations every run; they cover every tile configuration the dispatcher can choose
+(direct-fragment, split-K, 64x64, 128x128)."""
+import ctypes
+import random
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import hashfill, maxabs
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(i):
+    r = random.Random(1000 + i)
+    big = i % 6 == 0
+    k = r.choice([1, 3, 3, 3, 5, 7])
+    stride = r.choice([1, 1, 1, 2])
+    dil = r.choice([1, 1, 2, 3]) if k > 1 and stride == 1 else 1
+    c0 = r.choice([4, 8, 12, 32, 64, 72])
+    c1 = r.choice([0, 0, 8, 32, 64]) if not big else 0
+    cout = r.choice([4, 8, 20, 64, 128, 136]) if not big else r.choice([64, 128])
+    n = r.choice([1, 2, 3]) if not big else r.choice([4, 8])
+    H = r.choice([5, 12, 17, 33, 50]) if not big else r.choice([150, 200])
+    W = r.choice([7, 12, 21, 40, 50]) if not big else r.choice([160, 200])
+    pad = r.choice([dil * (k - 1) // 2, 0]) if k > 1 else 0
+    if (H + 2 * pad - dil * (k - 1) - 1) // stride + 1 < 1 or (W + 2 * pad - dil * (k - 1) - 1) // stride + 1 < 1:
+        pad = dil * (k - 1) // 2
+    return dict(k=k, stride=stride, dil=dil, c0=c0, c1=c1, cout=cout, n=n, H=H, W=W, pad=pad, act=r.choice(["none", "relu", "lrelu", "tanh"]),
+                add=r.random() < 0.6, after=r.random() < 0.5, in_slack=r.choice([0, 8]), out_slack=r.choice([0, 4, 16]))
+
+
+@pytest.mark.parametrize("i", range(48))
+def test_random_conv(i):
+    from streamingflow_amd import _lib, packing, runtime
+    c = _cfg(i)
+    k, n, H, W, c0, c1, cout = c["k"], c["n"], c["H"], c["W"], c["c0"], c["c1"], c["cout"]
+    x0 = hashfill.normal(f"rc_x0_{i}", (n, c0, H, W), 1)
+    x1 = hashfill.normal(f"rc_x1_{i}", (n, c1, H, W), 2) if c1 else None
+    w = hashfill.uniform(f"rc_w_{i}", (cout, c0 + c1, k, k), -1, 1, 3) * (3.0 / ((c0 + c1) * k * k)) ** 0.5
+    b = hashfill.uniform(f"rc_b_{i}", (cout,), -0.5, 0.5, 4)
+    sc = hashfill.uniform(f"rc_s_{i}", (cout,), 0.5, 1.5, 5)
+    xin = torch.cat([x0, x1], 1) if c1 else x0
+    y = F.conv2d(xin, w, None, c["stride"], c["pad"], c["dil"]) * sc.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+    Ho, Wo = y.shape[-2:]
+    add = hashfill.normal(f"rc_a_{i}", (n, cout, Ho, Wo), 6) if c["add"] else None
+    act = {"none": lambda t: t, "relu": F.relu, "lrelu": lambda t: F.leaky_relu(t, 0.1), "tanh": torch.tanh}[c["act"]]
+    want = act(y + add) if (c["add"] and c["after"]) else (act(y) + add if c["add"] else act(y))
+
+    pk = packing.Pack(None)
+    cw = packing.conv_w(pk, w.cuda(), c0, c1, sc.cuda(), b.cuda(), c["act"], dil=c["dil"], stride=c["stride"], pad=c["pad"])
+    # inputs live inside wider NHWC tensors (channel stride > channels), output goes to a channel slice
+    cs0 = c0 + c["in_slack"]
+    a0 = torch.randn((n, H, W, cs0), device="cuda")
+    a0[..., :c0] = x0.permute(0, 2, 3, 1).cuda()
+    a1 = None
+    if c1:
+        a1 = torch.randn((n, H, W, c1 + 4), device="cuda")
+        a1[..., :c1] = x1.permute(0, 2, 3, 1).cuda()
+    ocs, oco = cout + c["out_slack"], c["out_slack"] // 2 // 4 * 4
+    out = torch.full((n, Ho, Wo, ocs), 7.0, device="cuda")
+    addn = add.permute(0, 2, 3, 1).contiguous().cuda() if add is not None else None
+    L = _lib.lib()
+    ws = runtime.workspace(L.sf_conv2d_ex_ws_bytes(), "cuda")
+    _lib.check(L.sf_conv2d_ex_fwd(ctypes.byref(cw), runtime.ptr(a0), cs0, runtime.ptr(a1), c1 + 4 if c1 else 0, runtime.ptr(addn), cout,
+                                  int(c["after"]), ctypes.c_void_p(out.data_ptr()), ocs, oco, n, H, W, 0, runtime.ptr(ws), ws.numel() * 4,
+                                  runtime.stream_ptr()), "conv2d_ex")
+    got = out[..., oco:oco + cout].permute(0, 3, 1, 2)
+    assert maxabs(got, want) <= 2e-4, c
+    # nothing outside the output slice was touched
+    if ocs > cout:
+        rest = torch.cat([out[..., :oco], out[..., oco + cout:]], -1)
+        assert float((rest - 7.0).abs().max()) == 0.0
