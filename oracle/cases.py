@@ -266,6 +266,7 @@ TEMPORAL_CASES = {
     "camera_c70": (70, 3, 64, 0, 0, True, (1, 3, 24, 16)),        # 64 + 6 ego-pose channels (config.py:141)
     "lidar_c256_b2": (256, 3, 64, 0, 0, True, (2, 3, 16, 16)),
     "rf2_nopool_c16": (16, 2, 16, 0, 0, False, (1, 2, 12, 20)),
+    "inbetween2_c24": (24, 3, 16, 0, 2, True, (1, 3, 12, 12)),      # Bottleneck3D layers between the temporal blocks
 }
 
 

@@ -75,6 +75,25 @@ class TemporalBlock(nn.Module):
                                             nn.BatchNorm3d(self.out_channels))
 
 
+class Bottleneck3D(nn.Module):
+    """layers/temporal.py:333-391: 1x1x1 down -> causal conv -> 1x1x1 up, residual (projected when channels change)."""
+
+    def __init__(self, in_channels, out_channels=None, kernel_size=(2, 3, 3), dilation=(1, 1, 1)):
+        super().__init__()
+        if tuple(dilation) != (1, 1, 1) or tuple(kernel_size) not in ((2, 3, 3), (1, 3, 3)):
+            raise NotImplementedError("Bottleneck3D: kernels (2,3,3) / (1,3,3), dilation 1")
+        bottleneck_channels = in_channels // 2
+        out_channels = out_channels or in_channels
+        self.in_channels, self.out_channels, self.bottleneck_channels = in_channels, out_channels, bottleneck_channels
+        self.layers = nn.Sequential(OrderedDict([
+            ("conv_down_project", conv_1x1x1_norm_activated(in_channels, bottleneck_channels)),
+            ("conv", CausalConv3d(bottleneck_channels, bottleneck_channels, kernel_size=kernel_size)),
+            ("conv_up_project", conv_1x1x1_norm_activated(bottleneck_channels, out_channels))]))
+        self.projection = None
+        if out_channels != in_channels:
+            self.projection = nn.Sequential(nn.Conv3d(in_channels, out_channels, kernel_size=1, bias=False), nn.BatchNorm3d(out_channels))
+
+
 def _p4(c):
     return (c + 3) // 4 * 4
 
@@ -83,8 +102,6 @@ class TemporalModel(PackedModule):
     def __init__(self, in_channels, receptive_field, input_shape, start_out_channels=64, extra_in_channels=0,
                  n_spatial_layers_between_temporal_layers=0, use_pyramid_pooling=True, with_cp=False):
         super().__init__()
-        if n_spatial_layers_between_temporal_layers:
-            raise NotImplementedError("Bottleneck3D in-between layers (0 in every shipped config) are not built")
         self.receptive_field = receptive_field
         h, w = input_shape
         self.input_shape = (int(h), int(w))
@@ -93,6 +110,7 @@ class TemporalModel(PackedModule):
         for _ in range(receptive_field - 1):
             modules.append(TemporalBlock(cin, cout, use_pyramid_pooling=bool(use_pyramid_pooling),
                                          pool_sizes=[(2, h, w)] if use_pyramid_pooling else None))
+            modules.extend(Bottleneck3D(cout, cout, kernel_size=(1, 3, 3)) for _ in range(n_spatial_layers_between_temporal_layers))
             cin = cout
             cout += extra_in_channels
         self.out_channels = cin
@@ -105,6 +123,9 @@ class TemporalModel(PackedModule):
     def _pack(self):
         pk = packing.Pack([])
         for blk in self.model:
+            if isinstance(blk, Bottleneck3D):
+                pk.struct.append(self._pack_bottleneck(pk, blk))
+                continue
             C, Ch, Co = blk.in_channels, blk.half_channels, blk.out_channels
             Cp, Chp = _p4(C), _p4(Ch)
             dev = blk.aggregation[0].conv.weight.device
@@ -171,6 +192,69 @@ class TemporalModel(PackedModule):
             pk.struct.append(W)
         return pk
 
+    @staticmethod
+    def _pack_bottleneck(pk, blk):
+        C, Cb, Co = blk.in_channels, blk.bottleneck_channels, blk.out_channels
+        Cp, Cbp = _p4(C), _p4(Cb)
+        if Co % 4:
+            raise RuntimeError("Bottleneck3D out_channels must be a multiple of 4")
+        dev = blk.layers.conv.conv.weight.device
+        W = {"kind": "bottleneck", "Cp": Cp, "Cbp": Cbp, "Co": Co}
+
+        def fold(bn, n, npad):
+            sc, bi = packing.bn_fold(bn)
+            s, b = torch.zeros(npad, device=dev), torch.zeros(npad, device=dev)
+            s[:n], b[:n] = sc, bi
+            return s, b
+        d = blk.layers.conv_down_project
+        w = torch.zeros((Cbp, Cp, 1, 1), device=dev)
+        w[:Cb, :C] = d.conv.weight.detach()[:, :, 0, 0, 0][:, :, None, None]
+        W["down"] = packing.conv_w(pk, w, Cp, 0, *fold(d.norm, Cb, Cbp), "relu", pad=0)
+        c = blk.layers.conv
+        w3 = c.conv.weight.detach()                                       # [Cb][Cb][kt][3][3]
+        kt = w3.shape[2]
+        W["kt"] = kt
+        w = torch.zeros((Cbp, kt * Cbp, 3, 3), device=dev)
+        for t in range(kt):
+            w[:Cb, t * Cbp:t * Cbp + Cb] = w3[:, :, t]
+        W["conv"] = packing.conv_w(pk, w, Cbp, Cbp if kt == 2 else 0, *fold(c.norm, Cb, Cbp), "relu", pad=1)
+        u = blk.layers.conv_up_project
+        w = torch.zeros((Co, Cbp, 1, 1), device=dev)
+        w[:, :Cb] = u.conv.weight.detach()[:, :, 0, 0, 0][:, :, None, None]
+        sc, bi = packing.bn_fold(u.norm)
+        W["up"] = packing.conv_w(pk, w, Cbp, 0, sc, bi, "relu", pad=0)
+        if blk.projection is not None:
+            sc, bi = packing.bn_fold(blk.projection[1])
+            w = torch.zeros((Co, Cp, 1, 1), device=dev)
+            w[:, :C] = blk.projection[0].weight.detach()[:, :, 0, 0, 0][:, :, None, None]
+            W["proj"] = packing.conv_w(pk, w, Cp, 0, sc, bi, "none", pad=0)
+        elif Cp != Co:
+            raise RuntimeError("Bottleneck3D without projection needs in_channels == out_channels (multiple of 4)")
+        return W
+
+    def _bottleneck(self, W, x, b, T, H, Wd):
+        """x [b*T, H, W, Cp] -> [b*T, H, W, Co]   (layers/temporal.py:386-391)."""
+        dev = x.device
+        n = b * T
+        Cp, Cbp, Co = W["Cp"], W["Cbp"], W["Co"]
+        A = torch.zeros((b, T + 1, H, Wd, Cbp), dtype=torch.float32, device=dev)      # one zero frame = the causal time padding
+        for bi in range(b):
+            self._conv(W["down"], x[bi * T:], Cp, 0, T, H, Wd, A[bi, 1:], Cbp, 0)
+        y = torch.empty((n, H, Wd, Cbp), dtype=torch.float32, device=dev)
+        for bi in range(b):
+            if W["kt"] == 2:
+                self._conv(W["conv"], A[bi, :T], Cbp, 0, T, H, Wd, y[bi * T:], Cbp, 0, in1=A[bi, 1:], in1_cs=Cbp, in1_co=0)
+            else:
+                self._conv(W["conv"], A[bi, 1:], Cbp, 0, T, H, Wd, y[bi * T:], Cbp, 0)
+        if "proj" in W:
+            res = torch.empty((n, H, Wd, Co), dtype=torch.float32, device=dev)
+            self._conv(W["proj"], x, Cp, 0, n, H, Wd, res, Co, 0)
+        else:
+            res = x
+        out = torch.empty((n, H, Wd, Co), dtype=torch.float32, device=dev)
+        self._conv(W["up"], y, Cbp, 0, n, H, Wd, out, Co, 0, add=res, add_cs=Co)
+        return out
+
     # ---- device side ------------------------------------------------------------------------------
     @staticmethod
     def _conv(w, in0, in0_cs, in0_co, n, H, Wd, out, out_cs, out_co, in1=None, in1_cs=0, in1_co=0, add=None, add_cs=0):
@@ -223,7 +307,7 @@ class TemporalModel(PackedModule):
         if self.training:
             raise RuntimeError("streamingflow_amd.TemporalModel is inference-only (BatchNorm statistics are folded): call .eval()")
         b, s, c, h, w = x.shape
-        if self.model and self.model[0].use_pyramid_pooling and (h, w) != self.input_shape:
+        if len(self.model) and getattr(self.model[0], "use_pyramid_pooling", False) and (h, w) != self.input_shape:
             raise RuntimeError(f"pyramid pooling was built for a {self.input_shape} grid, got {(h, w)}")
         packs = self.packed().struct
         Cp = _p4(c)
@@ -232,6 +316,6 @@ class TemporalModel(PackedModule):
             xf = torch.nn.functional.pad(xf, (0, 0, 0, 0, 0, Cp - c))
         y = runtime.to_nhwc(xf)
         for W in packs:
-            y = self._block(W, y, b, s, h, w)
+            y = self._bottleneck(W, y, b, s, h, w) if W.get("kind") == "bottleneck" else self._block(W, y, b, s, h, w)
         y = self.final_conv.forward_nhwc(y)
         return runtime.to_nchw(y).view(b, s, -1, h, w)

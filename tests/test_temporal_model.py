@@ -34,8 +34,6 @@ def test_product_state_dict_matches_reference(tag):
                       n_spatial_layers_between_temporal_layers=inb, use_pyramid_pooling=pyr)
     assert {k: list(v.shape) for k, v in m.state_dict().items()} == keys
     assert m.out_channels == start
-    with pytest.raises(NotImplementedError):
-        TemporalModel(cin, rf, (h, w), n_spatial_layers_between_temporal_layers=1)
 
 
 @pytest.mark.gpu
