@@ -43,6 +43,7 @@ def parse():
                     "takes a batch and loops over it; here same-structure samples run through the kernels together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary sections (next-row components, ODE step alone)")
     return ap.parse_args()
 
 
@@ -237,7 +238,7 @@ def main():
 
     # ---- camera lift-splat voxel pooling feeding the BEV tensor (HBM-bound gather) ----
     lift = None
-    if rank == 0 and world == 1:     # secondary figures: single-GPU runs only (no rank may lag behind the others at N > 1)
+    if rank == 0 and world == 1 and not a.no_extras:     # secondary figures: single-GPU runs only (no rank may lag behind the others at N > 1)
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import liftbench
@@ -249,7 +250,7 @@ def main():
             lift = {"error": repr(ex)}
 
     vox = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.no_extras:
         try:
             import voxelbench
             vox = voxelbench.run(reps=10, cpu=(world == 1 and not a.no_cpu_baseline), dev=dev)
@@ -259,7 +260,7 @@ def main():
             vox = {"error": repr(ex)}
 
     dec = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.no_extras:
         try:
             import decoderbench
             dec = decoderbench.run(reps=5, cpu=(world == 1 and not a.no_cpu_baseline), dev=dev)
