@@ -194,6 +194,18 @@ def main():
                 "hbm_frac": by / t / 1e9 / PEAK_HBM_GBS}
     step_only = {"single_sample": time_step(1, H // 4, W // 4, 50), "batch8": time_step(8, H // 4, W // 4, 20),
                  "stress_latent_200x200": time_step(1, H, W, 5)}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:      # the same unit of work on the host cores (oracle, 16 threads)
+        from oracle import ref_torch as R
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        s_c, p_c = torch.randn((1, C, H // 4, W // 4)) * 0.5, torch.randn((1, C, H // 4, W // 4)) * 0.5
+        with torch.no_grad():
+            R.ode_step(sd, "gru_ode", s_c, p_c, dt, a.solver, True, hashfill.HashedNoise(0))
+            t0 = time.perf_counter()
+            for _ in range(5):
+                R.ode_step(sd, "gru_ode", s_c, p_c, dt, a.solver, True, hashfill.HashedNoise(0))
+            tc = (time.perf_counter() - t0) / 5
+        step_only["cpu_baseline"] = {"value": 1.0 / tc, "unit": "ODE-steps/s", "cores": min(os.cpu_count() or 1, 16), "kind": "port",
+                                     "sample": f"5 single-sample {a.solver} steps at latent 50x50x64, oracle/ref_torch.py:ode_step, {tc * 1e3:.1f} ms each"}
     pmc_step = os.path.join(ROOT, "profiles", "pmc_ode_step.json")
     if os.path.exists(pmc_step):
         try:
