@@ -2,7 +2,7 @@
 """bench.py — ODE-steps/s of the MI355X-native GRU-ODE future-state path (BASELINE.json metric).
 
 One "step" of this bench = one pass of the hot path over one batch of synthetic input: a full
-``FuturePredictionODE.forward`` on ``--batch`` samples (default 8) of BASELINE config 2 (C=64, BEV
+``FuturePredictionODE.forward`` on ``--batch`` samples (default 32) of BASELINE config 2 (C=64, BEV
 200x200, 3 camera + 5 LiDAR observations, 7 targets, variable-step Euler: 10 ODE steps + 8
 Bayesian jumps, SmallEncoder on 8 frames, SmallDecoder + 2x(SpatialGRU + res block) head on 7 frames
 per sample), inputs resident in HBM.  The reference's forward takes a batch and loops over it one
@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--timeset", default="shipped", help="oracle.cases.TIMESETS key (default: BASELINE config 2)")
     ap.add_argument("--solver", default="euler")
-    ap.add_argument("--batch", type=int, default=8, help="samples per forward on each GPU (the reference API "
+    ap.add_argument("--batch", type=int, default=32, help="samples per forward on each GPU (the reference API "
                     "takes a batch and loops over it; here same-structure samples run through the kernels together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

@@ -151,9 +151,8 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   }
   L.nprob = n;
   if (P <= 0) return SF_OK;
-  for (int i = 0; i < n; ++i) {   // the staged kernels keep per-tap element offsets in 32 bits
-    const double e0 = (double)ps[i].n_img * ps[i].Hin * ps[i].Win * ps[i].in0_cs;
-    const double e1 = (double)ps[i].n_img * ps[i].Hin * ps[i].Win * ps[i].in1_cs;
+  for (int i = 0; i < n; ++i) {   // the staged kernels keep per-tap element offsets (relative to the tile's first image) in 32 bits
+    const double e0 = 2.0 * ps[i].Hin * ps[i].Win * ps[i].in0_cs, e1 = 2.0 * ps[i].Hin * ps[i].Win * ps[i].in1_cs;
     if (!ps[i].gather && (e0 >= 2147483648.0 || e1 >= 2147483648.0)) return SF_ERR_UNSUPPORTED;
   }
   int cfg = pick_cfg(P, epi);

@@ -332,9 +332,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
   float* Bs = As + 2 * BM * ROW;             // [2][BN][ROW]
 
   // ---- problem fields used in the K loop, read from the kernarg segment once ------------------
-  const float* const in0 = P.in0;
-  const float* const in1 = P.in1;
-  const float* const gate = P.gate;
+  // the input pointers are rebased to the tile's first image, so the per-tap element offsets of the K loop
+  // (32 bit) only have to span the (at most two) images a tile touches, whatever the batch size
+  const int img0 = P.gather ? 0 : (p_tile * BN) / (P.Hout * P.Wout);          // block-uniform
+  const size_t img0_px = (size_t)img0 * P.Hin * P.Win;
+  const float* const in0 = P.in0 + img0_px * P.in0_cs;
+  const float* const in1 = P.in1 ? P.in1 + img0_px * P.in1_cs : nullptr;
+  const float* const gate = P.gate ? P.gate + img0_px * P.gate_cs : nullptr;
   const float* const in_scale = P.in_scale;
   const float* const wbase = P.w;
   const int c0 = P.c0, c01 = P.c0 + P.c1;
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
     int oy = rem / P.Wout, ox = rem - oy * P.Wout;
     b_iy0[i] = v ? oy * P.stride - P.pad : -(1 << 28);   // invalid pixel: never in range
     b_ix0[i] = ox * P.stride - P.pad;
-    b_base[i] = img * P.Hin * P.Win;
+    b_base[i] = (v ? img - img0 : 0) * P.Hin * P.Win;
     b_img[i] = img;
   }
   // weight rows: clamp instead of predicating (rows >= cout_pad are never stored by any epilogue)
