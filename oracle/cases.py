@@ -276,6 +276,10 @@ SPARSE_CASES = {
     "grid32x24x27": (dict(sparse_shape=[32, 24, 27]), 260, 2),
     "thin_c8": (dict(sparse_shape=[24, 24, 41], base_channels=8, output_channels=16,
                      encoder_channels=[[8, 8, 16], [16, 16, 16], [16, 16, 32], [32, 32]]), 150, 1),
+    # the class-default layout (block_type='conv_module': plain conv modules, each later stage opens with the strided conv)
+    "conv_module": (dict(sparse_shape=[24, 24, 41], block_type="conv_module", base_channels=16, output_channels=32,
+                         encoder_channels=[[16], [32, 32, 32], [64, 64, 64], [64, 64, 64]],
+                         encoder_paddings=[[1], [1, 1, 1], [1, 1, 1], [[0, 1, 1], 1, 1]]), 140, 1),
 }
 
 

@@ -142,7 +142,13 @@ def sparse_encoder_forward(sd, voxel_features, coors, batch_size, cfg):
     for i, blocks in enumerate(cfg["encoder_channels"]):
         for j in range(len(blocks)):
             p = f"encoder_layers.encoder_layer{i + 1}.{j}"
-            if j == len(blocks) - 1 and i != n_stage - 1:        # strided SparseConv3d + BN + ReLU
+            if cfg.get("block_type", "basicblock") == "conv_module":        # sparse_encoder.py:166-179, :203-213
+                if i != 0 and j == 0:
+                    y, coords, shape = sparse_conv(x, coords, shape, npw(p + ".0.weight"), 2, cfg["encoder_paddings"][i][j])
+                else:
+                    y = subm_conv(x, coords, shape, npw(p + ".0.weight"))
+                x = _bn_relu(y, sd, p + ".1")
+            elif j == len(blocks) - 1 and i != n_stage - 1:      # strided SparseConv3d + BN + ReLU
                 pad = cfg["encoder_paddings"][i][j]
                 y, coords, shape = sparse_conv(x, coords, shape, npw(p + ".0.weight"), 2, pad)
                 x = _bn_relu(y, sd, p + ".1")
@@ -196,7 +202,13 @@ def sparse_encoder_forward_dense(sd, voxel_features, coors, batch_size, cfg):
     for i, blocks in enumerate(cfg["encoder_channels"]):
         for j in range(len(blocks)):
             p = f"encoder_layers.encoder_layer{i + 1}.{j}"
-            if j == len(blocks) - 1 and i != n_stage - 1:
+            if cfg.get("block_type", "basicblock") == "conv_module":
+                if i != 0 and j == 0:
+                    y, m = dense_sparse_conv(x, m, sd[p + ".0.weight"].numpy(), 2, cfg["encoder_paddings"][i][j])
+                else:
+                    y, _ = dense_subm_conv(x, m, sd[p + ".0.weight"].numpy())
+                x = bn(y, m, p + ".1")
+            elif j == len(blocks) - 1 and i != n_stage - 1:
                 y, m = dense_sparse_conv(x, m, sd[p + ".0.weight"].numpy(), 2, cfg["encoder_paddings"][i][j])
                 x = bn(y, m, p + ".1")
             else:
@@ -230,7 +242,7 @@ def state_dict_shapes(cfg):
     for i, blocks in enumerate(cfg["encoder_channels"]):
         for j, cout in enumerate(blocks):
             p = f"encoder_layers.encoder_layer{i + 1}.{j}"
-            if j == len(blocks) - 1 and i != n_stage - 1:
+            if cfg.get("block_type", "basicblock") == "conv_module" or (j == len(blocks) - 1 and i != n_stage - 1):
                 conv(p + ".0", (3, 3, 3), cin, cout)
                 bn(p + ".1", cout)
             else:

@@ -3,7 +3,7 @@ SURVEY.md §8f N2, second half.
 
 Same constructor arguments, ``forward(voxel_features, coors, batch_size)`` and ``state_dict`` keys as the
 reference configuration StreamingFlow builds (streamingflow.py:111: ``block_type='basicblock'``, order
-conv-norm-act): spconv weights ``[kx, ky, kz, Cin, Cout]``, ``BatchNorm1d(eps=1e-3)``; coordinates are
+conv-norm-act; ``block_type='conv_module'`` — the class default — is built too): spconv weights ``[kx, ky, kz, Cin, Cout]``, ``BatchNorm1d(eps=1e-3)``; coordinates are
 ``(batch, x, y, z)`` in ``sparse_shape = (X, Y, Z)``.
 
 Every sparse convolution is the implicit-GEMM kernel of the dense path reading a neighbour table
@@ -62,8 +62,11 @@ class SparseEncoder(PackedModule):
                  base_channels=16, output_channels=128, encoder_channels=((16,), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
                  encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)), block_type="conv_module"):
         super().__init__()
-        if block_type != "basicblock" or tuple(order) != ("conv", "norm", "act"):
-            raise NotImplementedError("only the configuration StreamingFlow builds: block_type='basicblock', order conv-norm-act")
+        if block_type not in ("basicblock", "conv_module"):
+            raise AssertionError("block_type must be 'conv_module' or 'basicblock'")
+        if tuple(order) != ("conv", "norm", "act"):
+            raise NotImplementedError("only the post-activation order (conv, norm, act) is built")
+        self.block_type = block_type
         self.sparse_shape = [int(v) for v in sparse_shape]
         self.in_channels, self.base_channels, self.output_channels = in_channels, base_channels, output_channels
         self.encoder_channels, self.encoder_paddings = encoder_channels, encoder_paddings
@@ -76,7 +79,12 @@ class SparseEncoder(PackedModule):
             stage = []
             for j, cout in enumerate(tuple(blocks)):
                 pad = tuple(encoder_paddings[i])[j]
-                if j == len(blocks) - 1 and i != len(encoder_channels) - 1:
+                if block_type == "conv_module":          # sparse_encoder.py:166-179, :203-213
+                    if i != 0 and j == 0:
+                        stage.append(_convmodule(cin, cout, 3, 2, pad, False, f"spconv{i + 1}", eps, mom))
+                    else:
+                        stage.append(_convmodule(cin, cout, 3, 1, pad, True, f"subm{i + 1}", eps, mom))
+                elif j == len(blocks) - 1 and i != len(encoder_channels) - 1:
                     stage.append(_convmodule(cin, cout, 3, 2, pad, False, f"spconv{i + 1}", eps, mom))
                 else:
                     if cin != cout:
@@ -174,6 +182,10 @@ class SparseEncoder(PackedModule):
                         tab = self._table(coords, coords, B, shape, k3, one3, zero3, True)
                     y = self._conv(W[f"{i}.{j}.c1"], x, tab, n)
                     x = self._conv(W[f"{i}.{j}.c2"], y, tab, n, add=x, act_after_add=True)
+                elif blk[0].subm:                       # conv_module: submanifold conv + BN + ReLU
+                    if tab is None and n:
+                        tab = self._table(coords, coords, B, shape, k3, one3, zero3, True)
+                    x = self._conv(W[f"{i}.{j}"], x, tab, n)
                 else:
                     x, coords, shape, n = self._strided(W[f"{i}.{j}"], blk[0], x, coords, B, shape, n)
                     tab = None

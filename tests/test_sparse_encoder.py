@@ -36,15 +36,16 @@ def test_product_state_dict_names():
     m = SparseEncoder(cfg["in_channels"], cfg["sparse_shape"], base_channels=cfg["base_channels"], output_channels=cfg["output_channels"],
                       encoder_channels=cfg["encoder_channels"], encoder_paddings=cfg["encoder_paddings"], block_type="basicblock")
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == SR.state_dict_shapes(cfg)
-    with pytest.raises(NotImplementedError):
-        SparseEncoder(5, [8, 8, 8])                     # block_type='conv_module' is not what StreamingFlow builds
+    with pytest.raises(AssertionError):
+        SparseEncoder(5, [8, 8, 8], block_type="bottleneck")
 
 
 def _build(tag):
     from streamingflow_amd.models.sparse_encoder import SparseEncoder
     cfg = cases.sparse_cfg(tag)
     m = SparseEncoder(cfg["in_channels"], cfg["sparse_shape"], base_channels=cfg["base_channels"], output_channels=cfg["output_channels"],
-                      encoder_channels=cfg["encoder_channels"], encoder_paddings=cfg["encoder_paddings"], block_type="basicblock").eval()
+                      encoder_channels=cfg["encoder_channels"], encoder_paddings=cfg["encoder_paddings"],
+                      block_type=cfg.get("block_type", "basicblock")).eval()
     sd = cases.sparse_state_dict(tag)
     m.load_state_dict(sd)
     return m.cuda(), sd, cfg
