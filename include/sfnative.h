@@ -117,6 +117,12 @@ const char* sf_status_string(int status);
 /* layout: [n][C][HW] <-> [n][HW][C] */
 int sf_nchw_to_nhwc(const float* src, float* dst, int n, int C, int HW, void* stream);
 int sf_nhwc_to_nchw(const float* src, float* dst, int n, int C, int HW, void* stream);
+/* the same with the n images src_stride / dst_stride floats apart: frames read out of / written into a
+ * [B][T][C][H][W] tensor (future_prediction_ode.py:36-49, :63-64) without an intermediate stack */
+int sf_nchw_to_nhwc_strided(const float* src, size_t src_stride, float* dst, size_t dst_stride, int n, int C, int HW,
+                            void* stream);
+int sf_nhwc_to_nchw_strided(const float* src, size_t src_stride, float* dst, size_t dst_stride, int n, int C, int HW,
+                            void* stream);
 
 /* generic fused conv (test hook and building block): y = act(conv(cat[in0,in1])*scale + bias) + add */
 int sf_conv2d_fwd(const sf_conv_w* w, const float* in0, const float* in1, const float* add, float* out,

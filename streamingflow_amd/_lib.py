@@ -79,6 +79,8 @@ SIGNATURES = {
     "sf_status_string": (C.c_char_p, [_i]),
     "sf_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sf_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sf_nchw_to_nhwc_strided": (_i, [_vp, _sz, _vp, _sz, _i, _i, _i, _vp]),
+    "sf_nhwc_to_nchw_strided": (_i, [_vp, _sz, _vp, _sz, _i, _i, _i, _vp]),
     "sf_conv2d_fwd": (_i, [C.POINTER(ConvW), _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sf_conv2d_repeat": (_i, [C.POINTER(ConvW), _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sf_gru_cell_fwd": (_i, [C.POINTER(GruW), _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),

@@ -12,6 +12,8 @@ namespace sf {
 hipError_t launch_conv(const ConvLaunch& L, int epi, int cfg, hipStream_t stream);
 hipError_t launch_conv_direct(const ConvLaunch& L, int epi, int mt, int ks, hipStream_t stream);
 hipError_t launch_transpose(const float* in, float* out, int n, int rows, int cols, hipStream_t s);
+hipError_t launch_transpose_strided(const float* in, float* out, int n, int rows, int cols, size_t in_stride, size_t out_stride,
+                                    hipStream_t s);
 hipError_t launch_maxpool2(const float* in, float* out, int n, int Hin, int Win, int C, int ceil_pad, hipStream_t s);
 hipError_t launch_mean_from_partials(const float* part, float* out, int n, int nslab, int C, int hw, hipStream_t s);
 hipError_t launch_upsample2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s);
@@ -496,6 +498,19 @@ int sf_nchw_to_nhwc(const float* src, float* dst, int n, int C, int HW, void* st
 int sf_nhwc_to_nchw(const float* src, float* dst, int n, int C, int HW, void* stream) {
   if (!src || !dst) return SF_ERR_INVALID;
   SF_HIP(launch_transpose(src, dst, n, HW, C, (hipStream_t)stream));
+  return SF_OK;
+}
+
+/* the same with the n images `src_stride` / `dst_stride` floats apart (>= C*HW): frames picked out of / written into a
+ * larger [B][T][C][H][W] tensor without an intermediate copy */
+int sf_nchw_to_nhwc_strided(const float* src, size_t src_stride, float* dst, size_t dst_stride, int n, int C, int HW, void* stream) {
+  if (!src || !dst || src_stride < (size_t)C * HW || dst_stride < (size_t)C * HW) return SF_ERR_INVALID;
+  SF_HIP(launch_transpose_strided(src, dst, n, C, HW, src_stride, dst_stride, (hipStream_t)stream));
+  return SF_OK;
+}
+int sf_nhwc_to_nchw_strided(const float* src, size_t src_stride, float* dst, size_t dst_stride, int n, int C, int HW, void* stream) {
+  if (!src || !dst || src_stride < (size_t)C * HW || dst_stride < (size_t)C * HW) return SF_ERR_INVALID;
+  SF_HIP(launch_transpose_strided(src, dst, n, HW, C, src_stride, dst_stride, (hipStream_t)stream));
   return SF_OK;
 }
 

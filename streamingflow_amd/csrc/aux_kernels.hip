@@ -11,10 +11,12 @@ __device__ __forceinline__ void st4a(float* p, float4 v) { *reinterpret_cast<flo
 // ---- [N][C][HW] <-> [N][HW][C] -------------------------------------------------------------
 // 32x32 tiles through LDS (+1 pad): both the read and the write are 128-B contiguous per row.
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                        int rows, int cols) {
-  // in: [N][rows][cols] -> out: [N][cols][rows]
+                                                        int rows, int cols, size_t in_stride, size_t out_stride) {
+  // in: image i at in + i*in_stride, [rows][cols] -> out: image i at out + i*out_stride, [cols][rows]
   __shared__ float tile[32][33];
-  const size_t img = (size_t)blockIdx.z * rows * cols;
+  in += (size_t)blockIdx.z * in_stride;
+  out += (size_t)blockIdx.z * out_stride;
+  const size_t img = 0;
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
@@ -30,11 +32,15 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
   }
 }
 
-hipError_t launch_transpose(const float* in, float* out, int n, int rows, int cols, hipStream_t s) {
+hipError_t launch_transpose_strided(const float* in, float* out, int n, int rows, int cols, size_t in_stride, size_t out_stride,
+                                    hipStream_t s) {
   if (n <= 0 || rows <= 0 || cols <= 0) return hipSuccess;
   dim3 grid((cols + 31) / 32, (rows + 31) / 32, n);
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols, in_stride, out_stride);
   return hipGetLastError();
+}
+hipError_t launch_transpose(const float* in, float* out, int n, int rows, int cols, hipStream_t s) {
+  return launch_transpose_strided(in, out, n, rows, cols, (size_t)rows * cols, (size_t)rows * cols, s);
 }
 
 // ---- 2x2 max-pool (stride 2, floor) and nearest x2 upsample, NHWC ----------------------------

@@ -9,7 +9,7 @@ reference layout exists only at ``forward``'s boundary.
 import torch
 import torch.nn as nn
 
-from .. import runtime, schedule as sched
+from .. import _lib, runtime, schedule as sched
 from ..layers.convolutions import Block, DeepLabHead
 from ..layers.temporal import SpatialGRU
 from ..layers.temporal_ode_bayes import NNFOwithBayesianJumps
@@ -32,12 +32,14 @@ class FuturePredictionODE(nn.Module):
         self.spatial_grus = nn.ModuleList(grus)
         self.res_blocks = nn.ModuleList(blocks)
 
-    def observations(self, camera_states, lidar_states, camera_timestamp, lidar_timestamp, bs):
-        """Merge + time-sort one sample's observations (:36-49); returns (times, [frames NCHW])."""
+    def observations(self, camera_states, lidar_states, camera_timestamp, lidar_timestamp, bs, with_order=False):
+        """Merge + time-sort one sample's observations (:36-49); returns (times, [frames NCHW])
+        (+ the (source tensor, frame index) of every observation with ``with_order``)."""
         cam_ts = camera_timestamp[bs].tolist() if camera_states is not None else []
         lid_ts = lidar_timestamp[bs].tolist() if lidar_states is not None else []
         times, order = sched.merge_observations(cam_ts, lid_ts)
-        return times, [(camera_states if src == 0 else lidar_states)[bs, i] for src, i in order]
+        frames = [(camera_states if src == 0 else lidar_states)[bs, i] for src, i in order]
+        return (times, frames, order) if with_order else (times, frames)
 
     def head_nhwc(self, x):
         """x: [T, B, H, W, C] decoded predictions -> [T, B, H, W, C] (:56-62)."""
@@ -53,18 +55,54 @@ class FuturePredictionODE(nn.Module):
             x = x.view(T, B, H, W, C)
         return x
 
-    def _run_group(self, frames, scs):
-        """frames[b][o]: NCHW observation o of sample b (time order); scs: one Schedule per sample,
-        all with the same structure.  Returns [B, T, C, H, W]."""
+    def _gather_obs(self, frames, sources, states):
+        """[n_obs, B, H, W, C] NHWC from the per-sample observation frames.  When every sample of the group takes
+        observation o from the same (tensor, frame index) and the group is a run of consecutive samples — the
+        normal case — each observation is ONE strided transpose straight out of camera_states / lidar_states."""
         B, n_obs = len(frames), len(frames[0])
-        stacked = torch.stack([frames[b][o] for o in range(n_obs) for b in range(B)], dim=0)
-        obs = runtime.to_nhwc(stacked)
-        obs = obs.view(n_obs, B, *obs.shape[1:])
+        src0 = sources[0][0]
+        same = all(s[0] == src0 for s in sources) and all(s[1] == sources[0][1] + k for k, s in enumerate(sources))
+        ok = same and all(states[src] is not None and states[src].is_contiguous() and states[src].dtype == torch.float32
+                          for src, _ in src0)
+        if not ok:
+            stacked = torch.stack([frames[b][o] for o in range(n_obs) for b in range(B)], dim=0)
+            obs = runtime.to_nhwc(stacked)
+            return obs.view(n_obs, B, *obs.shape[1:])
+        _, C, H, W = states[src0[0][0]].shape[1:]
+        dev = states[src0[0][0]].device
+        obs = torch.empty((n_obs, B, H, W, C), dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        b0 = sources[0][1]
+        for o, (src, i) in enumerate(src0):
+            t = states[src]
+            first = t[b0, i]
+            _lib.check(L.sf_nchw_to_nhwc_strided(runtime.ptr(first), t.shape[1] * C * H * W, runtime.ptr(obs[o]), C * H * W, B, C, H * W,
+                                                 runtime.stream_ptr(dev)), "nchw_to_nhwc_strided")
+        return obs
+
+    def _run_group(self, frames, scs, sources=None, states=None, out=None, members=None):
+        """frames[b][o]: NCHW observation o of sample b (time order); scs: one Schedule per sample,
+        all with the same structure.  Returns [B, T, C, H, W] (written into out[members] when the group is a run of
+        consecutive samples of the final tensor)."""
+        B = len(frames)
+        obs = self._gather_obs(frames, sources, states) if sources is not None else None
+        if obs is None:
+            n_obs = len(frames[0])
+            stacked = torch.stack([frames[b][o] for o in range(n_obs) for b in range(B)], dim=0)
+            obs = runtime.to_nhwc(stacked)
+            obs = obs.view(n_obs, B, *obs.shape[1:])
         _, x = self.gru_ode.forward_nhwc(scs if B > 1 else scs[0], obs)
         y = self.head_nhwc(x)                                   # [T, B, H, W, C]
-        T = y.shape[0]
-        out = runtime.to_nchw(y.view(T * B, *y.shape[2:]))
-        return out.view(T, B, *out.shape[1:]).permute(1, 0, 2, 3, 4)
+        T, _, H, W, C = y.shape
+        if out is True:          # the group is the whole batch, in order: write [B, T, C, H, W] directly
+            res = torch.empty((B, T, C, H, W), dtype=torch.float32, device=y.device)
+            L = _lib.lib()
+            for t in range(T):                                  # frame (t, b) -> res[b, t]: one strided transpose per t
+                _lib.check(L.sf_nhwc_to_nchw_strided(runtime.ptr(y[t]), H * W * C, runtime.ptr(res[0, t]), T * C * H * W, B, C,
+                                                     H * W, runtime.stream_ptr(y.device)), "nhwc_to_nchw_strided")
+            return res
+        res = runtime.to_nchw(y.view(T * B, H, W, C))
+        return res.view(T, B, *res.shape[1:]).permute(1, 0, 2, 3, 4)
 
     def forward(self, future_prediction_input, camera_states, lidar_states, camera_timestamp, lidar_timestamp,
                 target_timestamp):
@@ -76,14 +114,19 @@ class FuturePredictionODE(nn.Module):
         runtime.require_cuda(some)
         b = some.shape[0]
         groups, meta = {}, []
+        states = (camera_states, lidar_states)
         for bs in range(b):
-            times, frames = self.observations(camera_states, lidar_states, camera_timestamp, lidar_timestamp, bs)
+            times, frames, order = self.observations(camera_states, lidar_states, camera_timestamp, lidar_timestamp, bs, with_order=True)
             sc = self.gru_ode.make_schedule(times, self.delta_t, target_timestamp[bs].tolist())
             groups.setdefault(sc.key(), []).append(bs)
-            meta.append((frames, sc))
+            meta.append((frames, sc, (tuple(order), bs)))
         outs = [None] * b
         for members in groups.values():
-            y = self._run_group([meta[i][0] for i in members], [meta[i][1] for i in members])
+            fr, scs, srcs = [meta[i][0] for i in members], [meta[i][1] for i in members], [meta[i][2] for i in members]
+            whole = len(groups) == 1 and members == list(range(b))
+            y = self._run_group(fr, scs, srcs, states, True if whole else None, members)
+            if whole:
+                return y, 0
             for k, i in enumerate(members):
                 outs[i] = y[k]
         return torch.stack(outs, dim=0), 0
