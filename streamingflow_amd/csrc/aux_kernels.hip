@@ -300,8 +300,96 @@ static hipError_t launch_dw_t(const float* in, float* out, const float* wdw, con
   return hipGetLastError();
 }
 
+// C == 64 (the shipped width): lane = channel, so every load / store is one coalesced 256-B row, the 49 weights of
+// the lane's channel sit in registers and nothing goes through LDS.  A wave produces 4 output rows x `seg` columns;
+// its 10 x 7 input window (+ one prefetched column) lives in registers and slides along x: one new column (10 row
+// loads, issued one step before they are used) per step, the column slots rotate by compile-time renaming (the x loop is unrolled by 8), 4 x 49 FMAs, and the channels-last LayerNorm
+// is two butterfly reductions over the wave.  Taps are accumulated in the same (ky, kx) order as the generic kernel.
+// Wave-wide sum without LDS traffic: four DPP steps inside each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror), then the four row sums are read into SGPRs.  (__shfl_xor lowers to ds_bpermute_b32: 12 LDS round trips per
+// pixel for the two LayerNorm reductions.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum64(float v) {
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror
+  const int iv = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(iv, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(iv, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+__global__ __launch_bounds__(256, 3) void dwconv7_ln_c64_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             const float* __restrict__ wdw, const float* __restrict__ bdw,
+                                                             const float* __restrict__ lnw, const float* __restrict__ lnb, int n,
+                                                             int H, int W, float eps, int seg) {
+  constexpr int C = 64, R = 4;
+  const int lane = threadIdx.x & 63;
+  // everything but `lane` is wave-uniform: row / column addresses stay in SGPRs, loads are saddr + lane offset
+  const long wv = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nseg = (W + seg - 1) / seg, nrb = (H + R - 1) / R;
+  if (wv >= (long)n * nrb * nseg) return;
+  const int sg = (int)(wv % nseg);
+  const long t = wv / nseg;
+  const int rb = (int)(t % nrb), img = (int)(t / nrb);
+  const int y0 = rb * R, x0 = sg * seg, x1 = (x0 + seg < W) ? x0 + seg : W;
+  float w[49];
+#pragma unroll
+  for (int k = 0; k < 49; ++k) w[k] = wdw[k * C + lane];
+  const float bias = bdw[lane], gam = lnw[lane], bet = lnb[lane];
+  const float* src = in + (size_t)img * H * W * C;
+  float* dst = out + (size_t)img * H * W * C;
+  float win[R + 6][8];
+  auto load_col = [&](int x, int slot) {
+    const bool xok = (x >= 0) & (x < W);
+#pragma unroll
+    for (int r = 0; r < R + 6; ++r) {
+      const int y = y0 - 3 + r;
+      const bool ok = xok & (y >= 0) & (y < H);
+      const float* rowp = src + (ok ? ((size_t)y * W + x) * C : (size_t)0);
+      const float v = rowp[lane];
+      win[r][slot] = ok ? v : 0.f;
+    }
+  };
+#pragma unroll
+  for (int kx = 0; kx < 7; ++kx) load_col(x0 - 3 + kx, kx);
+  for (int xb = x0; xb < x1; xb += 8) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {        // window position kx lives in slot (p + kx) % 8; slot (p + 7) % 8 is filled one step ahead
+      const int x = xb + p;
+      if (x < x1) {                       // wave-uniform
+        load_col(x + 4, (p + 7) % 8);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (y0 + r < H) {               // wave-uniform
+            float acc = bias;
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+              for (int kx = 0; kx < 7; ++kx) acc += win[r + ky][(p + kx) % 8] * w[ky * 7 + kx];
+            const float mean = wave_sum64(acc) * (1.f / C);
+            const float d = acc - mean;
+            const float rstd = 1.f / sqrtf(wave_sum64(d * d) * (1.f / C) + eps);
+            (dst + ((size_t)(y0 + r) * W + x) * C)[lane] = d * rstd * gam + bet;
+          }
+        }
+      }
+    }
+  }
+}
+
 hipError_t launch_dwconv7_ln(const float* in, float* out, const float* wdw, const float* bdw, const float* lnw,
                              const float* lnb, int n, int H, int W, int C, float eps, hipStream_t s) {
+  if (C == 64 && (long)n * H * W >= 65536) {   // large maps: register-window kernel (below that the LDS-tile kernel has more waves)
+    const int seg = 40;
+    const long waves = (long)n * ((H + 3) / 4) * ((W + seg - 1) / seg);
+    hipLaunchKernelGGL(dwconv7_ln_c64_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, in, out, wdw, bdw, lnw, lnb, n, H, W, eps,
+                       seg);
+    return hipGetLastError();
+  }
   switch (C) {
     case 8:  return launch_dw_t<8, 1>(in, out, wdw, bdw, lnw, lnb, n, H, W, eps, s);
     case 16: return launch_dw_t<16, 2>(in, out, wdw, bdw, lnw, lnb, n, H, W, eps, s);

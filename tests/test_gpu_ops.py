@@ -95,6 +95,26 @@ def test_golden_head_blocks(pair8):
     assert maxabs(net.spatial_grus[1](seq, seq[:, 0]), g["spatial_gru_seq"]) <= TOL
 
 
+@pytest.mark.parametrize("n,H,W", [(2, 181, 187), (1, 256, 260), (1, 64, 64)])
+def test_convnext_block_c64_vs_torch(n, H, W):
+    """C == 64 maps of >= 65536 pixels take the register-window depthwise + LayerNorm kernel, smaller ones the LDS-tile
+    kernel; both against the reference formulation (convolutions.py:310-346) in torch fp32 on the CPU, with
+    gamma = 1 so that the block's body is not scaled away."""
+    import streamingflow_amd.layers.convolutions as Cv
+    torch.manual_seed(H * 7 + W)
+    blk = Cv.Block(64, layer_scale_init_value=1.0).eval()
+    with torch.no_grad():
+        blk.norm.weight.uniform_(0.5, 1.5); blk.norm.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(n, 64, H, W)
+    with torch.no_grad():
+        y = F.conv2d(x, blk.dwconv.weight, blk.dwconv.bias, padding=3, groups=64).permute(0, 2, 3, 1)
+        y = F.layer_norm(y, (64,), blk.norm.weight, blk.norm.bias, 1e-6)
+        y = blk.pwconv2(F.gelu(blk.pwconv1(y)))
+        ref = x + (blk.gamma * y).permute(0, 3, 1, 2)
+        got = blk.cuda()(x.cuda())
+    assert maxabs(got, ref) <= TOL
+
+
 @pytest.mark.parametrize("solver", ["euler", "midpoint"])
 @pytest.mark.parametrize("impute", [True, False])
 def test_golden_ode_step(pair8, solver, impute):
