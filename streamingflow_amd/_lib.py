@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsfnative.so")
+LIB_PATH = os.environ.get("SF_LIB_PATH") or os.path.join(_HERE, "libsfnative.so")   # SF_LIB_PATH: experiment builds only
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)

@@ -11,6 +11,7 @@
 namespace sf {
 hipError_t launch_conv(const ConvLaunch& L, int epi, int cfg, hipStream_t stream);
 hipError_t launch_conv_direct(const ConvLaunch& L, int epi, int mt, int ks, hipStream_t stream);
+hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant, hipStream_t stream);
 hipError_t launch_transpose(const float* in, float* out, int n, int rows, int cols, hipStream_t s);
 hipError_t launch_transpose_strided(const float* in, float* out, int n, int rows, int cols, size_t in_stride, size_t out_stride,
                                     hipStream_t s);
@@ -110,7 +111,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, l_cfg, mid_tiles, split_cfg; };
+struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, l_cfg, mid_tiles, split_cfg, glds, glds_var; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -125,6 +126,8 @@ const Tune& tune() {
     x.split_min_chunks = geti("SF_SPLIT_MINCH", 2);
     x.mid_tiles = geti("SF_MID_TILES", 640);
     x.l_cfg = geti("SF_L_CFG", 0);                 // experimental large-P tiling override (5..9)
+    x.glds = geti("SF_GLDS", 3);                   // LDS-DMA staging for large plain layers: bit 0 = 128-cout tiles, bit 1 = 64-cout tiles (0: register staging everywhere)
+    x.glds_var = geti("SF_GLDS_VAR", -1);          // -1: shipped choice; 0..8: force a variant of launch_conv_glds (experiments)
     x.split_cfg = geti("SF_SPLIT_CFG", 4);         // tile config of the mid-P split-K launches without a LayerNorm epilogue (4 | 1)
     x.split_from = geti("SF_SPLIT_FROM", 100);     // only layers with at least this many K chunks (the 7x7)
     return x;
@@ -247,7 +250,25 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     if (fits) cfg = (split_mid && tune().split_cfg == 1 && (epi == EPI_AFFINE || epi == EPI_BLEND || epi == EPI_SAMPLE)) ? 1 : 4;
     else for (int i = 0; i < n; ++i) { L.p[i].nsplit = 0; L.p[i].slab = nullptr; L.p[i].counters = nullptr; }
   }
+  // Plain large layers (no reset gate / SE scale / neighbour table / split-K): LDS-DMA staging with the barrier in the
+  // middle of the MFMA stream (conv_glds_kernel).  Measured (profiles/r01_v_*): 128x128 tiles +2 %, 64-cout layers
+  // +7 % on 64x128 tiles once there are >= 1024 of them, +3 % on 64x64 tiles below that.
+  int glds_tile = -1, glds_var = 4;
+  if (tune().glds && (cfg == 1 || cfg == 9) && (epi == EPI_AFFINE || epi == EPI_BLEND)) {
+    bool ok = true;
+    long pmin = 1L << 40;
+    for (int i = 0; i < n; ++i) {
+      const ConvProblem& q = L.p[i];
+      ok = ok && !q.gate && !q.in_scale && !q.gather && q.nsplit <= 1;
+      const long Pi = (long)q.n_img * q.Hout * q.Wout;
+      pmin = Pi < pmin ? Pi : pmin;
+    }
+    if (ok && cfg == 9 && (tune().glds & 1)) glds_tile = 0;
+    if (ok && cfg == 1 && (tune().glds & 2)) { glds_tile = 1; glds_var = pmin >= 131072 ? 6 : 4; }
+    if (tune().glds_var >= 0) glds_var = tune().glds_var;
+  }
   auto launch = [&]() -> hipError_t {
+    if (glds_tile >= 0) return launch_conv_glds(L, epi, glds_tile, glds_var, st);
     return cfg == 3 ? launch_conv_direct(L, epi, mt, ks, st) : launch_conv(L, epi, cfg, st);
   };
   if (!g_prof.on) {

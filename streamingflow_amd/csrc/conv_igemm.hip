@@ -70,6 +70,12 @@ __device__ __forceinline__ float2 lds_read_b64(const float* p) {
 #define SF_SETPRIO 1
 #endif
 constexpr bool SETPRIO = SF_SETPRIO;
+#ifndef SF_GDIAG
+#define SF_GDIAG 0  // same for the LDS-DMA kernel: 1 = weights only, 2 = pixels only, 3 = every chunk re-reads chunk 0, 4 = no DMA
+#endif
+#ifndef SF_DIAG
+#define SF_DIAG 0   // timing probes of the staged main loop (tools/experiments/diag_loop.sh); 0 = the product
+#endif
 constexpr int LDS_ROW = 36;   // floats per staged row: 32 K values + 4 pad
 constexpr int BK = 32;
 
@@ -537,11 +543,29 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
   for (int it = 0; it < niter; ++it) {
     const int nxt = (it + 1) * KS + kg;
     const bool has_next = nxt < nchunks;
+#if SF_DIAG == 0
     if (has_next) load_chunk(cb + nxt);
     if (it * KS + kg < nchunks) compute(it & 1);
     if (has_next) store_chunk((it + 1) & 1);
     __syncthreads();
+#elif SF_DIAG == 1   // MFMA + fragment reads + barrier, no staging (results meaningless: timing probe only)
+    if (it * KS + kg < nchunks) compute(it & 1);
+    __syncthreads();
+#elif SF_DIAG == 2   // MFMA + fragment reads, no barrier
+    if (it * KS + kg < nchunks) compute(it & 1);
+#elif SF_DIAG == 4   // global loads issued, never written to LDS
+    if (has_next) load_chunk(cb + nxt);
+    if (it * KS + kg < nchunks) compute(it & 1);
+    __syncthreads();
+#elif SF_DIAG == 5   // LDS writes of stale registers, no global loads
+    if (it * KS + kg < nchunks) compute(it & 1);
+    if (has_next) store_chunk((it + 1) & 1);
+    __syncthreads();
+#endif
   }
+#if SF_DIAG == 4
+  if (niter < 0) store_chunk(0);   // keeps the staged registers alive
+#endif
 
   // ---- in-workgroup split-K reduction (fixed order) ----------------------------------------
   if constexpr (KS > 1) {
@@ -622,6 +646,349 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
 
   // ---- epilogue --------------------------------------------------------------------------------
   run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
+}
+
+// ---- LDS-DMA variant of the staged kernel (large pixel counts, plain layers) ----------------------
+// Same tiles and the same MFMA / fragment-read loop as conv_igemm_kernel, but the operands go global -> LDS with
+// global_load_lds_dwordx4: no VGPR round trip, no ds_write, no staging registers.  NB unpadded LDS buffers of a
+// 32-deep chunk, NB-1 chunks in flight, a counted vmcnt retires the oldest and one barrier per chunk publishes it.
+// An LDS-DMA instruction writes 64 x 16 B = eight 128-B rows contiguously, so rows are unpadded and the eight
+// 16-B slots of a row are XOR-swizzled with (row >> 1) & 7 — applied to the per-lane SOURCE address.  Zero padding /
+// out-of-range lanes read a zero page (a DMA cannot be masked).  Layers with a gate, an SE scale or a neighbour
+// table stay on conv_igemm_kernel.  (tools/experiments/diag_loop.sh: without its staging the shipped loop runs at
+// 134 instead of 115 TFLOP/s on a 7-frame 128->128 layer; global loads cost 10 %, the LDS writes 6 %.)
+__device__ __attribute__((aligned(16))) const float g_zero_page_dma[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int MT, int NT, int WM, int WN, int EPI, int NB, bool INTERLEAVE, int PIPE>
+__global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunch L) {
+  constexpr int NWV = WM * WN;
+  constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
+  constexpr int ROWS = BM + BN;
+  static_assert((BM / 8) % NWV == 0 && (BN / 8) % NWV == 0, "A and B rows must split evenly over the waves");
+  constexpr int GA = BM / 8 / NWV, GB = BN / 8 / NWV;   // LDS-DMA instructions per wave per chunk: weights / pixels
+  constexpr int G = GA + GB;
+  constexpr int LA = NB - 1;                     // chunks in flight
+  constexpr int BUF = ROWS * 32;                 // floats per buffer
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [NB][ROWS][32]
+
+  const ConvProblem& P = L.p[blockIdx.y];
+  const int Ptot = P.n_img * P.Hout * P.Wout;
+  const int n_mt = (P.cout_pad + BM - 1) / BM;
+  const int m_tile = blockIdx.x % n_mt;
+  const int p_tile = blockIdx.x / n_mt;
+  if (p_tile * BN >= Ptot) return;   // block-uniform
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int j = lane & 15, g = lane >> 4;
+
+  const int img0 = (p_tile * BN) / (P.Hout * P.Wout);          // block-uniform
+  const size_t img0_px = (size_t)img0 * P.Hin * P.Win;
+  const float* const in0 = P.in0 + img0_px * P.in0_cs;
+  const float* const in1 = P.in1 ? P.in1 + img0_px * P.in1_cs : nullptr;
+  const int c0 = P.c0, c01 = P.c0 + P.c1;
+  const int in0_cs = P.in0_cs, in1_cs = P.in1_cs;
+  const int Win = P.Win, in_up = P.in_up, dil = P.dil, KW = P.KW;
+  const int Hlog = P.Hin << P.in_up, Wlog = P.Win << P.in_up;
+  const int HWout = P.Hout * P.Wout;
+
+  // staging slots.  Weight slot q (q < GA) of this wave fills rows (wave*GA + q)*8 .. +7 of the A block, pixel slot q
+  // rows (wave*GB + q)*8 .. +7 of the B block; this lane: row + lane/8, 16-B slot lane%8 holding K values
+  // 4*k4 .. 4*k4+3 with k4 = slot ^ ((row >> 1) & 7)   (row counted inside the buffer: A rows first)
+  const float* a_src[GA];
+#pragma unroll
+  for (int q = 0; q < GA; ++q) {
+    const int r = (wave * GA + q) * 8 + (lane >> 3);
+    const int k4 = (lane & 7) ^ ((r >> 1) & 7);
+    int grow = m_tile * BM + r;
+    grow = grow < P.cout_pad ? grow : P.cout_pad - 1;
+    a_src[q] = P.w + (size_t)grow * P.ktot + k4 * 4;
+  }
+  int b_c4[GB], b_iy0[GB], b_ix0[GB], b_base[GB];
+#pragma unroll
+  for (int q = 0; q < GB; ++q) {
+    const int pr = (wave * GB + q) * 8 + (lane >> 3);
+    b_c4[q] = 4 * ((lane & 7) ^ (((BM + pr) >> 1) & 7));
+    const int gp = p_tile * BN + pr;
+    const bool v = gp < Ptot;
+    const int img = v ? gp / HWout : 0;
+    const int rem = gp - img * HWout;
+    const int oy = rem / P.Wout, ox = rem - oy * P.Wout;
+    b_iy0[q] = v ? oy * P.stride - P.pad : -(1 << 28);
+    b_ix0[q] = ox * P.stride - P.pad;
+    b_base[q] = (v ? img - img0 : 0) * P.Hin * P.Win;
+  }
+
+  const int kcpt = P.cin_pad / BK;
+  const int nchunks = P.KH * P.KW * kcpt;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int cur_kc = 0, cur_ty = 0, cur_tx = 0;     // cursor of the next chunk to ISSUE
+  int tap_off0[GB], tap_off1[GB];
+  bool tap_fresh = true;
+
+  typedef __attribute__((address_space(3))) void lds_void;
+  // one LDS-DMA of the chunk at the cursor: slot q of G (weights first); the last slot advances the cursor
+  auto issue_one = [&](int chunk, int buf, int q) {
+#if SF_GDIAG == 3   // probe: every chunk re-reads the addresses of chunk 0
+    chunk = 0;
+#endif
+#if SF_GDIAG == 4
+    return;
+#endif
+#if SF_GDIAG == 2
+    if (q < GA) return;
+#endif
+#if SF_GDIAG == 1
+    if (q >= GA) return;
+#endif
+    if (q < GA) {
+      float* dst = smem + buf * BUF + (wave * GA + q) * 8 * 32;
+#if defined(__HIP_DEVICE_COMPILE__)     // the host pass must not see the target builtin (it silently drops the kernel stub)
+      __builtin_amdgcn_global_load_lds(a_src[q] + (size_t)chunk * BK, (lds_void*)dst, 16, 0, 0);
+#else
+      (void)dst; (void)chunk;
+#endif
+    } else {
+      const int qb = q - GA;
+      if (tap_fresh && qb == 0) {
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+          const int iy = b_iy0[i] + cur_ty * dil, ix = b_ix0[i] + cur_tx * dil;
+          const bool in = (iy >= 0) & (iy < Hlog) & (ix >= 0) & (ix < Wlog);
+          const int px = in ? b_base[i] + (iy >> in_up) * Win + (ix >> in_up) : 0;
+          tap_off0[i] = in ? px * in0_cs : -1;
+          tap_off1[i] = px * in1_cs - c0;
+        }
+      }
+      const int c = cur_kc * BK + b_c4[qb];
+      const bool s0 = c < c0;
+      const bool s1 = (!s0) & (c < c01);
+      const bool ok = (tap_off0[qb] >= 0) & (s0 | s1);
+      const float* src = ok ? (s1 ? in1 + (tap_off1[qb] + c) : in0 + (tap_off0[qb] + c)) : g_zero_page_dma;
+      float* dst = smem + buf * BUF + (BM + (wave * GB + qb) * 8) * 32;
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_global_load_lds(src, (lds_void*)dst, 16, 0, 0);
+#else
+      (void)dst; (void)src;
+#endif
+    }
+#if SF_GDIAG != 3
+    if (q == G - 1) {
+      ++cur_kc;
+      tap_fresh = false;
+      if (cur_kc == kcpt) {
+        cur_kc = 0;
+        tap_fresh = true;
+        if (++cur_tx == KW) { cur_tx = 0; ++cur_ty; }
+      }
+    }
+#endif
+  };
+
+  const int sx = (j >> 1) & 7;
+  auto koff = [&](int t4) { return 4 * ((2 * t4 + (g >> 1)) ^ sx) + ((2 * g) & 3); };
+  // MFMAs of one chunk; with INTERLEAVE the LDS-DMAs of chunk `ichunk` (if >= 0) are issued between the k-groups
+  auto compute = [&](int buf, int ichunk, int ibuf) {
+    const float* a = smem + buf * BUF + (wm * MT * 16 + j) * 32;
+    const float* b = smem + buf * BUF + (BM + wn * NT * 16 + j) * 32;
+    float2 fa[2][MT], fb[2][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) fa[0][m] = lds_read_b64(a + m * 16 * 32 + koff(0));
+#pragma unroll
+    for (int n = 0; n < NT; ++n) fb[0][n] = lds_read_b64(b + n * 16 * 32 + koff(0));
+    constexpr int NG = BK / 8;
+#pragma unroll
+    for (int t4 = 0; t4 < NG; ++t4) {
+      const int cur = t4 & 1, nxt = cur ^ 1;
+      if (t4 < NG - 1) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) fa[nxt][m] = lds_read_b64(a + m * 16 * 32 + koff(t4 + 1));
+#pragma unroll
+        for (int n = 0; n < NT; ++n) fb[nxt][n] = lds_read_b64(b + n * 16 * 32 + koff(t4 + 1));
+      }
+      if (INTERLEAVE && ichunk >= 0) {      // block-uniform
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+          if (q * NG / G == t4) issue_one(ichunk, ibuf, q);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][m].x, fb[cur][n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][m].y, fb[cur][n].y, acc[m][n], 0, 0, 0);
+      if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  if constexpr (PIPE > 0) {
+    // Barrier in the middle of the MFMA stream (two buffers): the last k-group of chunk c is multiplied AFTER the
+    // barrier that publishes chunk c+1, from fragments read before it, and the first fragments of chunk c+1 are read
+    // under those MFMAs — a wave leaves the barrier with 2*MT*NT MFMAs ready to issue instead of a DMA-issue +
+    // LDS-read-latency bubble.  The DMAs of chunk c+2 go out right after the same barrier (its buffer is free then).
+    static_assert(NB == 2, "mid-stream barrier variant is double buffered");
+    constexpr int NG = BK / 8;
+    float2 fa[2][MT], fb[2][NT];
+    auto read_frags = [&](int buf, int t4, int set) {
+      const float* a = smem + buf * BUF + (wm * MT * 16 + j) * 32;
+      const float* b = smem + buf * BUF + (BM + wn * NT * 16 + j) * 32;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) fa[set][m] = lds_read_b64(a + m * 16 * 32 + koff(t4));
+#pragma unroll
+      for (int n = 0; n < NT; ++n) fb[set][n] = lds_read_b64(b + n * 16 * 32 + koff(t4));
+    };
+    auto mfmas = [&](int set) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][m].x, fb[set][n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][m].y, fb[set][n].y, acc[m][n], 0, 0, 0);
+      if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll
+    for (int q = 0; q < G; ++q) issue_one(0, 0, q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nchunks > 1) {
+#pragma unroll
+      for (int q = 0; q < G; ++q) issue_one(1, 1, q);
+    }
+    read_frags(0, 0, 0);
+    for (int c = 0; c < nchunks; ++c) {
+      const int buf = c & 1;
+#pragma unroll
+      for (int t4 = 0; t4 < NG - 1; ++t4) {
+        read_frags(buf, t4 + 1, (t4 + 1) & 1);
+        mfmas(t4 & 1);
+      }
+      const bool next = c + 1 < nchunks, next2 = c + 2 < nchunks;
+      if (next) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(buf ^ 1, 0, 0);
+        if (PIPE == 2 && next2) {
+#pragma unroll
+          for (int q = 0; q < G; ++q) issue_one(c + 2, buf, q);
+        }
+      }
+      mfmas((NG - 1) & 1);
+      if (PIPE == 1 && next2) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) issue_one(c + 2, buf, q);
+      }
+    }
+    run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
+    return;
+  }
+
+  // prologue: LA chunks in flight, the first one retired
+#pragma unroll
+  for (int c = 0; c < LA; ++c)
+    if (c < nchunks) {      // block-uniform
+#pragma unroll
+      for (int q = 0; q < G; ++q) issue_one(c, c, q);
+    }
+  if (LA > 1 && nchunks >= LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int bc = 0, bi = LA;           // buffer of the chunk being computed / of the chunk being issued
+  for (int c = 0; c < nchunks; ++c) {
+    const bool more = c + LA < nchunks;
+    if (!INTERLEAVE && more) {
+#pragma unroll
+      for (int q = 0; q < G; ++q) issue_one(c + LA, bi, q);
+    }
+    compute(bc, more ? c + LA : -1, bi);
+    if (LA > 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bc = bc == NB - 1 ? 0 : bc + 1;
+    bi = bi == NB - 1 ? 0 : bi + 1;
+  }
+  run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
+}
+
+template <int MT, int NT, int WM, int WN, int EPI, int NB, bool IL, int PIPE>
+static hipError_t launch_glds_t(const ConvLaunch& L, hipStream_t stream) {
+  constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
+  constexpr int lds = NB * (BM + BN) * 32 * 4;
+  auto kern = conv_glds_kernel<MT, NT, WM, WN, EPI, NB, IL, PIPE>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  int maxblocks = 0;
+  for (int i = 0; i < L.nprob; ++i) {
+    const ConvProblem& P = L.p[i];
+    int Ptot = P.n_img * P.Hout * P.Wout;
+    int nb = ((Ptot + BN - 1) / BN) * ((P.cout_pad + BM - 1) / BM);
+    if (nb > maxblocks) maxblocks = nb;
+  }
+  if (maxblocks == 0) return hipSuccess;
+  hipLaunchKernelGGL(kern, dim3(maxblocks, L.nprob), dim3(64 * WM * WN), lds, stream, L);
+  return hipGetLastError();
+}
+
+template <int MT, int NT, int WM, int WN, int NB, bool IL, int PIPE = 0>
+static hipError_t launch_glds_e(const ConvLaunch& L, int epi, hipStream_t stream) {
+  if (epi == EPI_AFFINE) return launch_glds_t<MT, NT, WM, WN, EPI_AFFINE, NB, IL, PIPE>(L, stream);
+  if (epi == EPI_BLEND) return launch_glds_t<MT, NT, WM, WN, EPI_BLEND, NB, IL, PIPE>(L, stream);
+  return hipErrorInvalidValue;
+}
+
+// tile: 0 = 128 cout x 128 px (2x4 waves of 64x32), 1 = 64 x 64 (2x2 waves of 32x32);  variant: buffers / issue placement
+hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant, hipStream_t stream) {
+  if (tile == 0) {
+    switch (variant) {
+      case 0: return launch_glds_e<4, 2, 2, 4, 2, false>(L, epi, stream);
+      case 1: return launch_glds_e<4, 2, 2, 4, 2, true>(L, epi, stream);
+      case 2: return launch_glds_e<4, 2, 2, 4, 3, false>(L, epi, stream);
+      case 3: return launch_glds_e<4, 2, 2, 4, 3, true>(L, epi, stream);
+      case 4: return launch_glds_e<4, 2, 2, 4, 2, false, 1>(L, epi, stream);
+      case 5: return launch_glds_e<4, 2, 2, 4, 2, false, 2>(L, epi, stream);
+      case 6: case 7: case 8: return launch_glds_e<4, 2, 2, 4, 2, false, 1>(L, epi, stream);
+    }
+  } else {
+    switch (variant) {
+      case 0: return launch_glds_e<2, 2, 2, 2, 2, false>(L, epi, stream);
+      case 1: return launch_glds_e<2, 2, 2, 2, 2, true>(L, epi, stream);
+      case 2: return launch_glds_e<2, 2, 2, 2, 3, false>(L, epi, stream);
+      case 3: return launch_glds_e<2, 2, 2, 2, 3, true>(L, epi, stream);
+      case 4: return launch_glds_e<2, 2, 2, 2, 2, false, 1>(L, epi, stream);
+      case 5: return launch_glds_e<2, 2, 2, 2, 2, false, 2>(L, epi, stream);
+      case 6: return launch_glds_e<2, 2, 2, 4, 2, false, 1>(L, epi, stream);   // 64 cout x 128 px, 8 waves of 32x32
+      case 7: return launch_glds_e<4, 2, 1, 4, 2, false, 1>(L, epi, stream);   // 64 cout x 128 px, 4 waves of 64x32
+      case 8: return launch_glds_e<4, 2, 1, 8, 2, false, 1>(L, epi, stream);   // 64 cout x 256 px, 8 waves of 64x32
+    }
+  }
+  return hipErrorInvalidValue;
 }
 
 // ---- ping-pong variant of the staged kernel (large pixel counts) ------------------------------
