@@ -706,6 +706,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
     grow = grow < P.cout_pad ? grow : P.cout_pad - 1;
     a_src[q] = P.w + (size_t)grow * P.ktot + k4 * 4;
   }
+  // Buffer form of the DMA (the shipped path, taken when both channel counts are multiples of the chunk depth so that
+  // a chunk comes from ONE source tensor): the weight rows and each source tensor get a raw buffer descriptor in
+  // SGPRs; a lane's address is a 32-bit byte offset, the weight chunk advances through the scalar offset, and lanes
+  // that must read zero (padding taps, pixels past the end, channels past cin) pass offset -1: the hardware range
+  // check fails and the DMA writes 0 — no zero page, no 64-bit pointer arithmetic, no divergent source select.
+  const bool usrc = (c0 % BK == 0) & (P.c1 % BK == 0 || in1 == nullptr);       // block-uniform
+  int a_voff[GA];
+#pragma unroll
+  for (int q = 0; q < GA; ++q) a_voff[q] = (int)((a_src[q] - P.w) * sizeof(float));
+#if defined(__HIP_DEVICE_COMPILE__)
+  auto make_rsrc = [](const float* base, size_t bytes) {
+    const unsigned nrec = bytes < 0x7fffffffull ? (unsigned)bytes : 0x7fffffffu;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (int)nrec, 0x00020000);
+  };
+  const size_t imgs_left = (size_t)(P.n_img - img0);
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(P.w, (size_t)P.cout_pad * P.ktot * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rsrc0 = make_rsrc(in0, imgs_left * P.Hin * P.Win * in0_cs * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(in1 ? in1 : in0, in1 ? imgs_left * P.Hin * P.Win * in1_cs * sizeof(float) : 0);
+#endif
   int b_c4[GB], b_iy0[GB], b_ix0[GB], b_base[GB];
 #pragma unroll
   for (int q = 0; q < GB; ++q) {
@@ -751,8 +770,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
 #endif
     if (q < GA) {
       float* dst = smem + buf * BUF + (wave * GA + q) * 8 * 32;
-#if defined(__HIP_DEVICE_COMPILE__)     // the host pass must not see the target builtin (it silently drops the kernel stub)
-      __builtin_amdgcn_global_load_lds(a_src[q] + (size_t)chunk * BK, (lds_void*)dst, 16, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)     // the host pass must not see the target builtins (it silently drops the kernel stub)
+      if (usrc) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)dst, 16, a_voff[q], chunk * (BK * 4), 0, 0);
+      else __builtin_amdgcn_global_load_lds(a_src[q] + (size_t)chunk * BK, (lds_void*)dst, 16, 0, 0);
 #else
       (void)dst; (void)chunk;
 #endif
@@ -769,15 +789,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
         }
       }
       const int c = cur_kc * BK + b_c4[qb];
-      const bool s0 = c < c0;
-      const bool s1 = (!s0) & (c < c01);
-      const bool ok = (tap_off0[qb] >= 0) & (s0 | s1);
-      const float* src = ok ? (s1 ? in1 + (tap_off1[qb] + c) : in0 + (tap_off0[qb] + c)) : g_zero_page_dma;
       float* dst = smem + buf * BUF + (BM + (wave * GB + qb) * 8) * 32;
 #if defined(__HIP_DEVICE_COMPILE__)
-      __builtin_amdgcn_global_load_lds(src, (lds_void*)dst, 16, 0, 0);
+      if (usrc) {
+        const bool from1 = cur_kc * BK >= c0;                               // wave-uniform: the whole chunk reads in1
+        const bool ok = (tap_off0[qb] >= 0) & (c < c01);
+        const int voff = ok ? (c + (from1 ? tap_off1[qb] : tap_off0[qb])) * 4 : -1;
+        if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (lds_void*)dst, 16, voff, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (lds_void*)dst, 16, voff, 0, 0, 0);
+      } else {
+        const bool s0 = c < c0;
+        const bool s1 = (!s0) & (c < c01);
+        const bool ok = (tap_off0[qb] >= 0) & (s0 | s1);
+        const float* src = ok ? (s1 ? in1 + (tap_off1[qb] + c) : in0 + (tap_off0[qb] + c)) : g_zero_page_dma;
+        __builtin_amdgcn_global_load_lds(src, (lds_void*)dst, 16, 0, 0);
+      }
 #else
-      (void)dst; (void)src;
+      (void)dst; (void)c;
 #endif
     }
 #if SF_GDIAG != 3
