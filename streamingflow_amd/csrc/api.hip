@@ -260,6 +260,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     for (int i = 0; i < n; ++i) {
       const ConvProblem& q = L.p[i];
       ok = ok && !q.gate && !q.in_scale && !q.gather && q.nsplit <= 1;
+      ok = ok && (q.c0 % 32 == 0) && (q.c1 % 32 == 0);   // a 32-deep chunk reads one source tensor
       // 32-bit byte offsets: over the two images a tile can touch, and over the packed weights
       ok = ok && 8.0 * q.Hin * q.Win * q.in0_cs < 2147483648.0 && 8.0 * q.Hin * q.Win * q.in1_cs < 2147483648.0 &&
            4.0 * q.cout_pad * q.ktot < 2147483648.0;

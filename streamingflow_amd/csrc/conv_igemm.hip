@@ -654,11 +654,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
 // 32-deep chunk, NB-1 chunks in flight, a counted vmcnt retires the oldest and one barrier per chunk publishes it.
 // An LDS-DMA instruction writes 64 x 16 B = eight 128-B rows contiguously, so rows are unpadded and the eight
 // 16-B slots of a row are XOR-swizzled with (row >> 1) & 7 — applied to the per-lane SOURCE address.  Zero padding /
-// out-of-range lanes read a zero page (a DMA cannot be masked).  Layers with a gate, an SE scale or a neighbour
-// table stay on conv_igemm_kernel.  (tools/experiments/diag_loop.sh: without its staging the shipped loop runs at
+// out-of-range lanes fail the buffer range check (a DMA cannot be masked).  Layers with a gate, an SE scale, a
+// neighbour table or channel counts that are not multiples of 32 stay on conv_igemm_kernel.  (tools/experiments/diag_loop.sh: without its staging the shipped loop runs at
 // 134 instead of 115 TFLOP/s on a 7-frame 128->128 layer; global loads cost 10 %, the LDS writes 6 %.)
-__device__ __attribute__((aligned(16))) const float g_zero_page_dma[4] = {0.f, 0.f, 0.f, 0.f};
-
 template <int MT, int NT, int WM, int WN, int EPI, int NB, bool INTERLEAVE, int PIPE>
 __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunch L) {
   constexpr int NWV = WM * WN;
@@ -697,24 +695,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
   // staging slots.  Weight slot q (q < GA) of this wave fills rows (wave*GA + q)*8 .. +7 of the A block, pixel slot q
   // rows (wave*GB + q)*8 .. +7 of the B block; this lane: row + lane/8, 16-B slot lane%8 holding K values
   // 4*k4 .. 4*k4+3 with k4 = slot ^ ((row >> 1) & 7)   (row counted inside the buffer: A rows first)
-  const float* a_src[GA];
+  int a_voff[GA];
 #pragma unroll
   for (int q = 0; q < GA; ++q) {
     const int r = (wave * GA + q) * 8 + (lane >> 3);
     const int k4 = (lane & 7) ^ ((r >> 1) & 7);
     int grow = m_tile * BM + r;
     grow = grow < P.cout_pad ? grow : P.cout_pad - 1;
-    a_src[q] = P.w + (size_t)grow * P.ktot + k4 * 4;
+    a_voff[q] = (grow * P.ktot + k4 * 4) * (int)sizeof(float);
   }
-  // Buffer form of the DMA (the shipped path, taken when both channel counts are multiples of the chunk depth so that
-  // a chunk comes from ONE source tensor): the weight rows and each source tensor get a raw buffer descriptor in
-  // SGPRs; a lane's address is a 32-bit byte offset, the weight chunk advances through the scalar offset, and lanes
-  // that must read zero (padding taps, pixels past the end, channels past cin) pass offset -1: the hardware range
-  // check fails and the DMA writes 0 — no zero page, no 64-bit pointer arithmetic, no divergent source select.
-  const bool usrc = (c0 % BK == 0) & (P.c1 % BK == 0 || in1 == nullptr);       // block-uniform
-  int a_voff[GA];
-#pragma unroll
-  for (int q = 0; q < GA; ++q) a_voff[q] = (int)((a_src[q] - P.w) * sizeof(float));
 #if defined(__HIP_DEVICE_COMPILE__)
   auto make_rsrc = [](const float* base, size_t bytes) {
     const unsigned nrec = bytes < 0x7fffffffull ? (unsigned)bytes : 0x7fffffffu;
@@ -771,8 +760,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
     if (q < GA) {
       float* dst = smem + buf * BUF + (wave * GA + q) * 8 * 32;
 #if defined(__HIP_DEVICE_COMPILE__)     // the host pass must not see the target builtins (it silently drops the kernel stub)
-      if (usrc) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)dst, 16, a_voff[q], chunk * (BK * 4), 0, 0);
-      else __builtin_amdgcn_global_load_lds(a_src[q] + (size_t)chunk * BK, (lds_void*)dst, 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)dst, 16, a_voff[q], chunk * (BK * 4), 0, 0);
 #else
       (void)dst; (void)chunk;
 #endif
@@ -791,19 +779,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
       const int c = cur_kc * BK + b_c4[qb];
       float* dst = smem + buf * BUF + (BM + (wave * GB + qb) * 8) * 32;
 #if defined(__HIP_DEVICE_COMPILE__)
-      if (usrc) {
-        const bool from1 = cur_kc * BK >= c0;                               // wave-uniform: the whole chunk reads in1
-        const bool ok = (tap_off0[qb] >= 0) & (c < c01);
-        const int voff = ok ? (c + (from1 ? tap_off1[qb] : tap_off0[qb])) * 4 : -1;
-        if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (lds_void*)dst, 16, voff, 0, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (lds_void*)dst, 16, voff, 0, 0, 0);
-      } else {
-        const bool s0 = c < c0;
-        const bool s1 = (!s0) & (c < c01);
-        const bool ok = (tap_off0[qb] >= 0) & (s0 | s1);
-        const float* src = ok ? (s1 ? in1 + (tap_off1[qb] + c) : in0 + (tap_off0[qb] + c)) : g_zero_page_dma;
-        __builtin_amdgcn_global_load_lds(src, (lds_void*)dst, 16, 0, 0);
-      }
+      const bool from1 = cur_kc * BK >= c0;                               // wave-uniform: the whole chunk reads in1
+      const bool ok = (tap_off0[qb] >= 0) & (c < c01);
+      const int voff = ok ? (c + (from1 ? tap_off1[qb] : tap_off0[qb])) * 4 : -1;
+      if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (lds_void*)dst, 16, voff, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (lds_void*)dst, 16, voff, 0, 0, 0);
 #else
       (void)dst; (void)c;
 #endif
@@ -900,35 +880,34 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
     for (int q = 0; q < G; ++q) issue_one(0, 0, q);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (nchunks > 1) {
-#pragma unroll
-      for (int q = 0; q < G; ++q) issue_one(1, 1, q);
-    }
-    read_frags(0, 0, 0);
+    // Iteration c starts right after the barrier that published chunk c: read its first fragments, multiply the LAST
+    // k-group of chunk c-1 (read before the barrier) under that latency, start the DMAs of chunk c+1 into the buffer
+    // the barrier just freed, then k-groups 0..NG-2 of chunk c.  No LDS read is in flight across the back edge, so the
+    // compiler's lgkmcnt bookkeeping stays exact.
     for (int c = 0; c < nchunks; ++c) {
       const int buf = c & 1;
+      read_frags(buf, 0, 0);
+      if (PIPE == 2 && c + 1 < nchunks) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) issue_one(c + 1, buf ^ 1, q);
+      }
+      if (c > 0) mfmas((NG - 1) & 1);
+      if (PIPE == 1 && c + 1 < nchunks) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) issue_one(c + 1, buf ^ 1, q);
+      }
 #pragma unroll
       for (int t4 = 0; t4 < NG - 1; ++t4) {
         read_frags(buf, t4 + 1, (t4 + 1) & 1);
         mfmas(t4 & 1);
       }
-      const bool next = c + 1 < nchunks, next2 = c + 2 < nchunks;
-      if (next) {
+      if (c + 1 < nchunks) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        read_frags(buf ^ 1, 0, 0);
-        if (PIPE == 2 && next2) {
-#pragma unroll
-          for (int q = 0; q < G; ++q) issue_one(c + 2, buf, q);
-        }
-      }
-      mfmas((NG - 1) & 1);
-      if (PIPE == 1 && next2) {
-#pragma unroll
-        for (int q = 0; q < G; ++q) issue_one(c + 2, buf, q);
       }
     }
+    mfmas((NG - 1) & 1);
     run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
     return;
   }
