@@ -126,7 +126,7 @@ const Tune& tune() {
     x.split_min_chunks = geti("SF_SPLIT_MINCH", 2);
     x.mid_tiles = geti("SF_MID_TILES", 640);
     x.l_cfg = geti("SF_L_CFG", 0);                 // experimental large-P tiling override (5..9)
-    x.glds = geti("SF_GLDS", 3);                   // LDS-DMA staging for large plain layers: bit 0 = 128-cout tiles, bit 1 = 64-cout tiles (0: register staging everywhere)
+    x.glds = geti("SF_GLDS", 7);                   // LDS-DMA staging for large plain layers: bit 0 = 128-cout tiles, bit 1 = 64-cout tiles, bit 2 = LayerNorm-epilogue tiles (0: register staging everywhere)
     x.glds_var = geti("SF_GLDS_VAR", -1);          // -1: shipped choice; 0..8: force a variant of launch_conv_glds (experiments)
     x.split_cfg = geti("SF_SPLIT_CFG", 4);         // tile config of the mid-P split-K launches without a LayerNorm epilogue (4 | 1)
     x.split_from = geti("SF_SPLIT_FROM", 100);     // only layers with at least this many K chunks (the 7x7)
@@ -254,7 +254,8 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   // middle of the MFMA stream (conv_glds_kernel).  Measured (profiles/r01_v_*): 128x128 tiles +2 %, 64-cout layers
   // +7 % on 64x128 tiles once there are >= 1024 of them, +3 % on 64x64 tiles below that.
   int glds_tile = -1, glds_var = 4;
-  if (tune().glds && (cfg == 1 || cfg == 9) && (epi == EPI_AFFINE || epi == EPI_BLEND)) {
+  if (tune().glds && (((cfg == 1 || cfg == 9) && (epi == EPI_AFFINE || epi == EPI_BLEND)) ||
+                      (cfg == 2 && (epi == EPI_LNG || epi == EPI_TRUST) && (tune().glds & 4)))) {
     bool ok = true;
     long pmin = 1L << 40;
     for (int i = 0; i < n; ++i) {
@@ -269,6 +270,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     }
     if (ok && cfg == 9 && (tune().glds & 1)) glds_tile = 0;
     if (ok && cfg == 1 && (tune().glds & 2)) { glds_tile = 1; glds_var = pmin >= 131072 ? 6 : 4; }
+    if (ok && cfg == 2) glds_tile = 2;
     if (tune().glds_var >= 0) glds_var = tune().glds_var;
   }
   auto launch = [&]() -> hipError_t {
@@ -320,19 +322,26 @@ struct SplitScope {
 // ---- modules ---------------------------------------------------------------------------------
 
 // conv-GRU cell (temporal.py:44-57): gates -> blend.  gates buffer g: [P][2C] = [u | r]
-int gru_cell(const sf_gru_w& w, const float* x, const float* s, float* out, float* g, int n, int H, int W,
+// rs: optional [P][C] scratch.  Large pixel counts: the gates epilogue also writes (1 - r) * s there and the candidate
+// convolution reads cat[x, rs] as a plain layer (LDS-DMA staging); otherwise the gate is applied while staging.
+bool pregate(long P, const sf_conv_w& cand) {
+  return P >= LARGE_P && tune().glds && (cand.c0 % 32 == 0) && (cand.c1 % 32 == 0);
+}
+int gru_cell(const sf_gru_w& w, const float* x, const float* s, float* out, float* g, float* rs, int n, int H, int W,
              hipStream_t st, int ode_derivative = 0) {
   const int C = w.cand.cout;
+  const bool pre = rs && pregate((long)n * H * W, w.cand);
   ConvProblem a = problem(w.gates, x, s, g, n, H, W);
+  if (pre) { a.out2 = rs; a.out2_cs = C; a.e1 = s; a.e1_cs = C; a.gate_from = C; }
   SF_TRY(run1(a, EPI_AFFINE, st));
-  ConvProblem b = problem(w.cand, x, s, out, n, H, W);
-  b.gate = g; b.gate_cs = 2 * C; b.gate_co = C;
+  ConvProblem b = problem(w.cand, x, pre ? rs : s, out, n, H, W);
+  if (!pre) { b.gate = g; b.gate_cs = 2 * C; b.gate_co = C; }
   b.e0 = g; b.e0_cs = 2 * C; b.e1 = s; b.e1_cs = C;
   b.mode = ode_derivative ? 1 : 0;
   return run1(b, EPI_BLEND, st);
 }
 
-size_t dual_ws_floats(int C, int P) { return 2 * al((size_t)P * 2 * C) + 6 * al((size_t)P * C); }
+size_t dual_ws_floats(int C, int P) { return 2 * al((size_t)P * 2 * C) + 8 * al((size_t)P * C); }
 
 // temporal_ode_bayes.py:92-131 / :239-275
 // B images (samples) are processed as one pixel space; coef_stride = floats between the
@@ -348,17 +357,28 @@ int dual_cell(const sf_dual_w& w, const float* x, const float* s, float* out, in
   float* t1 = A.take((size_t)P * C);
   float* sk = A.take((size_t)P * C);
   float* t2 = A.take((size_t)P * C);
+  float* rs1 = A.take((size_t)P * C);
+  float* rs2 = A.take((size_t)P * C);
   if (!A.ok()) return SF_ERR_WORKSPACE;
+  const bool pre = pregate(P, w.cand1) && pregate(P, w.cand2);
   ConvProblem ps[2];
   // gates of both cells (cell 2 sees cat[s,s]: duplicate input folded into the packed weights)
   ps[0] = problem(w.gates1, x, s, g1, B, H, W);
   ps[1] = problem(w.gates2, s, nullptr, g2, B, H, W);
+  if (pre) {
+    ps[0].out2 = rs1; ps[0].out2_cs = C; ps[0].e1 = s; ps[0].e1_cs = C; ps[0].gate_from = C;
+    ps[1].out2 = rs2; ps[1].out2_cs = C; ps[1].e1 = s; ps[1].e1_cs = C; ps[1].gate_from = C;
+  }
   SF_TRY(run(ps, 2, EPI_AFFINE, st));
   // candidates + blend
-  ps[0] = problem(w.cand1, x, s, h1, B, H, W);
-  ps[0].gate = g1; ps[0].gate_cs = 2 * C; ps[0].gate_co = C; ps[0].e0 = g1; ps[0].e0_cs = 2 * C; ps[0].e1 = s; ps[0].e1_cs = C;
-  ps[1] = problem(w.cand2, s, s, h2, B, H, W);
-  ps[1].gate = g2; ps[1].gate_cs = 2 * C; ps[1].gate_co = C; ps[1].e0 = g2; ps[1].e0_cs = 2 * C; ps[1].e1 = s; ps[1].e1_cs = C;
+  ps[0] = problem(w.cand1, x, pre ? rs1 : s, h1, B, H, W);
+  ps[0].e0 = g1; ps[0].e0_cs = 2 * C; ps[0].e1 = s; ps[0].e1_cs = C;
+  ps[1] = problem(w.cand2, s, pre ? rs2 : s, h2, B, H, W);
+  ps[1].e0 = g2; ps[1].e0_cs = 2 * C; ps[1].e1 = s; ps[1].e1_cs = C;
+  if (!pre) {
+    ps[0].gate = g1; ps[0].gate_cs = 2 * C; ps[0].gate_co = C;
+    ps[1].gate = g2; ps[1].gate_cs = 2 * C; ps[1].gate_co = C;
+  }
   SF_TRY(run(ps, 2, EPI_BLEND, st));
   // rnn_state2 = conv_decoder_2(h2)
   SF_TRY(run1(problem(w.dec2, h2, nullptr, r2, B, H, W), EPI_AFFINE, st));
@@ -626,14 +646,17 @@ int sf_conv2d_repeat(const sf_conv_w* w, const float* in0, const float* in1, con
   return SF_OK;
 }
 
-size_t sf_gru_cell_ws_bytes(int C, int n_img, int H, int W) { return al((size_t)n_img * H * W * 2 * C) * sizeof(float); }
+size_t sf_gru_cell_ws_bytes(int C, int n_img, int H, int W) {
+  return (al((size_t)n_img * H * W * 2 * C) + al((size_t)n_img * H * W * C)) * sizeof(float);
+}
 int sf_gru_cell_fwd(const sf_gru_w* w, const float* x, const float* s, float* out, int n_img, int H, int W, float* ws,
                     size_t ws_bytes, void* stream) {
   if (!w || !x || !s || !out || !valid_w(w->gates) || !valid_w(w->cand)) return SF_ERR_INVALID;
   Arena A(ws, ws_bytes);
   float* g = A.take((size_t)n_img * H * W * 2 * w->cand.cout);
+  float* rs = A.take((size_t)n_img * H * W * w->cand.cout);
   if (!A.ok()) return SF_ERR_WORKSPACE;
-  return gru_cell(*w, x, s, out, g, n_img, H, W, (hipStream_t)stream, 0);
+  return gru_cell(*w, x, s, out, g, rs, n_img, H, W, (hipStream_t)stream, 0);
 }
 // SpatialGRUODECell.forward — temporal_ode_bayes.py:35-61: dh = u * (h~ - s)
 int sf_gru_ode_cell_fwd(const sf_gru_w* w, const float* x, const float* s, float* out, int n_img, int H, int W, float* ws,
@@ -641,12 +664,13 @@ int sf_gru_ode_cell_fwd(const sf_gru_w* w, const float* x, const float* s, float
   if (!w || !x || !s || !out || !valid_w(w->gates) || !valid_w(w->cand)) return SF_ERR_INVALID;
   Arena A(ws, ws_bytes);
   float* g = A.take((size_t)n_img * H * W * 2 * w->cand.cout);
+  float* rs = A.take((size_t)n_img * H * W * w->cand.cout);
   if (!A.ok()) return SF_ERR_WORKSPACE;
-  return gru_cell(*w, x, s, out, g, n_img, H, W, (hipStream_t)stream, 1);
+  return gru_cell(*w, x, s, out, g, rs, n_img, H, W, (hipStream_t)stream, 1);
 }
 
 size_t sf_spatial_gru_ws_bytes(int C, int n_img, int H, int W) {
-  return (al((size_t)n_img * H * W * 2 * C) + 2 * al((size_t)n_img * H * W * C)) * sizeof(float);
+  return (al((size_t)n_img * H * W * 2 * C) + 3 * al((size_t)n_img * H * W * C)) * sizeof(float);
 }
 int sf_spatial_gru_fwd(const sf_gru_w* w, const float* x, const float* state0, float* out, int T, int n_img, int H,
                        int W, float* ws, size_t ws_bytes, void* stream) {
@@ -659,13 +683,14 @@ int sf_spatial_gru_fwd(const sf_gru_w* w, const float* x, const float* state0, f
   float* g = A.take(P * 2 * C);
   float* sa = A.take(P * C);
   float* sb = A.take(P * C);
+  float* rs = A.take(P * C);
   if (!A.ok()) return SF_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const float* cur = state0;
   for (int t = 0; t < T; ++t) {   // temporal.py:35-39
     // without a decoder (BEVerse SpatialGRU, basic_modules.py:225-284) the states ARE the output
     float* nxt = has_dec ? ((t & 1) ? sb : sa) : out + t * P * C;
-    SF_TRY(gru_cell(*w, x + t * P * Cx, cur, nxt, g, n_img, H, W, st));
+    SF_TRY(gru_cell(*w, x + t * P * Cx, cur, nxt, g, rs, n_img, H, W, st));
     if (has_dec)
       SF_TRY(run1(problem(w->decoder, nxt, nullptr, out + t * P * w->decoder.cout, n_img, H, W), EPI_AFFINE, st));
     cur = nxt;

@@ -129,6 +129,12 @@ __device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[
               y.x = act_apply(y.x, P.act); y.y = act_apply(y.y, P.act);
               y.z = act_apply(y.z, P.act); y.w = act_apply(y.w, P.act);
             }
+            if (P.out2 && c >= P.gate_from) {   // GRU gates, reset half: also emit (1 - r) * s, the candidate conv's input
+              const int cg = c - P.gate_from;
+              const float4 sv = ld4(P.e1 + (size_t)gp * P.e1_cs + cg);
+              st4(P.out2 + (size_t)gp * P.out2_cs + cg,
+                  make_float4(sv.x * (1.f - y.x), sv.y * (1.f - y.y), sv.z * (1.f - y.z), sv.w * (1.f - y.w)));
+            }
           } else {  // EPI_BLEND  (temporal.py:56, temporal_ode_bayes.py:145,160; BEVerse cells apply BN+ReLU first)
             v.x = act_apply(v.x, P.act); v.y = act_apply(v.y, P.act);
             v.z = act_apply(v.z, P.act); v.w = act_apply(v.w, P.act);
@@ -972,27 +978,22 @@ static hipError_t launch_glds_e(const ConvLaunch& L, int epi, hipStream_t stream
 
 // tile: 0 = 128 cout x 128 px (2x4 waves of 64x32), 1 = 64 x 64 (2x2 waves of 32x32);  variant: buffers / issue placement
 hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant, hipStream_t stream) {
+  if (tile == 2) {   // LayerNorm epilogues: one wave holds all (<= 64) output channels of its pixels; 64 cout x 128 px, 4 waves
+    if (epi == EPI_LNG) return launch_glds_t<4, 2, 1, 4, EPI_LNG, 2, false, 1>(L, stream);
+    if (epi == EPI_TRUST) return launch_glds_t<4, 2, 1, 4, EPI_TRUST, 2, false, 1>(L, stream);
+    return hipErrorInvalidValue;
+  }
   if (tile == 0) {
     switch (variant) {
-      case 0: return launch_glds_e<4, 2, 2, 4, 2, false>(L, epi, stream);
-      case 1: return launch_glds_e<4, 2, 2, 4, 2, true>(L, epi, stream);
-      case 2: return launch_glds_e<4, 2, 2, 4, 3, false>(L, epi, stream);
-      case 3: return launch_glds_e<4, 2, 2, 4, 3, true>(L, epi, stream);
-      case 4: return launch_glds_e<4, 2, 2, 4, 2, false, 1>(L, epi, stream);
-      case 5: return launch_glds_e<4, 2, 2, 4, 2, false, 2>(L, epi, stream);
-      case 6: case 7: case 8: return launch_glds_e<4, 2, 2, 4, 2, false, 1>(L, epi, stream);
+      case 0: return launch_glds_e<4, 2, 2, 4, 2, false, 0>(L, epi, stream);   // barrier at the end of the chunk
+      default: return launch_glds_e<4, 2, 2, 4, 2, false, 1>(L, epi, stream);  // barrier in the middle of the MFMA stream
     }
   } else {
     switch (variant) {
-      case 0: return launch_glds_e<2, 2, 2, 2, 2, false>(L, epi, stream);
-      case 1: return launch_glds_e<2, 2, 2, 2, 2, true>(L, epi, stream);
-      case 2: return launch_glds_e<2, 2, 2, 2, 3, false>(L, epi, stream);
-      case 3: return launch_glds_e<2, 2, 2, 2, 3, true>(L, epi, stream);
+      case 0: return launch_glds_e<2, 2, 2, 2, 2, false, 0>(L, epi, stream);
       case 4: return launch_glds_e<2, 2, 2, 2, 2, false, 1>(L, epi, stream);
-      case 5: return launch_glds_e<2, 2, 2, 2, 2, false, 2>(L, epi, stream);
       case 6: return launch_glds_e<2, 2, 2, 4, 2, false, 1>(L, epi, stream);   // 64 cout x 128 px, 8 waves of 32x32
       case 7: return launch_glds_e<4, 2, 1, 4, 2, false, 1>(L, epi, stream);   // 64 cout x 128 px, 4 waves of 64x32
-      case 8: return launch_glds_e<4, 2, 1, 8, 2, false, 1>(L, epi, stream);   // 64 cout x 256 px, 8 waves of 64x32
     }
   }
   return hipErrorInvalidValue;
