@@ -282,7 +282,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     return SF_OK;
   }
   ProfRec r;
-  r.key = cfg * 8 + epi; r.flops = 0; r.bytes = 0;
+  r.key = (glds_tile < 0 ? cfg : glds_tile == 0 ? 10 : glds_tile == 2 ? 13 : glds_var == 6 ? 12 : 11) * 8 + epi; r.flops = 0; r.bytes = 0;
   for (int i = 0; i < n; ++i) {
     const ConvProblem& q = ps[i];
     const double Pi = (double)q.n_img * q.Hout * q.Wout;

@@ -72,6 +72,15 @@ def main():
                      (512, 128, 1, 7, 200, 200), (128, 128, 3, 7, 200, 200), (256, 256, 3, 8, 50, 50), (128, 128, 3, 7, 100, 100), (64, 256, 1, 7, 200, 200)]:
             conv_case(*args)
         return
+    if "--nsweep" in sys.argv:
+        # batch dependence of the large-tile kernels: 7 frames live in the 256 MB Infinity Cache, 224 stream from HBM
+        for n in (7, 28, 112, 224):
+            conv_case(128, 128, 3, n, 200, 200)
+        for n in (7, 28, 112, 224):
+            conv_case(64, 64, 3, n, 200, 200)
+        for n in (7, 224):
+            conv_case(128, 64, 3, n, 200, 200, 1, 64)
+        return
     if "--tail" in sys.argv:
         # tail-quantisation probe: 256x256 images = 1024 64-pixel-row tiles each
         for n in (1, 2, 3, 4, 5, 8, 16):

@@ -23,14 +23,14 @@ def main():
     fetch, write = load("pmcb_fetch"), load("pmcb_write")
     rows = []
     for k in fetch:
-        if "conv_igemm" not in k and "conv_direct" not in k:
+        if "conv_igemm" not in k and "conv_direct" not in k and "conv_glds" not in k:
             continue
         f, w = fetch[k], write.get(k, [0.0])
         rows.append({"kernel": k, "launches": len(f), "fetch_kib_avg_raw": sum(f) / len(f), "write_kib_avg": sum(w) / len(w),
                      "hbm_bytes_per_launch": (2.0 * sum(f) / len(f) + sum(w) / len(w)) * 1024.0,
                      "total_hbm_bytes": (2.0 * sum(f) + sum(w)) * 1024.0})
     rows.sort(key=lambda r: -r["total_hbm_bytes"])
-    want = sys.argv[1] if len(sys.argv) > 1 else "conv_igemm_kernel<4, 2, 2, 4, 1, 0"
+    want = sys.argv[1] if len(sys.argv) > 1 else "conv_glds_kernel<4, 2, 2, 4, 0"   # 128x128 tiles, affine epilogue
     dom = next((r for r in rows if want in r["kernel"]), rows[0])
     out = {"kernel": dom["kernel"], "hbm_bytes_per_launch": dom["hbm_bytes_per_launch"],
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --steps 1 --warmup 1; "
