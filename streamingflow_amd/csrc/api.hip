@@ -262,9 +262,9 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       const ConvProblem& q = L.p[i];
       ok = ok && !q.gate && !q.in_scale && !q.gather && q.nsplit <= 1;
       ok = ok && (q.c0 % 32 == 0) && (q.c1 % 32 == 0);   // a 32-deep chunk reads one source tensor
-      // 32-bit byte offsets: over the two images a tile can touch, and over the packed weights
-      ok = ok && 8.0 * q.Hin * q.Win * q.in0_cs < 2147483648.0 && 8.0 * q.Hin * q.Win * q.in1_cs < 2147483648.0 &&
-           4.0 * q.cout_pad * q.ktot < 2147483648.0;
+      // 32-bit byte offsets: over the images a (<= 256-pixel) tile can touch, and over the packed weights
+      const double span = (256.0 / ((double)q.Hout * q.Wout) + 2.0) * q.Hin * q.Win * 4.0;   // bytes per channel stride unit
+      ok = ok && span * q.in0_cs < 2147483648.0 && span * q.in1_cs < 2147483648.0 && 4.0 * q.cout_pad * q.ktot < 2147483648.0;
       const long Pi = (long)q.n_img * q.Hout * q.Wout;
       pmin = Pi < pmin ? Pi : pmin;
     }

@@ -36,15 +36,61 @@ def _cfg(i):
 
 @pytest.mark.parametrize("i", range(48))
 def test_random_conv(i):
+    _run(_cfg(i), i)
+
+
+# Layers the dispatcher sends to the LDS-DMA kernel (conv_glds_kernel: channel counts multiples of 32, >= 640 tiles of
+# 64x64, no split-K): both tile families (cout 64 / 128, below and above 131072 pixels), two concatenated sources,
+# stride 2, dilation, nearest x2 upsampling on read, no padding, odd sizes whose last tile is ragged, and many small
+# images so that one 128-pixel tile spans several of them.
+_DMA = [
+    dict(k=3, stride=1, dil=1, c0=64, c1=64, cout=64, n=2, H=181, W=187, pad=1),
+    dict(k=3, stride=1, dil=1, c0=32, c1=96, cout=128, n=4, H=150, W=231, pad=1),
+    dict(k=3, stride=2, dil=1, c0=64, c1=0, cout=128, n=3, H=301, W=403, pad=1),
+    dict(k=3, stride=1, dil=12, c0=64, c1=0, cout=128, n=4, H=200, W=200, pad=12),
+    dict(k=1, stride=1, dil=1, c0=96, c1=32, cout=64, n=5, H=200, W=173, pad=0),
+    dict(k=5, stride=1, dil=1, c0=32, c1=0, cout=192, n=2, H=120, W=131, pad=0),
+    dict(k=3, stride=1, dil=1, c0=64, c1=0, cout=64, n=2, H=100, W=100, pad=1, in_up=1),
+    dict(k=3, stride=1, dil=1, c0=32, c1=32, cout=128, n=2, H=130, W=140, pad=1, in_up=1),
+    dict(k=3, stride=1, dil=1, c0=64, c1=64, cout=128, n=600, H=15, W=17, pad=1),
+    dict(k=3, stride=1, dil=2, c0=64, c1=0, cout=64, n=3000, H=7, W=7, pad=2),
+    dict(k=7, stride=1, dil=1, c0=64, c1=64, cout=64, n=17, H=50, W=50, pad=3),
+    dict(k=3, stride=1, dil=1, c0=128, c1=0, cout=256, n=8, H=50, W=50, pad=1),
+]
+
+
+@pytest.mark.parametrize("i", range(len(_DMA)))
+def test_dma_conv(i):
+    c = dict(act=["none", "relu", "lrelu", "tanh"][i % 4], add=i % 3 != 0, after=i % 2 == 0, in_slack=8 * (i % 2), out_slack=[0, 4, 16][i % 3])
+    c.update(_DMA[i])
+    from streamingflow_amd import _lib
+    L = _lib.lib()
+    NK = _lib.SF_PROF_KEYS
+    calls, ms = (ctypes.c_int32 * NK)(), (ctypes.c_double * NK)()
+    fl, by = (ctypes.c_double * NK)(), (ctypes.c_double * NK)()
+    L.sf_prof_enable(1)
+    try:
+        _run(c, 100 + i)
+        torch.cuda.synchronize()
+        L.sf_prof_collect(calls, ms, fl, by)
+    finally:
+        L.sf_prof_enable(0)
+    used = [_lib.KERNEL_NAMES[k] for k in range(NK) if calls[k]]
+    assert used and all(u.startswith("conv_glds") for u in used), used   # the case really ran on the LDS-DMA kernel
+
+
+def _run(c, i):
     from streamingflow_amd import _lib, packing, runtime
-    c = _cfg(i)
     k, n, H, W, c0, c1, cout = c["k"], c["n"], c["H"], c["W"], c["c0"], c["c1"], c["cout"]
+    up = c.get("in_up", 0)
     x0 = hashfill.normal(f"rc_x0_{i}", (n, c0, H, W), 1)
     x1 = hashfill.normal(f"rc_x1_{i}", (n, c1, H, W), 2) if c1 else None
     w = hashfill.uniform(f"rc_w_{i}", (cout, c0 + c1, k, k), -1, 1, 3) * (3.0 / ((c0 + c1) * k * k)) ** 0.5
     b = hashfill.uniform(f"rc_b_{i}", (cout,), -0.5, 0.5, 4)
     sc = hashfill.uniform(f"rc_s_{i}", (cout,), 0.5, 1.5, 5)
     xin = torch.cat([x0, x1], 1) if c1 else x0
+    if up:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
     y = F.conv2d(xin, w, None, c["stride"], c["pad"], c["dil"]) * sc.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
     Ho, Wo = y.shape[-2:]
     add = hashfill.normal(f"rc_a_{i}", (n, cout, Ho, Wo), 6) if c["add"] else None
@@ -67,7 +113,7 @@ def test_random_conv(i):
     L = _lib.lib()
     ws = runtime.workspace(L.sf_conv2d_ex_ws_bytes(), "cuda")
     _lib.check(L.sf_conv2d_ex_fwd(ctypes.byref(cw), runtime.ptr(a0), cs0, runtime.ptr(a1), c1 + 4 if c1 else 0, runtime.ptr(addn), cout,
-                                  int(c["after"]), ctypes.c_void_p(out.data_ptr()), ocs, oco, n, H, W, 0, runtime.ptr(ws), ws.numel() * 4,
+                                  int(c["after"]), ctypes.c_void_p(out.data_ptr()), ocs, oco, n, H, W, up, runtime.ptr(ws), ws.numel() * 4,
                                   runtime.stream_ptr()), "conv2d_ex")
     got = out[..., oco:oco + cout].permute(0, 3, 1, 2)
     assert maxabs(got, want) <= 2e-4, c
