@@ -111,7 +111,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, l_cfg, mid_tiles, split_cfg, glds, glds_var; };
+struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, l_cfg, mid_tiles, split_cfg, glds, glds_var, small_dma; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -128,6 +128,7 @@ const Tune& tune() {
     x.l_cfg = geti("SF_L_CFG", 0);                 // experimental large-P tiling override (5..9)
     x.glds = geti("SF_GLDS", 7);                   // LDS-DMA staging for large plain layers: bit 0 = 128-cout tiles, bit 1 = 64-cout tiles, bit 2 = LayerNorm-epilogue tiles (0: register staging everywhere)
     x.glds_var = geti("SF_GLDS_VAR", -1);          // -1: shipped choice; 0..8: force a variant of launch_conv_glds (experiments)
+    x.small_dma = geti("SF_SMALL_DMA", -1);        // experiment: >= 0 sends the plain layers below LARGE_P to the LDS-DMA kernel on 32x32 tiles
     x.split_cfg = geti("SF_SPLIT_CFG", 4);         // tile config of the mid-P split-K launches without a LayerNorm epilogue (4 | 1)
     x.split_from = geti("SF_SPLIT_FROM", 100);     // only layers with at least this many K chunks (the 7x7)
     return x;
@@ -271,6 +272,14 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     if (ok && cfg == 9 && (tune().glds & 1)) glds_tile = 0;
     if (ok && cfg == 1 && (tune().glds & 2)) { glds_tile = 1; glds_var = pmin >= 131072 ? 6 : 4; }
     if (ok && cfg == 2) glds_tile = 2;
+  }
+  if (tune().small_dma >= 0 && (cfg == 0 || cfg == 3) && (epi == EPI_AFFINE || epi == EPI_BLEND)) {   // experiment
+    bool ok = true;
+    for (int i = 0; i < n; ++i) {
+      const ConvProblem& q = L.p[i];
+      ok = ok && !q.gate && !q.in_scale && !q.gather && q.nsplit <= 1 && (q.c0 % 32 == 0) && (q.c1 % 32 == 0);
+    }
+    if (ok) { glds_tile = 3; glds_var = tune().small_dma; }
     if (tune().glds_var >= 0) glds_var = tune().glds_var;
   }
   auto launch = [&]() -> hipError_t {

@@ -855,7 +855,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
     // barrier that publishes chunk c+1, from fragments read before it, and the first fragments of chunk c+1 are read
     // under those MFMAs — a wave leaves the barrier with 2*MT*NT MFMAs ready to issue instead of a DMA-issue +
     // LDS-read-latency bubble.  The DMAs of chunk c+2 go out right after the same barrier (its buffer is free then).
-    static_assert(NB == 2, "mid-stream barrier variant is double buffered");
     constexpr int NG = BK / 8;
     float2 fa[2][MT], fb[2][NT];
     auto read_frags = [&](int buf, int t4, int set) {
@@ -882,25 +881,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
       if (SETPRIO) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     };
+    // prologue: LA = NB-1 chunks in flight, the first one retired and published
 #pragma unroll
-    for (int q = 0; q < G; ++q) issue_one(0, 0, q);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int c = 0; c < LA; ++c)
+      if (c < nchunks) {      // block-uniform
+#pragma unroll
+        for (int q = 0; q < G; ++q) issue_one(c, c, q);
+      }
+    if (LA > 1 && nchunks >= LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // Iteration c starts right after the barrier that published chunk c: read its first fragments, multiply the LAST
-    // k-group of chunk c-1 (read before the barrier) under that latency, start the DMAs of chunk c+1 into the buffer
-    // the barrier just freed, then k-groups 0..NG-2 of chunk c.  No LDS read is in flight across the back edge, so the
-    // compiler's lgkmcnt bookkeeping stays exact.
+    // k-group of chunk c-1 (read before the barrier) under that latency, start the DMAs of chunk c+LA into the buffer
+    // the barrier just freed (chunk c-1's), then k-groups 0..NG-2 of chunk c, then retire chunk c+1 (a counted vmcnt:
+    // the LA-1 younger chunks stay in flight).  No LDS read is in flight across the back edge, so the compiler's
+    // lgkmcnt bookkeeping stays exact.
+    int buf = 0, ibuf = LA;
     for (int c = 0; c < nchunks; ++c) {
-      const int buf = c & 1;
+      const bool more = c + LA < nchunks;
       read_frags(buf, 0, 0);
-      if (PIPE == 2 && c + 1 < nchunks) {
+      if (PIPE == 2 && more) {
 #pragma unroll
-        for (int q = 0; q < G; ++q) issue_one(c + 1, buf ^ 1, q);
+        for (int q = 0; q < G; ++q) issue_one(c + LA, ibuf, q);
       }
       if (c > 0) mfmas((NG - 1) & 1);
-      if (PIPE == 1 && c + 1 < nchunks) {
+      if (PIPE == 1 && more) {
 #pragma unroll
-        for (int q = 0; q < G; ++q) issue_one(c + 1, buf ^ 1, q);
+        for (int q = 0; q < G; ++q) issue_one(c + LA, ibuf, q);
       }
 #pragma unroll
       for (int t4 = 0; t4 < NG - 1; ++t4) {
@@ -908,10 +915,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
         mfmas(t4 & 1);
       }
       if (c + 1 < nchunks) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (LA > 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
+      buf = buf == NB - 1 ? 0 : buf + 1;
+      ibuf = ibuf == NB - 1 ? 0 : ibuf + 1;
     }
     mfmas((NG - 1) & 1);
     run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
@@ -982,6 +992,9 @@ hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant,
     if (epi == EPI_LNG) return launch_glds_t<4, 2, 1, 4, EPI_LNG, 2, false, 1>(L, stream);
     if (epi == EPI_TRUST) return launch_glds_t<4, 2, 1, 4, EPI_TRUST, 2, false, 1>(L, stream);
     return hipErrorInvalidValue;
+  }
+  if (tile == 3) {   // small pixel counts (experiment, SF_SMALL_DMA): 32 cout x 32 px, 4 waves of 16x16
+    return launch_glds_e<1, 1, 2, 2, 2, false, 1>(L, epi, stream);
   }
   if (tile == 0) {
     switch (variant) {
