@@ -128,7 +128,7 @@ const Tune& tune() {
     x.l_cfg = geti("SF_L_CFG", 0);                 // experimental large-P tiling override (5..9)
     x.glds = geti("SF_GLDS", 7);                   // LDS-DMA staging for large plain layers: bit 0 = 128-cout tiles, bit 1 = 64-cout tiles, bit 2 = LayerNorm-epilogue tiles (0: register staging everywhere)
     x.glds_var = geti("SF_GLDS_VAR", -1);          // -1: shipped choice; 0..8: force a variant of launch_conv_glds (experiments)
-    x.small_dma = geti("SF_SMALL_DMA", -1);        // experiment: >= 0 sends the plain layers below LARGE_P to the LDS-DMA kernel on 32x32 tiles
+    x.small_dma = geti("SF_SMALL_DMA", 1);         // >= 0: plain layers below LARGE_P run on the LDS-DMA kernel (32x32 tiles); bit 0: GRU candidates too (pre-gated state)
     x.split_cfg = geti("SF_SPLIT_CFG", 4);         // tile config of the mid-P split-K launches without a LayerNorm epilogue (4 | 1)
     x.split_from = geti("SF_SPLIT_FROM", 100);     // only layers with at least this many K chunks (the 7x7)
     return x;
@@ -273,7 +273,11 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     if (ok && cfg == 1 && (tune().glds & 2)) { glds_tile = 1; glds_var = pmin >= 131072 ? 6 : 4; }
     if (ok && cfg == 2) glds_tile = 2;
   }
-  if (tune().small_dma >= 0 && (cfg == 0 || cfg == 3) && (epi == EPI_AFFINE || epi == EPI_BLEND)) {   // experiment
+  // small pixel counts: the same kernel on 32x32 tiles beats the direct-fragment kernel by 5-15 % per plain layer
+  // (profiles/r01_v_sweep_glds_wide_tiles.txt; single-sample rollout 5.10 -> 4.64 ms with the pre-gated candidates).
+  // SF_SMALL_DMA=-1 switches it off, 0 keeps the reset gate in the candidate's staging.  LayerNorm epilogues on
+  // 64x32 tiles were slower than the direct kernel and stay there.
+  if (tune().small_dma >= 0 && (cfg == 0 || cfg == 3) && (epi == EPI_AFFINE || epi == EPI_BLEND)) {
     bool ok = true;
     for (int i = 0; i < n; ++i) {
       const ConvProblem& q = L.p[i];
@@ -334,7 +338,8 @@ struct SplitScope {
 // rs: optional [P][C] scratch.  Large pixel counts: the gates epilogue also writes (1 - r) * s there and the candidate
 // convolution reads cat[x, rs] as a plain layer (LDS-DMA staging); otherwise the gate is applied while staging.
 bool pregate(long P, const sf_conv_w& cand) {
-  return P >= LARGE_P && tune().glds && (cand.c0 % 32 == 0) && (cand.c1 % 32 == 0);
+  const bool dma = P >= LARGE_P ? tune().glds != 0 : (tune().small_dma >= 0 && (tune().small_dma & 1));
+  return dma && (cand.c0 % 32 == 0) && (cand.c1 % 32 == 0);
 }
 int gru_cell(const sf_gru_w& w, const float* x, const float* s, float* out, float* g, float* rs, int n, int H, int W,
              hipStream_t st, int ode_derivative = 0) {

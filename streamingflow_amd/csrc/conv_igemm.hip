@@ -993,7 +993,7 @@ hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant,
     if (epi == EPI_TRUST) return launch_glds_t<4, 2, 1, 4, EPI_TRUST, 2, false, 1>(L, stream);
     return hipErrorInvalidValue;
   }
-  if (tile == 3) {   // small pixel counts (experiment, SF_SMALL_DMA): 32 cout x 32 px, 4 waves of 16x16
+  if (tile == 3) {   // small pixel counts (one 50x50 latent): 32 cout x 32 px, 4 waves of 16x16
     return launch_glds_e<1, 1, 2, 2, 2, false, 1>(L, epi, stream);
   }
   if (tile == 0) {
