@@ -60,7 +60,8 @@ struct Arena {
 };
 inline size_t al(size_t n) { return (n + 63) & ~size_t(63); }
 
-constexpr int LARGE_P = 8192;   // pixels from which the 64x64 / 64x128 tiles are used
+int large_p();   // pixels from which the 64x64 / 64x128 tiles are used (12288; SF_LARGE_P)
+#define LARGE_P large_p()
 constexpr int ASPP_SLABS = 64;
 
 int pick_cfg(int P, int epi) {
@@ -111,7 +112,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, l_cfg, mid_tiles, split_cfg, glds, glds_var, small_dma; };
+struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, l_cfg, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -129,12 +130,15 @@ const Tune& tune() {
     x.glds = geti("SF_GLDS", 7);                   // LDS-DMA staging for large plain layers: bit 0 = 128-cout tiles, bit 1 = 64-cout tiles, bit 2 = LayerNorm-epilogue tiles (0: register staging everywhere)
     x.glds_var = geti("SF_GLDS_VAR", -1);          // -1: shipped choice; 0..8: force a variant of launch_conv_glds (experiments)
     x.small_dma = geti("SF_SMALL_DMA", 1);         // >= 0: plain layers below LARGE_P run on the LDS-DMA kernel (32x32 tiles); bit 0: GRU candidates too (pre-gated state)
+    x.large_p = geti("SF_LARGE_P", 12288);      // measured: a 4-sample rollout (10000 px) is 18 % faster on the small-P kernels, 8 samples (20000 px) on the large tiles
     x.split_cfg = geti("SF_SPLIT_CFG", 4);         // tile config of the mid-P split-K launches without a LayerNorm epilogue (4 | 1)
     x.split_from = geti("SF_SPLIT_FROM", 100);     // only layers with at least this many K chunks (the 7x7)
     return x;
   }();
   return t;
 }
+
+int large_p() { return tune().large_p; }
 
 // Scratch for the cross-workgroup split-K path, carved from the caller's workspace by the
 // top-level entry points (SplitScope) — thread-local pointer, no global allocation.
