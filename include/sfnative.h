@@ -317,7 +317,7 @@ int sf_hard_voxelize_fwd(const float* points, int num_points, int num_features, 
  * sf_sparse_conv_fwd — the convolution (spconv/conv.py:114-214 + BatchNorm1d + ReLU of
  *   make_sparse_convmodule / SparseBasicBlock, sparse_block.py:88-107, :110-176):
  *   out[j] = act(scale * sum_t W_t^T . feats[nbr[j][t]] + bias) + add   (act_after_add: act(... + add));
- *   w packs [Cout][Cin][ntaps][1] (kh = ntaps, kw = 1); feats rows have feats_cs floats.
+ *   w packs [Cout][Cin][ntaps][1] (kh = ntaps, kw = 1); feats has n_in rows of feats_cs floats.
  * sf_sparse_to_dense_fwd — SparseConvTensor.dense() + permute/view of sparse_encoder.py:131-137 as NHWC:
  *   out [batch][X][Y][C*D], channel c*D + z (zero where no site is active). */
 size_t sf_sparse_index_ws_bytes(int n_in, int ntaps);
@@ -327,8 +327,8 @@ int sf_sparse_out_sites_fwd(const int32_t* in_coords, int n_in, int batch, const
 int sf_sparse_table_fwd(const int32_t* in_coords, int n_in, const int32_t* out_coords, int n_out, int batch,
                         const int32_t* shape, const int32_t* ksize, const int32_t* stride, const int32_t* padding, int subm,
                         int32_t* nbr, void* ws, size_t ws_bytes, void* stream);
-int sf_sparse_conv_fwd(const sf_conv_w* w, const float* feats, int feats_cs, const int32_t* nbr, int n_out, const float* add,
-                       int act_after_add, float* out, float* ws, size_t ws_bytes, void* stream);
+int sf_sparse_conv_fwd(const sf_conv_w* w, const float* feats, int feats_cs, int n_in, const int32_t* nbr, int n_out,
+                       const float* add, int act_after_add, float* out, float* ws, size_t ws_bytes, void* stream);
 int sf_sparse_to_dense_fwd(const float* feats, const int32_t* coords, int n, int C, int batch, int X, int Y, int D, float* out,
                            void* stream);
 

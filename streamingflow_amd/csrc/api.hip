@@ -265,10 +265,10 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     long pmin = 1L << 40;
     for (int i = 0; i < n; ++i) {
       const ConvProblem& q = L.p[i];
-      ok = ok && !q.gate && !q.in_scale && !q.gather && q.nsplit <= 1;
+      ok = ok && !q.gate && !q.in_scale && q.nsplit <= 1;
       ok = ok && (q.c0 % 32 == 0) && (q.c1 % 32 == 0);   // a 32-deep chunk reads one source tensor
-      // 32-bit byte offsets: over the images a (<= 256-pixel) tile can touch, and over the packed weights
-      const double span = (256.0 / ((double)q.Hout * q.Wout) + 2.0) * q.Hin * q.Win * 4.0;   // bytes per channel stride unit
+      // 32-bit byte offsets: over the images a (<= 256-pixel) tile can touch (sparse: over all feature rows), and over the packed weights
+      const double span = q.gather ? 4.0 * q.Win : (256.0 / ((double)q.Hout * q.Wout) + 2.0) * q.Hin * q.Win * 4.0;   // bytes per channel stride unit
       ok = ok && span * q.in0_cs < 2147483648.0 && span * q.in1_cs < 2147483648.0 && 4.0 * q.cout_pad * q.ktot < 2147483648.0;
       const long Pi = (long)q.n_img * q.Hout * q.Wout;
       pmin = Pi < pmin ? Pi : pmin;
@@ -617,14 +617,15 @@ int sf_upsample_bilinear2_add_fwd(const float* in, const float* skip, float* out
 }
 
 /* sparse (gather) convolution: out[j] = act(scale * sum_t W_t . feats[nbr[j][t]] + bias) (+ add), see sfnative.h */
-int sf_sparse_conv_fwd(const sf_conv_w* w, const float* feats, int feats_cs, const int32_t* nbr, int n_out, const float* add,
-                       int act_after_add, float* out, float* ws, size_t ws_bytes, void* stream) {
-  if (!w || !valid_w(*w) || !feats || !nbr || !out || n_out < 0 || w->kw != 1 || w->c1 != 0 || feats_cs < w->c0 || (feats_cs % 4))
+int sf_sparse_conv_fwd(const sf_conv_w* w, const float* feats, int feats_cs, int n_in, const int32_t* nbr, int n_out,
+                       const float* add, int act_after_add, float* out, float* ws, size_t ws_bytes, void* stream) {
+  if (!w || !valid_w(*w) || !feats || !nbr || !out || n_out < 0 || n_in < 1 || w->kw != 1 || w->c1 != 0 || feats_cs < w->c0 ||
+      (feats_cs % 4))
     return SF_ERR_INVALID;
   if (n_out == 0) return SF_OK;
   Arena A(ws, ws_bytes);
   SplitScope sp(A, (hipStream_t)stream);
-  ConvProblem p = problem(*w, feats, nullptr, out, 1, 1, 1, 0);
+  ConvProblem p = problem(*w, feats, nullptr, out, 1, 1, n_in, 0);   // the input "image" is the n_in feature rows
   p.in0_cs = feats_cs;
   p.Hout = 1; p.Wout = n_out;
   p.gather = nbr;

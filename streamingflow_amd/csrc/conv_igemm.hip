@@ -697,6 +697,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
   const int Win = P.Win, in_up = P.in_up, dil = P.dil, KW = P.KW;
   const int Hlog = P.Hin << P.in_up, Wlog = P.Win << P.in_up;
   const int HWout = P.Hout * P.Wout;
+  const int* const gather = P.gather;
+  const int KHg = P.KH;
 
   // staging slots.  Weight slot q (q < GA) of this wave fills rows (wave*GA + q)*8 .. +7 of the A block, pixel slot q
   // rows (wave*GB + q)*8 .. +7 of the B block; this lane: row + lane/8, 16-B slot lane%8 holding K values
@@ -773,13 +775,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
     } else {
       const int qb = q - GA;
       if (tap_fresh && qb == 0) {
+        if (gather) {      // block-uniform: sparse convolution, the neighbour table replaces the pixel arithmetic
 #pragma unroll
-        for (int i = 0; i < GB; ++i) {
-          const int iy = b_iy0[i] + cur_ty * dil, ix = b_ix0[i] + cur_tx * dil;
-          const bool in = (iy >= 0) & (iy < Hlog) & (ix >= 0) & (ix < Wlog);
-          const int px = in ? b_base[i] + (iy >> in_up) * Win + (ix >> in_up) : 0;
-          tap_off0[i] = in ? px * in0_cs : -1;
-          tap_off1[i] = px * in1_cs - c0;
+          for (int i = 0; i < GB; ++i) {
+            const int gp = p_tile * BN + (wave * GB + i) * 8 + (lane >> 3);
+            const int px = gp < Ptot ? gather[(size_t)gp * KHg + cur_ty] : -1;
+            tap_off0[i] = px >= 0 ? px * in0_cs : -1;
+            tap_off1[i] = (px >= 0 ? px : 0) * in1_cs - c0;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < GB; ++i) {
+            const int iy = b_iy0[i] + cur_ty * dil, ix = b_ix0[i] + cur_tx * dil;
+            const bool in = (iy >= 0) & (iy < Hlog) & (ix >= 0) & (ix < Wlog);
+            const int px = in ? b_base[i] + (iy >> in_up) * Win + (ix >> in_up) : 0;
+            tap_off0[i] = in ? px * in0_cs : -1;
+            tap_off1[i] = px * in1_cs - c0;
+          }
         }
       }
       const int c = cur_kc * BK + b_c4[qb];

@@ -155,7 +155,7 @@ class SparseEncoder(PackedModule):
         dev = feats.device
         out = torch.empty((n_out, w.cout), dtype=torch.float32, device=dev)
         ws = runtime.workspace(L.sf_conv2d_ex_ws_bytes(), dev)
-        _lib.check(L.sf_sparse_conv_fwd(C.byref(w), ptr(feats), feats.shape[1], ptr(nbr), n_out, ptr(add), int(act_after_add), ptr(out),
+        _lib.check(L.sf_sparse_conv_fwd(C.byref(w), ptr(feats), feats.shape[1], feats.shape[0], ptr(nbr), n_out, ptr(add), int(act_after_add), ptr(out),
                                         ptr(ws), ws.numel() * 4, runtime.stream_ptr(dev)), "sparse_conv")
         return out
 
