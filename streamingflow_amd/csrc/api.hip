@@ -127,7 +127,7 @@ const Tune& tune() {
     x.split_min_chunks = geti("SF_SPLIT_MINCH", 2);
     x.mid_tiles = geti("SF_MID_TILES", 640);
     x.l_cfg = geti("SF_L_CFG", 0);                 // experimental large-P tiling override (5..9)
-    x.glds = geti("SF_GLDS", 7);                   // LDS-DMA staging for large plain layers: bit 0 = 128-cout tiles, bit 1 = 64-cout tiles, bit 2 = LayerNorm-epilogue tiles (0: register staging everywhere)
+    x.glds = geti("SF_GLDS", 15);                  // LDS-DMA staging for large plain layers: bit 0 = 128-cout tiles, bit 1 = 64-cout tiles, bit 2 = LayerNorm-epilogue tiles, bit 3 = cross-workgroup split-K launches (0: register staging everywhere)
     x.glds_var = geti("SF_GLDS_VAR", -1);          // -1: shipped choice; 0..8: force a variant of launch_conv_glds (experiments)
     x.small_dma = geti("SF_SMALL_DMA", 1);         // >= 0: plain layers below LARGE_P run on the LDS-DMA kernel (32x32 tiles); bit 0: GRU candidates too (pre-gated state)
     x.large_p = geti("SF_LARGE_P", 12288);      // measured: a 4-sample rollout (10000 px) is 18 % faster on the small-P kernels, 8 samples (20000 px) on the large tiles
@@ -281,6 +281,16 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   // (profiles/r01_v_sweep_glds_wide_tiles.txt; single-sample rollout 5.10 -> 4.64 ms with the pre-gated candidates).
   // SF_SMALL_DMA=-1 switches it off, 0 keeps the reset gate in the candidate's staging.  LayerNorm epilogues on
   // 64x32 tiles were slower than the direct kernel and stay there.
+  if ((tune().glds & 8) && cfg == 4 && epi != EPI_SAMPLE) {   // cross-workgroup split-K launches (the slab hand-off is shared)
+    bool ok = true;
+    for (int i = 0; i < n; ++i) {
+      const ConvProblem& q = L.p[i];
+      const double span = (256.0 / ((double)q.Hout * q.Wout) + 2.0) * q.Hin * q.Win * 4.0;
+      ok = ok && !q.gate && !q.in_scale && !q.gather && (q.c0 % 32 == 0) && (q.c1 % 32 == 0) && span * q.in0_cs < 2147483648.0 &&
+           span * q.in1_cs < 2147483648.0 && 4.0 * q.cout_pad * q.ktot < 2147483648.0;
+    }
+    if (ok) glds_tile = 4;
+  }
   if (tune().small_dma >= 0 && (cfg == 0 || cfg == 3) && (epi == EPI_AFFINE || epi == EPI_BLEND)) {
     bool ok = true;
     for (int i = 0; i < n; ++i) {
@@ -299,7 +309,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     return SF_OK;
   }
   ProfRec r;
-  r.key = (glds_tile < 0 ? cfg : glds_tile == 0 ? 10 : glds_tile == 2 ? 13 : glds_var == 6 ? 12 : 11) * 8 + epi; r.flops = 0; r.bytes = 0;
+  r.key = (glds_tile < 0 || glds_tile == 4 ? cfg : glds_tile == 0 ? 10 : glds_tile == 2 ? 13 : glds_var == 6 ? 12 : 11) * 8 + epi; r.flops = 0; r.bytes = 0;
   for (int i = 0; i < n; ++i) {
     const ConvProblem& q = ps[i];
     const double Pi = (double)q.n_img * q.Hout * q.Wout;

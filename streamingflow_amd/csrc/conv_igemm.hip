@@ -304,6 +304,59 @@ __device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[
   }
 }
 
+// ---- cross-workgroup split-K: slab publish, ticket, last arriver reduces in slice order ------
+// (cdna_hip_programming.md "In-launch split-K reduction": plain slab stores, every wave drains,
+// barrier, ONE agent-scope release + ticket; the last arriver does ONE agent-scope acquire, then
+// plain loads.  Placement independent; fixed summation order => bitwise reproducible.)
+// Returns false for the workgroups that are done (not the last arriver of their tile).
+template <int MT, int NT, int NW>
+__device__ __forceinline__ bool splitk_handoff(const ConvProblem& P, f32x4 (&acc)[MT][NT], const int nsplit, const int wave,
+                                               const int lane, const int tid, float* smem) {
+  constexpr int PER_WAVE = MT * NT * 4 * 64;
+  float* tile_slab = P.slab + (size_t)blockIdx.x * nsplit * NW * PER_WAVE;
+  {
+    float* my = tile_slab + ((size_t)blockIdx.z * NW + wave) * PER_WAVE + lane;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) my[((m * NT + n) * 4 + q) * 64] = acc[m][n][q];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* flag = reinterpret_cast<int*>(smem);
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned* cnt = P.counters + blockIdx.x;
+    const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == (unsigned)(nsplit - 1));
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  if (*flag == 0) return false;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < nsplit; ++z) {
+    const float* r = tile_slab + ((size_t)z * NW + wave) * PER_WAVE + lane;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[m][n][q] += r[((m * NT + n) * 4 + q) * 64];
+  }
+  return true;
+}
+
 template <int MT, int NT, int WM, int WN, int KS, int EPI, int KB = 32, bool SWZ = false>
 __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const ConvLaunch L) {
   constexpr int BKc = KB;          // K depth of one staged chunk (32, or 64 when cin_pad % 64 == 0)
@@ -600,55 +653,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
     }
   }
 
-  // ---- cross-workgroup split-K: slab publish, ticket, last arriver reduces in slice order ------
-  // (cdna_hip_programming.md "In-launch split-K reduction": plain slab stores, every wave drains,
-  // barrier, ONE agent-scope release + ticket; the last arriver does ONE agent-scope acquire, then
-  // plain loads.  Placement independent; fixed summation order => bitwise reproducible.)
-  if (nsplit > 1) {
-    constexpr int PER_WAVE = MT * NT * 4 * 64;
-    constexpr int NW = WM * WN;
-    float* tile_slab = P.slab + (size_t)blockIdx.x * nsplit * NW * PER_WAVE;
-    {
-      float* my = tile_slab + ((size_t)blockIdx.z * NW + wave) * PER_WAVE + lane;
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) my[((m * NT + n) * 4 + q) * 64] = acc[m][n][q];
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int* flag = reinterpret_cast<int*>(smem);
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      unsigned* cnt = P.counters + blockIdx.x;
-      const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = (t == (unsigned)(nsplit - 1));
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-      }
-      *flag = last;
-    }
-    __syncthreads();
-    if (*flag == 0) return;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < nsplit; ++z) {
-      const float* r = tile_slab + ((size_t)z * NW + wave) * PER_WAVE + lane;
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[m][n][q] += r[((m * NT + n) * 4 + q) * 64];
-    }
-  }
+  if (nsplit > 1 && !splitk_handoff<MT, NT, WM * WN>(P, acc, nsplit, wave, lane, tid, smem)) return;   // block-uniform
 
   // ---- epilogue --------------------------------------------------------------------------------
   run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
@@ -738,7 +743,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
   }
 
   const int kcpt = P.cin_pad / BK;
-  const int nchunks = P.KH * P.KW * kcpt;
+  const int nchunks_all = P.KH * P.KW * kcpt;
+  // cross-workgroup split-K: this workgroup owns chunks [cb, cb + nchunks)
+  const int nsplit = P.nsplit > 1 ? P.nsplit : 1;
+  if ((int)blockIdx.z >= nsplit) return;   // block-uniform
+  const int cps = (nchunks_all + nsplit - 1) / nsplit;
+  const int cb = (int)blockIdx.z * cps;
+  const int nchunks = (nchunks_all - cb) < cps ? (nchunks_all - cb) : cps;
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -746,7 +757,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
 #pragma unroll
     for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  int cur_kc = 0, cur_ty = 0, cur_tx = 0;     // cursor of the next chunk to ISSUE
+  int cur_kc = cb % kcpt, cur_ty = (cb / kcpt) / KW, cur_tx = (cb / kcpt) % KW;     // cursor of the next chunk to ISSUE
   int tap_off0[GB], tap_off1[GB];
   bool tap_fresh = true;
 
@@ -898,7 +909,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
     for (int c = 0; c < LA; ++c)
       if (c < nchunks) {      // block-uniform
 #pragma unroll
-        for (int q = 0; q < G; ++q) issue_one(c, c, q);
+        for (int q = 0; q < G; ++q) issue_one(cb + c, c, q);
       }
     if (LA > 1 && nchunks >= LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -914,12 +925,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
       read_frags(buf, 0, 0);
       if (PIPE == 2 && more) {
 #pragma unroll
-        for (int q = 0; q < G; ++q) issue_one(c + LA, ibuf, q);
+        for (int q = 0; q < G; ++q) issue_one(cb + c + LA, ibuf, q);
       }
       if (c > 0) mfmas((NG - 1) & 1);
       if (PIPE == 1 && more) {
 #pragma unroll
-        for (int q = 0; q < G; ++q) issue_one(c + LA, ibuf, q);
+        for (int q = 0; q < G; ++q) issue_one(cb + c + LA, ibuf, q);
       }
 #pragma unroll
       for (int t4 = 0; t4 < NG - 1; ++t4) {
@@ -936,6 +947,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
       ibuf = ibuf == NB - 1 ? 0 : ibuf + 1;
     }
     mfmas((NG - 1) & 1);
+    if (nsplit > 1) {      // block-uniform
+      __syncthreads();     // the hand-off flag lives in the staging buffers: every wave is done reading them
+      if (!splitk_handoff<MT, NT, NWV>(P, acc, nsplit, wave, lane, tid, smem)) return;
+    }
     run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
     return;
   }
@@ -945,7 +960,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
   for (int c = 0; c < LA; ++c)
     if (c < nchunks) {      // block-uniform
 #pragma unroll
-      for (int q = 0; q < G; ++q) issue_one(c, c, q);
+      for (int q = 0; q < G; ++q) issue_one(cb + c, c, q);
     }
   if (LA > 1 && nchunks >= LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -955,7 +970,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
     const bool more = c + LA < nchunks;
     if (!INTERLEAVE && more) {
 #pragma unroll
-      for (int q = 0; q < G; ++q) issue_one(c + LA, bi, q);
+      for (int q = 0; q < G; ++q) issue_one(cb + c + LA, bi, q);
     }
     compute(bc, more ? c + LA : -1, bi);
     if (LA > 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
@@ -965,6 +980,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
     bc = bc == NB - 1 ? 0 : bc + 1;
     bi = bi == NB - 1 ? 0 : bi + 1;
   }
+  if (nsplit > 1 && !splitk_handoff<MT, NT, NWV>(P, acc, nsplit, wave, lane, tid, smem)) return;
   run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
 }
 
@@ -987,7 +1003,9 @@ static hipError_t launch_glds_t(const ConvLaunch& L, hipStream_t stream) {
     if (nb > maxblocks) maxblocks = nb;
   }
   if (maxblocks == 0) return hipSuccess;
-  hipLaunchKernelGGL(kern, dim3(maxblocks, L.nprob), dim3(64 * WM * WN), lds, stream, L);
+  int zs = 1;
+  for (int i = 0; i < L.nprob; ++i) zs = L.p[i].nsplit > zs ? L.p[i].nsplit : zs;
+  hipLaunchKernelGGL(kern, dim3(maxblocks, L.nprob, zs), dim3(64 * WM * WN), lds, stream, L);
   return hipGetLastError();
 }
 
@@ -1003,6 +1021,15 @@ hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant,
   if (tile == 2) {   // LayerNorm epilogues: one wave holds all (<= 64) output channels of its pixels; 64 cout x 128 px, 4 waves
     if (epi == EPI_LNG) return launch_glds_t<4, 2, 1, 4, EPI_LNG, 2, false, 1>(L, stream);
     if (epi == EPI_TRUST) return launch_glds_t<4, 2, 1, 4, EPI_TRUST, 2, false, 1>(L, stream);
+    return hipErrorInvalidValue;
+  }
+  if (tile == 4) {   // cross-workgroup split-K launches: 64 cout x 64 px, 4 waves of 64x16 (all channels of a pixel in one wave)
+    switch (epi) {
+      case EPI_AFFINE: return launch_glds_t<4, 1, 1, 4, EPI_AFFINE, 2, false, 1>(L, stream);
+      case EPI_BLEND:  return launch_glds_t<4, 1, 1, 4, EPI_BLEND, 2, false, 1>(L, stream);
+      case EPI_LNG:    return launch_glds_t<4, 1, 1, 4, EPI_LNG, 2, false, 1>(L, stream);
+      case EPI_TRUST:  return launch_glds_t<4, 1, 1, 4, EPI_TRUST, 2, false, 1>(L, stream);
+    }
     return hipErrorInvalidValue;
   }
   if (tile == 3) {   // small pixel counts (one 50x50 latent): 32 cout x 32 px, 4 waves of 16x16
