@@ -112,7 +112,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, l_cfg, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p; };
+struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, l_cfg, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -130,6 +130,7 @@ const Tune& tune() {
     x.glds = geti("SF_GLDS", 15);                  // LDS-DMA staging for large plain layers: bit 0 = 128-cout tiles, bit 1 = 64-cout tiles, bit 2 = LayerNorm-epilogue tiles, bit 3 = cross-workgroup split-K launches (0: register staging everywhere)
     x.glds_var = geti("SF_GLDS_VAR", -1);          // -1: shipped choice; 0..8: force a variant of launch_conv_glds (experiments)
     x.small_dma = geti("SF_SMALL_DMA", 1);         // >= 0: plain layers below LARGE_P run on the LDS-DMA kernel (32x32 tiles); bit 0: GRU candidates too (pre-gated state)
+    x.narrow = geti("SF_NARROW", 9);             // tile variant for layers with <= 32 output channels (32 cout x 128 px; -1: the 64-row tiles)
     x.large_p = geti("SF_LARGE_P", 12288);      // measured: a 4-sample rollout (10000 px) is 18 % faster on the small-P kernels, 8 samples (20000 px) on the large tiles
     x.split_cfg = geti("SF_SPLIT_CFG", 4);         // tile config of the mid-P split-K launches without a LayerNorm epilogue (4 | 1)
     x.split_from = geti("SF_SPLIT_FROM", 100);     // only layers with at least this many K chunks (the 7x7)
@@ -274,7 +275,12 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       pmin = Pi < pmin ? Pi : pmin;
     }
     if (ok && cfg == 9 && (tune().glds & 1)) glds_tile = 0;
-    if (ok && cfg == 1 && (tune().glds & 2)) { glds_tile = 1; glds_var = pmin >= 131072 ? 6 : 4; }
+    if (ok && cfg == 1 && (tune().glds & 2)) {
+      glds_tile = 1; glds_var = pmin >= 131072 ? 6 : 4;
+      bool narrow = true;      // every problem has at most 32 output channels: half of a 64-row tile would multiply zeros
+      for (int i = 0; i < n; ++i) narrow = narrow && L.p[i].cout_pad <= 32;
+      if (narrow && tune().narrow >= 0) glds_var = tune().narrow;
+    }
     if (ok && cfg == 2) glds_tile = 2;
   }
   // small pixel counts: the same kernel on 32x32 tiles beats the direct-fragment kernel by 5-15 % per plain layer

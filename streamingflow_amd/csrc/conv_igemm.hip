@@ -1046,6 +1046,7 @@ hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant,
       case 4: return launch_glds_e<2, 2, 2, 2, 2, false, 1>(L, epi, stream);
       case 6: return launch_glds_e<2, 2, 2, 4, 2, false, 1>(L, epi, stream);   // 64 cout x 128 px, 8 waves of 32x32
       case 7: return launch_glds_e<4, 2, 1, 4, 2, false, 1>(L, epi, stream);   // 64 cout x 128 px, 4 waves of 64x32
+      case 9: return launch_glds_e<1, 4, 2, 2, 2, false, 1>(L, epi, stream);   // 32 cout x 128 px, 4 waves of 16x64 (32-channel sparse stage)
     }
   }
   return hipErrorInvalidValue;
