@@ -141,6 +141,10 @@ const Tune& tune() {
 
 int large_p() { return tune().large_p; }
 
+// LDS-DMA kernel: a 32-deep K chunk must come from ONE source tensor (a single input, or two whose channel counts are
+// multiples of the chunk depth); channels past cin are zero-filled by the range check either way
+bool one_source_per_chunk(const ConvProblem& q) { return q.c1 == 0 || ((q.c0 % 32 == 0) && (q.c1 % 32 == 0)); }
+
 // Scratch for the cross-workgroup split-K path, carved from the caller's workspace by the
 // top-level entry points (SplitScope) — thread-local pointer, no global allocation.
 struct SplitCtx { float* slab; size_t slab_floats; unsigned* counters; int ncounters; };
@@ -267,7 +271,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     for (int i = 0; i < n; ++i) {
       const ConvProblem& q = L.p[i];
       ok = ok && !q.gate && !q.in_scale && q.nsplit <= 1;
-      ok = ok && (q.c0 % 32 == 0) && (q.c1 % 32 == 0);   // a 32-deep chunk reads one source tensor
+      ok = ok && one_source_per_chunk(q);
       // 32-bit byte offsets: over the images a (<= 256-pixel) tile can touch (sparse: over all feature rows), and over the packed weights
       const double span = q.gather ? 4.0 * q.Win : (256.0 / ((double)q.Hout * q.Wout) + 2.0) * q.Hin * q.Win * 4.0;   // bytes per channel stride unit
       ok = ok && span * q.in0_cs < 2147483648.0 && span * q.in1_cs < 2147483648.0 && 4.0 * q.cout_pad * q.ktot < 2147483648.0;
@@ -292,7 +296,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     for (int i = 0; i < n; ++i) {
       const ConvProblem& q = L.p[i];
       const double span = (256.0 / ((double)q.Hout * q.Wout) + 2.0) * q.Hin * q.Win * 4.0;
-      ok = ok && !q.gate && !q.in_scale && !q.gather && (q.c0 % 32 == 0) && (q.c1 % 32 == 0) && span * q.in0_cs < 2147483648.0 &&
+      ok = ok && !q.gate && !q.in_scale && !q.gather && one_source_per_chunk(q) && span * q.in0_cs < 2147483648.0 &&
            span * q.in1_cs < 2147483648.0 && 4.0 * q.cout_pad * q.ktot < 2147483648.0;
     }
     if (ok) glds_tile = 4;
@@ -301,7 +305,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     bool ok = true;
     for (int i = 0; i < n; ++i) {
       const ConvProblem& q = L.p[i];
-      ok = ok && !q.gate && !q.in_scale && !q.gather && q.nsplit <= 1 && (q.c0 % 32 == 0) && (q.c1 % 32 == 0);
+      ok = ok && !q.gate && !q.in_scale && !q.gather && q.nsplit <= 1 && one_source_per_chunk(q);
     }
     if (ok) { glds_tile = 3; glds_var = tune().small_dma; }
     if (tune().glds_var >= 0) glds_var = tune().glds_var;
