@@ -112,7 +112,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, l_cfg, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -126,7 +126,6 @@ const Tune& tune() {
     x.split_target = geti("SF_SPLIT_WGS", 512);    // aim for this many workgroups per launch
     x.split_min_chunks = geti("SF_SPLIT_MINCH", 2);
     x.mid_tiles = geti("SF_MID_TILES", 640);
-    x.l_cfg = geti("SF_L_CFG", 0);                 // experimental large-P tiling override (5..9)
     x.glds = geti("SF_GLDS", 15);                  // LDS-DMA staging for large plain layers: bit 0 = 128-cout tiles, bit 1 = 64-cout tiles, bit 2 = LayerNorm-epilogue tiles, bit 3 = cross-workgroup split-K launches (0: register staging everywhere)
     x.glds_var = geti("SF_GLDS_VAR", -1);          // -1: shipped choice; 0..8: force a variant of launch_conv_glds (experiments)
     x.small_dma = geti("SF_SMALL_DMA", 1);         // >= 0: plain layers below LARGE_P run on the LDS-DMA kernel (32x32 tiles); bit 0: GRU candidates too (pre-gated state)
@@ -178,15 +177,12 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     if (cfg == 0) cfg = 1;
   }
   if (cfg == 1 && (epi == EPI_AFFINE || epi == EPI_BLEND)) {
-    if (tune().l_cfg > 0) cfg = tune().l_cfg;
-    else if (tune().l_cfg == 0) {
-      // measured (profiles/r01_e_sweep_large_tiles.txt): 128x128 tiles with 8 waves win 7-10 % once
-      // there are >= ~1000 of them and cout is a multiple of 128; 64x64 wins everywhere else
-      bool big = true;
-      for (int i = 0; i < n; ++i)
-        big = big && (ps[i].cout_pad % 128 == 0) && ((long)ps[i].n_img * ps[i].Hout * ps[i].Wout >= 131072);
-      if (big) cfg = 9;
-    }
+    // measured (profiles/r01_e_sweep_large_tiles.txt): 128x128 tiles with 8 waves win 7-10 % once
+    // there are >= ~1000 of them and cout is a multiple of 128; 64x64 wins everywhere else
+    bool big = true;
+    for (int i = 0; i < n; ++i)
+      big = big && (ps[i].cout_pad % 128 == 0) && ((long)ps[i].n_img * ps[i].Hout * ps[i].Wout >= 131072);
+    if (big) cfg = 9;
   }
   // small pixel counts: direct-fragment kernel (no LDS staging), see conv_igemm.hip
   int mt = 0, ks = 1;

@@ -1061,234 +1061,6 @@ hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant,
   return hipErrorInvalidValue;
 }
 
-// ---- ping-pong variant of the staged kernel (large pixel counts) ------------------------------
-// Measured on the kernel above: whatever the tile shape, chunk depth or occupancy, the fp32 MFMA pipe
-// idles ~35 % of the time — the waves of a SIMD drift into lockstep (all stage, then all multiply).
-// Here a workgroup is two groups of 4 waves (2 waves per SIMD) that share the weight tile but own
-// different pixel halves, and the groups alternate by construction: while group 0 multiplies chunk c,
-// group 1 writes its staged operands of a later chunk to LDS and vice versa, one barrier per phase.
-// Each SIMD therefore always has one wave in its MFMA phase and one in its memory phase.
-//   phase 2c  : G0: issue loads(c+1), MFMA(c)      G1: ds_write(c+1)   (loads issued in phase 2c-1)
-//   phase 2c+1: G1: issue loads(c+2), MFMA(c)      G0: ds_write(c+1)
-// Group g stages its own pixel rows (B) and half of the shared weight rows (A).
-template <int MT, int NT, int EPI>
-__global__ __launch_bounds__(512) void conv_pp_kernel(const ConvLaunch L) {
-  constexpr int ROW = BK + 4, F4 = BK / 4;
-  constexpr int BM = 32 * MT;             // weight rows of the workgroup (2x2 waves of MT x NT tiles per group)
-  constexpr int BNG = 32 * NT;            // pixels per group
-  constexpr int BN = 2 * BNG;             // pixels per workgroup
-  constexpr int TG = 256, ROWS_PER_PASS = TG / F4;   // 32
-  constexpr int A_SLOTS = (BM / 2) / ROWS_PER_PASS;
-  constexpr int B_SLOTS = BNG / ROWS_PER_PASS;
-  static_assert((BM / 2) % ROWS_PER_PASS == 0 && BNG % ROWS_PER_PASS == 0, "tile/threads mismatch");
-
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                        // [2][BM][ROW]
-  float* Bs = smem + 2 * BM * ROW;         // [2][BN][ROW]
-
-  const ConvProblem& P = L.p[blockIdx.y];
-  const int Ptot = P.n_img * P.Hout * P.Wout;
-  const int n_mt = (P.cout_pad + BM - 1) / BM;
-  const int m_tile = blockIdx.x % n_mt;
-  const int p_tile = blockIdx.x / n_mt;
-  if (p_tile * BN >= Ptot) return;   // block-uniform
-
-  const int tid = threadIdx.x;
-  const int grp = __builtin_amdgcn_readfirstlane(tid / TG);
-  const int t = tid - grp * TG;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int lane = t & 63;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int j = lane & 15, g = lane >> 4;
-
-  const float* const in0 = P.in0;
-  const float* const in1 = P.in1;
-  const float* const gate = P.gate;
-  const float* const in_scale = P.in_scale;
-  const float* const wbase = P.w;
-  const int c0 = P.c0, c01 = P.c0 + P.c1;
-  const int in0_cs = P.in0_cs, in1_cs = P.in1_cs, gate_cs = P.gate_cs, gate_co = P.gate_co;
-  const int Win = P.Win, in_up = P.in_up, dil = P.dil, KW = P.KW;
-  const int Hlog = P.Hin << P.in_up, Wlog = P.Win << P.in_up;
-  const bool has_aux = (gate != nullptr) | (in_scale != nullptr);
-
-  const int k4 = t % F4, row0 = t / F4;
-  const int HWout = P.Hout * P.Wout;
-  int b_iy0[B_SLOTS], b_ix0[B_SLOTS], b_base[B_SLOTS], b_img[B_SLOTS];
-#pragma unroll
-  for (int i = 0; i < B_SLOTS; ++i) {
-    int gp = p_tile * BN + grp * BNG + row0 + i * ROWS_PER_PASS;
-    bool v = gp < Ptot;
-    int img = v ? gp / HWout : 0;
-    int rem = gp - img * HWout;
-    int oy = rem / P.Wout, ox = rem - oy * P.Wout;
-    b_iy0[i] = v ? oy * P.stride - P.pad : -(1 << 28);
-    b_ix0[i] = ox * P.stride - P.pad;
-    b_base[i] = img * P.Hin * P.Win;
-    b_img[i] = img;
-  }
-  size_t a_off[A_SLOTS];
-#pragma unroll
-  for (int i = 0; i < A_SLOTS; ++i) {
-    int grow = m_tile * BM + grp * (BM / 2) + row0 + i * ROWS_PER_PASS;
-    grow = grow < P.cout_pad ? grow : P.cout_pad - 1;
-    a_off[i] = (size_t)grow * P.ktot + k4 * 4;
-  }
-
-  const int kcpt = P.cin_pad / BK;
-  const int nchunks = P.KH * P.KW * kcpt;
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int a = 0; a < MT; ++a)
-#pragma unroll
-    for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  float4 ra[A_SLOTS], rb[B_SLOTS], rx[B_SLOTS];
-  int bflag[B_SLOTS], tap_pix[B_SLOTS];
-  bool tap_fresh = true;
-  int cur_kc = 0, cur_ty = 0, cur_tx = 0;   // every group walks the chunks 0, 1, 2, ... in order
-
-  auto load_chunk = [&](int chunk) {
-    const float* wp = wbase + (size_t)chunk * BK;
-#pragma unroll
-    for (int i = 0; i < A_SLOTS; ++i) ra[i] = ld4(wp + a_off[i]);
-    const int c = cur_kc * BK + k4 * 4;
-    const bool s0 = c < c0;
-    const bool s1 = (!s0) & (c < c01);
-    const int cc = c - c0;
-    if (tap_fresh) {
-#pragma unroll
-      for (int i = 0; i < B_SLOTS; ++i) {
-        const int iy = b_iy0[i] + cur_ty * dil, ix = b_ix0[i] + cur_tx * dil;
-        const bool in = (iy >= 0) & (iy < Hlog) & (ix >= 0) & (ix < Wlog);
-        tap_pix[i] = in ? b_base[i] + (iy >> in_up) * Win + (ix >> in_up) : -1;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < B_SLOTS; ++i) {
-      const bool ok = (tap_pix[i] >= 0) & (s0 | s1);
-      const size_t pix = ok ? (size_t)tap_pix[i] : 0;
-      const float* p = s1 ? in1 + pix * in1_cs + cc : in0 + pix * in0_cs + (s0 ? c : 0);
-      rb[i] = ld4(p);
-      int fl = ok ? 1 : 0;
-      if (has_aux) {
-        const bool m1 = ok & s0 & (in_scale != nullptr);
-        const bool m2 = ok & s1 & (gate != nullptr);
-        const float* q = m1 ? in_scale + (size_t)b_img[i] * c0 + c : (m2 ? gate + pix * gate_cs + gate_co + cc : in0);
-        rx[i] = ld4(q);
-        fl |= (m1 ? 2 : 0) | (m2 ? 4 : 0);
-      }
-      bflag[i] = fl;
-    }
-    cur_kc += 1;
-    tap_fresh = false;
-    if (cur_kc == kcpt) {
-      cur_kc = 0;
-      tap_fresh = true;
-      if (++cur_tx == KW) { cur_tx = 0; ++cur_ty; }
-    }
-  };
-
-  auto store_chunk = [&](int buf) {
-    float* a = As + buf * BM * ROW + grp * (BM / 2) * ROW;
-    float* b = Bs + buf * BN * ROW + grp * BNG * ROW;
-#pragma unroll
-    for (int i = 0; i < A_SLOTS; ++i) st4(a + (row0 + i * ROWS_PER_PASS) * ROW + k4 * 4, ra[i]);
-#pragma unroll
-    for (int i = 0; i < B_SLOTS; ++i) {
-      float4 v = rb[i];
-      const int fl = bflag[i];
-      if (has_aux) {
-        const float4 x = rx[i];
-        const bool sc = fl & 2, gt = fl & 4;
-        v.x *= sc ? x.x : (gt ? 1.f - x.x : 1.f); v.y *= sc ? x.y : (gt ? 1.f - x.y : 1.f);
-        v.z *= sc ? x.z : (gt ? 1.f - x.z : 1.f); v.w *= sc ? x.w : (gt ? 1.f - x.w : 1.f);
-      }
-      if (!(fl & 1)) v = zero4();
-      st4(b + (row0 + i * ROWS_PER_PASS) * ROW + k4 * 4, v);
-    }
-  };
-
-  auto compute = [&](int buf) {
-    const float* a = As + buf * BM * ROW + (wm * MT * 16 + j) * ROW + 2 * g;
-    const float* b = Bs + buf * BN * ROW + (grp * BNG + wn * NT * 16 + j) * ROW + 2 * g;
-    float2 fa[2][MT], fb[2][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) fa[0][m] = lds_read_b64(a + m * 16 * ROW);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) fb[0][n] = lds_read_b64(b + n * 16 * ROW);
-#pragma unroll
-    for (int t4 = 0; t4 < BK / 8; ++t4) {
-      const int cur = t4 & 1, nxt = cur ^ 1;
-      if (t4 < BK / 8 - 1) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) fa[nxt][m] = lds_read_b64(a + m * 16 * ROW + 8 * (t4 + 1));
-#pragma unroll
-        for (int n = 0; n < NT; ++n) fb[nxt][n] = lds_read_b64(b + n * 16 * ROW + 8 * (t4 + 1));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][m].x, fb[cur][n].x, acc[m][n], 0, 0, 0);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][m].y, fb[cur][n].y, acc[m][n], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  // prologue: everybody stages its share of chunk 0; group 1 already issues the loads of chunk 1
-  load_chunk(0);
-  store_chunk(0);
-  if (grp == 1 && nchunks > 1) load_chunk(1);
-  __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    if (grp == 0) {                       // phase 2c
-      if (c + 1 < nchunks) load_chunk(c + 1);
-      compute(c & 1);
-    } else if (c + 1 < nchunks) {
-      store_chunk((c + 1) & 1);
-    }
-    __syncthreads();
-    if (grp == 1) {                       // phase 2c+1
-      if (c + 2 < nchunks) load_chunk(c + 2);
-      compute(c & 1);
-    } else if (c + 1 < nchunks) {
-      store_chunk((c + 1) & 1);
-    }
-    __syncthreads();
-  }
-  run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + grp * BNG + wn * NT * 16, lane, Ptot, HWout);
-}
-
-template <int MT, int NT, int EPI>
-static hipError_t launch_pp(const ConvLaunch& L, hipStream_t stream) {
-  constexpr int BM = 32 * MT, BN = 64 * NT;
-  constexpr int lds = 2 * (BM + BN) * (BK + 4) * 4;
-  auto kern = conv_pp_kernel<MT, NT, EPI>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
-  int maxblocks = 0;
-  for (int i = 0; i < L.nprob; ++i) {
-    const ConvProblem& P = L.p[i];
-    int Ptot = P.n_img * P.Hout * P.Wout;
-    int nb = ((Ptot + BN - 1) / BN) * ((P.cout_pad + BM - 1) / BM);
-    if (nb > maxblocks) maxblocks = nb;
-  }
-  if (maxblocks == 0) return hipSuccess;
-  hipLaunchKernelGGL(kern, dim3(maxblocks, L.nprob), dim3(512), lds, stream, L);
-  return hipGetLastError();
-}
-
 // ---- direct-fragment kernel (small pixel counts: the 50x50 BEV latent of the GRU-ODE) -------
 // At 2500 pixels a layer has only 157 pixel tiles: nothing is shared between the waves of a
 // workgroup (each K-group has its own K slice), so staging through LDS buys no reuse and only
@@ -1542,119 +1314,10 @@ hipError_t launch_conv(const ConvLaunch& L, int epi, int cfg, hipStream_t stream
         case EPI_SAMPLE: return launch_cfg<4, 1, 1, 4, 1, EPI_SAMPLE>(L, stream);
       }
       break;
-    // experimental large-P tilings (selected with SF_L_CFG, see api.hip)
-    case 5:   // 128 cout x 64 px, 2x2 waves of 64x32
-      switch (epi) {
-        case EPI_AFFINE: return launch_cfg<4, 2, 2, 2, 1, EPI_AFFINE>(L, stream);
-        case EPI_BLEND:  return launch_cfg<4, 2, 2, 2, 1, EPI_BLEND>(L, stream);
-      }
-      break;
-    case 6:   // 64 cout x 128 px, 2x2 waves of 32x64
-      switch (epi) {
-        case EPI_AFFINE: return launch_cfg<2, 4, 2, 2, 1, EPI_AFFINE>(L, stream);
-        case EPI_BLEND:  return launch_cfg<2, 4, 2, 2, 1, EPI_BLEND>(L, stream);
-      }
-      break;
-    case 7:   // 128 x 128, 2x2 waves of 64x64
-      switch (epi) {
-        case EPI_AFFINE: return launch_cfg<4, 4, 2, 2, 1, EPI_AFFINE>(L, stream);
-        case EPI_BLEND:  return launch_cfg<4, 4, 2, 2, 1, EPI_BLEND>(L, stream);
-      }
-      break;
-    case 8:   // 64 cout x 128 px, 8 waves (2x4) of 32x32
-      switch (epi) {
-        case EPI_AFFINE: return launch_cfg<2, 2, 2, 4, 1, EPI_AFFINE>(L, stream);
-        case EPI_BLEND:  return launch_cfg<2, 2, 2, 4, 1, EPI_BLEND>(L, stream);
-      }
-      break;
     case 9:   // 128 x 128, 8 waves (2x4) of 64x32
       switch (epi) {
         case EPI_AFFINE: return launch_cfg<4, 2, 2, 4, 1, EPI_AFFINE>(L, stream);
         case EPI_BLEND:  return launch_cfg<4, 2, 2, 4, 1, EPI_BLEND>(L, stream);
-      }
-      break;
-    case 20:  // ping-pong, 64 cout x 128 px per workgroup (2 groups of 2x2 waves of 32x32)
-      switch (epi) {
-        case EPI_AFFINE: return launch_pp<2, 2, EPI_AFFINE>(L, stream);
-        case EPI_BLEND:  return launch_pp<2, 2, EPI_BLEND>(L, stream);
-      }
-      break;
-    case 21:  // ping-pong, 128 cout x 128 px (2 groups of 2x2 waves of 64x32)
-      switch (epi) {
-        case EPI_AFFINE: return launch_pp<4, 2, EPI_AFFINE>(L, stream);
-        case EPI_BLEND:  return launch_pp<4, 2, EPI_BLEND>(L, stream);
-      }
-      break;
-    case 22:  // ping-pong, 128 cout x 256 px (2 groups of 2x2 waves of 64x64)
-      switch (epi) {
-        case EPI_AFFINE: return launch_pp<4, 4, EPI_AFFINE>(L, stream);
-        case EPI_BLEND:  return launch_pp<4, 4, EPI_BLEND>(L, stream);
-      }
-      break;
-    case 17:  // 64x64 tile, unpadded swizzled LDS rows (32 KB: 5 workgroups per CU)
-      switch (epi) {
-        case EPI_AFFINE: return launch_cfg<2, 2, 2, 2, 1, EPI_AFFINE, 32, true>(L, stream);
-        case EPI_BLEND:  return launch_cfg<2, 2, 2, 2, 1, EPI_BLEND, 32, true>(L, stream);
-      }
-      break;
-    case 18:  // 128x128 tile, 8 waves, swizzled rows (64 KB: 2 workgroups per CU)
-      switch (epi) {
-        case EPI_AFFINE: return launch_cfg<4, 2, 2, 4, 1, EPI_AFFINE, 32, true>(L, stream);
-        case EPI_BLEND:  return launch_cfg<4, 2, 2, 4, 1, EPI_BLEND, 32, true>(L, stream);
-      }
-      break;
-    case 15:  // 64x64 tile, 16-deep chunks (20 KB of LDS: up to 8 workgroups per CU)
-      switch (epi) {
-        case EPI_AFFINE: return launch_cfg<2, 2, 2, 2, 1, EPI_AFFINE, 16>(L, stream);
-        case EPI_BLEND:  return launch_cfg<2, 2, 2, 2, 1, EPI_BLEND, 16>(L, stream);
-      }
-      break;
-    case 16:  // 128x128 tile, 8 waves, 16-deep chunks
-      switch (epi) {
-        case EPI_AFFINE: return launch_cfg<4, 2, 2, 4, 1, EPI_AFFINE, 16>(L, stream);
-        case EPI_BLEND:  return launch_cfg<4, 2, 2, 4, 1, EPI_BLEND, 16>(L, stream);
-      }
-      break;
-    case 13:  // 64x64 tile, 64-deep chunks (half the barriers; needs cin_pad % 64 == 0)
-      switch (epi) {
-        case EPI_AFFINE: return launch_cfg<2, 2, 2, 2, 1, EPI_AFFINE, 64>(L, stream);
-        case EPI_BLEND:  return launch_cfg<2, 2, 2, 2, 1, EPI_BLEND, 64>(L, stream);
-      }
-      break;
-    case 14:  // 128x128 tile, 8 waves, 64-deep chunks
-      switch (epi) {
-        case EPI_AFFINE: return launch_cfg<4, 2, 2, 4, 1, EPI_AFFINE, 64>(L, stream);
-        case EPI_BLEND:  return launch_cfg<4, 2, 2, 4, 1, EPI_BLEND, 64>(L, stream);
-      }
-      break;
-    case 23:  // 64 cout x 128 px, 4 waves (1x4) of 64x32, 16-deep chunks (30 KB of LDS: 5 workgroups per CU)
-      switch (epi) {
-        case EPI_AFFINE: return launch_cfg<4, 2, 1, 4, 1, EPI_AFFINE, 16>(L, stream);
-        case EPI_BLEND:  return launch_cfg<4, 2, 1, 4, 1, EPI_BLEND, 16>(L, stream);
-      }
-      break;
-    case 25:  // 128 x 128, 8 waves (2x4) of 64x32, 16-deep chunks (40 KB: 4 workgroups per CU)  [= cfg 16]
-      switch (epi) {
-        case EPI_AFFINE: return launch_cfg<4, 2, 2, 4, 1, EPI_AFFINE, 16>(L, stream);
-        case EPI_BLEND:  return launch_cfg<4, 2, 2, 4, 1, EPI_BLEND, 16>(L, stream);
-      }
-      break;
-    case 10:  // 64 cout x 128 px, 4 waves (1x4) of 64x32
-      switch (epi) {
-        case EPI_AFFINE: return launch_cfg<4, 2, 1, 4, 1, EPI_AFFINE>(L, stream);
-        case EPI_BLEND:  return launch_cfg<4, 2, 1, 4, 1, EPI_BLEND>(L, stream);
-      }
-      break;
-    case 11:  // 64 cout x 256 px, 4 waves (1x4) of 64x64
-      switch (epi) {
-        case EPI_AFFINE: return launch_cfg<4, 4, 1, 4, 1, EPI_AFFINE>(L, stream);
-        case EPI_BLEND:  return launch_cfg<4, 4, 1, 4, 1, EPI_BLEND>(L, stream);
-      }
-      break;
-    case 12:  // 64 cout x 256 px, 8 waves (1x8) of 64x32
-      switch (epi) {
-        case EPI_AFFINE: return launch_cfg<4, 2, 1, 8, 1, EPI_AFFINE>(L, stream);
-        case EPI_BLEND:  return launch_cfg<4, 2, 1, 8, 1, EPI_BLEND>(L, stream);
       }
       break;
     case 2:   // LN-capable large tile: 4 waves x (64 cout x 32 px)
