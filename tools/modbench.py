@@ -81,6 +81,15 @@ def main():
         for n in (7, 224):
             conv_case(128, 64, 3, n, 200, 200, 1, 64)
         return
+    if "--fixedcost" in sys.argv:
+        # time = rounds x (a + c x chunks): the same layer at K = 1, 2, 4, 8, 36 chunks of 32 (1x1 convs of 32..256 channels, 3x3 of 128)
+        for cin in (32, 64, 128, 256):
+            conv_case(cin, 128, 1, 112, 200, 200)
+        conv_case(128, 128, 3, 112, 200, 200)
+        for cin in (32, 64, 128, 256):
+            conv_case(cin, 64, 1, 112, 200, 200)
+        conv_case(64, 64, 3, 112, 200, 200)
+        return
     if "--tail" in sys.argv:
         # tail-quantisation probe: 256x256 images = 1024 64-pixel-row tiles each
         for n in (1, 2, 3, 4, 5, 8, 16):
