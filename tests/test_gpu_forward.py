@@ -76,6 +76,40 @@ def test_config2_full_size_vs_oracle_and_reference_stats():
     assert maxabs(y, yr) <= TOL_E2E
 
 
+class _SameNoise:
+    """k-th draw: one hashed sample, repeated over the batch (any batch size sees the same per-sample noise)."""
+
+    def __init__(self):
+        self.k = 0
+
+    def __call__(self, shape, dtype=torch.float32, device="cpu"):
+        e = hashfill.normal(f"same_eps{self.k}", (1,) + tuple(shape[1:]), 7)
+        self.k += 1
+        return e.expand(shape[0], *e.shape[1:]).contiguous()
+
+
+def test_config2_batch32_equals_single_sample():
+    """The bench workload (32 samples per forward: 224-frame tensors of up to 4.6 GB, tiles that straddle images, the
+    large-tile LDS-DMA kernels with 32-bit rebased offsets) against the single-sample forward (small-P kernels) on 32
+    copies of one sample: every copy must equal the single-sample result to 1e-4 and the copies must agree with each
+    other (same kernels, different tile positions and addresses)."""
+    C, H, W, B = 64, 200, 200, 32
+    cts, lts, tts, dt = cases.timeset("shipped")
+    net, _ = build_pair(C, "euler", True, True, dt)
+    cam, lid = cases.bev_inputs(C, H, W, 3, 5)
+    cam, lid = cam.cuda(), lid.cuda()
+    pres = cases.present_input(cam, lid)
+    net.gru_ode.noise = _SameNoise()
+    y1, _ = net(pres, cam, lid, cts, lts, tts)
+    rep = lambda t: t.expand(B, *t.shape[1:]).contiguous()
+    net.gru_ode.noise = _SameNoise()
+    yb, _ = net(rep(pres), rep(cam), rep(lid), cts.expand(B, -1).contiguous(), lts.expand(B, -1).contiguous(),
+                tts.expand(B, -1).contiguous())
+    assert yb.shape == (B,) + tuple(y1.shape[1:])
+    assert float((yb - yb[:1]).abs().max()) <= 1e-6
+    assert float((yb - y1).abs().max()) <= 1e-4
+
+
 def test_rollout_properties_long_horizon():
     """Size-independent properties at full size (46-step streaming schedule, C=64, 50x50 latent):
     (1) the rollout is deterministic for fixed eps (bitwise: fixed-order reductions, no atomics);
