@@ -121,3 +121,34 @@ def _run(c, i):
     if ocs > cout:
         rest = torch.cat([out[..., :oco], out[..., oco + cout:]], -1)
         assert float((rest - 7.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("i", [0, 1, 3, 8])
+def test_dma_conv_is_bitwise_reproducible(i):
+    """A race between the LDS-DMA writes, the fragment reads and the mid-stream barrier would show up as run-to-run
+    differences: 20 launches of the same layer (other kernels interleaved to vary the timing) must agree bit for bit."""
+    from streamingflow_amd import _lib, packing, runtime
+    c = _DMA[i]
+    n, H, W, c0, c1, cout, k = c["n"], c["H"], c["W"], c["c0"], c["c1"], c["cout"], c["k"]
+    g = torch.Generator(device="cuda").manual_seed(1234 + i)
+    a0 = torch.randn((n, H, W, c0), device="cuda", generator=g)
+    a1 = torch.randn((n, H, W, c1), device="cuda", generator=g) if c1 else None
+    w = torch.randn((cout, c0 + c1, k, k), device="cuda", generator=g) * 0.05
+    pk = packing.Pack(None)
+    cw = packing.conv_w(pk, w, c0, c1, act="lrelu", dil=c["dil"], stride=c["stride"], pad=c["pad"])
+    Ho = (H + 2 * c["pad"] - c["dil"] * (k - 1) - 1) // c["stride"] + 1
+    Wo = (W + 2 * c["pad"] - c["dil"] * (k - 1) - 1) // c["stride"] + 1
+    L = _lib.lib()
+    ws = runtime.workspace(L.sf_conv2d_ex_ws_bytes(), "cuda")
+    outs = []
+    for r in range(20):
+        out = torch.empty((n, Ho, Wo, cout), device="cuda")
+        _lib.check(L.sf_conv2d_ex_fwd(ctypes.byref(cw), runtime.ptr(a0), c0, runtime.ptr(a1), c1, None, cout, 0,
+                                      ctypes.c_void_p(out.data_ptr()), cout, 0, n, H, W, 0, runtime.ptr(ws), ws.numel() * 4,
+                                      runtime.stream_ptr()), "conv2d_ex")
+        if r % 3 == 1:
+            torch.randn(1 << (10 + r), device="cuda").sum()      # unrelated work in between
+        outs.append(out)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
