@@ -143,6 +143,9 @@ int large_p() { return tune().large_p; }
 // LDS-DMA kernel: a 32-deep K chunk must come from ONE source tensor (a single input, or two whose channel counts are
 // multiples of the chunk depth); channels past cin are zero-filled by the range check either way
 bool one_source_per_chunk(const ConvProblem& q) { return q.c1 == 0 || ((q.c0 % 32 == 0) && (q.c1 % 32 == 0)); }
+// ... and an SE input scale is applied to the pixel fragments from a small LDS table: single input, <= 256 channels,
+// a (<= 256-pixel) tile touching at most 4 images
+bool scale_ok(const ConvProblem& q) { return !q.in_scale || (q.c1 == 0 && q.cin_pad <= 256 && (long)q.Hout * q.Wout >= 128); }
 
 // Scratch for the cross-workgroup split-K path, carved from the caller's workspace by the
 // top-level entry points (SplitScope) — thread-local pointer, no global allocation.
@@ -260,13 +263,13 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   // middle of the MFMA stream (conv_glds_kernel).  Measured (profiles/r01_v_*): 128x128 tiles +2 %, 64-cout layers
   // +7 % on 64x128 tiles once there are >= 1024 of them, +3 % on 64x64 tiles below that.
   int glds_tile = -1, glds_var = 4;
-  if (tune().glds && (((cfg == 1 || cfg == 9) && (epi == EPI_AFFINE || epi == EPI_BLEND)) ||
+  if (tune().glds && (((cfg == 1 || cfg == 9) && (epi == EPI_AFFINE || epi == EPI_BLEND || epi == EPI_SAMPLE)) ||
                       (cfg == 2 && (epi == EPI_LNG || epi == EPI_TRUST) && (tune().glds & 4)))) {
     bool ok = true;
     long pmin = 1L << 40;
     for (int i = 0; i < n; ++i) {
       const ConvProblem& q = L.p[i];
-      ok = ok && !q.gate && !q.in_scale && q.nsplit <= 1;
+      ok = ok && !q.gate && scale_ok(q) && q.nsplit <= 1;
       ok = ok && one_source_per_chunk(q);
       // 32-bit byte offsets: over the images a (<= 256-pixel) tile can touch (sparse: over all feature rows), and over the packed weights
       const double span = q.gather ? 4.0 * q.Win : (256.0 / ((double)q.Hout * q.Wout) + 2.0) * q.Hin * q.Win * 4.0;   // bytes per channel stride unit
@@ -281,7 +284,10 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       for (int i = 0; i < n; ++i) narrow = narrow && L.p[i].cout_pad <= 32;
       if (narrow && tune().narrow >= 0) glds_var = tune().narrow;
     }
-    if (ok && cfg == 2) glds_tile = 2;
+    bool scaled = false;
+    for (int i = 0; i < n; ++i) scaled = scaled || (L.p[i].in_scale != nullptr);
+    if (ok && cfg == 2 && !scaled) glds_tile = 2;
+    if (scaled && glds_tile == 2) glds_tile = -1;
   }
   // small pixel counts: the same kernel on 32x32 tiles beats the direct-fragment kernel by 5-15 % per plain layer
   // (profiles/r01_v_sweep_glds_wide_tiles.txt; single-sample rollout 5.10 -> 4.64 ms with the pre-gated candidates).
@@ -297,11 +303,11 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     }
     if (ok) glds_tile = 4;
   }
-  if (tune().small_dma >= 0 && (cfg == 0 || cfg == 3) && (epi == EPI_AFFINE || epi == EPI_BLEND)) {
+  if (tune().small_dma >= 0 && (cfg == 0 || cfg == 3) && (epi == EPI_AFFINE || epi == EPI_BLEND || epi == EPI_SAMPLE)) {
     bool ok = true;
     for (int i = 0; i < n; ++i) {
       const ConvProblem& q = L.p[i];
-      ok = ok && !q.gate && !q.in_scale && !q.gather && q.nsplit <= 1 && one_source_per_chunk(q);
+      ok = ok && !q.gate && scale_ok(q) && !q.gather && q.nsplit <= 1 && one_source_per_chunk(q);
     }
     if (ok) { glds_tile = 3; glds_var = tune().small_dma; }
     if (tune().glds_var >= 0) glds_var = tune().glds_var;

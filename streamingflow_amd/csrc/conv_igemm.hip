@@ -671,7 +671,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
 // out-of-range lanes fail the buffer range check (a DMA cannot be masked).  Layers with a gate, an SE scale, a
 // neighbour table or channel counts that are not multiples of 32 stay on conv_igemm_kernel.  (tools/experiments/diag_loop.sh: without its staging the shipped loop runs at
 // 134 instead of 115 TFLOP/s on a 7-frame 128->128 layer; global loads cost 10 %, the LDS writes 6 %.)
-template <int MT, int NT, int WM, int WN, int EPI, int NB, bool INTERLEAVE, int PIPE>
+template <int MT, int NT, int WM, int WN, int EPI, int NB, bool SCALE>
 __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunch L) {
   constexpr int NWV = WM * WN;
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
@@ -712,6 +712,26 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
   const int HWout = P.Hout * P.Wout;
   const int* const gather = P.gather;
   const int KHg = P.KH;
+  // SE-scaled input (res_models.py:161-165 feeding the next conv): a DMA cannot multiply, so the per-(image, channel)
+  // scale is applied to the pixel fragments after they are read from LDS.  The scale rows of the (at most SC_IMGS)
+  // images this tile touches sit behind the staging buffers; a lane's pixel of n-tile n belongs to image slot simg[n].
+  constexpr int SC_IMGS = 4;
+  const float* const in_scale = SCALE ? P.in_scale : nullptr;       // block-uniform; the plain instantiation carries none of this
+  float* const sc_lds = smem + NB * BUF;          // [SC_IMGS][cin_pad]
+  const int cin_pad = P.cin_pad;
+  int simg[NT];
+  if (SCALE && in_scale) {
+    for (int idx = tid; idx < SC_IMGS * cin_pad; idx += 64 * NWV) {
+      const int si = idx / cin_pad, c = idx - si * cin_pad;
+      sc_lds[idx] = (img0 + si < P.n_img && c < c0) ? in_scale[(size_t)(img0 + si) * c0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int gp = p_tile * BN + (wn * NT + n) * 16 + j;
+      simg[n] = (gp < Ptot ? gp / HWout - img0 : 0) * cin_pad;
+    }
+  }
 
   // staging slots.  Weight slot q (q < GA) of this wave fills rows (wave*GA + q)*8 .. +7 of the A block, pixel slot q
   // rows (wave*GB + q)*8 .. +7 of the B block; this lane: row + lane/8, 16-B slot lane%8 holding K values
@@ -840,130 +860,46 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
 
   const int sx = (j >> 1) & 7;
   auto koff = [&](int t4) { return 4 * ((2 * t4 + (g >> 1)) ^ sx) + ((2 * g) & 3); };
-  // MFMAs of one chunk; with INTERLEAVE the LDS-DMAs of chunk `ichunk` (if >= 0) are issued between the k-groups
-  auto compute = [&](int buf, int ichunk, int ibuf) {
+  // Barrier in the middle of the MFMA stream (two buffers): the last k-group of chunk c is multiplied AFTER the
+  // barrier that publishes chunk c+1, from fragments read before it, and the first fragments of chunk c+1 are read
+  // under those MFMAs — a wave leaves the barrier with 2*MT*NT MFMAs ready to issue instead of a DMA-issue +
+  // LDS-read-latency bubble.  The DMAs of chunk c+2 go out right after the same barrier (its buffer is free then).
+  constexpr int NG = BK / 8;
+  float2 fa[2][MT], fb[2][NT], fs[2][NT];
+  int kc_cmp = cb % kcpt;     // channel chunk of the chunk being multiplied (the issue cursor runs ahead)
+  auto read_frags = [&](int buf, int t4, int set) {
     const float* a = smem + buf * BUF + (wm * MT * 16 + j) * 32;
     const float* b = smem + buf * BUF + (BM + wn * NT * 16 + j) * 32;
-    float2 fa[2][MT], fb[2][NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) fa[0][m] = lds_read_b64(a + m * 16 * 32 + koff(0));
+    for (int m = 0; m < MT; ++m) fa[set][m] = lds_read_b64(a + m * 16 * 32 + koff(t4));
 #pragma unroll
-    for (int n = 0; n < NT; ++n) fb[0][n] = lds_read_b64(b + n * 16 * 32 + koff(0));
-    constexpr int NG = BK / 8;
+    for (int n = 0; n < NT; ++n) fb[set][n] = lds_read_b64(b + n * 16 * 32 + koff(t4));
+    if (SCALE && in_scale) {      // logical K pair of this lane in the k-group: 8*t4 + 2*g, +1 (the slot swizzle only moves storage)
 #pragma unroll
-    for (int t4 = 0; t4 < NG; ++t4) {
-      const int cur = t4 & 1, nxt = cur ^ 1;
-      if (t4 < NG - 1) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) fa[nxt][m] = lds_read_b64(a + m * 16 * 32 + koff(t4 + 1));
-#pragma unroll
-        for (int n = 0; n < NT; ++n) fb[nxt][n] = lds_read_b64(b + n * 16 * 32 + koff(t4 + 1));
-      }
-      if (INTERLEAVE && ichunk >= 0) {      // block-uniform
-#pragma unroll
-        for (int q = 0; q < G; ++q)
-          if (q * NG / G == t4) issue_one(ichunk, ibuf, q);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (SETPRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][m].x, fb[cur][n].x, acc[m][n], 0, 0, 0);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][m].y, fb[cur][n].y, acc[m][n], 0, 0, 0);
-      if (SETPRIO) __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int n = 0; n < NT; ++n) fs[set][n] = lds_read_b64(sc_lds + simg[n] + kc_cmp * BK + 8 * t4 + 2 * g);
     }
   };
-
-  if constexpr (PIPE > 0) {
-    // Barrier in the middle of the MFMA stream (two buffers): the last k-group of chunk c is multiplied AFTER the
-    // barrier that publishes chunk c+1, from fragments read before it, and the first fragments of chunk c+1 are read
-    // under those MFMAs — a wave leaves the barrier with 2*MT*NT MFMAs ready to issue instead of a DMA-issue +
-    // LDS-read-latency bubble.  The DMAs of chunk c+2 go out right after the same barrier (its buffer is free then).
-    constexpr int NG = BK / 8;
-    float2 fa[2][MT], fb[2][NT];
-    auto read_frags = [&](int buf, int t4, int set) {
-      const float* a = smem + buf * BUF + (wm * MT * 16 + j) * 32;
-      const float* b = smem + buf * BUF + (BM + wn * NT * 16 + j) * 32;
+  auto mfmas = [&](int set) {
+    if (SCALE && in_scale) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m) fa[set][m] = lds_read_b64(a + m * 16 * 32 + koff(t4));
-#pragma unroll
-      for (int n = 0; n < NT; ++n) fb[set][n] = lds_read_b64(b + n * 16 * 32 + koff(t4));
-    };
-    auto mfmas = [&](int set) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (SETPRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][m].x, fb[set][n].x, acc[m][n], 0, 0, 0);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][m].y, fb[set][n].y, acc[m][n], 0, 0, 0);
-      if (SETPRIO) __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    // prologue: LA = NB-1 chunks in flight, the first one retired and published
-#pragma unroll
-    for (int c = 0; c < LA; ++c)
-      if (c < nchunks) {      // block-uniform
-#pragma unroll
-        for (int q = 0; q < G; ++q) issue_one(cb + c, c, q);
-      }
-    if (LA > 1 && nchunks >= LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // Iteration c starts right after the barrier that published chunk c: read its first fragments, multiply the LAST
-    // k-group of chunk c-1 (read before the barrier) under that latency, start the DMAs of chunk c+LA into the buffer
-    // the barrier just freed (chunk c-1's), then k-groups 0..NG-2 of chunk c, then retire chunk c+1 (a counted vmcnt:
-    // the LA-1 younger chunks stay in flight).  No LDS read is in flight across the back edge, so the compiler's
-    // lgkmcnt bookkeeping stays exact.
-    int buf = 0, ibuf = LA;
-    for (int c = 0; c < nchunks; ++c) {
-      const bool more = c + LA < nchunks;
-      read_frags(buf, 0, 0);
-      if (PIPE == 2 && more) {
-#pragma unroll
-        for (int q = 0; q < G; ++q) issue_one(cb + c + LA, ibuf, q);
-      }
-      if (c > 0) mfmas((NG - 1) & 1);
-      if (PIPE == 1 && more) {
-#pragma unroll
-        for (int q = 0; q < G; ++q) issue_one(cb + c + LA, ibuf, q);
-      }
-#pragma unroll
-      for (int t4 = 0; t4 < NG - 1; ++t4) {
-        read_frags(buf, t4 + 1, (t4 + 1) & 1);
-        mfmas(t4 & 1);
-      }
-      if (c + 1 < nchunks) {
-        if (LA > 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      }
-      buf = buf == NB - 1 ? 0 : buf + 1;
-      ibuf = ibuf == NB - 1 ? 0 : ibuf + 1;
+      for (int n = 0; n < NT; ++n) { fb[set][n].x *= fs[set][n].x; fb[set][n].y *= fs[set][n].y; }
     }
-    mfmas((NG - 1) & 1);
-    if (nsplit > 1) {      // block-uniform
-      __syncthreads();     // the hand-off flag lives in the staging buffers: every wave is done reading them
-      if (!splitk_handoff<MT, NT, NWV>(P, acc, nsplit, bid, wave, lane, tid, smem)) return;
-    }
-    run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
-    return;
-  }
-
-  // prologue: LA chunks in flight, the first one retired
+    __builtin_amdgcn_sched_barrier(0);
+    if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][m].x, fb[set][n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][m].y, fb[set][n].y, acc[m][n], 0, 0, 0);
+    if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // prologue: LA = NB-1 chunks in flight, the first one retired and published
 #pragma unroll
   for (int c = 0; c < LA; ++c)
     if (c < nchunks) {      // block-uniform
@@ -973,30 +909,48 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
   if (LA > 1 && nchunks >= LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  int bc = 0, bi = LA;           // buffer of the chunk being computed / of the chunk being issued
+  // Iteration c starts right after the barrier that published chunk c: read its first fragments, multiply the LAST
+  // k-group of chunk c-1 (read before the barrier) under that latency, start the DMAs of chunk c+LA into the buffer
+  // the barrier just freed (chunk c-1's), then k-groups 0..NG-2 of chunk c, then retire chunk c+1 (a counted vmcnt:
+  // the LA-1 younger chunks stay in flight).  No LDS read is in flight across the back edge, so the compiler's
+  // lgkmcnt bookkeeping stays exact.
+  int buf = 0, ibuf = LA;
   for (int c = 0; c < nchunks; ++c) {
     const bool more = c + LA < nchunks;
-    if (!INTERLEAVE && more) {
+    read_frags(buf, 0, 0);
+    if (c > 0) mfmas((NG - 1) & 1);
+    if (more) {
 #pragma unroll
-      for (int q = 0; q < G; ++q) issue_one(cb + c + LA, bi, q);
+      for (int q = 0; q < G; ++q) issue_one(cb + c + LA, ibuf, q);
     }
-    compute(bc, more ? c + LA : -1, bi);
-    if (LA > 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    bc = bc == NB - 1 ? 0 : bc + 1;
-    bi = bi == NB - 1 ? 0 : bi + 1;
+#pragma unroll
+    for (int t4 = 0; t4 < NG - 1; ++t4) {
+      read_frags(buf, t4 + 1, (t4 + 1) & 1);
+      mfmas(t4 & 1);
+    }
+    if (c + 1 < nchunks) {
+      if (LA > 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    buf = buf == NB - 1 ? 0 : buf + 1;
+    ibuf = ibuf == NB - 1 ? 0 : ibuf + 1;
+    kc_cmp = kc_cmp + 1 == kcpt ? 0 : kc_cmp + 1;
   }
-  if (nsplit > 1 && !splitk_handoff<MT, NT, NWV>(P, acc, nsplit, bid, wave, lane, tid, smem)) return;
+  mfmas((NG - 1) & 1);
+  if (nsplit > 1) {      // block-uniform
+    __syncthreads();     // the hand-off flag lives in the staging buffers: every wave is done reading them
+    if (!splitk_handoff<MT, NT, NWV>(P, acc, nsplit, bid, wave, lane, tid, smem)) return;
+  }
   run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
 }
 
-template <int MT, int NT, int WM, int WN, int EPI, int NB, bool IL, int PIPE>
+template <int MT, int NT, int WM, int WN, int EPI, bool SCALE = false, int NB = 2>
 static hipError_t launch_glds_t(const ConvLaunch& L, hipStream_t stream) {
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
-  constexpr int lds = NB * (BM + BN) * 32 * 4;
-  auto kern = conv_glds_kernel<MT, NT, WM, WN, EPI, NB, IL, PIPE>;
+  constexpr int lds = NB * (BM + BN) * 32 * 4 + 4 * 256 * 4;   // staging buffers + the SE scale rows of up to 4 images x 256 channels
+  auto kern = conv_glds_kernel<MT, NT, WM, WN, EPI, NB, SCALE>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1018,45 +972,52 @@ static hipError_t launch_glds_t(const ConvLaunch& L, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <int MT, int NT, int WM, int WN, int NB, bool IL, int PIPE = 0>
+template <int MT, int NT, int WM, int WN>
 static hipError_t launch_glds_e(const ConvLaunch& L, int epi, hipStream_t stream) {
-  if (epi == EPI_AFFINE) return launch_glds_t<MT, NT, WM, WN, EPI_AFFINE, NB, IL, PIPE>(L, stream);
-  if (epi == EPI_BLEND) return launch_glds_t<MT, NT, WM, WN, EPI_BLEND, NB, IL, PIPE>(L, stream);
+  if (epi == EPI_AFFINE) return launch_glds_t<MT, NT, WM, WN, EPI_AFFINE>(L, stream);
+  if (epi == EPI_BLEND) return launch_glds_t<MT, NT, WM, WN, EPI_BLEND>(L, stream);
+  return hipErrorInvalidValue;
+}
+// SE-scaled inputs (the two p_model layers behind an SELayer): affine and sampling epilogues
+template <int MT, int NT, int WM, int WN>
+static hipError_t launch_glds_s(const ConvLaunch& L, int epi, hipStream_t stream) {
+  if (epi == EPI_AFFINE) return launch_glds_t<MT, NT, WM, WN, EPI_AFFINE, true>(L, stream);
+  if (epi == EPI_SAMPLE) return launch_glds_t<MT, NT, WM, WN, EPI_SAMPLE, true>(L, stream);
   return hipErrorInvalidValue;
 }
 
 // tile: 0 = 128 cout x 128 px (2x4 waves of 64x32), 1 = 64 x 64 (2x2 waves of 32x32);  variant: buffers / issue placement
 hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant, hipStream_t stream) {
+  bool scaled = false;
+  for (int i = 0; i < L.nprob; ++i) scaled = scaled || (L.p[i].in_scale != nullptr);
+  if (scaled || epi == EPI_SAMPLE) {     // 64x64 tiles (large P), 32x32 (one latent)
+    if (tile == 3) return launch_glds_s<1, 1, 2, 2>(L, epi, stream);
+    if (tile == 1 || tile == 0) return launch_glds_s<2, 2, 2, 2>(L, epi, stream);
+    return hipErrorInvalidValue;
+  }
   if (tile == 2) {   // LayerNorm epilogues: one wave holds all (<= 64) output channels of its pixels; 64 cout x 128 px, 4 waves
-    if (epi == EPI_LNG) return launch_glds_t<4, 2, 1, 4, EPI_LNG, 2, false, 1>(L, stream);
-    if (epi == EPI_TRUST) return launch_glds_t<4, 2, 1, 4, EPI_TRUST, 2, false, 1>(L, stream);
+    if (epi == EPI_LNG) return launch_glds_t<4, 2, 1, 4, EPI_LNG>(L, stream);
+    if (epi == EPI_TRUST) return launch_glds_t<4, 2, 1, 4, EPI_TRUST>(L, stream);
     return hipErrorInvalidValue;
   }
   if (tile == 4) {   // cross-workgroup split-K launches: 64 cout x 64 px, 4 waves of 64x16 (all channels of a pixel in one wave)
     switch (epi) {
-      case EPI_AFFINE: return launch_glds_t<4, 1, 1, 4, EPI_AFFINE, 2, false, 1>(L, stream);
-      case EPI_BLEND:  return launch_glds_t<4, 1, 1, 4, EPI_BLEND, 2, false, 1>(L, stream);
-      case EPI_LNG:    return launch_glds_t<4, 1, 1, 4, EPI_LNG, 2, false, 1>(L, stream);
-      case EPI_TRUST:  return launch_glds_t<4, 1, 1, 4, EPI_TRUST, 2, false, 1>(L, stream);
+      case EPI_AFFINE: return launch_glds_t<4, 1, 1, 4, EPI_AFFINE>(L, stream);
+      case EPI_BLEND:  return launch_glds_t<4, 1, 1, 4, EPI_BLEND>(L, stream);
+      case EPI_LNG:    return launch_glds_t<4, 1, 1, 4, EPI_LNG>(L, stream);
+      case EPI_TRUST:  return launch_glds_t<4, 1, 1, 4, EPI_TRUST>(L, stream);
     }
     return hipErrorInvalidValue;
   }
   if (tile == 3) {   // small pixel counts (one 50x50 latent): 32 cout x 32 px, 4 waves of 16x16
-    return launch_glds_e<1, 1, 2, 2, 2, false, 1>(L, epi, stream);
+    return launch_glds_e<1, 1, 2, 2>(L, epi, stream);
   }
-  if (tile == 0) {
-    switch (variant) {
-      case 0: return launch_glds_e<4, 2, 2, 4, 2, false, 0>(L, epi, stream);   // barrier at the end of the chunk
-      default: return launch_glds_e<4, 2, 2, 4, 2, false, 1>(L, epi, stream);  // barrier in the middle of the MFMA stream
-    }
-  } else {
-    switch (variant) {
-      case 0: return launch_glds_e<2, 2, 2, 2, 2, false, 0>(L, epi, stream);
-      case 4: return launch_glds_e<2, 2, 2, 2, 2, false, 1>(L, epi, stream);
-      case 6: return launch_glds_e<2, 2, 2, 4, 2, false, 1>(L, epi, stream);   // 64 cout x 128 px, 8 waves of 32x32
-      case 7: return launch_glds_e<4, 2, 1, 4, 2, false, 1>(L, epi, stream);   // 64 cout x 128 px, 4 waves of 64x32
-      case 9: return launch_glds_e<1, 4, 2, 2, 2, false, 1>(L, epi, stream);   // 32 cout x 128 px, 4 waves of 16x64 (32-channel sparse stage)
-    }
+  if (tile == 0) return launch_glds_e<4, 2, 2, 4>(L, epi, stream);     // 128 cout x 128 px, 8 waves of 64x32
+  switch (variant) {
+    case 4: return launch_glds_e<2, 2, 2, 2>(L, epi, stream);   // 64 cout x 64 px, 4 waves of 32x32
+    case 6: return launch_glds_e<2, 2, 2, 4>(L, epi, stream);   // 64 cout x 128 px, 8 waves of 32x32
+    case 7: return launch_glds_e<4, 2, 1, 4>(L, epi, stream);   // 64 cout x 128 px, 4 waves of 64x32
+    case 9: return launch_glds_e<1, 4, 2, 2>(L, epi, stream);   // 32 cout x 128 px, 4 waves of 16x64 (narrow layers: 16- / 32-channel sparse stages)
   }
   return hipErrorInvalidValue;
 }
