@@ -662,15 +662,17 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
   run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
 }
 
-// ---- LDS-DMA variant of the staged kernel (large pixel counts, plain layers) ----------------------
-// Same tiles and the same MFMA / fragment-read loop as conv_igemm_kernel, but the operands go global -> LDS with
-// global_load_lds_dwordx4: no VGPR round trip, no ds_write, no staging registers.  NB unpadded LDS buffers of a
-// 32-deep chunk, NB-1 chunks in flight, a counted vmcnt retires the oldest and one barrier per chunk publishes it.
-// An LDS-DMA instruction writes 64 x 16 B = eight 128-B rows contiguously, so rows are unpadded and the eight
-// 16-B slots of a row are XOR-swizzled with (row >> 1) & 7 — applied to the per-lane SOURCE address.  Zero padding /
-// out-of-range lanes fail the buffer range check (a DMA cannot be masked).  Layers with a gate, an SE scale, a
-// neighbour table or channel counts that are not multiples of 32 stay on conv_igemm_kernel.  (tools/experiments/diag_loop.sh: without its staging the shipped loop runs at
-// 134 instead of 115 TFLOP/s on a 7-frame 128->128 layer; global loads cost 10 %, the LDS writes 6 %.)
+// ---- LDS-DMA kernel: the shipped implicit-GEMM kernel for every layer whose operands can be staged by a DMA ----------
+// Same tiles and MFMA order as conv_igemm_kernel, but the operands go global -> LDS with buffer_load_dwordx4 ... lds:
+// no VGPR round trip, no ds_write, no staging registers.  NB (2) unpadded LDS buffers of a 32-deep chunk.  An LDS-DMA
+// instruction writes 64 x 16 B = eight 128-B rows contiguously, so rows are unpadded and the eight 16-B slots of a row
+// are XOR-swizzled with (row >> 1) & 7 — applied to the per-lane SOURCE address.  Zero padding / out-of-range lanes
+// fail the buffer range check (a DMA cannot be masked).  Handled here: channel concat of two inputs (multiples of 32
+// channels) or one input of any width, stride, dilation, nearest x2 upsampling on read, the neighbour table of a sparse
+// convolution, cross-workgroup split-K, and (SCALE instantiation) a per-(image, channel) SE scale applied to the pixel
+// fragments after the LDS read.  A reset-gate multiply is not: the GRU gates launch writes (1 - r) * s instead.
+// (tools/experiments/diag_loop.sh: without its staging the register-staged loop runs at 134 instead of 115 TFLOP/s on a
+// 7-frame 128->128 layer — global loads cost 10 %, the LDS writes 6 %; this kernel reaches 126, 134 at 224 frames.)
 template <int MT, int NT, int WM, int WN, int EPI, int NB, bool SCALE>
 __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunch L) {
   constexpr int NWV = WM * WN;
