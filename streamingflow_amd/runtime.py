@@ -20,12 +20,13 @@ def require_cuda(*tensors):
 
 
 def workspace(nbytes, device):
-    """Grow-only fp32 scratch buffer per device (pointer is stable while it does not grow)."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    """Grow-only fp32 scratch buffer per (device, stream) (pointer is stable while it does not grow)."""
+    dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)     # one scratch per stream: forwards on different streams may overlap
     cur = _WORKSPACES.get(key)
     need = (int(nbytes) + 3) // 4 + 1024
     if cur is None or cur.numel() < need:
-        _WORKSPACES[key] = cur = torch.empty(need, dtype=torch.float32, device=torch.device("cuda", key))
+        _WORKSPACES[key] = cur = torch.empty(need, dtype=torch.float32, device=torch.device("cuda", dev))
     return cur
 
 
