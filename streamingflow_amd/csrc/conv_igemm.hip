@@ -18,6 +18,7 @@
 //   i.e. four consecutive channels of one pixel => NHWC float4 stores, and per-pixel channel
 //   reductions (LayerNorm, 1x1->2 logits) are in-register sums + two xor-shuffles (16, 32).
 #include "sf_device.h"
+#include <cstdlib>
 
 namespace sf {
 
@@ -70,9 +71,16 @@ __device__ __forceinline__ float2 lds_read_b64(const float* p) {
 #define SF_SETPRIO 1
 #endif
 constexpr bool SETPRIO = SF_SETPRIO;
-#ifndef SF_XCD_SWIZZLE
-#define SF_XCD_SWIZZLE 0   // XCD-contiguous tile order in the LDS-DMA kernel: measured flat on single layers, -1.8 % on the bench
-#endif
+// log2 of the XCD tile chunk of the LDS-DMA kernel's large launches (SF_XCD_CHUNK = 32 tiles; 0 switches the order off)
+static int xcd_chunk_log2() {
+  static const int v = [] {
+    const char* e = std::getenv("SF_XCD_CHUNK");
+    int c = e ? std::atoi(e) : 32, l = -1;
+    while (c > 0) { ++l; c >>= 1; }
+    return l;
+  }();
+  return v;
+}
 #ifndef SF_GDIAG
 #define SF_GDIAG 0  // same for the LDS-DMA kernel: 1 = weights only, 2 = pixels only, 3 = every chunk re-reads chunk 0, 4 = no DMA
 #endif
@@ -688,11 +696,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
   const ConvProblem& P = L.p[blockIdx.y];
   const int Ptot = P.n_img * P.Hout * P.Wout;
   const int n_mt = (P.cout_pad + BM - 1) / BM;
-  // Optional XCD-aware tile order (off: it measured flat, the layers are not L2-miss bound): workgroups are dealt
-  // round-robin to the 8 XCDs (each with its own L2), so workgroup b runs on XCD b % 8; giving XCD x the contiguous
-  // tile range [x * gridDim.x/8, (x+1) * gridDim.x/8) keeps the halo rows that neighbouring pixel tiles share in ONE
-  // L2 instead of three (the host pads gridDim.x to a multiple of 8)
-  const int bid = SF_XCD_SWIZZLE ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  // XCD-aware tile order for large launches.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+  // workgroup b runs on XCD b % 8.  With the plain order the three pixel rows a 3x3 tile reads are tiles of three
+  // different XCDs and every L2 fetches them again (6.1 GB of fabric traffic per launch of the dominant kernel for
+  // 3.2 GB of algorithmic bytes); here XCD x takes the chunks x, x+8, ... of 2^k consecutive tiles, which keeps the
+  // halo rows in one L2 (3.8 GB) while the chunks still balance the tail.  The host pads gridDim.x to 8 chunks and
+  // only asks for it when a launch has thousands of tiles (a small launch would leave XCDs idle).
+  int bid = (int)blockIdx.x;
+  if (L.xcd_shift) {      // block-uniform
+    const int sh = L.xcd_shift - 1, i = bid >> 3;
+    bid = ((((i >> sh) << 3) + (bid & 7)) << sh) + (i & ((1 << sh) - 1));
+  }
   const int m_tile = bid % n_mt;
   const int p_tile = bid / n_mt;
   if (p_tile * BN >= Ptot) return;   // block-uniform
@@ -969,8 +983,14 @@ static hipError_t launch_glds_t(const ConvLaunch& L, hipStream_t stream) {
   if (maxblocks == 0) return hipSuccess;
   int zs = 1;
   for (int i = 0; i < L.nprob; ++i) zs = L.p[i].nsplit > zs ? L.p[i].nsplit : zs;
-  if (SF_XCD_SWIZZLE) maxblocks = (maxblocks + 7) & ~7;      // see the tile order in the kernel
-  hipLaunchKernelGGL(kern, dim3(maxblocks, L.nprob, zs), dim3(64 * WM * WN), lds, stream, L);
+  ConvLaunch LL = L;
+  LL.xcd_shift = 0;
+  if (xcd_chunk_log2() >= 0 && maxblocks >= 4096 && zs == 1) {      // see the tile order in the kernel
+    const int span = 8 << xcd_chunk_log2();
+    maxblocks = (maxblocks + span - 1) / span * span;
+    LL.xcd_shift = xcd_chunk_log2() + 1;
+  }
+  hipLaunchKernelGGL(kern, dim3(maxblocks, L.nprob, zs), dim3(64 * WM * WN), lds, stream, LL);
   return hipGetLastError();
 }
 

@@ -70,6 +70,7 @@ struct ConvProblem {
 struct ConvLaunch {
   ConvProblem p[SF_MAX_GROUP];
   int nprob;
+  int xcd_shift;   // LDS-DMA kernel, large launches: log2 of the XCD tile chunk + 1 (0: workgroup b computes tile b)
 };
 
 }  // namespace sf
