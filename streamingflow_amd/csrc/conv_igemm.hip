@@ -965,7 +965,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
 template <int MT, int NT, int WM, int WN, int EPI, bool SCALE = false, int NB = 2>
 static hipError_t launch_glds_t(const ConvLaunch& L, hipStream_t stream) {
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
-  constexpr int lds = NB * (BM + BN) * 32 * 4 + 4 * 256 * 4;   // staging buffers + the SE scale rows of up to 4 images x 256 channels
+  constexpr int lds = NB * (BM + BN) * 32 * 4 + (SCALE ? 4 * 256 * 4 : 0);   // staging buffers (+ the SE scale rows of up to 4 images x 256 channels)
   auto kern = conv_glds_kernel<MT, NT, WM, WN, EPI, NB, SCALE>;
   static bool attr_done = false;
   if (!attr_done) {
