@@ -19,10 +19,10 @@ for d in sorted(glob.glob(os.path.join(R, "gpurun_out", "pmcd_*"))):
     fs = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
     if not fs: continue
     for r in csv.DictReader(open(fs[-1])):
-        if "conv_igemm_kernel<4, 2, 2, 4, 1, 0" in r["Kernel_Name"] and r["Grid_Size"] == "1120256":
-            agg["L128x128w8 128->128 3x3 n7"][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        if "conv_igemm_kernel<2, 2, 2, 2, 1, 0" in r["Kernel_Name"] and r["Grid_Size"] == "1120000":
-            agg["L64x64 64->64 3x3 n7"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "conv_glds_kernel<4, 2, 2, 4, 0" in r["Kernel_Name"] and r["Grid_Size"] == "1120256":
+            agg["LDS-DMA 128x128 tiles, 128->128 3x3 n7 (and the two other 7-frame 128-cout layers of --bigconvs)"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "conv_glds_kernel<2, 2, 2, 4, 0" in r["Kernel_Name"] and r["Grid_Size"] == "1120256":
+            agg["LDS-DMA 64x128 tiles, 64->64 3x3 n7"][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(os.path.join(R, "gpurun_out", "pmc_diag.txt"), "w") as f:
     for k, v in agg.items():
         f.write(k + "\n")
