@@ -371,9 +371,15 @@ int sf_event_destroy(void* ev);
 /* Per-launch profiler for bench.py (off by default): when enabled every implicit-GEMM launch is
  * bracketed by hipEvents on its own stream.  sf_prof_collect fills SF_PROF_KEYS-entry arrays indexed by
  * kernel key = tile_config*8 + epilogue (calls, total ms, algorithmic flops, algorithmic bytes). */
-#define SF_PROF_KEYS 112
+#define SF_PROF_KEYS 120
 int sf_prof_enable(int on);
 int sf_prof_collect(int32_t* calls, double* ms, double* flops, double* bytes);
+
+/* Diagnostic builds of the library only (hipcc -DSF_STAMP; the product build returns SF_ERR_UNSUPPORTED): `buf` is a
+ * device buffer of 64 slots x 4096 workgroups x 8 uint64; every implicit-GEMM launch then takes the next slot (mod 64)
+ * and wave 0 of each workgroup records s_memrealtime (100 MHz) at entry / prologue done / first chunk landed / K loop
+ * done / split-K hand-off done / epilogue stores issued / stores drained.  NULL switches it off. */
+int sf_debug_stamps(void* buf);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
 
 SF_COEF_STRIDE = 12
-SF_PROF_KEYS = 112
+SF_PROF_KEYS = 120
 ACT = {"none": 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4, "gelu": 5}
 SOLVER = {"euler": 0, "midpoint": 1, "rk4": 2}
 OP_JUMP, OP_STEP = 0, 1
@@ -147,11 +147,13 @@ SIGNATURES = {
     "sf_event_destroy": (_i, [_vp]),
     "sf_prof_enable": (_i, [_i]),
     "sf_prof_collect": (_i, [i32p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "sf_debug_stamps": (_i, [_vp]),
 }
 
 # kernel key = tile_config*8 + epilogue  (csrc/conv_igemm.hip launch_conv; configs 10..13: the LDS-DMA kernel conv_glds_kernel)
-KERNEL_NAMES = {c * 8 + e: (f"conv_glds<{cn[3:]},{en}>" if cn.startswith("dma") else f"conv_igemm<{cn},{en}>") for c, cn in enumerate(("S16x64k4", "L64x64", "LN64x128", "direct16px", "T64x64splitK", "L128x64", "L64x128", "L128x128w4", "L64x128w8", "L128x128w8",
-                                                                       "dma128x128w8", "dma64x64", "dma64x128w8", "dmaLN64x128"))
+KERNEL_NAMES = {c * 8 + e: (f"conv_glds<{cn[3:]},{en}>" if cn.startswith("dma") else f"conv_sp<{cn[2:]},{en}>" if cn.startswith("sp") else f"conv_igemm<{cn},{en}>")
+                for c, cn in enumerate(("S16x64k4", "L64x64", "LN64x128", "direct16px", "T64x64splitK", "L128x64", "L64x128", "L128x128w4", "L64x128w8", "L128x128w8",
+                                        "dma128x128w8", "dma64x64", "dma64x128w8", "dmaLN64x128", "sp64x32"))
                 for e, en in enumerate(("affine", "blend", "ln_gelu", "trust", "sample"))}
 
 _LIB = None

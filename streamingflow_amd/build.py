@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsfnative.so")
-SOURCES = ["conv_igemm.hip", "aux_kernels.hip", "api.hip", "lift_splat.hip", "voxelize.hip", "sparse_index.hip", "eval_kernels.hip"]
+SOURCES = ["conv_igemm.hip", "conv_sp.hip", "aux_kernels.hip", "api.hip", "lift_splat.hip", "voxelize.hip", "sparse_index.hip", "eval_kernels.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
@@ -22,7 +22,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    headers = [os.path.join(CSRC, "sf_device.h"), os.path.join(HERE, "..", "include", "sfnative.h")]
+    headers = [os.path.join(CSRC, "sf_device.h"), os.path.join(CSRC, "sf_math.h"), os.path.join(HERE, "..", "include", "sfnative.h")]
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -12,6 +12,9 @@ namespace sf {
 hipError_t launch_conv(const ConvLaunch& L, int epi, int cfg, hipStream_t stream);
 hipError_t launch_conv_direct(const ConvLaunch& L, int epi, int mt, int ks, hipStream_t stream);
 hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant, hipStream_t stream);
+hipError_t set_stamp_buffer(unsigned long long* p);
+hipError_t set_stamp_buffer_sp(unsigned long long* p);
+hipError_t launch_conv_sp(const ConvLaunch& L, int epi, bool scaled, int bn, hipStream_t stream);
 hipError_t launch_transpose(const float* in, float* out, int n, int rows, int cols, hipStream_t s);
 hipError_t launch_transpose_strided(const float* in, float* out, int n, int rows, int cols, size_t in_stride, size_t out_stride,
                                     hipStream_t s);
@@ -112,11 +115,16 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int sp, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
     Tune x;
+    x.sp = geti("SF_SP", 1);                       // small pixel counts: the loader / consumer kernel of conv_sp.hip (0: the round-1 kernels)
+    x.sp_split_wgs = geti("SF_SP_SPLIT_WGS", 240); // ... K ranges are split across about this many workgroups per launch
+    x.sp_bn = geti("SF_SP_BN", 0);                 // ... pixels per tile (0: by the amount of work, see sp_bn)
+    x.sp_max_p = geti("SF_SP_MAX_P", 4096);        // ... used below this many pixels (one 50x50 latent; measured: from two samples on the round-1 kernels are as fast or faster)
+    x.sp_wide_work = geti("SF_SP_WIDE_WORK", 1000);// ... 64-pixel tiles + split K from this many (64x64 tile) x (64-deep chunk) units per launch
     x.direct = geti("SF_DIRECT", 1);
     x.mt = geti("SF_DIRECT_MT", 0);
     x.ks = geti("SF_DIRECT_KS", 0);
@@ -140,6 +148,10 @@ const Tune& tune() {
 
 int large_p() { return tune().large_p; }
 
+// diagnostic builds (-DSF_STAMP): conv launches take consecutive slots (mod 64) of the stamp buffer
+int g_stamp_slot = 0;
+bool g_stamp_on = false;
+
 // LDS-DMA kernel: a 32-deep K chunk must come from ONE source tensor (a single input, or two whose channel counts are
 // multiples of the chunk depth); channels past cin are zero-filled by the range check either way
 bool one_source_per_chunk(const ConvProblem& q) { return q.c1 == 0 || ((q.c0 % 32 == 0) && (q.c1 % 32 == 0)); }
@@ -154,6 +166,40 @@ thread_local SplitCtx* g_split = nullptr;
 constexpr size_t SPLIT_SLAB_FLOATS = size_t(8) << 20;   // 32 MB: 2048 (tile, slice) pairs of 64x64 fp32
 constexpr int SPLIT_COUNTERS = 4096;
 constexpr size_t SPLIT_WS_FLOATS = SPLIT_SLAB_FLOATS + SPLIT_COUNTERS + 128;
+
+// Small-P kernel (conv_sp.hip): every problem of the launch must be stageable by its loaders — no reset-gate multiply
+// while staging (the gates launch pre-gates the state), no neighbour table, one source tensor per 32-deep sub-chunk,
+// an SE input scale only on a single input of <= 256 channels (all problems or none), 32-bit DMA offsets
+bool sp_takes(const ConvProblem* ps, int n, int epi) {
+  if (!tune().sp) return false;
+  int scaled = 0;
+  for (int i = 0; i < n; ++i) {
+    const ConvProblem& q = ps[i];
+    const long Pi = (long)q.n_img * q.Hout * q.Wout;
+    if (Pi >= tune().sp_max_p || q.gather || q.gate || !one_source_per_chunk(q)) return false;
+    if ((epi == EPI_LNG || epi == EPI_TRUST) && q.cout_pad > 64) return false;
+    if (q.in_scale) {
+      ++scaled;
+      if (q.c1 != 0 || q.cin_pad > 256 || (long)q.Hout * q.Wout < 32) return false;   // a 64-pixel tile touches <= 4 images
+    }
+    const double span = (64.0 / ((double)q.Hout * q.Wout) + 2.0) * q.Hin * q.Win * 4.0;
+    if (span * q.in0_cs >= 2147483648.0 || span * q.in1_cs >= 2147483648.0 || 4.0 * q.cout_pad * q.ktot >= 2147483648.0) return false;
+  }
+  if (scaled && (scaled != n || (epi != EPI_AFFINE && epi != EPI_SAMPLE))) return false;
+  return true;
+}
+// pixels per tile of the small-P kernel.  Measured on the 11 conv launches of an Euler step at 50x50 (profiles/r02_*):
+// 64-pixel tiles with the K range split across workgroups win where a launch has a lot of work (both gate / candidate
+// pairs, the 128 -> 128 layers of p_model, the 7x7), 32-pixel tiles without a hand-off elsewhere
+int sp_bn(const ConvProblem* ps, int n) {
+  if (tune().sp_bn) return tune().sp_bn;
+  double work = 0;
+  for (int i = 0; i < n; ++i)
+    work += (double)((ps[i].n_img * ps[i].Hout * ps[i].Wout + 63) / 64) * ((ps[i].cout_pad + 63) / 64) * ((ps[i].KH * ps[i].KW * (ps[i].cin_pad / 32) + 1) / 2);
+  return work >= tune().sp_wide_work ? 64 : 32;
+}
+// pixels per SE partial-sum row the producing conv's epilogue writes (the SE gate kernel sums ceil(P / this) rows)
+int chansum_tile_px(const ConvProblem& producer, int epi) { return sp_takes(&producer, 1, epi) ? sp_bn(&producer, 1) : 16; }
 
 int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   ConvLaunch L;
@@ -171,6 +217,61 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   for (int i = 0; i < n; ++i) {   // the staged kernels keep per-tap element offsets (relative to the tile's first image) in 32 bits
     const double e0 = 2.0 * ps[i].Hin * ps[i].Win * ps[i].in0_cs, e1 = 2.0 * ps[i].Hin * ps[i].Win * ps[i].in1_cs;
     if (!ps[i].gather && (e0 >= 2147483648.0 || e1 >= 2147483648.0)) return SF_ERR_UNSUPPORTED;
+  }
+  if (sp_takes(ps, n, epi)) {
+    // K ranges are split across workgroups (sc1 slab hand-off) so that the launch has about sp_split_wgs workgroups of
+    // equal length: a 2500-pixel layer has only 40 tiles of 64 pixels per 64 output channels
+    const int bn = sp_bn(ps, n);
+    double work_total = 0;
+    for (int i = 0; i < n; ++i) {
+      const int tiles = ((ps[i].n_img * ps[i].Hout * ps[i].Wout + bn - 1) / bn) * ((ps[i].cout_pad + 63) / 64);
+      work_total += (double)tiles * ((ps[i].KH * ps[i].KW * (ps[i].cin_pad / 32) + 1) / 2);
+    }
+    const double per_wg = work_total / tune().sp_split_wgs;      // chunks per workgroup at the target
+    size_t slab_off = 0;
+    int cnt_off = 0;
+    for (int i = 0; i < n && g_split && tune().split && bn == 64; ++i) {
+      ConvProblem& q = L.p[i];
+      const int tiles = ((q.n_img * q.Hout * q.Wout + bn - 1) / bn) * ((q.cout_pad + 63) / 64);
+      const int nch = (q.KH * q.KW * (q.cin_pad / 32) + 1) / 2;
+      int ns = per_wg > 0 ? (int)(nch / per_wg + 0.5) : 1;
+      if (ns > nch / 3) ns = nch / 3;      // at least 3 chunks per slice
+      if (ns > 8) ns = 8;
+      if (ns < 2) continue;
+      const int cps = (nch + ns - 1) / ns;
+      ns = (nch + cps - 1) / cps;      // every slice non-empty
+      if (ns < 2) continue;
+      const size_t per = (size_t)64 * bn;
+      if (slab_off + (size_t)tiles * ns * per > g_split->slab_floats || cnt_off + tiles > g_split->ncounters) continue;
+      q.nsplit = ns;
+      q.slab = g_split->slab + slab_off;
+      q.counters = g_split->counters + cnt_off;
+      slab_off += (size_t)tiles * ns * per;
+      cnt_off += tiles;
+    }
+    L.stamp_slot = g_stamp_slot;
+    if (g_stamp_on) g_stamp_slot = (g_stamp_slot + 1) % 64;
+    bool scaled = false;
+    for (int i = 0; i < n; ++i) scaled = scaled || (ps[i].in_scale != nullptr);
+    if (!g_prof.on) {
+      SF_HIP(launch_conv_sp(L, epi, scaled, bn, st));
+      return SF_OK;
+    }
+    ProfRec r;
+    r.key = 14 * 8 + epi; r.flops = 0; r.bytes = 0;
+    for (int i = 0; i < n; ++i) {
+      const ConvProblem& q = ps[i];
+      const double Pi = (double)q.n_img * q.Hout * q.Wout;
+      const double K = (double)q.KH * q.KW * (q.c0 + q.c1);
+      r.flops += 2.0 * Pi * q.cout * K;
+      r.bytes += 4.0 * ((double)q.n_img * q.Hin * q.Win * (q.c0 + q.c1) + (double)q.cout * K + Pi * q.cout);
+    }
+    r.a = g_prof.get(); r.b = g_prof.get();
+    SF_HIP(hipEventRecord(r.a, st));
+    SF_HIP(launch_conv_sp(L, epi, scaled, bn, st));
+    SF_HIP(hipEventRecord(r.b, st));
+    g_prof.recs.push_back(r);
+    return SF_OK;
   }
   int cfg = pick_cfg(P, epi);
   bool gathered = false;
@@ -312,6 +413,8 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     if (ok) { glds_tile = 3; glds_var = tune().small_dma; }
     if (tune().glds_var >= 0) glds_var = tune().glds_var;
   }
+  L.stamp_slot = g_stamp_slot;
+  if (g_stamp_on) g_stamp_slot = (g_stamp_slot + 1) % 64;
   auto launch = [&]() -> hipError_t {
     if (glds_tile >= 0) return launch_conv_glds(L, epi, glds_tile, glds_var, st);
     return cfg == 3 ? launch_conv_direct(L, epi, mt, ks, st) : launch_conv(L, epi, cfg, st);
@@ -450,7 +553,9 @@ int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p
   const int C = w.C, C2 = 2 * C, HW = H * W, P = B * HW;
   if (B < 1 || B > 64) return SF_ERR_UNSUPPORTED;
   const bool tiles = (B == 1);
-  const int nt = tiles ? (P + 15) / 16 : SE_SLABS;
+  ConvProblem probe = problem(w.rb0.conv2, s, nullptr, nullptr, B, H, W);
+  const int tpx = chansum_tile_px(probe, EPI_AFFINE);   // both SE producers are plain 3x3 layers of the same pixel count
+  const int nt = tiles ? (P + tpx - 1) / tpx : SE_SLABS;
   float* a = A.take((size_t)P * C);
   float* pr = A.take((size_t)P * C2);
   float* y1 = A.take((size_t)P * C2);
@@ -1045,6 +1150,16 @@ int sf_graph_launch(void* exec, void* stream) {
 }
 int sf_graph_destroy(void* exec) {
   SF_HIP(hipGraphExecDestroy((hipGraphExec_t)exec));
+  return SF_OK;
+}
+
+/* Diagnostic builds (-DSF_STAMP) only: `buf` = 64 slots x 4096 workgroups x 8 uint64 device buffer (NULL switches the
+ * stamps off); conv launches then record in-kernel s_memrealtime stamps into consecutive slots.  SF_ERR_UNSUPPORTED
+ * in the product build. */
+int sf_debug_stamps(void* buf) {
+  if (set_stamp_buffer((unsigned long long*)buf) != hipSuccess || set_stamp_buffer_sp((unsigned long long*)buf) != hipSuccess) return SF_ERR_UNSUPPORTED;
+  g_stamp_on = buf != nullptr;
+  g_stamp_slot = 0;
   return SF_OK;
 }
 

@@ -22,6 +22,13 @@
 
 namespace sf {
 
+#ifdef SF_STAMP
+__device__ unsigned long long* g_sf_stamps = nullptr;
+hipError_t set_stamp_buffer(unsigned long long* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_sf_stamps), &p, sizeof(p)); }
+#else
+hipError_t set_stamp_buffer(unsigned long long*) { return hipErrorNotSupported; }
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -693,6 +700,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
   constexpr int BUF = ROWS * 32;                 // floats per buffer
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [NB][ROWS][32]
 
+  SF_STAMP_AT(L, 0);
   const ConvProblem& P = L.p[blockIdx.y];
   const int Ptot = P.n_img * P.Hout * P.Wout;
   const int n_mt = (P.cout_pad + BM - 1) / BM;
@@ -916,6 +924,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
     __builtin_amdgcn_sched_barrier(0);
   };
   // prologue: LA = NB-1 chunks in flight, the first one retired and published
+  SF_STAMP_AT(L, 1);
 #pragma unroll
   for (int c = 0; c < LA; ++c)
     if (c < nchunks) {      // block-uniform
@@ -925,41 +934,76 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
   if (LA > 1 && nchunks >= LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  SF_STAMP_AT(L, 2);
   // Iteration c starts right after the barrier that published chunk c: read its first fragments, multiply the LAST
   // k-group of chunk c-1 (read before the barrier) under that latency, start the DMAs of chunk c+LA into the buffer
   // the barrier just freed (chunk c-1's), then k-groups 0..NG-2 of chunk c, then retire chunk c+1 (a counted vmcnt:
   // the LA-1 younger chunks stay in flight).  No LDS read is in flight across the back edge, so the compiler's
   // lgkmcnt bookkeeping stays exact.
   int buf = 0, ibuf = LA;
+#ifdef SF_STAMP
+  unsigned long long cyc_issue = 0, cyc_wait = 0, cyc_bar = 0;
+  const unsigned long long cyc_loop0 = __builtin_amdgcn_s_memtime();
+#endif
   for (int c = 0; c < nchunks; ++c) {
     const bool more = c + LA < nchunks;
     read_frags(buf, 0, 0);
     if (c > 0) mfmas((NG - 1) & 1);
+#ifdef SF_STAMP
+    const unsigned long long ti0 = __builtin_amdgcn_s_memtime();
+#endif
     if (more) {
 #pragma unroll
       for (int q = 0; q < G; ++q) issue_one(cb + c + LA, ibuf, q);
     }
+#ifdef SF_STAMP
+    cyc_issue += __builtin_amdgcn_s_memtime() - ti0;
+#endif
 #pragma unroll
     for (int t4 = 0; t4 < NG - 1; ++t4) {
       read_frags(buf, t4 + 1, (t4 + 1) & 1);
       mfmas(t4 & 1);
     }
     if (c + 1 < nchunks) {
+#ifdef SF_STAMP
+      const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
       if (LA > 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef SF_STAMP
+      const unsigned long long tw1 = __builtin_amdgcn_s_memtime();
+      cyc_wait += tw1 - tw0;
+#endif
       __builtin_amdgcn_s_barrier();
+#ifdef SF_STAMP
+      cyc_bar += __builtin_amdgcn_s_memtime() - tw1;
+#endif
     }
     buf = buf == NB - 1 ? 0 : buf + 1;
     ibuf = ibuf == NB - 1 ? 0 : ibuf + 1;
     kc_cmp = kc_cmp + 1 == kcpt ? 0 : kc_cmp + 1;
   }
   mfmas((NG - 1) & 1);
+  SF_STAMP_AT(L, 3);
+#ifdef SF_STAMP
+  SF_STAMP_VAL(L, 8, __builtin_amdgcn_s_memtime() - cyc_loop0);
+  SF_STAMP_VAL(L, 9, cyc_issue);
+  SF_STAMP_VAL(L, 10, cyc_wait);
+  SF_STAMP_VAL(L, 11, cyc_bar);
+  SF_STAMP_VAL(L, 12, (unsigned long long)nchunks);
+#endif
   if (nsplit > 1) {      // block-uniform
     __syncthreads();     // the hand-off flag lives in the staging buffers: every wave is done reading them
     if (!splitk_handoff<MT, NT, NWV>(P, acc, nsplit, bid, wave, lane, tid, smem)) return;
   }
+  SF_STAMP_AT(L, 4);
   run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
+#ifdef SF_STAMP
+  SF_STAMP_AT(L, 5);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SF_STAMP_AT(L, 6);
+#endif
 }
 
 template <int MT, int NT, int WM, int WN, int EPI, bool SCALE = false, int NB = 2>
@@ -1057,6 +1101,7 @@ hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant,
 template <int MT, int EPI>
 __global__ __launch_bounds__(512) void conv_direct_kernel(const ConvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  SF_STAMP_AT(L, 0);
   const ConvProblem& P = L.p[blockIdx.y];
   const int Ptot = P.n_img * P.Hout * P.Wout;
   constexpr int BM = 16 * MT;
@@ -1169,7 +1214,12 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(const ConvLaunch L) {
     }
   };
 
+  SF_STAMP_AT(L, 1);
   if (n_my > 0) load(a0, b0, x0, f0, kg);
+#ifdef SF_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SF_STAMP_AT(L, 2);
+#endif
   for (int i = 0; i < n_my; i += 2) {
     if (i + 1 < n_my) load(a1, b1, x1, f1, kg + (i + 1) * KS);
     compute(a0, b0, x0, f0);
@@ -1177,6 +1227,7 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(const ConvLaunch L) {
     if (i + 1 < n_my) compute(a1, b1, x1, f1);
   }
 
+  SF_STAMP_AT(L, 3);
   // fixed-order split-K reduction through LDS
   if (KS > 1) {
     constexpr int PER_WAVE = MT * 4 * 64;
@@ -1197,7 +1248,13 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(const ConvLaunch L) {
         for (int q = 0; q < 4; ++q) acc[m][0][q] += r[(m * 4 + q) * 64];
     }
   }
+  SF_STAMP_AT(L, 4);
   run_epilogue<MT, 1, EPI>(P, acc, m_tile * BM, p_tile * 16, lane, Ptot, HWout);
+#ifdef SF_STAMP
+  SF_STAMP_AT(L, 5);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SF_STAMP_AT(L, 6);
+#endif
 }
 
 template <int MT, int EPI>

@@ -1,0 +1,632 @@
+// Small-pixel-count implicit-GEMM convolution for the GRU-ODE latent (one to four 50x50 samples): the kernel behind
+// every layer of ode_step / the Bayesian jump when P = n_img*Hout*Wout < 12288.  gfx950 only.
+//
+// Why a second kernel.  In-kernel time stamps of the round-1 small-P kernels (tools/r02/stamps.py, profiles/r02_*)
+// showed where a 2500-pixel layer loses its time: every wave issued its own LDS-DMAs (~550 cycles of address
+// arithmetic + issue per 32-deep chunk at one wave per SIMD), owned ONE 16x16 accumulator (LDS-read latency + the
+// 40-cycle dependent MFMA latency exposed: ~750 cycles for 8 MFMAs), one wave ran the whole epilogue behind a chain of
+// dependent global loads (4-7 us for the LayerNorm / trusting-gate tails), and a cross-workgroup split-K hand-off cost
+// 5-14 us in the agent-scope release fence.  Structure here, one 768-thread workgroup per CU:
+//   * roles: waves 8-11 are LOADERS (all im2col address arithmetic + buffer_load ... lds issue), waves 0-7 CONSUMERS
+//     (ds_read_b128 + MFMA only).  Two consumers and one loader share each SIMD, so the matrix pipe has two
+//     instruction streams to draw from and the DMA issue runs beside them instead of in front of them.
+//   * tile 64 cout x 32 px; a K chunk is 64 deep (two 32-deep sub-chunks in the packed K order, each a [96 rows][32]
+//     block with the 16-B slots XOR-swizzled by (row>>1)&7 through the DMA's per-lane SOURCE address); ring of 3 chunk
+//     buffers, 2 chunks in flight, one s_barrier per chunk placed between a chunk's fragment reads and its MFMAs.
+//   * consumer (mh, kq): cout half mh, K quarter kq of every chunk (16 K values = one ds_read_b128 per 16-row
+//     fragment): 4 fragment reads feed 16 MFMAs on 4 accumulators.  In-workgroup split-K over the 4 quarters, reduced
+//     through LDS in a fixed order.
+//   * distributed epilogue: after the reduction lane (pixel, channel quad) of the 512 consumer lanes owns ONE float4 of
+//     the tile; LayerNorm / softmax statistics are 16-lane shuffles; every epilogue operand is loaded up front in one
+//     round trip.
+//   * cross-workgroup split-K (long K: the 7x7 trusting-gate conv): partial tiles leave with sc1 (write-through)
+//     stores, one agent-scope ticket per workgroup, the last arriver re-reads all slices with sc1 loads in slice order
+//     (MI355X_MICROARCH.md, hand-off table row 1): no release / acquire fence.  Bitwise reproducible.
+#include "sf_math.h"
+
+namespace sf {
+
+#ifdef SF_STAMP
+__device__ unsigned long long* g_sf_stamps = nullptr;     // diagnostic builds: one copy per translation unit (no relocatable device code)
+hipError_t set_stamp_buffer_sp(unsigned long long* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_sf_stamps), &p, sizeof(p)); }
+#else
+hipError_t set_stamp_buffer_sp(unsigned long long*) { return hipErrorNotSupported; }
+#endif
+
+constexpr int SP_BM = 64;                     // output channels per tile
+constexpr int SP_NB = 3, SP_LA = SP_NB - 1;   // chunk buffers of the LDS ring / chunks in flight
+constexpr int SP_RED_PITCH = 68;              // reduction buffer [4 quarters][BN px][68] (inside the ring)
+constexpr int SP_SC_IMGS = 4;                 // SE scale rows kept in LDS: images a pixel tile can touch
+constexpr int SP_SC_FLOATS = SP_SC_IMGS * 256;
+constexpr int SP_MISC = 64;                   // hand-off flag
+constexpr int SP_THREADS = 768;               // 8 consumer + 4 loader waves
+// NT = 16-pixel n-tiles per consumer wave: the tile is 64 cout x (16 NT) px
+template <int NT>
+struct SpGeo {
+  static constexpr int BN = 16 * NT;
+  static constexpr int ROWS = SP_BM + BN;     // rows of one sub-chunk block (weights first)
+  static constexpr int SUBF = ROWS * 32;      // floats per sub-chunk block
+  static constexpr int BUFF = 2 * SUBF;       // floats per chunk buffer
+  static constexpr int RING = SP_NB * BUFF;   // NT 2: 72 KB, NT 4: 96 KB
+  static constexpr int NBI = BN / 32;         // pixel row blocks (8 rows) per loader and sub-chunk
+  static constexpr int DPC = 2 * (2 + NBI);   // DMA instructions per loader and chunk
+  static constexpr int NPX = BN / 32;         // epilogue items (pixel, channel quad) per consumer lane
+  static_assert(4 * BN * SP_RED_PITCH + 512 <= RING, "reduction buffer + channel-sum scratch live in the ring");
+};
+template <int NT>
+constexpr int sp_lds_bytes(bool scale) { return (SpGeo<NT>::RING + SP_MISC + (scale ? SP_SC_FLOATS : 0)) * 4; }
+
+typedef __attribute__((address_space(3))) void sp_lds_void;
+
+__device__ __forceinline__ f32x4 sp_lds_read128(const float* p) {
+  typedef const __attribute__((address_space(3))) f32x4 lds_f4;
+  return *(lds_f4*)p;   // explicit LDS address space: ds_read_b128
+}
+// raw workgroup barrier fenced for the compiler (no LDS access may move across it); the callers drain their own counters
+__device__ __forceinline__ void sp_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ float sp_reduce16(float v) {   // sum over the 16 lanes (channel quads) of a pixel
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+
+// ---- epilogues in the (pixel, channel-quad) layout -------------------------------------------------------------------
+// v: the lane's four consecutive output channels c..c+3 of pixel gp (pre-activation accumulator sums).
+// `on`: the lane owns a real element (consumer wave, pixel < P, channel < cout); lanes that are not `on` load from safe
+// addresses and store nothing.  y_out (AFFINE): the stored value, zero where not `on` (for the SE channel sums).
+template <int EPI>
+__device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, const int gp, const int c, const bool on,
+                                            const int HWout, float4& y_out) {
+  const int img = on ? gp / HWout : 0;
+  const size_t gpz = on ? (size_t)gp : 0;
+  const int cz = on ? c : 0;
+
+  if constexpr (EPI == EPI_AFFINE || EPI == EPI_BLEND) {
+    // all operands first (one round trip), arithmetic after
+    const float4 sc = P.scale ? spm_ld4(P.scale + cz) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 bi = P.bias ? spm_ld4(P.bias + (P.bias_per_img ? (size_t)img * P.cout : 0) + cz) : spm_zero4();
+    float4 ad = spm_zero4(), as = make_float4(1.f, 1.f, 1.f, 1.f), u = spm_zero4(), s = spm_zero4(), sv = spm_zero4();
+    bool gate_out = false;
+    int cg = 0;
+    if constexpr (EPI == EPI_AFFINE) {
+      if (P.add) ad = spm_ld4(P.add + gpz * P.add_cs + cz);
+      if (P.add && P.add_scale) as = spm_ld4(P.add_scale + (size_t)img * P.cout + cz);
+      gate_out = P.out2 && cz >= P.gate_from;
+      cg = gate_out ? cz - P.gate_from : 0;
+      if (P.out2) sv = spm_ld4(P.e1 + gpz * P.e1_cs + cg);
+    } else {
+      u = spm_ld4(P.e0 + gpz * P.e0_cs + cz);
+      s = spm_ld4(P.e1 + gpz * P.e1_cs + cz);
+    }
+    v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
+    float4 y;
+    if constexpr (EPI == EPI_AFFINE) {
+      const bool act_last = (P.mode & 2) != 0;
+      y = act_last ? v : spm_act4(v, P.act);
+      if (P.clamp_from >= 0) {
+        if (c + 0 >= P.clamp_from) y.x = fminf(fmaxf(y.x, P.clamp_lo), P.clamp_hi);
+        if (c + 1 >= P.clamp_from) y.y = fminf(fmaxf(y.y, P.clamp_lo), P.clamp_hi);
+        if (c + 2 >= P.clamp_from) y.z = fminf(fmaxf(y.z, P.clamp_lo), P.clamp_hi);
+        if (c + 3 >= P.clamp_from) y.w = fminf(fmaxf(y.w, P.clamp_lo), P.clamp_hi);
+      }
+      if (P.add) { y.x += ad.x * as.x; y.y += ad.y * as.y; y.z += ad.z * as.z; y.w += ad.w * as.w; }
+      if (act_last) y = spm_act4(y, P.act);
+      if (on && gate_out)   // GRU gates, reset half: also emit (1 - r) * s, the candidate conv's input
+        spm_st4(P.out2 + gpz * P.out2_cs + cg, make_float4(sv.x * (1.f - y.x), sv.y * (1.f - y.y), sv.z * (1.f - y.z), sv.w * (1.f - y.w)));
+    } else {
+      v = spm_act4(v, P.act);
+      if (P.mode & 1) y = make_float4(u.x * (v.x - s.x), u.y * (v.y - s.y), u.z * (v.z - s.z), u.w * (v.w - s.w));
+      else y = make_float4((1.f - u.x) * s.x + u.x * v.x, (1.f - u.y) * s.y + u.y * v.y, (1.f - u.z) * s.z + u.z * v.z, (1.f - u.w) * s.w + u.w * v.w);
+    }
+    if (on) spm_st4(P.out + gpz * P.out_cs + P.out_co + c, y);
+    y_out = on ? y : spm_zero4();
+  }
+
+  if constexpr (EPI == EPI_LNG || EPI == EPI_TRUST) {
+    // one 64-row tile holds every channel of its pixels (cout_pad <= 64, checked on the host)
+    const bool cv = c < P.cout;
+    const float inv_c = 1.f / (float)P.cout;
+    const size_t po = gpz * P.cout + cz;
+    const float4 lw = spm_ld4(P.scale + cz), lb = spm_ld4(P.bias + cz);
+    float4 sk = spm_zero4(), w0 = spm_zero4(), w1 = spm_zero4(), r2 = spm_zero4(), r1 = spm_zero4(), st = spm_zero4(), base = spm_zero4(), b2in = spm_zero4();
+    float c0f = 0.f, c1f = 0.f;
+    if constexpr (EPI == EPI_TRUST) {
+      sk = spm_ld4(P.e0 + po);
+      w0 = spm_ld4(P.e1 + cz); w1 = spm_ld4(P.e1 + P.cout + cz);
+      r2 = spm_ld4(P.e2 + po); r1 = spm_ld4(P.e3 + po);
+      if (P.mode & 1) { st = spm_ld4(P.e4 + po); base = spm_ld4(P.e5 + po); }
+      if (P.out2 && (P.mode & 2)) b2in = spm_ld4(P.out2 + po);
+      const float* cf = P.coef ? P.coef + (size_t)img * P.coef_stride : nullptr;
+      c0f = cf ? cf[0] : 0.f;
+      c1f = (cf && P.out2) ? cf[1] : 0.f;
+    }
+    const bool do_ln = (EPI == EPI_TRUST) || (P.mode & 1);
+    if (do_ln) {   // convolutions.py:303-308 (channels_first LayerNorm over the pixel's channels)
+      const float mean = sp_reduce16(cv ? (v.x + v.y) + (v.z + v.w) : 0.f) * inv_c;
+      const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+      const float var = sp_reduce16(cv ? (dx * dx + dy * dy) + (dz * dz + dw * dw) : 0.f) * inv_c;
+      const float rstd = 1.f / sqrtf(var + P.eps);
+      v.x = lw.x * (dx * rstd) + lb.x; v.y = lw.y * (dy * rstd) + lb.y;
+      v.z = lw.z * (dz * rstd) + lb.z; v.w = lw.w * (dw * rstd) + lb.w;
+    }
+    v.x = spm_gelu(v.x); v.y = spm_gelu(v.y); v.z = spm_gelu(v.z); v.w = spm_gelu(v.w);
+    if constexpr (EPI == EPI_LNG) {
+      if (on) spm_st4(P.out + gpz * P.out_cs + P.out_co + c, v);
+    } else {
+      // trusting gate tail (temporal_ode_bayes.py:124-131 / :268-275, convolutions.py:375-380)
+      const float b0 = v.x + sk.x, b1 = v.y + sk.y, b2 = v.z + sk.z, b3 = v.w + sk.w;
+      const float z0 = sp_reduce16(cv ? (w0.x * b0 + w0.y * b1) + (w0.z * b2 + w0.w * b3) : 0.f);
+      const float z1 = sp_reduce16(cv ? (w1.x * b0 + w1.y * b1) + (w1.z * b2 + w1.w * b3) : 0.f);
+      const float zm = fmaxf(z0, z1);
+      const float ez0 = expf(z0 - zm), ez1 = expf(z1 - zm);
+      const float g0 = ez0 / (ez0 + ez1), g1 = ez1 / (ez0 + ez1);
+      float4 cur;
+      cur.x = r2.x * g0 + r1.x * g1; cur.y = r2.y * g0 + r1.y * g1;
+      cur.z = r2.z * g0 + r1.z * g1; cur.w = r2.w * g0 + r1.w * g1;
+      if (on) {
+        if (P.mode & 1) {   // derivative: d = cur - s ; out = base + coef0*d
+          const float4 d = make_float4(cur.x - st.x, cur.y - st.y, cur.z - st.z, cur.w - st.w);
+          if (P.out2) {
+            float4 a2 = (P.mode & 2) ? b2in : base;
+            a2.x += c1f * d.x; a2.y += c1f * d.y; a2.z += c1f * d.z; a2.w += c1f * d.w;
+            spm_st4(P.out2 + po, a2);
+          }
+          spm_st4(P.out + po, make_float4(base.x + c0f * d.x, base.y + c0f * d.y, base.z + c0f * d.z, base.w + c0f * d.w));
+        } else {
+          spm_st4(P.out + po, cur);
+        }
+      }
+    }
+  }
+
+  if constexpr (EPI == EPI_SAMPLE) {
+    // packed cout rows are interleaved: rows 4q..4q+3 = (loc ch, loc ch+1, raw ch, raw ch+1), ch = 8*(row>>4) + 2*((row>>2)&3)
+    const int Chalf = P.cout >> 1;
+    const int ch = ((c >> 4) << 3) + 2 * ((c >> 2) & 3);
+    const bool ok = on && ch < Chalf;
+    const int chz = ok ? ch : 0;
+    const float4 bi = P.bias ? spm_ld4(P.bias + cz) : spm_zero4();
+    const float2 e = *reinterpret_cast<const float2*>(P.e0 + (ok ? gpz : 0) * Chalf + chz);
+    const float q0 = spm_act(v.x + bi.x, P.act), q1 = spm_act(v.y + bi.y, P.act);
+    const float q2 = spm_act(v.z + bi.z, P.act), q3 = spm_act(v.w + bi.w, P.act);
+    if (ok) {
+      float2 o;
+      o.x = q0 + e.x * (spm_softplus(q2) + 1e-8f);     // model_utils.py:84,107-108
+      o.y = q1 + e.y * (spm_softplus(q3) + 1e-8f);
+      *reinterpret_cast<float2*>(P.out + gpz * Chalf + ch) = o;
+      if (P.out2) {   // raw q parameters, reference channel order [loc | raw]
+        *reinterpret_cast<float2*>(P.out2 + gpz * P.cout + ch) = make_float2(q0, q1);
+        *reinterpret_cast<float2*>(P.out2 + gpz * P.cout + Chalf + ch) = make_float2(q2, q3);
+      }
+    }
+  }
+}
+
+template <int EPI, bool SCALE, int NT>
+__global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L) {
+  typedef SpGeo<NT> G;
+  constexpr int BN = G::BN;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // ring | misc | SE scale rows
+  const ConvProblem& P = L.p[blockIdx.y];
+  const int HWout = P.Hout * P.Wout;
+  const int Ptot = P.n_img * HWout;
+  const int n_mt = (P.cout_pad + SP_BM - 1) / SP_BM;
+  const int m_tile = blockIdx.x % n_mt;
+  const int p_tile = blockIdx.x / n_mt;
+  if (p_tile * BN >= Ptot) return;                     // block-uniform
+  const int nsplit = P.nsplit > 1 ? P.nsplit : 1;
+  if ((int)blockIdx.z >= nsplit) return;               // block-uniform
+  const int kcpt = P.cin_pad >> 5;                     // 32-deep sub-chunks per tap
+  const int nsub_all = P.KH * P.KW * kcpt;
+  const int nch_all = (nsub_all + 1) >> 1;
+  const int cps = (nch_all + nsplit - 1) / nsplit;     // chunks per K slice (host: every slice non-empty)
+  const int cb = (int)blockIdx.z * cps;
+  const int nchunks = (nch_all - cb) < cps ? (nch_all - cb) : cps;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  float* const misc = smem + G::RING;
+  float* const sc_lds = misc + SP_MISC;      // SCALE instantiations only
+  const int img0 = (p_tile * BN) / HWout;              // block-uniform: first image this tile touches
+  const int cin_pad = P.cin_pad;
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // SE-scaled input (res_models.py:161-165 feeding the next conv): the per-(image, channel) scale rows of the images this
+  // tile touches go to LDS; the consumers multiply their pixel fragments by them.  Published by the first barrier.
+  auto fill_scale_rows = [&]() {
+    if (SCALE) {
+      const float* const in_scale = P.in_scale;
+      for (int idx = tid; idx < SP_SC_IMGS * cin_pad; idx += SP_THREADS) {
+        const int si = idx / cin_pad, ch = idx - si * cin_pad;
+        sc_lds[idx] = (in_scale && img0 + si < P.n_img && ch < P.c0) ? in_scale[(size_t)(img0 + si) * P.c0 + ch] : (in_scale ? 0.f : 1.f);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
+  SF_STAMP_AT(L, 0);
+
+  if (wave >= 8) {
+    // ================================= loader =================================================================
+    const int lw = wave - 8;
+    // a sub-chunk is 8 + BN/8 DMA instructions of 8 rows x 128 B: loader lw takes the weight row blocks lw and lw + 4
+    // and the pixel row blocks lw + 4 i
+    int a_voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = 8 * (lw + 4 * i) + (lane >> 3);
+      const int k4 = (lane & 7) ^ ((r >> 1) & 7);
+      int grow = m_tile * SP_BM + r;
+      grow = grow < P.cout_pad ? grow : P.cout_pad - 1;   // rows >= cout_pad are never stored
+      a_voff[i] = (grow * P.ktot + k4 * 4) * (int)sizeof(float);
+    }
+    int b_c4[G::NBI], iy0[G::NBI], ix0[G::NBI], pbase[G::NBI];
+#pragma unroll
+    for (int i = 0; i < G::NBI; ++i) {
+      const int pr = 8 * (lw + 4 * i) + (lane >> 3);
+      b_c4[i] = 4 * ((lane & 7) ^ ((pr >> 1) & 7));
+      const int gp = p_tile * BN + pr;
+      const bool pvalid = gp < Ptot;
+      const int img = pvalid ? gp / HWout : 0;
+      const int rem = gp - img * HWout;
+      const int oy = rem / P.Wout, ox = rem - oy * P.Wout;
+      iy0[i] = pvalid ? oy * P.stride - P.pad : -(1 << 28);
+      ix0[i] = ox * P.stride - P.pad;
+      pbase[i] = (pvalid ? img - img0 : 0) * P.Hin * P.Win;
+    }
+    const size_t img0_px = (size_t)img0 * P.Hin * P.Win;
+    const float* const in0 = P.in0 + img0_px * P.in0_cs;
+    const float* const in1 = P.in1 ? P.in1 + img0_px * P.in1_cs : nullptr;
+    const int c0 = P.c0, c01 = P.c0 + P.c1, in0_cs = P.in0_cs, in1_cs = P.in1_cs;
+    const int Win = P.Win, in_up = P.in_up, dil = P.dil, KW = P.KW;
+    const int Hlog = P.Hin << P.in_up, Wlog = P.Win << P.in_up;
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto make_rsrc = [](const float* base, size_t bytes) {
+      const unsigned nrec = bytes < 0x7fffffffull ? (unsigned)bytes : 0x7fffffffu;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (int)nrec, 0x00020000);
+    };
+    const size_t imgs_left = (size_t)(P.n_img - img0);
+    const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(P.w, (size_t)P.cout_pad * P.ktot * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rsrc0 = make_rsrc(in0, imgs_left * P.Hin * P.Win * in0_cs * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(in1 ? in1 : in0, in1 ? imgs_left * P.Hin * P.Win * in1_cs * sizeof(float) : 0);
+#else
+    (void)in0; (void)in1;
+#endif
+    // cursor of the next sub-chunk to fetch
+    int sc = 2 * cb;
+    int cur_kc = sc % kcpt, cur_ty = (sc / kcpt) / KW, cur_tx = (sc / kcpt) % KW;
+    bool tap_fresh = true;
+    int tap_off0[G::NBI], tap_off1[G::NBI];
+#pragma unroll
+    for (int i = 0; i < G::NBI; ++i) { tap_off0[i] = -1; tap_off1[i] = 0; }
+    auto issue_chunk = [&](const int buf) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bool live = sc < nsub_all;                       // wave-uniform (odd sub-chunk count: the last half is zero)
+        if (tap_fresh) {
+#pragma unroll
+          for (int i = 0; i < G::NBI; ++i) {
+            const int iy = iy0[i] + cur_ty * dil, ix = ix0[i] + cur_tx * dil;
+            const bool in = (iy >= 0) & (iy < Hlog) & (ix >= 0) & (ix < Wlog);
+            const int px = in ? pbase[i] + (iy >> in_up) * Win + (ix >> in_up) : 0;
+            tap_off0[i] = in ? px * in0_cs : -1;
+            tap_off1[i] = px * in1_cs - c0;
+          }
+        }
+        const bool from1 = cur_kc * 32 >= c0;                   // wave-uniform: the whole sub-chunk reads in1
+        const int soff = live ? sc * 128 : 0;
+        float* const blk = smem + buf * G::BUFF + s2 * G::SUBF;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // offset -1 fails the buffer range check: the DMA writes 0 (zero padding, channels past cin, the odd last half)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * lw) * 32), 16, live ? a_voff[0] : -1, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * (lw + 4)) * 32), 16, live ? a_voff[1] : -1, soff, 0, 0);
+#pragma unroll
+        for (int i = 0; i < G::NBI; ++i) {
+          const int c = cur_kc * 32 + b_c4[i];
+          const bool ok = live & (tap_off0[i] >= 0) & (c < c01);
+          const int vob = ok ? (c + (from1 ? tap_off1[i] : tap_off0[i])) * 4 : -1;
+          float* const dB = blk + (SP_BM + 8 * (lw + 4 * i)) * 32;
+          if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (sp_lds_void*)dB, 16, vob, 0, 0, 0);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (sp_lds_void*)dB, 16, vob, 0, 0, 0);
+        }
+#else
+        (void)blk; (void)soff; (void)from1; (void)live;
+#endif
+        ++sc;
+        ++cur_kc;
+        tap_fresh = false;
+        if (cur_kc == kcpt) {
+          cur_kc = 0;
+          tap_fresh = true;
+          if (++cur_tx == KW) { cur_tx = 0; ++cur_ty; }
+        }
+      }
+    };
+#ifdef SF_STAMP
+    unsigned long long l_issue = 0, l_wait = 0, l_bar = 0;
+#endif
+#pragma unroll
+    for (int c = 0; c < SP_LA; ++c)
+      if (c < nchunks) issue_chunk(c);                    // block-uniform
+    fill_scale_rows();
+    if (nchunks >= SP_LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::DPC * (SP_LA - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    sp_barrier();                                         // chunk 0 published
+    int ibuf = SP_LA % SP_NB;
+    for (int c = 0; c < nchunks; ++c) {
+      const bool more = c + SP_LA < nchunks;
+#ifdef SF_STAMP
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+      if (more) issue_chunk(ibuf);                        // into the buffer of chunk c-1: every consumer passed the barrier behind its reads
+#ifdef SF_STAMP
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+      l_issue += t1 - t0;
+#endif
+      if (c + 1 < nchunks) {
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::DPC * (SP_LA - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SF_STAMP
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        l_wait += t2 - t1;
+#endif
+        sp_barrier();                                     // chunk c+1 published
+#ifdef SF_STAMP
+        l_bar += __builtin_amdgcn_s_memtime() - t2;
+#endif
+      }
+      ibuf = ibuf == SP_NB - 1 ? 0 : ibuf + 1;
+    }
+#ifdef SF_STAMP
+    SF_STAMP_VAL_T(L, 13, l_issue, 512);
+    SF_STAMP_VAL_T(L, 14, l_wait, 512);
+    SF_STAMP_VAL_T(L, 15, l_bar, 512);
+#endif
+  } else {
+    // ================================= consumer ===============================================================
+    const int mh = wave & 1, kq = wave >> 1;
+    const int j = lane & 15, g = lane >> 4;
+    const int slot4 = ((((kq & 1) << 2) + g) ^ ((j >> 1) & 7)) * 4;
+    const int sub_off = (kq >> 1) * G::SUBF;
+    int a_off[2], b_off[NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) a_off[m] = sub_off + (32 * mh + 16 * m + j) * 32 + slot4;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b_off[n] = sub_off + (SP_BM + 16 * n + j) * 32 + slot4;
+    // SE-scaled input: the lane's four K values of a chunk are channels kc*32 + (kq&1)*16 + 4g .. +3 of its sub-chunk
+    int s_kc = (2 * cb + (kq >> 1)) % kcpt;
+    const int s_step = 2 % kcpt;
+    int simg[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int gp = p_tile * BN + 16 * n + j;
+      simg[n] = SCALE ? (gp < Ptot ? gp / HWout - img0 : 0) * cin_pad + ((kq & 1) << 4) + 4 * g : 0;
+    }
+    f32x4 fa[2][2], fb[2][NT];
+    auto read_frags = [&](const int buf, const int set) {
+      const float* base = smem + buf * G::BUFF;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) fa[set][m] = sp_lds_read128(base + a_off[m]);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) fb[set][n] = sp_lds_read128(base + b_off[n]);
+      if (SCALE) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const f32x4 s4 = sp_lds_read128(sc_lds + simg[n] + s_kc * 32);
+          fb[set][n] = fb[set][n] * s4;
+        }
+        s_kc += s_step;
+        if (s_kc >= kcpt) s_kc -= kcpt;
+      }
+    };
+    auto mfmas = [&](const int set) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][m][e], fb[set][n][e], acc[m][n], 0, 0, 0);
+    };
+    fill_scale_rows();
+    SF_STAMP_AT(L, 1);
+    sp_barrier();                         // chunk 0 published (and the SE scale rows)
+    SF_STAMP_AT(L, 2);
+    // the barrier that publishes chunk c+1 sits between the fragment reads of chunk c and its MFMAs: the reads of
+    // chunk c+1 are in flight under the MFMAs of chunk c
+    int buf = 0;
+#ifdef SF_STAMP
+    unsigned long long c_bar = 0;
+    const unsigned long long c_loop0 = __builtin_amdgcn_s_memtime();
+#define SP_BAR_T(stmt) { const unsigned long long tb_ = __builtin_amdgcn_s_memtime(); stmt; c_bar += __builtin_amdgcn_s_memtime() - tb_; }
+#else
+#define SP_BAR_T(stmt) stmt
+#endif
+    read_frags(0, 0);
+    for (int c = 0; c < nchunks; c += 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (c + 1 < nchunks) {
+        SP_BAR_T(sp_barrier());
+        buf = buf == SP_NB - 1 ? 0 : buf + 1;
+        read_frags(buf, 1);
+      }
+      mfmas(0);
+      if (c + 1 < nchunks) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (c + 2 < nchunks) {
+          SP_BAR_T(sp_barrier());
+          buf = buf == SP_NB - 1 ? 0 : buf + 1;
+          read_frags(buf, 0);
+        }
+        mfmas(1);
+      }
+    }
+#ifdef SF_STAMP
+    SF_STAMP_VAL(L, 8, __builtin_amdgcn_s_memtime() - c_loop0);
+    SF_STAMP_VAL(L, 11, c_bar);
+    SF_STAMP_VAL(L, 12, (unsigned long long)nchunks);
+#endif
+  }
+  // ================================= reduction over the K quarters + epilogue ===================================
+  SF_STAMP_AT(L, 3);
+  __syncthreads();                                        // every fragment read and every DMA of the ring is done
+  float* const red = smem;                                // [4][BN][SP_RED_PITCH]
+  if (wave < 8) {
+    const int mh = wave & 1, kq = wave >> 1, j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        spm_st4(red + ((kq * BN) + 16 * n + j) * SP_RED_PITCH + 32 * mh + 16 * m + 4 * g,
+                make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]));
+  }
+  __syncthreads();
+  // lane (pixel, channel quad): pixels 4*wave + lane/16 (+ 32 i), channels 4*(lane%16) .. +3
+  const int quad = lane & 15;
+  int px[G::NPX];
+  float4 v[G::NPX];
+#pragma unroll
+  for (int i = 0; i < G::NPX; ++i) {
+    px[i] = (wave < 8 ? 4 * wave : 0) + (lane >> 4) + 32 * i;
+    v[i] = spm_zero4();
+    if (wave < 8) {
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        const float4 t = spm_ld4(red + (kq * BN + px[i]) * SP_RED_PITCH + 4 * quad);
+        v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+      }
+    }
+  }
+  if (nsplit > 1) {        // block-uniform: cross-workgroup split-K hand-off, sc1 stores / ticket / sc1 loads
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+    float* const tile_slab = P.slab + (size_t)blockIdx.x * nsplit * (SP_BM * BN);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tile_slab, (short)0, nsplit * SP_BM * BN * 4, 0x00020000);
+    if (wave < 8) {
+#pragma unroll
+      for (int i = 0; i < G::NPX; ++i)
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v[i].x), __float_as_uint(v[i].y), __float_as_uint(v[i].z), __float_as_uint(v[i].w)},
+                                               rs, (px[i] * SP_BM + 4 * quad) * 4, (int)blockIdx.z * (SP_BM * BN * 4), 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* const flag = reinterpret_cast<int*>(misc);
+    if (tid == 0) {
+      unsigned* cnt = P.counters + blockIdx.x;
+      const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (t == (unsigned)(nsplit - 1));
+      if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0) return;
+    if (wave < 8) {
+#pragma unroll
+      for (int i = 0; i < G::NPX; ++i) v[i] = spm_zero4();
+      for (int z = 0; z < nsplit; ++z) {     // slice order, own slice included: the sum does not depend on who arrives last
+#pragma unroll
+        for (int i = 0; i < G::NPX; ++i) {
+          const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (px[i] * SP_BM + 4 * quad) * 4, z * (SP_BM * BN * 4), 16);
+          v[i].x += __uint_as_float(t[0]); v[i].y += __uint_as_float(t[1]); v[i].z += __uint_as_float(t[2]); v[i].w += __uint_as_float(t[3]);
+        }
+      }
+    }
+#endif
+  }
+  SF_STAMP_AT(L, 4);
+  const int c = m_tile * SP_BM + 4 * quad;
+  float4 ysum = spm_zero4();
+#pragma unroll
+  for (int i = 0; i < G::NPX; ++i) {
+    const int gp = p_tile * BN + px[i];
+    const bool on = (wave < 8) && gp < Ptot && c < P.cout;
+    float4 y = spm_zero4();
+    sp_epilogue<EPI>(P, v[i], gp, c, on, HWout, y);
+    ysum.x += y.x; ysum.y += y.y; ysum.z += y.z; ysum.w += y.w;
+  }
+  if constexpr (EPI == EPI_AFFINE) {
+    if (P.chansum) {   // block-uniform: per-tile channel sums of `out` for the next SE gate, fixed order
+      float* const cs_lds = smem + 4 * BN * SP_RED_PITCH;   // behind the reduction buffer
+      float4 t = ysum;
+      t.x += __shfl_xor(t.x, 16); t.y += __shfl_xor(t.y, 16); t.z += __shfl_xor(t.z, 16); t.w += __shfl_xor(t.w, 16);
+      t.x += __shfl_xor(t.x, 32); t.y += __shfl_xor(t.y, 32); t.z += __shfl_xor(t.z, 32); t.w += __shfl_xor(t.w, 32);
+      if (wave < 8 && lane < 16) spm_st4(cs_lds + wave * 64 + lane * 4, t);
+      __syncthreads();
+      if (wave == 0 && lane < 16) {
+        float4 a4 = spm_zero4();
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) {
+          const float4 b4 = spm_ld4(cs_lds + w8 * 64 + lane * 4);
+          a4.x += b4.x; a4.y += b4.y; a4.z += b4.z; a4.w += b4.w;
+        }
+        if (c < P.cout) spm_st4(P.chansum + (size_t)p_tile * P.cout + c, a4);
+      }
+    }
+  }
+#ifdef SF_STAMP
+  SF_STAMP_AT(L, 5);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SF_STAMP_AT(L, 6);
+#endif
+}
+
+template <int EPI, bool SCALE, int NT>
+static hipError_t launch_sp_t(const ConvLaunch& L, hipStream_t stream) {
+  auto kern = conv_sp_kernel<EPI, SCALE, NT>;
+  static bool attr_done[64] = {};      // the attribute is per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, sp_lds_bytes<NT>(SCALE));
+    if (e != hipSuccess) return e;
+    attr_done[dev] = true;
+  }
+  int maxblocks = 0, zs = 1;
+  for (int i = 0; i < L.nprob; ++i) {
+    const ConvProblem& P = L.p[i];
+    const int Ptot = P.n_img * P.Hout * P.Wout;
+    const int nb = ((Ptot + 16 * NT - 1) / (16 * NT)) * ((P.cout_pad + SP_BM - 1) / SP_BM);
+    maxblocks = nb > maxblocks ? nb : maxblocks;
+    zs = P.nsplit > zs ? P.nsplit : zs;
+  }
+  if (maxblocks == 0) return hipSuccess;
+  hipLaunchKernelGGL(kern, dim3(maxblocks, L.nprob, zs), dim3(SP_THREADS), sp_lds_bytes<NT>(SCALE), stream, L);
+  return hipGetLastError();
+}
+
+template <int NT>
+static hipError_t launch_sp_n(const ConvLaunch& L, int epi, bool scaled, hipStream_t stream) {
+  if (scaled) {
+    if (epi == EPI_AFFINE) return launch_sp_t<EPI_AFFINE, true, NT>(L, stream);
+    if (epi == EPI_SAMPLE) return launch_sp_t<EPI_SAMPLE, true, NT>(L, stream);
+    return hipErrorInvalidValue;
+  }
+  switch (epi) {
+    case EPI_AFFINE: return launch_sp_t<EPI_AFFINE, false, NT>(L, stream);
+    case EPI_BLEND:  return launch_sp_t<EPI_BLEND, false, NT>(L, stream);
+    case EPI_LNG:    return launch_sp_t<EPI_LNG, false, NT>(L, stream);
+    case EPI_TRUST:  return launch_sp_t<EPI_TRUST, false, NT>(L, stream);
+    case EPI_SAMPLE: return launch_sp_t<EPI_SAMPLE, false, NT>(L, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
+// bn: pixels per tile (32 or 64); scaled: every problem carries an SE input scale (single input, cin_pad <= 256)
+hipError_t launch_conv_sp(const ConvLaunch& L, int epi, bool scaled, int bn, hipStream_t stream) {
+  if (bn == 64) return launch_sp_n<4>(L, epi, scaled, stream);
+  if (bn == 32) return launch_sp_n<2>(L, epi, scaled, stream);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace sf

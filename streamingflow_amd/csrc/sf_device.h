@@ -71,6 +71,39 @@ struct ConvLaunch {
   ConvProblem p[SF_MAX_GROUP];
   int nprob;
   int xcd_shift;   // LDS-DMA kernel, large launches: log2 of the XCD tile chunk + 1 (0: workgroup b computes tile b)
+  int stamp_slot;  // diagnostic builds (-DSF_STAMP): launch slot of the in-kernel time stamps
 };
+
+// Diagnostic builds only (-DSF_STAMP, tools/r02/stamps.py): wave 0 of every workgroup records s_memrealtime (100 MHz)
+// at fixed points of the kernel into a debug buffer no other code reads.  The product build compiles none of it.
+#ifdef SF_STAMP
+#define SF_STAMP_WGS 4096
+// g_sf_stamps is defined in conv_igemm.hip (no relocatable device code: only the kernels of that file are stamped)
+#define SF_STAMP_AT(L, k)                                                                                             \
+  do {                                                                                                                \
+    if (g_sf_stamps && threadIdx.x == 0) {                                                                            \
+      const size_t wg_ = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                      \
+      if (wg_ < SF_STAMP_WGS) g_sf_stamps[((size_t)(L).stamp_slot * SF_STAMP_WGS + wg_) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    }                                                                                                                 \
+  } while (0)
+#define SF_STAMP_VAL_T(L, k, v, t)                                                                                    \
+  do {                                                                                                                \
+    if (g_sf_stamps && threadIdx.x == (t)) {                                                                          \
+      const size_t wg_ = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                      \
+      if (wg_ < SF_STAMP_WGS) g_sf_stamps[((size_t)(L).stamp_slot * SF_STAMP_WGS + wg_) * 16 + (k)] = (v);            \
+    }                                                                                                                 \
+  } while (0)
+#define SF_STAMP_VAL(L, k, v)                                                                                         \
+  do {                                                                                                                \
+    if (g_sf_stamps && threadIdx.x == 0) {                                                                            \
+      const size_t wg_ = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                      \
+      if (wg_ < SF_STAMP_WGS) g_sf_stamps[((size_t)(L).stamp_slot * SF_STAMP_WGS + wg_) * 16 + (k)] = (v);            \
+    }                                                                                                                 \
+  } while (0)
+#else
+#define SF_STAMP_AT(L, k) do { } while (0)
+#define SF_STAMP_VAL(L, k, v) do { } while (0)
+#define SF_STAMP_VAL_T(L, k, v, t) do { } while (0)
+#endif
 
 }  // namespace sf
