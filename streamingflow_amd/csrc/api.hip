@@ -115,7 +115,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int sp, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int sp, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -124,6 +124,7 @@ const Tune& tune() {
     x.sp_split_wgs = geti("SF_SP_SPLIT_WGS", 240); // ... K ranges are split across about this many workgroups per launch
     x.sp_bn = geti("SF_SP_BN", 0);                 // ... pixels per tile (0: by the amount of work, see sp_bn)
     x.sp_max_p = geti("SF_SP_MAX_P", 4096);        // ... used below this many pixels (one 50x50 latent; measured: from two samples on the round-1 kernels are as fast or faster)
+    x.sp_fuse_se = geti("SF_SP_FUSE_SE", 1);       // ... SE gates computed in the consuming layer's prologue (one sample)
     x.sp_wide_work = geti("SF_SP_WIDE_WORK", 1000);// ... 64-pixel tiles + split K from this many (64x64 tile) x (64-deep chunk) units per launch
     x.direct = geti("SF_DIRECT", 1);
     x.mt = geti("SF_DIRECT_MT", 0);
@@ -178,9 +179,10 @@ bool sp_takes(const ConvProblem* ps, int n, int epi) {
     const long Pi = (long)q.n_img * q.Hout * q.Wout;
     if (Pi >= tune().sp_max_p || q.gather || q.gate || !one_source_per_chunk(q)) return false;
     if ((epi == EPI_LNG || epi == EPI_TRUST) && q.cout_pad > 64) return false;
-    if (q.in_scale) {
+    if (q.in_scale || q.se_sum) {
       ++scaled;
       if (q.c1 != 0 || q.cin_pad > 256 || (long)q.Hout * q.Wout < 32) return false;   // a 64-pixel tile touches <= 4 images
+      if (q.se_sum && (q.n_img != 1 || q.c0 > 128 || q.c0 < 1 || q.se_cr < 1 || q.se_cr > 16 || q.c0 != q.cin_pad)) return false;
     }
     const double span = (64.0 / ((double)q.Hout * q.Wout) + 2.0) * q.Hin * q.Win * 4.0;
     if (span * q.in0_cs >= 2147483648.0 || span * q.in1_cs >= 2147483648.0 || 4.0 * q.cout_pad * q.ktot >= 2147483648.0) return false;
@@ -252,7 +254,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     L.stamp_slot = g_stamp_slot;
     if (g_stamp_on) g_stamp_slot = (g_stamp_slot + 1) % 64;
     bool scaled = false;
-    for (int i = 0; i < n; ++i) scaled = scaled || (ps[i].in_scale != nullptr);
+    for (int i = 0; i < n; ++i) scaled = scaled || (ps[i].in_scale != nullptr) || (ps[i].se_sum != nullptr);
     if (!g_prof.on) {
       SF_HIP(launch_conv_sp(L, epi, scaled, bn, st));
       return SF_OK;
@@ -486,56 +488,70 @@ int gru_cell(const sf_gru_w& w, const float* x, const float* s, float* out, floa
 
 size_t dual_ws_floats(int C, int P) { return 2 * al((size_t)P * 2 * C) + 8 * al((size_t)P * C); }
 
-// temporal_ode_bayes.py:92-131 / :239-275
+// scratch of one dual cell (temporal_ode_bayes.py:92-131 / :239-275)
+struct CellBufs {
+  float *g1, *g2, *h1, *h2, *r2, *t1, *sk, *t2, *rs1, *rs2;
+  bool take(Arena& A, int C, int P) {
+    g1 = A.take((size_t)P * 2 * C); g2 = A.take((size_t)P * 2 * C);
+    h1 = A.take((size_t)P * C); h2 = A.take((size_t)P * C); r2 = A.take((size_t)P * C);
+    t1 = A.take((size_t)P * C); sk = A.take((size_t)P * C); t2 = A.take((size_t)P * C);
+    rs1 = A.take((size_t)P * C); rs2 = A.take((size_t)P * C);
+    return A.ok();
+  }
+};
+void cell_gate_problems(const sf_dual_w& w, const float* x, const float* s, const CellBufs& b, bool pre, int B, int H, int W,
+                        ConvProblem& g1, ConvProblem& g2) {
+  const int C = w.C;
+  g1 = problem(w.gates1, x, s, b.g1, B, H, W);
+  g2 = problem(w.gates2, s, nullptr, b.g2, B, H, W);   // cell 2 sees cat[s,s]: duplicate input folded into the packed weights
+  if (pre) {
+    g1.out2 = b.rs1; g1.out2_cs = C; g1.e1 = s; g1.e1_cs = C; g1.gate_from = C;
+    g2.out2 = b.rs2; g2.out2_cs = C; g2.e1 = s; g2.e1_cs = C; g2.gate_from = C;
+  }
+}
+void cell_cand_problems(const sf_dual_w& w, const float* x, const float* s, const CellBufs& b, bool pre, int B, int H, int W,
+                        ConvProblem& c1, ConvProblem& c2) {
+  const int C = w.C;
+  c1 = problem(w.cand1, x, pre ? b.rs1 : s, b.h1, B, H, W);
+  c1.e0 = b.g1; c1.e0_cs = 2 * C; c1.e1 = s; c1.e1_cs = C;
+  c2 = problem(w.cand2, s, pre ? b.rs2 : s, b.h2, B, H, W);
+  c2.e0 = b.g2; c2.e0_cs = 2 * C; c2.e1 = s; c2.e1_cs = C;
+  if (!pre) {
+    c1.gate = b.g1; c1.gate_cs = 2 * C; c1.gate_co = C;
+    c2.gate = b.g2; c2.gate_cs = 2 * C; c2.gate_co = C;
+  }
+}
+// trusting gate + mix + integrator update   (:124-131, convolutions.py:348-380)
+int cell_tail(const sf_dual_w& w, const float* s, float* out, int derivative, const float* base, const float* coef,
+              int coef_stride, float* out2, int acc2, const CellBufs& b, int B, int H, int W, hipStream_t st) {
+  ConvProblem ps[2];
+  ps[0] = problem(w.tg7, b.h1, b.r2, b.t1, B, H, W); ps[0].mode = 1;       // 7x7 + LN + GELU
+  ps[1] = problem(w.tgproj, b.h1, b.r2, b.sk, B, H, W); ps[1].mode = 0;   // 1x1 projection + GELU
+  SF_TRY(run(ps, 2, EPI_LNG, st));
+  ConvProblem q = problem(w.tg1, b.t1, nullptr, b.t2, B, H, W); q.mode = 1;
+  SF_TRY(run1(q, EPI_LNG, st));
+  ConvProblem f = problem(w.tg3, b.t2, nullptr, out, B, H, W);
+  f.e0 = b.sk; f.e1 = w.w_logit; f.e2 = b.r2; f.e3 = b.h1; f.e4 = s; f.e5 = base ? base : s;
+  f.coef = coef; f.coef_stride = coef_stride; f.out2 = out2; f.mode = (derivative ? 1 : 0) | (acc2 ? 2 : 0);
+  if (derivative && !coef) return SF_ERR_INVALID;
+  return run1(f, EPI_TRUST, st);
+}
+
 // B images (samples) are processed as one pixel space; coef_stride = floats between the
 // coefficient records of consecutive images (0: one record shared by all)
 int dual_cell(const sf_dual_w& w, const float* x, const float* s, float* out, int derivative, const float* base,
               const float* coef, int coef_stride, float* out2, int acc2, int B, int H, int W, Arena& A, hipStream_t st) {
   const int C = w.C, P = B * H * W;
-  float* g1 = A.take((size_t)P * 2 * C);
-  float* g2 = A.take((size_t)P * 2 * C);
-  float* h1 = A.take((size_t)P * C);
-  float* h2 = A.take((size_t)P * C);
-  float* r2 = A.take((size_t)P * C);
-  float* t1 = A.take((size_t)P * C);
-  float* sk = A.take((size_t)P * C);
-  float* t2 = A.take((size_t)P * C);
-  float* rs1 = A.take((size_t)P * C);
-  float* rs2 = A.take((size_t)P * C);
-  if (!A.ok()) return SF_ERR_WORKSPACE;
+  CellBufs b;
+  if (!b.take(A, C, P)) return SF_ERR_WORKSPACE;
   const bool pre = pregate(P, w.cand1) && pregate(P, w.cand2);
   ConvProblem ps[2];
-  // gates of both cells (cell 2 sees cat[s,s]: duplicate input folded into the packed weights)
-  ps[0] = problem(w.gates1, x, s, g1, B, H, W);
-  ps[1] = problem(w.gates2, s, nullptr, g2, B, H, W);
-  if (pre) {
-    ps[0].out2 = rs1; ps[0].out2_cs = C; ps[0].e1 = s; ps[0].e1_cs = C; ps[0].gate_from = C;
-    ps[1].out2 = rs2; ps[1].out2_cs = C; ps[1].e1 = s; ps[1].e1_cs = C; ps[1].gate_from = C;
-  }
+  cell_gate_problems(w, x, s, b, pre, B, H, W, ps[0], ps[1]);     // gates of both cells in one launch
   SF_TRY(run(ps, 2, EPI_AFFINE, st));
-  // candidates + blend
-  ps[0] = problem(w.cand1, x, pre ? rs1 : s, h1, B, H, W);
-  ps[0].e0 = g1; ps[0].e0_cs = 2 * C; ps[0].e1 = s; ps[0].e1_cs = C;
-  ps[1] = problem(w.cand2, s, pre ? rs2 : s, h2, B, H, W);
-  ps[1].e0 = g2; ps[1].e0_cs = 2 * C; ps[1].e1 = s; ps[1].e1_cs = C;
-  if (!pre) {
-    ps[0].gate = g1; ps[0].gate_cs = 2 * C; ps[0].gate_co = C;
-    ps[1].gate = g2; ps[1].gate_cs = 2 * C; ps[1].gate_co = C;
-  }
+  cell_cand_problems(w, x, s, b, pre, B, H, W, ps[0], ps[1]);     // candidates + blend
   SF_TRY(run(ps, 2, EPI_BLEND, st));
-  // rnn_state2 = conv_decoder_2(h2)
-  SF_TRY(run1(problem(w.dec2, h2, nullptr, r2, B, H, W), EPI_AFFINE, st));
-  // trusting gate: 7x7 + LN + GELU  ||  1x1 projection + GELU
-  ps[0] = problem(w.tg7, h1, r2, t1, B, H, W); ps[0].mode = 1;
-  ps[1] = problem(w.tgproj, h1, r2, sk, B, H, W); ps[1].mode = 0;
-  SF_TRY(run(ps, 2, EPI_LNG, st));
-  ConvProblem q = problem(w.tg1, t1, nullptr, t2, B, H, W); q.mode = 1;
-  SF_TRY(run1(q, EPI_LNG, st));
-  ConvProblem f = problem(w.tg3, t2, nullptr, out, B, H, W);
-  f.e0 = sk; f.e1 = w.w_logit; f.e2 = r2; f.e3 = h1; f.e4 = s; f.e5 = base ? base : s;
-  f.coef = coef; f.coef_stride = coef_stride; f.out2 = out2; f.mode = (derivative ? 1 : 0) | (acc2 ? 2 : 0);
-  if (derivative && !coef) return SF_ERR_INVALID;
-  return run1(f, EPI_TRUST, st);
+  SF_TRY(run1(problem(w.dec2, b.h2, nullptr, b.r2, B, H, W), EPI_AFFINE, st));   // rnn_state2 = conv_decoder_2(h2)
+  return cell_tail(w, s, out, derivative, base, coef, coef_stride, out2, acc2, b, B, H, W, st);
 }
 
 constexpr int SE_SLABS = 64;
@@ -553,16 +569,18 @@ int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p
   const int C = w.C, C2 = 2 * C, HW = H * W, P = B * HW;
   if (B < 1 || B > 64) return SF_ERR_UNSUPPORTED;
   const bool tiles = (B == 1);
-  ConvProblem probe = problem(w.rb0.conv2, s, nullptr, nullptr, B, H, W);
-  const int tpx = chansum_tile_px(probe, EPI_AFFINE);   // both SE producers are plain 3x3 layers of the same pixel count
-  const int nt = tiles ? (P + tpx - 1) / tpx : SE_SLABS;
+  // rows of per-tile channel sums each SE producer writes (its kernel's pixel tile), or per-image slab sums
+  ConvProblem probe1 = problem(w.rb0.conv2, s, nullptr, nullptr, B, H, W), probe2 = problem(w.rb1.conv2, s, nullptr, nullptr, B, H, W);
+  const int tpx1 = chansum_tile_px(probe1, EPI_AFFINE), tpx2 = chansum_tile_px(probe2, EPI_AFFINE);
+  const int nt1 = tiles ? (P + tpx1 - 1) / tpx1 : SE_SLABS, nt2 = tiles ? (P + tpx2 - 1) / tpx2 : SE_SLABS;
+
   float* a = A.take((size_t)P * C);
   float* pr = A.take((size_t)P * C2);
   float* y1 = A.take((size_t)P * C2);
   float* b = A.take((size_t)P * C2);
   float* y2 = A.take((size_t)P * C2);
-  float* cs1 = A.take((size_t)B * nt * C2);
-  float* cs2 = A.take((size_t)B * nt * C2);
+  float* cs1 = A.take(tiles ? (size_t)nt1 * C2 : (size_t)B * SE_SLABS * C2);
+  float* cs2 = A.take(tiles ? (size_t)nt2 * C2 : (size_t)B * SE_SLABS * C2);
   float* sc1 = A.take((size_t)B * C2);
   float* sc2 = A.take((size_t)B * C2);
   if (!A.ok()) return SF_ERR_WORKSPACE;
@@ -574,18 +592,34 @@ int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p
   ConvProblem c2 = problem(w.rb0.conv2, a, nullptr, y1, B, H, W);
   c2.add = pr; c2.chansum = tiles ? cs1 : nullptr;
   SF_TRY(run1(c2, EPI_AFFINE, st));
-  if (!tiles) SF_HIP(launch_chan_partial(y1, cs1, B, HW, C2, SE_SLABS, st));
-  SF_HIP(launch_se_fc(cs1, nt, C2, C2 / 8, HW, w.se0_fc0, w.se0_fc2, sc1, B, st));
+  // SE gates.  One sample on the small-P kernel: the consuming layer computes the gate in its prologue from the
+  // producer's per-tile channel sums (two launches fewer per infer_state); otherwise the gate kernel
   ConvProblem c3 = problem(w.rb1.conv1, y1, nullptr, b, B, H, W);
-  c3.in_scale = sc1;
+  c3.se_sum = cs1; c3.se_fc0 = w.se0_fc0; c3.se_fc2 = w.se0_fc2; c3.se_out = sc1; c3.se_nt = nt1; c3.se_cr = C2 / 8;
+  c3.se_inv_hw = 1.f / (float)HW;
+  const bool fuse_se = tiles && tune().sp_fuse_se && sp_takes(&c3, 1, EPI_AFFINE);
+  if (!fuse_se) {
+    c3.se_sum = nullptr;
+    if (!tiles) SF_HIP(launch_chan_partial(y1, cs1, B, HW, C2, SE_SLABS, st));
+    SF_HIP(launch_se_fc(cs1, nt1, C2, C2 / 8, HW, w.se0_fc0, w.se0_fc2, sc1, B, st));
+    c3.in_scale = sc1;
+  }
   SF_TRY(run1(c3, EPI_AFFINE, st));
   ConvProblem c4 = problem(w.rb1.conv2, b, nullptr, y2, B, H, W);
   c4.add = y1; c4.add_scale = sc1; c4.chansum = tiles ? cs2 : nullptr;
   SF_TRY(run1(c4, EPI_AFFINE, st));
-  if (!tiles) SF_HIP(launch_chan_partial(y2, cs2, B, HW, C2, SE_SLABS, st));
-  SF_HIP(launch_se_fc(cs2, nt, C2, C2 / 8, HW, w.se1_fc0, w.se1_fc2, sc2, B, st));
   ConvProblem c5 = problem(w.last, y2, nullptr, p_out, B, H, W);
-  c5.in_scale = sc2; c5.e0 = eps; c5.out2 = q_out;
+  c5.e0 = eps; c5.out2 = q_out;
+  if (fuse_se) {
+    c5.se_sum = cs2; c5.se_fc0 = w.se1_fc0; c5.se_fc2 = w.se1_fc2; c5.se_out = nullptr; c5.se_nt = nt2; c5.se_cr = C2 / 8;
+    c5.se_inv_hw = 1.f / (float)HW;
+  }
+  if (!fuse_se || !sp_takes(&c5, 1, EPI_SAMPLE)) {
+    c5.se_sum = nullptr;
+    if (!tiles) SF_HIP(launch_chan_partial(y2, cs2, B, HW, C2, SE_SLABS, st));
+    SF_HIP(launch_se_fc(cs2, nt2, C2, C2 / 8, HW, w.se1_fc0, w.se1_fc2, sc2, B, st));
+    c5.in_scale = sc2;
+  }
   return run1(c5, EPI_SAMPLE, st);
 }
 
@@ -887,62 +921,115 @@ int sf_ode_step_fwd(const sf_dual_w* gru_c, const sf_pmodel_w* pm, int solver, i
   return ode_step(*gru_c, *pm, solver, impute, state_in, p_in, coef, 0, eps, state_out, p_out, zeros, 0, n_img, H, W, A, st);
 }
 
-size_t sf_nnfo_rollout_ws_bytes(int C, int n_img, int H, int W) {
-  const int P = n_img * H * W;
-  return (ode_step_ws_floats(C, P) + 5 * al((size_t)P * C) + SPLIT_WS_FLOATS) * sizeof(float);
+// ---- rollout as a list of stages -----------------------------------------------------------------------------------------
+// A stage = one dual cell (ODE derivative + integrator update, or a Bayesian jump) followed by an optional infer_state.
+// (Measured and rejected, profiles/README.md "two-stream rollout": running gru_cell_2 / conv_decoder_2 of stage j+1 on a
+// second stream beside stage j's infer_state — they only need the state — made the 18-op rollout 11 % slower: every
+// small-P workgroup owns a whole CU, so the two chains take turns instead of overlapping, and the split launches lose
+// the grouping of the two gate / candidate convolutions.)
+struct Stage {
+  const sf_dual_w* w;
+  const float* x; const float* s; float* out;
+  int derivative; const float* base; const float* coef; float* out2; int acc2;
+  bool infer_after; int draw; float* p_out;
+  int op_end;      // index of the op this stage completes (-1: an inner solver stage)
+};
+
+size_t rollout_ws_floats(int C, int P) {
+  const size_t cellw = dual_ws_floats(C, P), inf = infer_ws_floats(C, P);
+  return (cellw > inf ? cellw : inf) + 9 * al((size_t)P * C) + SPLIT_WS_FLOATS + 256;
 }
+
+int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const float* eps, int coef_stride, const int32_t* sel_nops,
+               int n_targets, float* out_states, int B, int H, int W, Arena& A, hipStream_t st) {
+  const size_t PC = (size_t)B * H * W * pm.C;
+  for (const Stage& g : stages) {
+    Arena Ac = A;
+    SF_TRY(dual_cell(*g.w, g.x, g.s, g.out, g.derivative, g.base, g.coef, coef_stride, g.out2, g.acc2, B, H, W, Ac, st));
+    if (g.op_end >= 0)
+      for (int t = 0; t < n_targets; ++t)
+        if (sel_nops[t] == g.op_end + 1)
+          SF_HIP(hipMemcpyAsync(out_states + (size_t)t * PC, g.out, PC * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (g.infer_after) {
+      Arena Ai = A;
+      SF_TRY(infer_state(pm, g.out, eps + (size_t)g.draw * PC, g.p_out, nullptr, B, H, W, Ai, st));
+    }
+  }
+  return SF_OK;
+}
+
+size_t sf_nnfo_rollout_ws_bytes(int C, int n_img, int H, int W) { return rollout_ws_floats(C, n_img * H * W) * sizeof(float); }
 int sf_nnfo_rollout_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const sf_pmodel_w* pm, int solver, int impute,
                         const int32_t* ops, int n_ops, const float* hx_obs, const float* eps, const float* coef,
                         int coef_per_image, const int32_t* sel_nops, int n_targets, float* out_states,
                         float* final_state, int n_img, int H, int W, float* ws, size_t ws_bytes, void* stream) {
   if (!gru_c || !gru_obs || !pm || !ops || !hx_obs || !eps || !sel_nops || !out_states || n_img < 1) return SF_ERR_INVALID;
   if (gru_c->C > 64 || (gru_c->C % 8)) return SF_ERR_UNSUPPORTED;
+  if (solver != SF_SOLVER_EULER && solver != SF_SOLVER_MIDPOINT && solver != SF_SOLVER_RK4) return SF_ERR_INVALID;
   const int C = gru_c->C, B = n_img;
   const size_t PC = (size_t)B * H * W * C;
   Arena A(ws, ws_bytes);
   SplitScope sp(A, (hipStream_t)stream);
   float* zeros = A.take(PC);
-  float* sA = A.take(PC);
-  float* sB = A.take(PC);
-  float* pA = A.take(PC);
-  float* pB = A.take(PC);
+  float* sbuf[2] = {A.take(PC), A.take(PC)};
+  float* pbuf[2] = {A.take(PC), A.take(PC)};
+  float* k = A.take(PC);       // solver stages (midpoint / RK4)
+  float* pk = A.take(PC);
+  float* acc = A.take(PC);
+  float* s3 = A.take(PC);
   if (!A.ok()) return SF_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   SF_HIP(hipMemsetAsync(zeros, 0, PC * sizeof(float), st));
-  SF_HIP(hipMemsetAsync(sA, 0, PC * sizeof(float), st));   // state = zeros  (temporal_ode_bayes.py:507)
-  SF_HIP(hipMemsetAsync(pA, 0, PC * sizeof(float), st));   // input: overwritten by the first jump (:565,574)
-  float *s = sA, *s2 = sB, *p = pA, *p2 = pB;
-  int draw = 0;
-  const int draws_per_step = solver == SF_SOLVER_EULER ? 1 : (solver == SF_SOLVER_MIDPOINT ? 2 : 4);
+  SF_HIP(hipMemsetAsync(sbuf[0], 0, PC * sizeof(float), st));   // state = zeros  (temporal_ode_bayes.py:507)
+  SF_HIP(hipMemsetAsync(pbuf[0], 0, PC * sizeof(float), st));   // input: overwritten by the first jump (:565,574)
+  int si = 0, pi = 0, draw = 0;
   const int cstride = coef_per_image ? SF_COEF_STRIDE : 0;
   const size_t step_stride = (size_t)SF_COEF_STRIDE * (coef_per_image ? B : 1);
+  std::vector<Stage> stages;
   for (int i = 0; i < n_ops; ++i) {
     const int kind = ops[2 * i], arg = ops[2 * i + 1];
+    // the imputed input this op leaves behind is only read by a following ODE step (:446-455); a jump ignores it
+    // (:327-344) and then overwrites it (:574), and nothing reads it after the last op: those infer_state passes
+    // are skipped (their noise draw keeps its index)
+    const bool next_is_step = (i + 1 < n_ops) && ops[2 * (i + 1)] == SF_OP_STEP;
+    const bool need_p = impute && next_is_step;
+    float* s = sbuf[si]; float* s2 = sbuf[si ^ 1];
+    float* p = pbuf[pi]; float* p2 = pbuf[pi ^ 1];
     if (kind == SF_OP_JUMP) {   // :562-574
-      Arena Bq = A;
-      SF_TRY(dual_cell(*gru_obs, hx_obs + (size_t)arg * PC, s, s2, 0, nullptr, nullptr, 0, nullptr, 0, B, H, W, Bq, st));
-      if (impute) {   // with IMPUTE off the imputed input is never read (:442-443): skip the dead pass
-        Arena D = A;
-        SF_TRY(infer_state(*pm, s2, eps + (size_t)draw * PC, p, nullptr, B, H, W, D, st));
-      }
+      stages.push_back(Stage{gru_obs, hx_obs + (size_t)arg * PC, s, s2, 0, nullptr, nullptr, nullptr, 0, need_p, draw, p, i});
       draw += 1;
-      float* t = s; s = s2; s2 = t;
+      si ^= 1;
     } else if (kind == SF_OP_STEP) {
       if (!coef) return SF_ERR_INVALID;
-      Arena Bq = A;
-      SF_TRY(ode_step(*gru_c, *pm, solver, impute, s, p, coef + (size_t)arg * step_stride, cstride,
-                      eps + (size_t)draw * PC, s2, p2, zeros, 1, B, H, W, Bq, st));
-      draw += draws_per_step;
-      float* t = s; s = s2; s2 = t;
-      t = p; p = p2; p2 = t;
+      const float* cf = coef + (size_t)arg * step_stride;
+      const float* x = impute ? p : zeros;
+      if (solver == SF_SOLVER_EULER) {
+        stages.push_back(Stage{gru_c, x, s, s2, 1, s, cf + 0, nullptr, 0, need_p, draw, p2, i});
+        draw += 1;
+      } else if (solver == SF_SOLVER_MIDPOINT) {
+        // k = s + dt/2 f(p, s); pk = infer(k) (:452 — evaluated even when IMPUTE is off); s' = s + dt f(pk, k)
+        stages.push_back(Stage{gru_c, x, s, k, 1, s, cf + 1, nullptr, 0, true, draw, pk, -1});
+        stages.push_back(Stage{gru_c, pk, k, s2, 1, s, cf + 0, nullptr, 0, need_p, draw + 1, p2, i});
+        draw += 2;
+      } else {
+        // RK4 (build-defined): acc = s + dt/6 k1 + dt/3 k2 + dt/3 k3 ; s' = acc + dt/6 k4.  Stage coefficient pairs
+        // {out coef, out2 coef} follow the four scalars in the coef record (SF_COEF_STRIDE in sfnative.h); stage inputs
+        // always come from infer_state, as in midpoint
+        const float* rk = cf + 4;
+        stages.push_back(Stage{gru_c, x, s, k, 1, s, rk + 0, acc, 0, true, draw, pk, -1});
+        stages.push_back(Stage{gru_c, pk, k, s3, 1, s, rk + 2, acc, 1, true, draw + 1, pk, -1});
+        stages.push_back(Stage{gru_c, pk, s3, k, 1, s, rk + 4, acc, 1, true, draw + 2, pk, -1});
+        stages.push_back(Stage{gru_c, pk, k, s2, 1, acc, rk + 6, nullptr, 0, need_p, draw + 3, p2, i});
+        draw += 4;
+      }
+      si ^= 1;
+      pi ^= 1;
     } else {
       return SF_ERR_INVALID;
     }
-    for (int t = 0; t < n_targets; ++t)
-      if (sel_nops[t] == i + 1)
-        SF_HIP(hipMemcpyAsync(out_states + (size_t)t * PC, s, PC * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
-  if (final_state) SF_HIP(hipMemcpyAsync(final_state, s, PC * sizeof(float), hipMemcpyDeviceToDevice, st));
+  SF_TRY(run_stages(stages, *pm, eps, cstride, sel_nops, n_targets, out_states, B, H, W, A, st));
+  if (final_state) SF_HIP(hipMemcpyAsync(final_state, sbuf[si], PC * sizeof(float), hipMemcpyDeviceToDevice, st));
   return SF_OK;
 }
 

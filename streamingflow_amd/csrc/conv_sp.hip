@@ -37,7 +37,7 @@ constexpr int SP_BM = 64;                     // output channels per tile
 constexpr int SP_NB = 3, SP_LA = SP_NB - 1;   // chunk buffers of the LDS ring / chunks in flight
 constexpr int SP_RED_PITCH = 68;              // reduction buffer [4 quarters][BN px][68] (inside the ring)
 constexpr int SP_SC_IMGS = 4;                 // SE scale rows kept in LDS: images a pixel tile can touch
-constexpr int SP_SC_FLOATS = SP_SC_IMGS * 256;
+constexpr int SP_SC_FLOATS = SP_SC_IMGS * 256 + 1280;   // + scratch of the in-kernel SE gate (6 partial rows + mean + hidden)
 constexpr int SP_MISC = 64;                   // hand-off flag
 constexpr int SP_THREADS = 768;               // 8 consumer + 4 loader waves
 // NT = 16-pixel n-tiles per consumer wave: the tile is 64 cout x (16 NT) px
@@ -246,7 +246,60 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
   // SE-scaled input (res_models.py:161-165 feeding the next conv): the per-(image, channel) scale rows of the images this
   // tile touches go to LDS; the consumers multiply their pixel fragments by them.  Published by the first barrier.
   auto fill_scale_rows = [&]() {
-    if (SCALE) {
+    if (SCALE && P.se_sum) {   // block-uniform: compute the gate here (one image; fixed summation order; host: C <= 128, Cr <= 16)
+      const int C = P.c0, Cr = P.se_cr, nt = P.se_nt;
+      float* const part = sc_lds + SP_SC_IMGS * 256;    // [G][C]
+      float* const mean = part + 768;                   // [C]
+      float* const hid = mean + 256;                    // [Cr]
+      const int G = SP_THREADS / C;                     // tile rows summed in parallel
+      const int ch = tid % C, grp = tid / C;
+      // every global operand up front: one round trip instead of three
+      float f2[16];
+#pragma unroll
+      for (int h = 0; h < 16; ++h) f2[h] = (tid < C && h < Cr) ? P.se_fc2[tid * Cr + h] : 0.f;
+      const int hrow = wave < Cr ? wave : 0;
+      const float f0a = (lane < C) ? P.se_fc0[hrow * C + lane] : 0.f;
+      const float f0b = (lane + 64 < C) ? P.se_fc0[hrow * C + lane + 64] : 0.f;
+      const float f0c = (wave + 12 < Cr && lane < C) ? P.se_fc0[(wave + 12) * C + lane] : 0.f;
+      const float f0d = (wave + 12 < Cr && lane + 64 < C) ? P.se_fc0[(wave + 12) * C + lane + 64] : 0.f;
+      if (grp < G) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int t = grp;
+        for (; t + 3 * G < nt; t += 4 * G) {
+          s0 += P.se_sum[(size_t)t * C + ch]; s1 += P.se_sum[(size_t)(t + G) * C + ch];
+          s2 += P.se_sum[(size_t)(t + 2 * G) * C + ch]; s3 += P.se_sum[(size_t)(t + 3 * G) * C + ch];
+        }
+        for (; t < nt; t += G) s0 += P.se_sum[(size_t)t * C + ch];
+        part[grp * C + ch] = (s0 + s1) + (s2 + s3);
+      }
+      __syncthreads();
+      if (tid < C) {
+        float s = 0.f;
+        for (int q = 0; q < G; ++q) s += part[q * C + tid];
+        mean[tid] = s * P.se_inv_hw;
+      }
+      __syncthreads();
+      {   // hidden units wave and wave + 12 (12 waves, Cr <= 16)
+        float s = f0a * (lane < C ? mean[lane] : 0.f) + f0b * (lane + 64 < C ? mean[lane + 64] : 0.f);
+        float u = f0c * (lane < C ? mean[lane] : 0.f) + f0d * (lane + 64 < C ? mean[lane + 64] : 0.f);
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); u += __shfl_xor(u, o); }
+        if (lane == 0 && wave < Cr) hid[wave] = s > 0.f ? s : 0.f;
+        if (lane == 0 && wave + 12 < Cr) hid[wave + 12] = u > 0.f ? u : 0.f;
+      }
+      __syncthreads();
+      for (int idx = tid; idx < SP_SC_IMGS * cin_pad; idx += SP_THREADS) {
+        float sv = 0.f;
+        if (idx < C) {      // idx == tid here (C <= 128 < SP_THREADS)
+          float s = 0.f;
+#pragma unroll
+          for (int h = 0; h < 16; ++h) s += f2[h] * (h < Cr ? hid[h] : 0.f);
+          sv = 1.f / (1.f + expf(-s));
+          if (P.se_out && blockIdx.x == 0 && blockIdx.z == 0) P.se_out[idx] = sv;
+        }
+        sc_lds[idx] = sv;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if (SCALE) {
       const float* const in_scale = P.in_scale;
       for (int idx = tid; idx < SP_SC_IMGS * cin_pad; idx += SP_THREADS) {
         const int si = idx / cin_pad, ch = idx - si * cin_pad;

@@ -64,6 +64,15 @@ struct ConvProblem {
   // sparse (gather) convolution: the input row of output row p under kernel tap t is gather[p*KH + t]
   // (-1: inactive site); geometry is then n_img = 1, Hout = 1, Wout = number of output rows, KW = 1
   const int* gather;
+  // small-P kernel, one image: the SE gate of the input (res_models.py:161-165) is computed in the consuming layer's
+  // prologue from the per-tile channel sums the producer wrote: scale = sigmoid(fc2 relu(fc0 mean)), every workgroup
+  // for itself; workgroup 0 also stores it to se_out (the residual of the next layer is scaled by it)
+  const float* se_sum;    // [se_nt][c0] per-tile channel sums (null: in_scale holds the gate, or no gate)
+  const float* se_fc0;    // [se_cr][c0]
+  const float* se_fc2;    // [c0][se_cr]
+  float* se_out;          // [c0] (may be null)
+  int se_nt, se_cr;
+  float se_inv_hw;
 };
 
 #define SF_MAX_GROUP 4
