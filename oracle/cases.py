@@ -91,6 +91,23 @@ FPODE_CASES = {
 }
 
 
+# BASELINE config 5 (streaming fine interval: 40 targets at 0.05 s -> 46 ODE steps) and config 4 (8 s horizon:
+# 19 frames), small enough to keep whole outputs: tests/golden/fpode_stream.npz.  rk4 has no reference
+# implementation (build-defined): checked against the oracle only.
+FPODE_STREAM_CASES = {
+    "c8_16_stream40_euler":    (8, 16, 16, "stream40", "euler", True, True, False),
+    "c8_16_stream40_midpoint": (8, 16, 16, "stream40", "midpoint", True, True, False),
+    "c16_24_stream40_euler":   (16, 24, 24, "stream40", "euler", True, True, False),
+    "c8_16_future16_euler":    (8, 16, 16, "future16", "euler", True, True, False),
+    "c8_16_stream40_noimpute": (8, 16, 16, "stream40", "midpoint", False, True, False),
+}
+# full-size statistics (tests/golden/big_stats.json "cases"): tag -> (C, H, W, timeset, solver, impute, variable)
+BIG_CASES = {
+    "config4_future16": (64, 200, 200, "future16", "euler", True, True),
+    "config1_c32":      (32, 200, 200, "config1", "euler", True, False),
+}
+
+
 # BEVerse-named secondary classes: tag -> (in_channels, latent_dim, h, w, n_future)
 BEVERSE_CASES = {
     "config1_c32": (32, 16, 50, 50, 4),     # BASELINE config 1: FuturePrediction(32, 16, 3, 3) at 50x50

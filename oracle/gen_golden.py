@@ -76,9 +76,9 @@ def gen_ops(m):
     print("ops_c8.npz", {k: v.shape for k, v in out.items()})
 
 
-def gen_fpode(m):
+def gen_fpode(m, table=None, fname="fpode.npz", keep_decoded=True):
     out = {}
-    for name, (C, H, W, ts, solver, impute, variable, eps0) in cases.FPODE_CASES.items():
+    for name, (C, H, W, ts, solver, impute, variable, eps0) in (table or cases.FPODE_CASES).items():
         cts, lts, tts, dt = cases.timeset(ts)
         net, _ = build_ref(m, C, solver, impute, variable, dt)
         cam, lid = cases.bev_inputs(C, H, W, cts.shape[1], lts.shape[1])
@@ -91,9 +91,10 @@ def gen_fpode(m):
         assert aux == 0
         out[name + "/out"] = _np(y)
         out[name + "/nnfo_state"] = _np(grabbed["nnfo"][0])
-        out[name + "/nnfo_x"] = _np(grabbed["nnfo"][2])
+        if keep_decoded:
+            out[name + "/nnfo_x"] = _np(grabbed["nnfo"][2])
         print(name, y.shape, float(y.abs().max()))
-    np.savez_compressed(os.path.join(OUT, "fpode.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
 def reference_schedule(m, times, T, delta_t, variable):
@@ -195,17 +196,15 @@ def gen_beverse(m):
     np.savez_compressed(os.path.join(OUT, "beverse.npz"), **out)
 
 
-def gen_big(m):
-    """G7: C=64, BEV 200x200, shipped schedule — statistics only."""
-    C, H, W = 64, 200, 200
-    cts, lts, tts, dt = cases.timeset("shipped")
-    net, _ = build_ref(m, C, "euler", True, True, dt)
-    cam, lid = cases.bev_inputs(C, H, W, 3, 5)
+def _big_stats(m, C, H, W, ts, solver, impute, variable):
+    cts, lts, tts, dt = cases.timeset(ts)
+    net, _ = build_ref(m, C, solver, impute, variable, dt)
+    cam, lid = cases.bev_inputs(C, H, W, cts.shape[1], lts.shape[1])
     x_in = cases.present_input(cam, lid)
     grabbed = {}
     net.gru_ode.register_forward_hook(lambda mod, a, o: grabbed.__setitem__("nnfo", o))
     with torch.no_grad(), refimport.patched_standard_normal(hashfill.HashedNoise(cases.EPS_SEED)):
-        y, _ = net(x_in, cam, lid, cts, lts, tts)
+        y, _ = net(x_in, cam, lid if lts.shape[1] else torch.zeros((1, 0, C, H, W)), cts, lts, tts)
     stats = {}
     for k, t in (("out", y), ("nnfo_state", grabbed["nnfo"][0]), ("nnfo_x", grabbed["nnfo"][2])):
         flat = t.reshape(-1).double()
@@ -214,7 +213,19 @@ def gen_big(m):
                     "std": flat.std().item(), "sum": flat.sum().item(),
                     "sample_idx": idx.tolist(), "samples": flat[idx].tolist()}
         print(k, stats[k]["shape"], stats[k]["mean"], stats[k]["absmax"], stats[k]["std"])
-    with open(os.path.join(OUT, "big_stats.json"), "w") as f:
+    return stats
+
+
+def gen_big(m, only_cases=False):
+    """G7: full-size forwards — statistics only.  Top level: C=64, BEV 200x200, shipped schedule (BASELINE config 2);
+    "cases": config 4 (19 frames) and config 1 (C=32, 4 fixed Euler steps), oracle.cases.BIG_CASES."""
+    path = os.path.join(OUT, "big_stats.json")
+    if only_cases and os.path.exists(path):
+        stats = json.load(open(path))
+    else:
+        stats = _big_stats(m, 64, 200, 200, "shipped", "euler", True, True)
+    stats["cases"] = {tag: _big_stats(m, *cfg) for tag, cfg in cases.BIG_CASES.items()}
+    with open(path, "w") as f:
         json.dump(stats, f)
 
 
@@ -431,7 +442,7 @@ def main():
         gen_eval()
     if "labels" in todo:
         gen_labels()
-    if not set(todo) - {"lift", "voxel", "decoder", "temporal", "eval", "labels"}:
+    if not set(todo) - {"lift", "voxel", "decoder", "temporal", "eval", "labels"} and not a.big:
         return
     m = refimport.modules()
     if "ops" in todo:
@@ -442,8 +453,12 @@ def main():
         gen_schedules(m)
     if "beverse" in todo:
         gen_beverse(m)
+    if "fpode_stream" in todo:
+        gen_fpode(m, cases.FPODE_STREAM_CASES, "fpode_stream.npz", keep_decoded=False)
     if a.big or "big" in todo:
         gen_big(m)
+    if "big_cases" in todo:
+        gen_big(m, only_cases=True)
 
 
 if __name__ == "__main__":

@@ -289,10 +289,15 @@ class NNFOwithBayesianJumps(nn.Module):
         if len(scs) not in (1, B) or any(x.key() != s0.key() for x in scs):
             raise ValueError("batched rollout needs one schedule, or one per sample with identical structure")
         per_image = len(scs) > 1 and any(x.dts != s0.dts for x in scs)
+        # draws the kernels will read: one per jump, DRAWS_PER_STEP[solver] per step (a schedule built for another solver
+        # would make them read past the end of eps)
+        need = s0.n_jumps + sched.DRAWS_PER_STEP[self.solver] * s0.n_steps
         if eps is None:
-            eps = self._draw_eps(s0.n_draws, B, h, w, dev)
+            eps = self._draw_eps(need, B, h, w, dev)
         elif eps.dim() == 4:
             eps = eps[:, None]
+        if eps.shape[0] < need or tuple(eps.shape[1:]) != (B, h, w, C):
+            raise ValueError(f"eps must be [{need}, {B}, {h}, {w}, {C}] for solver {self.solver!r}, got {tuple(eps.shape)}")
         coef_np = np.stack([x.coef_array() for x in scs], axis=1) if per_image else s0.coef_array()
         coef = torch.from_numpy(np.ascontiguousarray(coef_np)).to(dev)
         L = _lib.lib()

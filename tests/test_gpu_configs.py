@@ -1,0 +1,91 @@
+"""GPU parity at the BASELINE configurations the round-1 suite did not run: config 1 exactly as SURVEY.md §8d states
+it, config 4 (8 s horizon: 16 future steps, 19 frames) and config 5 (streaming 0.05 s x 40: 46 ODE steps; euler and
+midpoint against the real reference's outputs, rk4 — build-defined — against the oracle; the captured hipGraph of the
+whole 46-step rollout against eager, bitwise, for all three solvers)."""
+import json
+import os
+
+import pytest
+import torch
+
+from util import GOLD, cases, hashfill, gold, maxabs, build_pair
+from oracle import ref_torch as R
+
+pytestmark = pytest.mark.gpu
+TOL_E2E = 1e-3      # north star: <= 1e-3 max-abs on the fp32 BEV output
+
+
+def _forward(C, H, W, ts, solver, impute, variable, eps0=False):
+    cts, lts, tts, dt = cases.timeset(ts)
+    net, sd = build_pair(C, solver, impute, variable, dt)
+    cam, lid = cases.bev_inputs(C, H, W, cts.shape[1], lts.shape[1])
+    net.gru_ode.noise = hashfill.HashedNoise(cases.EPS_SEED, zero=eps0)
+    y, aux = net(cases.present_input(cam, lid).cuda(), cam.cuda(), lid.cuda() if lts.shape[1] else None, cts,
+                 lts if lts.shape[1] else None, tts)
+    assert aux == 0
+    return y, sd, (cam, lid, cts, lts, tts, dt)
+
+
+@pytest.mark.parametrize("name", list(cases.FPODE_STREAM_CASES))
+def test_stream_and_long_horizon_golden(name):
+    C, H, W, ts, solver, impute, variable, eps0 = cases.FPODE_STREAM_CASES[name]
+    y, _, _ = _forward(C, H, W, ts, solver, impute, variable, eps0)
+    assert maxabs(y, gold("fpode_stream.npz")[name + "/out"]) <= TOL_E2E
+
+
+@pytest.mark.parametrize("C,HW", [(8, 16), (16, 24)])
+def test_stream40_rk4_full_rollout_vs_oracle(C, HW):
+    """RK4 over the whole 46-step schedule (184 cell evaluations chained) against the oracle's composition."""
+    y, sd, (cam, lid, cts, lts, tts, dt) = _forward(C, HW, HW, "stream40", "rk4", True, True)
+    with torch.no_grad():
+        yr, _ = R.future_prediction_ode_forward(sd, cases.present_input(cam, lid), cam, lid, cts, lts, tts, dt, 2, "rk4",
+                                                True, True, hashfill.HashedNoise(cases.EPS_SEED))
+    assert maxabs(y, yr) <= TOL_E2E
+
+
+@pytest.mark.parametrize("solver", ["euler", "midpoint", "rk4"])
+def test_stream40_hipgraph_equals_eager(solver):
+    """Config 5 as the north star words it: the whole 46-step rollout at C=64, 50x50 captured into ONE hipGraph; the
+    replay equals the eager rollout bitwise, for every solver, also with fresh inputs of the same schedule."""
+    from streamingflow_amd import schedule as S
+    C, h, w = 64, 50, 50
+    cts, lts, tts, dt = cases.timeset("stream40")
+    net, _ = build_pair(C, solver, True, True, dt)
+    ode = net.gru_ode
+    times, _ = S.merge_observations(cts[0].tolist(), lts[0].tolist())
+    sc = S.build_schedule(times, tts[0].tolist(), dt, True, solver)
+    assert sc.n_steps == 46 and sc.n_jumps == 8
+    for k in range(2):
+        hx = (hashfill.normal(f"s40hx{k}", (8, h, w, C), 61) * 0.5).cuda()
+        eps = hashfill.normal(f"s40eps{k}", (sc.n_draws, h, w, C), 62).cuda()
+        ode.use_graph = False
+        a, fa = ode.rollout_nhwc(hx, sc, eps)
+        a, fa = a.clone(), fa.clone()
+        ode.use_graph = True
+        b, fb = ode.rollout_nhwc(hx, sc, eps)
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b) and torch.equal(fa, fb), (solver, k)
+    assert len(ode._graphs) == 1
+    ode.use_graph = False
+
+
+def _check_stats(y, st):
+    flat = y.reshape(-1).double().cpu()
+    assert list(y.shape) == st["shape"]
+    assert float((flat[torch.tensor(st["sample_idx"])] - torch.tensor(st["samples"])).abs().max()) <= TOL_E2E
+    assert abs(flat.mean().item() - st["mean"]) <= 1e-4
+    assert abs(flat.abs().max().item() - st["absmax"]) <= TOL_E2E
+
+
+@pytest.mark.parametrize("tag", list(cases.BIG_CASES))
+def test_full_size_vs_reference_stats_and_oracle(tag):
+    """config4_future16: C=64, 200x200, 19 decoded frames (evaluate.py --future-frames 16).  config1_c32: C=32, 200x200,
+    one observation, 4 fixed Euler steps.  Against the real reference's output statistics and against the oracle."""
+    C, H, W, ts, solver, impute, variable = cases.BIG_CASES[tag]
+    y, sd, (cam, lid, cts, lts, tts, dt) = _forward(C, H, W, ts, solver, impute, variable)
+    _check_stats(y, json.load(open(os.path.join(GOLD, "big_stats.json")))["cases"][tag]["out"])
+    torch.set_num_threads(min(os.cpu_count() or 8, 16))
+    with torch.no_grad():
+        yr, _ = R.future_prediction_ode_forward(sd, cases.present_input(cam, lid), cam, lid, cts, lts, tts, dt, 2, solver,
+                                                impute, variable, hashfill.HashedNoise(cases.EPS_SEED))
+    assert maxabs(y, yr) <= TOL_E2E

@@ -59,3 +59,41 @@ def test_fpode_forward(name):
                                                  solver, impute, variable, hashfill.HashedNoise(cases.EPS_SEED, zero=eps0))
     assert aux == 0
     assert maxabs(y, g[name + "/out"]) <= 1e-5
+
+
+@pytest.mark.parametrize("name", list(cases.FPODE_STREAM_CASES))
+def test_fpode_stream_forward(name):
+    """BASELINE configs 5 (46-step streaming schedule, euler / midpoint) and 4 (19 frames) at toy size: the oracle
+    against whole outputs of the real reference (tests/golden/fpode_stream.npz)."""
+    C, H, W, ts, solver, impute, variable, eps0 = cases.FPODE_STREAM_CASES[name]
+    if C > 8:
+        pytest.skip("kept small for the CPU suite")
+    g = gold("fpode_stream.npz")
+    cts, lts, tts, dt = cases.timeset(ts)
+    _, sd = build_pair(C, solver, impute, variable, dt, device="cpu")
+    cam, lid = cases.bev_inputs(C, H, W, cts.shape[1], lts.shape[1])
+    with torch.no_grad():
+        y, aux = R.future_prediction_ode_forward(sd, cases.present_input(cam, lid), cam, lid, cts, lts, tts, dt, 2,
+                                                 solver, impute, variable, hashfill.HashedNoise(cases.EPS_SEED, zero=eps0))
+    assert aux == 0
+    assert maxabs(y, g[name + "/out"]) <= 1e-5
+
+
+def test_config1_full_size_oracle_vs_reference_stats():
+    """BASELINE config 1 exactly as SURVEY.md §8d states it (C=32, BEV 200x200, one camera observation, four fixed Euler
+    steps): the oracle against the statistics of the real reference's output (tests/golden/big_stats.json)."""
+    import json
+    import os
+    from util import GOLD
+    st = json.load(open(os.path.join(GOLD, "big_stats.json")))["cases"]["config1_c32"]["out"]
+    C, H, W, ts, solver, impute, variable = cases.BIG_CASES["config1_c32"]
+    cts, lts, tts, dt = cases.timeset(ts)
+    _, sd = build_pair(C, solver, impute, variable, dt, device="cpu")
+    cam, lid = cases.bev_inputs(C, H, W, cts.shape[1], lts.shape[1])
+    with torch.no_grad():
+        y, _ = R.future_prediction_ode_forward(sd, cases.present_input(cam, lid), cam, lid, cts, lts, tts, dt, 2,
+                                               solver, impute, variable, hashfill.HashedNoise(cases.EPS_SEED))
+    assert list(y.shape) == st["shape"]
+    flat = y.reshape(-1).double()
+    assert float((flat[torch.tensor(st["sample_idx"])] - torch.tensor(st["samples"])).abs().max()) <= 1e-5
+    assert abs(flat.mean().item() - st["mean"]) <= 1e-6

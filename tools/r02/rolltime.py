@@ -19,7 +19,7 @@ def main():
     net, _ = build_pair(C, solver, True, True, dt)
     ode = net.gru_ode
     times, _ = S.merge_observations(cts[0].tolist(), lts[0].tolist())
-    sc = S.build_schedule(times, tts[0].tolist(), dt, True)
+    sc = S.build_schedule(times, tts[0].tolist(), dt, True, solver)
     hx = torch.randn(len(times), h, w, C, device="cuda") * 0.5
     e = torch.randn(sc.n_draws, h, w, C, device="cuda")
 
