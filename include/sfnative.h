@@ -4,6 +4,10 @@
  * entry point allocates, synchronises or keeps global mutable state, so a caller may capture any
  * sequence of them into a hipGraph (sf_graph_* below).
  *
+ * Process model: one process per GPU and one host thread launching on a device at a time (the only process-wide
+ * state are first-launch flags per device for the kernels' dynamic-LDS attribute and the opt-in profiler / debug
+ * stamps below); calls on different streams of one device may be enqueued from that thread and overlap.
+ *
  * The reference (synsin0/StreamingFlow) is pure Python/PyTorch on this path — it has no FFI.  The
  * functions below are therefore the operator boundary a maintainer would bind (ctypes stub in
  * INTEGRATION.md); each cites the reference function it replaces (paths relative to the reference

@@ -1011,11 +1011,15 @@ static hipError_t launch_glds_t(const ConvLaunch& L, hipStream_t stream) {
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   constexpr int lds = NB * (BM + BN) * 32 * 4 + (SCALE ? 4 * 256 * 4 : 0);   // staging buffers (+ the SE scale rows of up to 4 images x 256 channels)
   auto kern = conv_glds_kernel<MT, NT, WM, WN, EPI, NB, SCALE>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  // the attribute is per device (a process may touch more than one GPU); one process per GPU and one launching
+  // thread per device are the documented use (include/sfnative.h), so the flag needs no lock
+  static bool attr_done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done[dev] = true;
   }
   int maxblocks = 0;
   for (int i = 0; i < L.nprob; ++i) {
@@ -1303,12 +1307,15 @@ static hipError_t launch_cfg(const ConvLaunch& L, hipStream_t stream) {
   constexpr int red_bytes = (KS - 1) * WM * WN * MT * NT * 4 * 64 * 4;
   constexpr int lds = stage_bytes > red_bytes ? stage_bytes : red_bytes;
   auto kern = conv_igemm_kernel<MT, NT, WM, WN, KS, EPI, KB, SWZ>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  // the attribute is per device (a process may touch more than one GPU); one process per GPU and one launching
+  // thread per device are the documented use (include/sfnative.h), so the flag needs no lock
+  static bool attr_done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done[dev] = true;
   }
   int maxblocks = 0;
   for (int i = 0; i < L.nprob; ++i) {

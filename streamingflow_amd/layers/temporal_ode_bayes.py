@@ -192,6 +192,8 @@ class NNFOwithBayesianJumps(nn.Module):
         self.gru_obs = GRUObservationCell(input_size, hidden_size, min_log_sigma=min_log_sigma,
                                           max_log_sigma=max_log_sigma, bias=bias)
         self.skipco = cfg.MODEL.SMALL_ENCODER.SKIPCO
+        if self.skipco:      # res_models.py:98-109, :134-147 — not on the shipped path; never silently ignored
+            raise NotImplementedError("MODEL.SMALL_ENCODER.SKIPCO=True (encoder -> decoder skip connections) is not built")
         oc, fs = cfg.MODEL.ENCODER.OUT_CHANNELS, cfg.MODEL.SMALL_ENCODER.FILTER_SIZE
         self.srvp_encoder = SmallEncoder(oc, oc, fs)
         self.srvp_decoder = SmallDecoder(oc, oc, fs, self.skipco)
@@ -202,6 +204,7 @@ class NNFOwithBayesianJumps(nn.Module):
         self.noise = None    # None: torch.randn on the device; else callable(shape, dtype, device) -> NCHW eps per draw
         self.use_graph = False   # capture the rollout of each schedule structure into a hipGraph and replay it
         self._graphs = {}
+        self._graph_gens = None
         self.apply(init_weights)
 
     # ---- noise --------------------------------------------------------------------------------
@@ -271,6 +274,14 @@ class NNFOwithBayesianJumps(nn.Module):
             ptr(hx_obs), ptr(eps), ptr(coef), int(per_image), sel.ctypes.data_as(_lib.i32p), len(sel), ptr(out),
             ptr(final), B, h, w, ptr(ws), ws.numel() * 4, runtime.stream_ptr(hx_obs.device)), "nnfo_rollout")
 
+    def drop_graphs(self):
+        """Destroy every captured rollout graph of this module and release its static buffers."""
+        L = _lib.lib()
+        for g in self._graphs.values():
+            if g.get("exec") is not None:
+                L.sf_graph_destroy(g["exec"])
+        self._graphs.clear()
+
     def rollout_nhwc(self, hx_obs, sc, eps=None):
         """hx_obs: [n_obs, B, h, w, C] (or [n_obs, h, w, C] for one sample) encoded observations in
         time order; sc: one Schedule shared by all samples, or a list of B Schedules with the same
@@ -308,9 +319,13 @@ class NNFOwithBayesianJumps(nn.Module):
             ws = runtime.workspace(nbytes, dev)
             self._enqueue_rollout(s0, per_image, hx_obs, eps, coef, out, final, ws, B, h, w)
         else:
-            key = (s0.key(), per_image, tuple(hx_obs.shape), tuple(eps.shape), str(dev), self.solver, bool(self.impute),
-                   self.gru_c.packed() is None, id(self.gru_c.packed()), id(self.p_model.packed()),
-                   id(self.gru_obs.gru_d.packed()))
+            # a captured graph holds raw pointers into the packed weights: when any of the three packs was rebuilt
+            # (load_state_dict, .to(), in-place update) every cached graph is stale — destroy them and their buffers
+            gens = (self.gru_c.pack_generation(), self.p_model.pack_generation(), self.gru_obs.gru_d.pack_generation())
+            if self._graph_gens != gens:
+                self.drop_graphs()
+                self._graph_gens = gens
+            key = (s0.key(), per_image, tuple(hx_obs.shape), tuple(eps.shape), str(dev), self.solver, bool(self.impute))
             g = self._graphs.get(key)
             if g is None:
                 g = {"hx": torch.empty_like(hx_obs), "eps": torch.empty_like(eps), "coef": torch.empty_like(coef),

@@ -121,9 +121,11 @@ class FuturePredictionODE(nn.Module):
             groups.setdefault(sc.key(), []).append(bs)
             meta.append((frames, sc, (tuple(order), bs)))
         outs = [None] * b
-        for members in groups.values():
+        MAX_GROUP = 64       # libsfnative sizes its per-image SE scratch for 64 images per call
+        chunks = [m[i:i + MAX_GROUP] for m in groups.values() for i in range(0, len(m), MAX_GROUP)]
+        for members in chunks:
             fr, scs, srcs = [meta[i][0] for i in members], [meta[i][1] for i in members], [meta[i][2] for i in members]
-            whole = len(groups) == 1 and members == list(range(b))
+            whole = len(chunks) == 1 and members == list(range(b))
             y = self._run_group(fr, scs, srcs, states, True if whole else None, members)
             if whole:
                 return y, 0

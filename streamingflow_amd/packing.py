@@ -6,9 +6,6 @@ import torch
 
 from . import _lib
 
-BN_EPS = 1e-5
-
-
 def _round_up(v, m):
     return (v + m - 1) // m * m
 
@@ -34,7 +31,7 @@ class Pack:
 
 def bn_fold(bn, conv_bias=None):
     """eval-mode BatchNorm2d after a conv -> per-channel (scale, bias) on the accumulator."""
-    sc = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + BN_EPS)
+    sc = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
     bi = bn.bias.detach() - bn.running_mean.detach() * sc
     if conv_bias is not None:
         bi = bi + conv_bias.detach() * sc

@@ -59,9 +59,14 @@ def to_nchw(x):
     return out
 
 
+_PACK_GENERATION = [0]      # process-wide, monotonically increasing: never reused (unlike id() of a freed Pack)
+
+
 class PackedModule(torch.nn.Module):
     """Mixin: lazily packs the module's parameters for the HIP library and re-packs when any
-    parameter was replaced, moved or modified in place (load_state_dict, .to(), optimiser)."""
+    parameter was replaced, moved or modified in place (load_state_dict, .to(), optimiser).
+    ``pack_generation()`` identifies the current packed copy for caches that hold raw pointers into it
+    (captured hipGraphs): it changes exactly when ``packed()`` returns a new copy and is never reused."""
 
     def _param_signature(self):
         sig = []
@@ -77,8 +82,13 @@ class PackedModule(torch.nn.Module):
             require_cuda(first)
             with torch.no_grad():
                 pk = self._pack()
-            self.__dict__["_sf_pack"] = cache = (sig, pk)
+            _PACK_GENERATION[0] += 1
+            self.__dict__["_sf_pack"] = cache = (sig, pk, _PACK_GENERATION[0])
         return cache[1]
+
+    def pack_generation(self):
+        self.packed()
+        return self.__dict__["_sf_pack"][2]
 
     def _pack(self):
         raise NotImplementedError

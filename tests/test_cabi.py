@@ -52,3 +52,13 @@ def test_no_cpu_fallback():
     ts = torch.zeros(1, 1, dtype=torch.float64)
     with pytest.raises(RuntimeError):
         net(x, x, None, ts, None, ts)
+
+
+def test_unbuilt_options_fail_loudly():
+    import pytest
+    import streamingflow_amd as sfa
+    from util import make_cfg
+    cfg = make_cfg(8)
+    cfg.MODEL.SMALL_ENCODER.SKIPCO = True
+    with pytest.raises(NotImplementedError):
+        sfa.FuturePredictionODE(8, 8, 4, cfg)

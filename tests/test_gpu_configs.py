@@ -89,3 +89,44 @@ def test_full_size_vs_reference_stats_and_oracle(tag):
         yr, _ = R.future_prediction_ode_forward(sd, cases.present_input(cam, lid), cam, lid, cts, lts, tts, dt, 2, solver,
                                                 impute, variable, hashfill.HashedNoise(cases.EPS_SEED))
     assert maxabs(y, yr) <= TOL_E2E
+
+
+def test_hipgraph_cache_follows_weight_updates():
+    """A captured rollout graph holds raw pointers into the packed weights: after load_state_dict (new packs) the stale
+    graph must be dropped and re-captured, not replayed (the cache key used id() of freed objects)."""
+    from streamingflow_amd import schedule as S
+    C, h, w = 16, 12, 12
+    cts, lts, tts, dt = cases.timeset("shipped")
+    net, sd = build_pair(C, "euler", True, True, dt)
+    ode = net.gru_ode
+    times, _ = S.merge_observations(cts[0].tolist(), lts[0].tolist())
+    sc = S.build_schedule(times, tts[0].tolist(), dt, True)
+    hx = (hashfill.normal("gc_hx", (8, h, w, C), 71) * 0.5).cuda()
+    eps = hashfill.normal("gc_eps", (sc.n_draws, h, w, C), 72).cuda()
+    ode.use_graph = True
+    a, _ = ode.rollout_nhwc(hx, sc, eps)
+    a = a.clone()
+    gen0 = ode._graph_gens
+    sd2 = {k: (v * 1.25 if v.dtype.is_floating_point and "running_var" not in k else v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd2)
+    b, _ = ode.rollout_nhwc(hx, sc, eps)          # must re-capture with the new weights
+    b = b.clone()
+    assert ode._graph_gens != gen0 and len(ode._graphs) == 1
+    ode.use_graph = False
+    c, _ = ode.rollout_nhwc(hx, sc, eps)
+    assert torch.equal(b, c) and not torch.equal(a, b)
+
+
+def test_batch_larger_than_one_native_call():
+    """More samples than one native call takes (64 images of SE scratch): the batch is split transparently."""
+    C, H, W, B = 8, 16, 16, 66
+    cts, lts, tts, dt = cases.timeset("camera_only")
+    net, _ = build_pair(C, "euler", True, True, dt)
+    cam = hashfill.normal("b66", (2, cts.shape[1], C, H, W), 5).cuda()
+    net.gru_ode.noise = hashfill.HashedNoise(0, zero=True)
+    y2, _ = net(cam[:, -1:], cam, None, cts.expand(2, -1), None, tts.expand(2, -1))
+    rep = cam[:1].expand(B, -1, -1, -1, -1).contiguous()
+    net.gru_ode.noise = hashfill.HashedNoise(0, zero=True)
+    yb, _ = net(rep[:, -1:], rep, None, cts.expand(B, -1).contiguous(), None, tts.expand(B, -1).contiguous())
+    assert yb.shape[0] == B
+    assert float((yb - y2[:1]).abs().max()) <= 1e-5
