@@ -344,8 +344,11 @@ int sf_sparse_to_dense_fwd(const float* feats, const int32_t* coords, int n, int
  *   the thresholded 3x3 local maxima in row-major order (as torch.nonzero), count in the device int.
  * sf_group_pixels_fwd — group_pixels * foreground (instance.py:95-116, :136-137): offsets [2][H][W],
  *   foreground [H][W] bytes, instance [H][W] int64 = 1 + index of the nearest centre of (pixel + offset), 0 on background.
- * sf_instance_sums_fwd — per instance id (1..max_id): sum of (row + flow[0], col + flow[1]) in float64 and
- *   pixel count (flow may be NULL): the masked means of instance.py:213-236. */
+ * sf_instance_moments_fwd — F frames [F][H][W] of instance ids in one launch: per (frame, id in 1..max_id) pixel count,
+ *   exact integer sums of (row, col) and — when flow [F][2][H][W] and warped_fx are given — sums of (row + flow0,
+ *   col + flow1) in 2^-20 fixed point (int64).  Integer atomics only, so the sums do not depend on the arrival order:
+ *   the masked means of instance.py:213-236 for every frame of a sequence at once.
+ * sf_confusion_frames_fwd — sf_confusion_fwd per frame of F equally sized label-map pairs: out[F][K][K]. */
 /* sf_warp_affine_fwd — warp_features (utils/geometry.py:196-236): F.affine_grid(theta [B][2][3], align_corners=False)
  *   + F.grid_sample(mode nearest | bilinear, padding zeros, align_corners=False) on NCHW maps x [B][C][H][W]. */
 int sf_warp_affine_fwd(const float* x, const float* theta, int B, int C, int H, int W, int bilinear, float* out,
@@ -356,8 +359,10 @@ int sf_instance_centers_fwd(const float* center, int H, int W, float conf_thresh
                             int32_t* n_centers, void* ws, size_t ws_bytes, void* stream);
 int sf_group_pixels_fwd(const int32_t* centers, int n_centers, const float* offsets, const uint8_t* foreground, int H,
                         int W, int64_t* instance, void* stream);
-int sf_instance_sums_fwd(const int64_t* instance, const float* flow, int H, int W, int max_id, double* sums,
-                         int32_t* counts, void* stream);
+int sf_instance_moments_fwd(const int64_t* instance, const float* flow, int F, int H, int W, int max_id, int64_t* pos_sums,
+                            int64_t* warped_fx, int32_t* counts, void* stream);
+int sf_confusion_frames_fwd(const int64_t* a, const int64_t* b, long n_per_frame, int F, int K, int64_t* out, int32_t* bad,
+                            void* stream);
 
 /* hipGraph capture of whatever the caller enqueues between begin and end on `stream` (must not be
  * the legacy default stream). */

@@ -136,7 +136,8 @@ SIGNATURES = {
     "sf_instance_centers_ws_bytes": (_sz, [_i, _i]),
     "sf_instance_centers_fwd": (_i, [_vp, _i, _i, C.c_float, _vp, _i, _vp, _vp, _sz, _vp]),
     "sf_group_pixels_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
-    "sf_instance_sums_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "sf_instance_moments_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sf_confusion_frames_fwd": (_i, [_vp, _vp, C.c_long, _i, _i, _vp, _vp, _vp]),
     "sf_graph_begin": (_i, [_vp]),
     "sf_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "sf_graph_launch": (_i, [_vp, _vp]),

@@ -6,8 +6,10 @@
 //                             row-major list torch.nonzero returns (flags + exclusive scan + compaction)
 //   sf_group_pixels_fwd       group_pixels + foreground mask (instance.py:95-116, :136-137): nearest centre of
 //                             (pixel + offset), first minimum on ties
-//   sf_instance_sums_fwd      per-instance sums of (pixel position + flow) and pixel counts — the masked means of
-//                             make_instance_id_temporally_consistent (instance.py:213-236)
+//   sf_instance_moments_fwd   per (frame, instance) pixel counts and position sums, plain and flow-warped — the masked means
+//                             of make_instance_id_temporally_consistent (instance.py:213-236), all frames in one launch,
+//                             integer atomics only (order-independent)
+//   sf_confusion_frames_fwd   the joint histogram per frame of a whole label sequence in one launch
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -75,18 +77,42 @@ __global__ void group_pixels_kernel(const int* __restrict__ centers, int nc, con
   inst[idx] = fg[idx] ? (long long)(arg + 1) : 0LL;
 }
 
-__global__ void instance_sums_kernel(const long long* __restrict__ inst, const float* __restrict__ flow, int H, int W, int max_id,
-                                     double* __restrict__ sums, int* __restrict__ cnt) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= H * W) return;
+// Per (frame, instance id) pixel count, exact integer sums of (row, col) and sums of the flow-warped position
+// (row + flow0, col + flow1) in 2^-20 fixed point.  Integer atomics only: the result does not depend on the order the
+// pixels arrive in (bitwise reproducible), unlike a floating-point atomicAdd.
+constexpr double MOMENT_FX = 1048576.0;
+__global__ void instance_moments_kernel(const long long* __restrict__ inst, const float* __restrict__ flow, int F, int H, int W, int max_id,
+                                        unsigned long long* __restrict__ pos, unsigned long long* __restrict__ warped, int* __restrict__ cnt) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long plane = (long)H * W;
+  if (idx >= F * plane) return;
+  const int f = (int)(idx / plane);
+  const int pix = (int)(idx - f * plane);
   const long long id = inst[idx];
   if (id <= 0 || id > max_id) return;
-  const int i = idx / W, j = idx - i * W;
-  float x = (float)i, y = (float)j;
-  if (flow) { x = __fadd_rn(x, flow[idx]); y = __fadd_rn(y, flow[H * W + idx]); }
-  atomicAdd(sums + 2 * id, (double)x);
-  atomicAdd(sums + 2 * id + 1, (double)y);
-  atomicAdd(cnt + id, 1);
+  const int i = pix / W, j = pix - i * W;
+  const size_t slot = (size_t)f * (max_id + 1) + (size_t)id;
+  atomicAdd(pos + 2 * slot, (unsigned long long)i);
+  atomicAdd(pos + 2 * slot + 1, (unsigned long long)j);
+  atomicAdd(cnt + slot, 1);
+  if (warped) {
+    const float* fl = flow + (size_t)f * 2 * plane;
+    const float x = __fadd_rn((float)i, fl[pix]), y = __fadd_rn((float)j, fl[plane + pix]);
+    // two's complement: adding the unsigned image of a negative fixed-point value is the signed add
+    atomicAdd(warped + 2 * slot, (unsigned long long)llrint((double)x * MOMENT_FX));
+    atomicAdd(warped + 2 * slot + 1, (unsigned long long)llrint((double)y * MOMENT_FX));
+  }
+}
+
+// joint histograms of F label-map pairs of n elements each: out[f][b][a] (labels outside [0, K) set *bad)
+__global__ void confusion_frames_kernel(const long long* __restrict__ a, const long long* __restrict__ b, long n, int F, int K,
+                                        unsigned long long* __restrict__ out, int* __restrict__ bad) {
+  const long total = n * F;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long long x = a[i], y = b[i];
+    if (x < 0 || x >= K || y < 0 || y >= K) { *bad = 1; continue; }
+    atomicAdd(out + ((size_t)(i / n) * K + (size_t)y) * K + x, 1ULL);
+  }
 }
 
 // warp_features (utils/geometry.py:196-236): affine_grid(theta, align_corners=False) + grid_sample(mode, zeros
@@ -187,14 +213,32 @@ int sf_group_pixels_fwd(const int32_t* centers, int n_centers, const float* offs
   return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
 }
 
-int sf_instance_sums_fwd(const int64_t* instance, const float* flow, int H, int W, int max_id, double* sums, int32_t* counts,
-                         void* stream) {
-  if (!instance || !sums || !counts || H < 1 || W < 1 || max_id < 0) return SF_ERR_INVALID;
+int sf_instance_moments_fwd(const int64_t* instance, const float* flow, int F, int H, int W, int max_id, int64_t* pos_sums,
+                            int64_t* warped_fx, int32_t* counts, void* stream) {
+  if (!instance || !pos_sums || !counts || F < 1 || H < 1 || W < 1 || max_id < 0 || (warped_fx && !flow)) return SF_ERR_INVALID;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(sums, 0, (size_t)(max_id + 1) * 2 * sizeof(double), st) != hipSuccess) return SF_ERR_LAUNCH;
-  if (hipMemsetAsync(counts, 0, (size_t)(max_id + 1) * sizeof(int32_t), st) != hipSuccess) return SF_ERR_LAUNCH;
-  hipLaunchKernelGGL(instance_sums_kernel, dim3((H * W + 255) / 256), dim3(256), 0, st, reinterpret_cast<const long long*>(instance),
-                     flow, H, W, max_id, sums, counts);
+  const size_t slots = (size_t)F * (max_id + 1);
+  if (hipMemsetAsync(pos_sums, 0, slots * 2 * sizeof(int64_t), st) != hipSuccess) return SF_ERR_LAUNCH;
+  if (warped_fx && hipMemsetAsync(warped_fx, 0, slots * 2 * sizeof(int64_t), st) != hipSuccess) return SF_ERR_LAUNCH;
+  if (hipMemsetAsync(counts, 0, slots * sizeof(int32_t), st) != hipSuccess) return SF_ERR_LAUNCH;
+  const long total = (long)F * H * W;
+  hipLaunchKernelGGL(instance_moments_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                     reinterpret_cast<const long long*>(instance), flow, F, H, W, max_id, reinterpret_cast<unsigned long long*>(pos_sums),
+                     reinterpret_cast<unsigned long long*>(warped_fx), counts);
+  return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
+}
+
+int sf_confusion_frames_fwd(const int64_t* a, const int64_t* b, long n_per_frame, int F, int K, int64_t* out, int32_t* bad, void* stream) {
+  if (!out || !bad || K < 1 || F < 1 || n_per_frame < 0) return SF_ERR_INVALID;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(out, 0, (size_t)F * K * K * sizeof(int64_t), st) != hipSuccess) return SF_ERR_LAUNCH;
+  if (hipMemsetAsync(bad, 0, sizeof(int32_t), st) != hipSuccess) return SF_ERR_LAUNCH;
+  if (n_per_frame == 0) return SF_OK;
+  if (!a || !b) return SF_ERR_INVALID;
+  long blocks = (n_per_frame * F + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(confusion_frames_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const long long*>(a),
+                     reinterpret_cast<const long long*>(b), n_per_frame, F, K, reinterpret_cast<unsigned long long*>(out), bad);
   return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
 }
 

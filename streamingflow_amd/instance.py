@@ -1,10 +1,19 @@
-"""Instance post-processing of StreamingFlow's evaluation on the MI355X: the functions of
-streamingflow/utils/instance.py that ``evaluate.py`` calls, same names / arguments / returns.
+"""Instance post-processing of StreamingFlow's evaluation on the MI355X.
 
-Per-pixel work runs in libsfnative (``sf_instance_centers_fwd``: threshold + 3x3 NMS + ordered list,
-``sf_group_pixels_fwd``: nearest-centre assignment with the foreground mask, ``sf_instance_sums_fwd``:
-per-instance position sums for the temporal matching); the data-dependent control flow (id bookkeeping,
-Hungarian assignment on a handful of centres via scipy) stays on the host as in the reference.
+Drop-in for the functions of ``streamingflow/utils/instance.py`` that ``evaluate.py`` reaches (``find_instance_centers``
+:80-92, ``group_pixels`` :95-116, ``get_instance_segmentation_and_centers`` :119-140, ``update_instance_ids`` :143-160,
+``make_instance_seg_consecutive`` :163-168, ``make_instance_id_temporally_consistent`` :171-263,
+``predict_instance_segmentation_and_trajectories`` :370-428): same names, arguments and results.
+
+How it is computed here.
+  * Centres, pixel grouping: one kernel each (``sf_instance_centers_fwd``, ``sf_group_pixels_fwd``).
+  * Relabelling is a look-up table gathered on the device; "make ids consecutive" is the inverse index of a sorted
+    unique.
+  * Temporal consistency.  The ids a frame ends up with are a relabelling of its own raw instances, so everything the
+    matching needs — each raw instance's pixel count, centre, and centre displaced by the predicted flow — is computed
+    for ALL frames by one launch (``sf_instance_moments_fwd``: integer atomics, order-independent) and copied to the
+    host once.  The frame-to-frame assignment (Hungarian method on a handful of centres, ``scipy``) then only produces
+    one small table per frame, and the whole sequence is relabelled by a single gather.
 CUDA tensors only.
 """
 from typing import Tuple
@@ -16,160 +25,149 @@ from scipy.optimize import linear_sum_assignment
 from . import _lib, runtime
 from .runtime import ptr
 
+MOMENT_SCALE = 1.0 / 1048576.0      # sf_instance_moments_fwd: flow-warped sums are 2^-20 fixed point
+
 
 def find_instance_centers(center_prediction: torch.Tensor, conf_threshold: float = 0.1, nms_kernel_size: float = 3):
-    """instance.py:80-92.  center_prediction [1, H, W] -> [n, 2] int64 (row, col) in row-major order."""
-    assert len(center_prediction.shape) == 3
+    """[1, H, W] centre heat map -> [n, 2] int64 (row, col) of its thresholded 3x3 local maxima, row-major order."""
+    if center_prediction.dim() != 3:
+        raise AssertionError("center_prediction must be [1, H, W]")
     if nms_kernel_size != 3:
-        raise NotImplementedError("only the 3x3 NMS the reference uses")
+        raise NotImplementedError("only the 3x3 non-maximum suppression the reference uses is built")
     runtime.require_cuda(center_prediction)
-    c = runtime.f32c(center_prediction).view(center_prediction.shape[-2], center_prediction.shape[-1])
-    H, W = c.shape
+    H, W = center_prediction.shape[-2:]
+    heat = runtime.f32c(center_prediction).view(H, W)
     L = _lib.lib()
-    cap = H * W
-    centers = torch.empty((cap, 2), dtype=torch.int32, device=c.device)
-    n = torch.empty((), dtype=torch.int32, device=c.device)
-    ws = runtime.workspace(L.sf_instance_centers_ws_bytes(H, W), c.device)
-    _lib.check(L.sf_instance_centers_fwd(ptr(c), H, W, float(conf_threshold), ptr(centers), cap, ptr(n), ptr(ws), ws.numel() * 4,
-                                         runtime.stream_ptr(c.device)), "instance_centers")
-    return centers[: int(n.item())].long()
+    found = torch.empty((H * W, 2), dtype=torch.int32, device=heat.device)
+    count = torch.empty((), dtype=torch.int32, device=heat.device)
+    ws = runtime.workspace(L.sf_instance_centers_ws_bytes(H, W), heat.device)
+    _lib.check(L.sf_instance_centers_fwd(ptr(heat), H, W, float(conf_threshold), ptr(found), H * W, ptr(count), ptr(ws), ws.numel() * 4,
+                                         runtime.stream_ptr(heat.device)), "instance_centers")
+    return found[: int(count.item())].long()
 
 
 def group_pixels(centers: torch.Tensor, offset_predictions: torch.Tensor, foreground_mask: torch.Tensor = None) -> torch.Tensor:
-    """instance.py:95-116 (+ the foreground product of :136 when a mask is given) -> [1, H, W] int64 ids from 1."""
+    """Every pixel votes for the centre nearest to (pixel + predicted offset): [1, H, W] int64 ids from 1 (first centre
+    wins ties); pixels outside ``foreground_mask`` (when given) get 0."""
     runtime.require_cuda(centers, offset_predictions)
     H, W = offset_predictions.shape[-2:]
-    off = runtime.f32c(offset_predictions).view(2, H, W)
-    fg = torch.ones((H, W), dtype=torch.uint8, device=off.device) if foreground_mask is None else \
-        (foreground_mask.reshape(H, W) != 0).to(torch.uint8).contiguous()
-    c32 = centers.to(torch.int32).contiguous()
-    out = torch.empty((1, H, W), dtype=torch.int64, device=off.device)
-    _lib.check(_lib.lib().sf_group_pixels_fwd(ptr(c32), c32.shape[0], ptr(off), ptr(fg), H, W, ptr(out), runtime.stream_ptr(off.device)),
-               "group_pixels")
-    return out
+    votes = runtime.f32c(offset_predictions).view(2, H, W)
+    if foreground_mask is None:
+        inside = torch.ones((H, W), dtype=torch.uint8, device=votes.device)
+    else:
+        inside = (foreground_mask.reshape(H, W) != 0).to(torch.uint8).contiguous()
+    table = centers.to(torch.int32).contiguous()
+    ids = torch.empty((1, H, W), dtype=torch.int64, device=votes.device)
+    _lib.check(_lib.lib().sf_group_pixels_fwd(ptr(table), table.shape[0], ptr(votes), ptr(inside), H, W, ptr(ids),
+                                              runtime.stream_ptr(votes.device)), "group_pixels")
+    return ids
 
 
 def update_instance_ids(instance_seg, old_ids, new_ids):
-    """instance.py:143-160."""
-    indices = torch.arange(int(old_ids.max()) + 1, device=instance_seg.device)
-    indices[torch.as_tensor(old_ids, device=instance_seg.device).long()] = torch.as_tensor(new_ids, device=instance_seg.device).long()
-    return indices[instance_seg].long()
+    """Relabel: every id listed in ``old_ids`` becomes the matching entry of ``new_ids``, the others stay."""
+    dev = instance_seg.device
+    old = torch.as_tensor(old_ids, device=dev).long()
+    table = torch.arange(int(old.max()) + 1, device=dev)
+    table[old] = torch.as_tensor(new_ids, device=dev).long()
+    return table[instance_seg].long()
 
 
 def make_instance_seg_consecutive(instance_seg):
-    """instance.py:163-168."""
-    unique_ids = torch.unique(instance_seg)
-    new_ids = torch.arange(len(unique_ids), device=instance_seg.device)
-    return update_instance_ids(instance_seg, unique_ids, new_ids)
+    """Ids become 0..n-1 in the order of their old values."""
+    return torch.unique(instance_seg, return_inverse=True)[1].long()
 
 
 def get_instance_segmentation_and_centers(center_predictions, offset_predictions, foreground_mask, conf_threshold: float = 0.1,
                                           nms_kernel_size: float = 3, max_n_instance_centers: int = 100) -> Tuple[torch.Tensor, torch.Tensor]:
-    """instance.py:119-140."""
-    width, height = center_predictions.shape[-2:]
-    center_predictions = center_predictions.view(1, width, height)
-    offset_predictions = offset_predictions.view(2, width, height)
-    foreground_mask = foreground_mask.view(1, width, height)
-    centers = find_instance_centers(center_predictions, conf_threshold=conf_threshold, nms_kernel_size=nms_kernel_size)
-    if not len(centers):
-        return torch.zeros(center_predictions.shape, dtype=torch.int64, device=center_predictions.device), \
-            torch.zeros((0, 2), device=centers.device)
-    if len(centers) > max_n_instance_centers:
-        centers = centers[:max_n_instance_centers].clone()
-    instance_seg = group_pixels(centers, offset_predictions, foreground_mask)
-    instance_seg = make_instance_seg_consecutive(instance_seg)
-    return instance_seg.long(), centers
+    """One frame: ([1, H, W] int64 instance map with consecutive ids, [n, 2] centres)."""
+    H, W = center_predictions.shape[-2:]
+    heat = center_predictions.reshape(1, H, W)
+    peaks = find_instance_centers(heat, conf_threshold=conf_threshold, nms_kernel_size=nms_kernel_size)
+    if peaks.shape[0] == 0:
+        return torch.zeros((1, H, W), dtype=torch.int64, device=heat.device), torch.zeros((0, 2), device=heat.device)
+    peaks = peaks[:max_n_instance_centers].clone() if peaks.shape[0] > max_n_instance_centers else peaks
+    ids = group_pixels(peaks, offset_predictions.reshape(2, H, W), foreground_mask.reshape(1, H, W))
+    return make_instance_seg_consecutive(ids), peaks
 
 
-def _instance_means(inst, flow, max_id):
-    """Mean (row + flow0, col + flow1) of every instance id 1..max_id -> ([max_id + 1, 2] float32, counts)."""
-    H, W = inst.shape[-2:]
-    dev = inst.device
-    sums = torch.empty((max_id + 1, 2), dtype=torch.float64, device=dev)
-    cnt = torch.empty((max_id + 1,), dtype=torch.int32, device=dev)
-    i64 = inst.reshape(H, W).to(torch.int64).contiguous()
-    fl = runtime.f32c(flow).view(2, H, W) if flow is not None else None
-    _lib.check(_lib.lib().sf_instance_sums_fwd(ptr(i64), ptr(fl), H, W, int(max_id), ptr(sums), ptr(cnt), runtime.stream_ptr(dev)),
-               "instance_sums")
-    means = (sums / cnt.clamp(min=1).unsqueeze(1).double()).float()
-    return means, cnt
+def instance_moments(instance_seq, flow_seq=None):
+    """instance_seq [F, H, W] int64, flow_seq [F, 2, H, W] or None -> numpy (counts [F, K], centres [F, K, 2] float32,
+    flow-displaced centres [F, K, 2] float32 or None), K = largest id + 1; rows of absent ids are NaN."""
+    runtime.require_cuda(instance_seq)
+    F, H, W = instance_seq.shape
+    ids = instance_seq.to(torch.int64).contiguous()
+    top = int(ids.max().item())
+    dev = ids.device
+    pos = torch.empty((F, top + 1, 2), dtype=torch.int64, device=dev)
+    cnt = torch.empty((F, top + 1), dtype=torch.int32, device=dev)
+    fl = runtime.f32c(flow_seq).view(F, 2, H, W) if flow_seq is not None else None
+    moved = torch.empty_like(pos) if fl is not None else None
+    _lib.check(_lib.lib().sf_instance_moments_fwd(ptr(ids), ptr(fl), F, H, W, top, ptr(pos), ptr(moved), ptr(cnt), runtime.stream_ptr(dev)),
+               "instance_moments")
+    counts = cnt.cpu().numpy()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        denom = counts[..., None].astype(np.float64)
+        centres = (pos.cpu().numpy() / denom).astype(np.float32)
+        displaced = (moved.cpu().numpy() * MOMENT_SCALE / denom).astype(np.float32) if moved is not None else None
+    return counts, centres, displaced
 
 
 def make_instance_id_temporally_consistent(pred_inst, future_flow, matching_threshold=3.0):
-    """instance.py:171-263.  pred_inst [1, seq, h, w], future_flow [1, seq, 2, h, w] -> consistent ids [1, seq, h, w]."""
+    """pred_inst [1, T, h, w] per-frame instance maps, future_flow [1, T, 2, h, w] -> [1, T, h, w] with ids that follow the
+    instances through time: an instance of frame t+1 inherits the id of the frame-t instance whose flow-displaced centre
+    it is assigned to (Hungarian method) when they are closer than ``matching_threshold``; otherwise it gets a new id."""
     assert pred_inst.shape[0] == 1, "Assumes batch size = 1"
     runtime.require_cuda(pred_inst, future_flow)
-    consistent = [pred_inst[0, 0]]
-    largest_instance_id = consistent[0].max().item()
-    _, seq_len, h, w = pred_inst.shape
-    for t in range(seq_len - 1):
-        t_instance_ids = torch.unique(consistent[-1])[1:].cpu().numpy()
-        if len(t_instance_ids) == 0:
-            consistent.append(pred_inst[0, t + 1])
-            continue
-        means_t, _ = _instance_means(consistent[-1], future_flow[0, t], int(t_instance_ids.max()))
-        warped_centers = means_t[torch.as_tensor(t_instance_ids, device=means_t.device).long()]
-        n_instances = int(pred_inst[0, t + 1].max().item())
-        if n_instances == 0:
-            consistent.append(pred_inst[0, t + 1])
-            continue
-        centers, _ = _instance_means(pred_inst[0, t + 1], None, n_instances)
-        centers = centers[1:]
-        distances = torch.norm(centers.unsqueeze(0) - warped_centers.unsqueeze(1), dim=-1).cpu().numpy()
-        ids_t, ids_t_one = linear_sum_assignment(distances)
-        matching_distances = distances[ids_t, ids_t_one]
-        ids_t += 1
-        ids_t_one += 1
-        id_mapping = dict(zip(np.arange(1, len(t_instance_ids) + 1), t_instance_ids))
-        ids_t = np.vectorize(id_mapping.__getitem__, otypes=[np.int64])(ids_t)
-        ids_t = ids_t[matching_distances < matching_threshold]
-        ids_t_one = ids_t_one[matching_distances < matching_threshold]
-        remaining_ids = set(torch.unique(pred_inst[0, t + 1]).cpu().numpy()).difference(set(ids_t_one))
-        remaining_ids.remove(0)
-        for remaining_id in list(remaining_ids):
-            largest_instance_id += 1
-            ids_t = np.append(ids_t, largest_instance_id)
-            ids_t_one = np.append(ids_t_one, remaining_id)
-        consistent.append(update_instance_ids(pred_inst[0, t + 1], old_ids=torch.as_tensor(ids_t_one), new_ids=torch.as_tensor(ids_t)))
-    return torch.stack(consistent).unsqueeze(0)
+    frames = pred_inst[0]
+    T = frames.shape[0]
+    counts, centres, displaced = instance_moments(frames, future_flow[0])
+    K = counts.shape[1]
+    tables = np.tile(np.arange(K, dtype=np.int64), (T, 1))      # tables[t][raw id] = consistent id; frame 0 keeps its ids
+    next_new = int(np.flatnonzero(counts[0]).max(initial=0))      # largest id of the first frame
+    for t in range(T - 1):
+        raw_prev = np.flatnonzero(counts[t][1:]) + 1
+        raw_next = np.flatnonzero(counts[t + 1][1:]) + 1
+        if raw_prev.size == 0 or raw_next.size == 0:
+            continue                                              # nothing to carry over: frame t+1 keeps its raw ids
+        order = np.argsort(tables[t][raw_prev], kind="stable")    # previous instances by ascending consistent id
+        raw_prev = raw_prev[order]
+        carried = tables[t][raw_prev]
+        n_next = int(raw_next.max())                              # raw ids are consecutive 1..n_next
+        gap = np.linalg.norm(centres[t + 1, 1:n_next + 1][None, :, :] - displaced[t, raw_prev][:, None, :], axis=-1)
+        rows, cols = linear_sum_assignment(gap)
+        close = gap[rows, cols] < matching_threshold
+        table = tables[t + 1]
+        table[cols[close] + 1] = carried[rows[close]]
+        unmatched = np.setdiff1d(raw_next, cols[close] + 1)       # ascending
+        table[unmatched] = next_new + 1 + np.arange(unmatched.size)
+        next_new += int(unmatched.size)
+    lut = torch.from_numpy(tables).to(frames.device)
+    return torch.gather(lut, 1, frames.reshape(T, -1).long()).view_as(frames).unsqueeze(0)
 
 
 def predict_instance_segmentation_and_trajectories(output, compute_matched_centers=False, make_consistent=True, vehicles_id=1):
-    """instance.py:370-428."""
-    preds = output["segmentation"].detach()
-    preds = torch.argmax(preds, dim=2, keepdim=True)
-    foreground_masks = preds.squeeze(2) == vehicles_id
-    batch_size, seq_len = preds.shape[:2]
-    pred_inst = []
-    for b in range(batch_size):
-        frames = []
-        for t in range(seq_len):
-            inst_t, _ = get_instance_segmentation_and_centers(output["instance_center"][b, t].detach(), output["instance_offset"][b, t].detach(),
-                                                              foreground_masks[b, t].detach())
-            frames.append(inst_t)
-        pred_inst.append(torch.stack(frames, dim=0))
-    pred_inst = torch.stack(pred_inst).squeeze(2)
+    """Decoder output dict (``segmentation`` [b, T, classes, H, W], ``instance_center`` [b, T, 1, H, W], ``instance_offset`` and
+    ``instance_flow`` [b, T, 2, H, W]) -> [b, T, H, W] int64 instance ids (+ {id: [n, 2] (x, y) centre track} of the
+    instances of the first frame when ``compute_matched_centers``, batch size 1)."""
+    labels = output["segmentation"].detach().argmax(dim=2)
+    vehicles = labels == vehicles_id
+    B, T = labels.shape[:2]
+    centre_maps, offsets = output["instance_center"].detach(), output["instance_offset"].detach()
+    per_frame = torch.stack([torch.stack([get_instance_segmentation_and_centers(centre_maps[b, t], offsets[b, t], vehicles[b, t])[0][0]
+                                          for t in range(T)]) for b in range(B)])
     if make_consistent:
         if output["instance_flow"] is None:
             output["instance_flow"] = torch.zeros_like(output["instance_offset"])
-        consistent = torch.cat([make_instance_id_temporally_consistent(pred_inst[b:b + 1], output["instance_flow"][b:b + 1].detach())
-                                for b in range(batch_size)], dim=0)
+        flow = output["instance_flow"].detach()
+        tracked = torch.cat([make_instance_id_temporally_consistent(per_frame[b:b + 1], flow[b:b + 1]) for b in range(B)])
     else:
-        consistent = pred_inst
-    if compute_matched_centers:
-        assert batch_size == 1
-        matched_centers = {}
-        _, seq_len, h, w = consistent.shape
-        for t in range(seq_len):
-            max_id = int(consistent[0, t].max().item())
-            if max_id == 0:
-                continue
-            means, cnt = _instance_means(consistent[0, t], None, max_id)
-            means, cnt = means.cpu(), cnt.cpu()
-            for instance_id in torch.unique(consistent[0, 0])[1:].cpu().numpy():
-                if instance_id <= max_id and cnt[instance_id] > 0:
-                    matched_centers[instance_id] = matched_centers.get(instance_id, []) + [means[instance_id]]
-        for key, value in matched_centers.items():
-            matched_centers[key] = torch.stack(value).numpy()[:, ::-1]
-        return consistent, matched_centers
-    return consistent
+        tracked = per_frame
+    if not compute_matched_centers:
+        return tracked
+    assert B == 1
+    counts, centres, _ = instance_moments(tracked[0])
+    tracks = {}
+    for ident in (np.flatnonzero(counts[0][1:]) + 1).tolist():      # the instances of the first frame, wherever they reappear
+        seen = counts[:, ident] > 0
+        tracks[ident] = centres[seen, ident][:, ::-1]               # (row, col) -> (x, y)
+    return tracked, tracks

@@ -1,196 +1,186 @@
-"""Evaluation metrics of StreamingFlow on the MI355X: ``IntersectionOverUnion`` and
-``PanopticMetric`` with the reference's constructor arguments, ``update`` / ``compute`` / ``__call__`` and state
-names (streamingflow/metrics.py:15-261), without ``pytorch_lightning.metrics`` (removed upstream).
+"""IoU and panoptic-quality accumulators for StreamingFlow's evaluation on the MI355X.
 
-The per-pixel work — the joint label histogram behind the IoU statistics and behind PanopticMetric's
-``bincount(prediction + K * target)`` — is one integer kernel (``sf_confusion_fwd``: exact); the matching
-logic on the K x K matrix (a few dozen entries) stays on the host as in the reference.  States are plain
-tensors; ``streamingflow_amd.dist.reduce_counters`` sums them across ranks (the reference declares
-``dist_reduce_fx='sum'``).  CUDA tensors only.
+Drop-in for ``streamingflow/metrics.py`` (``IntersectionOverUnion`` :15-71, ``PanopticMetric`` :74-261): same
+constructor arguments, ``update`` / ``compute`` / ``__call__`` / ``reset`` and state names, no ``pytorch_lightning``.
+
+How it is computed here.  Every statistic of both metrics is a function of joint label histograms:
+  * IoU: tp / fp / fn / support of class c are the diagonal, column and row sums of the (target x prediction) histogram.
+  * PQ: a frame's segments are the instance ids themselves (id 0 = background "stuff", ids > 0 = vehicle "things");
+    the histogram of (ground-truth id, predicted id) gives every intersection, every segment area (its margins) and
+    hence every IoU.  A pair is a match when IoU > 0.5; ground-truth / predicted things that are in no match are the
+    false negatives / false positives; a matched vehicle whose ground-truth id was matched to a different predicted id
+    in an earlier frame is an id switch and counts as one false negative plus one false positive (:190-197).
+The histograms of a whole [batch, time] block come from ONE kernel launch (``sf_confusion_frames_fwd``, integer
+atomics: exact) and one device -> host copy; the bookkeeping on the resulting few-dozen-entry matrices is numpy.
 """
 from typing import Optional
 
+import numpy as np
 import torch
 import torch.nn as nn
 
 from . import _lib, runtime
 from .runtime import ptr
 
+THING_CLASS = 1     # PanopticMetric derives the semantic map as (instance > 0): every instance is of class 1
+
+
+def _as_labels(t):
+    return t.reshape(-1).to(torch.int64).contiguous()
+
 
 def confusion(pred, target, K):
-    """[K, K] int64, entry [t, p] = number of positions with target t and prediction p (labels must be in [0, K))."""
+    """([K, K] int64 with entry [t, p] = number of positions labelled t in ``target`` and p in ``pred``, device flag
+    that is non-zero when a label was outside [0, K))."""
     runtime.require_cuda(pred, target)
-    a = pred.reshape(-1).to(torch.int64).contiguous()
-    b = target.reshape(-1).to(torch.int64).contiguous()
+    a, b = _as_labels(pred), _as_labels(target)
     if a.numel() != b.numel():
         raise ValueError("prediction and target must have the same number of elements")
-    out = torch.empty((K, K), dtype=torch.int64, device=a.device)
-    bad = torch.empty((1,), dtype=torch.int32, device=a.device)
-    _lib.check(_lib.lib().sf_confusion_fwd(ptr(a), ptr(b), a.numel(), int(K), ptr(out), ptr(bad), runtime.stream_ptr(a.device)), "confusion")
-    return out, bad
+    hist = torch.empty((K, K), dtype=torch.int64, device=a.device)
+    flag = torch.empty((1,), dtype=torch.int32, device=a.device)
+    _lib.check(_lib.lib().sf_confusion_fwd(ptr(a), ptr(b), a.numel(), int(K), ptr(hist), ptr(flag), runtime.stream_ptr(a.device)), "confusion")
+    return hist, flag
 
 
-class _Metric(nn.Module):
-    def __init__(self):
+def frame_confusions(pred, target, n_frames, K):
+    """Per-frame joint histograms [n_frames, K, K] of two label tensors whose leading dims flatten to n_frames."""
+    runtime.require_cuda(pred, target)
+    a, b = _as_labels(pred), _as_labels(target)
+    if a.numel() != b.numel() or a.numel() % n_frames:
+        raise ValueError("prediction and target must hold n_frames equally sized maps")
+    hist = torch.empty((n_frames, K, K), dtype=torch.int64, device=a.device)
+    flag = torch.empty((1,), dtype=torch.int32, device=a.device)
+    _lib.check(_lib.lib().sf_confusion_frames_fwd(ptr(a), ptr(b), a.numel() // n_frames, int(n_frames), int(K), ptr(hist), ptr(flag),
+                                                  runtime.stream_ptr(a.device)), "confusion_frames")
+    return hist, flag
+
+
+class _Accumulator(nn.Module):
+    """Named float32 counters that follow the data to its device, reset to zero and sum over ranks."""
+
+    def __init__(self, names, size):
         super().__init__()
-        self._state_defaults = {}
+        self._counter_names = tuple(names)
+        for name in self._counter_names:
+            self.register_buffer(name, torch.zeros(size), persistent=False)
 
-    def add_state(self, name, default, dist_reduce_fx="sum"):
-        self._state_defaults[name] = default.clone()
-        self.register_buffer(name, default.clone(), persistent=False)
+    def _accumulate(self, name, increment):
+        state = getattr(self, name)
+        if state.device != increment.device:        # first update on another device: the state moves, not the data
+            for n in self._counter_names:
+                setattr(self, n, getattr(self, n).to(increment.device))
+            state = getattr(self, name)
+        state += increment.to(state.dtype)
 
     def reset(self):
-        for k, v in self._state_defaults.items():
-            getattr(self, k).copy_(v)
+        for name in self._counter_names:
+            getattr(self, name).zero_()
 
     def forward(self, *args, **kwargs):
         self.update(*args, **kwargs)
 
     def sync(self):
-        """Sum the states over the ranks of the default process group (no-op when not initialised)."""
+        """Sum the counters over the ranks of the default process group (the reference's ``dist_reduce_fx='sum'``)."""
         from . import dist
-        for k in self._state_defaults:
-            dist.reduce_counters(getattr(self, k))
+        for name in self._counter_names:
+            dist.reduce_counters(getattr(self, name))
 
 
-class IntersectionOverUnion(_Metric):
-    """metrics.py:15-71."""
-
+class IntersectionOverUnion(_Accumulator):
     def __init__(self, n_classes: int, ignore_index: Optional[int] = None, absent_score: float = 0.0, reduction: str = "none",
                  compute_on_step: bool = False):
-        super().__init__()
+        super().__init__(("true_positive", "false_positive", "false_negative", "support"), n_classes)
+        if reduction not in ("none", "sum", "elementwise_mean"):
+            raise ValueError("Reduction parameter unknown.")
         self.n_classes, self.ignore_index, self.absent_score, self.reduction = n_classes, ignore_index, absent_score, reduction
-        for name in ("true_positive", "false_positive", "false_negative", "support"):
-            self.add_state(name, torch.zeros(n_classes))
+        self._out_of_range = None       # device flag, OR-ed over every update since the last reset
 
     def update(self, prediction: torch.Tensor, target: torch.Tensor):
-        if prediction.ndim == target.ndim + 1:      # stat_scores_multiple_classes' argmax_dim=1 convention
-            prediction = torch.argmax(prediction, dim=1)
-        K = self.n_classes + 1                      # the extra bin pytorch-lightning keeps for an ignored label
-        conf, bad = confusion(prediction, target, K)
-        conf = conf.to(torch.float32)
-        diag = conf.diagonal()
-        self.true_positive += diag[: self.n_classes].to(self.true_positive.device)
-        self.false_positive += (conf.sum(0) - diag)[: self.n_classes]
-        self.false_negative += (conf.sum(1) - diag)[: self.n_classes]
-        self.support += conf.sum(1)[: self.n_classes]
-        self._bad = bad
+        if prediction.ndim == target.ndim + 1:      # class scores: the predicted label is the arg max over dim 1
+            prediction = prediction.argmax(dim=1)
+        n = self.n_classes
+        hist, flag = confusion(prediction, target, n + 1)      # one spare bin: label n is accepted and counted nowhere
+        self._out_of_range = flag if self._out_of_range is None else torch.maximum(self._out_of_range, flag)
+        hist = hist[:n].to(torch.float32)                       # rows = target classes 0..n-1
+        hit = hist[:, :n].diagonal()
+        self._accumulate("true_positive", hit)
+        self._accumulate("false_positive", hist[:, :n].sum(0) - hit)
+        self._accumulate("false_negative", hist.sum(1) - hit)
+        self._accumulate("support", hist.sum(1))
+
+    def reset(self):
+        super().reset()
+        self._out_of_range = None
 
     def compute(self):
-        if getattr(self, "_bad", None) is not None and int(self._bad.item()):
+        if self._out_of_range is not None and int(self._out_of_range.item()):
             raise RuntimeError("IntersectionOverUnion: a label outside [0, n_classes] was seen")
-        scores = torch.zeros(self.n_classes, device=self.true_positive.device, dtype=torch.float32)
-        for c in range(self.n_classes):
-            if c == self.ignore_index:
-                continue
-            tp, fp, fn, sup = self.true_positive[c], self.false_positive[c], self.false_negative[c], self.support[c]
-            if sup + tp + fp == 0:
-                scores[c] = self.absent_score
-                continue
-            scores[c] = tp.to(torch.float) / (tp + fp + fn)
-        if (self.ignore_index is not None) and (0 <= self.ignore_index < self.n_classes):
-            scores = torch.cat([scores[: self.ignore_index], scores[self.ignore_index + 1:]])
-        if self.reduction == "elementwise_mean":
-            return torch.mean(scores)
-        if self.reduction == "sum":
-            return torch.sum(scores)
-        if self.reduction == "none":
-            return scores
-        raise ValueError("Reduction parameter unknown.")
+        tp, fp, fn = self.true_positive, self.false_positive, self.false_negative
+        seen = (self.support + tp + fp) > 0
+        scores = torch.where(seen, tp / (tp + fp + fn).clamp(min=1), torch.full_like(tp, float(self.absent_score)))
+        keep = torch.ones(self.n_classes, dtype=torch.bool, device=scores.device)
+        if self.ignore_index is not None and 0 <= self.ignore_index < self.n_classes:
+            keep[self.ignore_index] = False
+        scores = scores[keep]
+        return {"none": lambda s: s, "sum": torch.sum, "elementwise_mean": torch.mean}[self.reduction](scores)
 
 
-class PanopticMetric(_Metric):
-    """metrics.py:74-261."""
-
+class PanopticMetric(_Accumulator):
     def __init__(self, n_classes: int, temporally_consistent: bool = True, vehicles_id: int = 1, compute_on_step: bool = False):
-        super().__init__()
+        super().__init__(("iou", "true_positive", "false_positive", "false_negative"), n_classes)
+        self.keys = list(self._counter_names)
         self.n_classes, self.temporally_consistent, self.vehicles_id = n_classes, temporally_consistent, vehicles_id
-        self.keys = ["iou", "true_positive", "false_positive", "false_negative"]
-        for k in self.keys:
-            self.add_state(k, torch.zeros(n_classes))
 
     def update(self, pred_instance, gt_instance):
+        """pred_instance, gt_instance: [batch, time, H, W] instance ids (0 = background)."""
         runtime.require_cuda(pred_instance, gt_instance)
-        batch_size, sequence_length = gt_instance.shape[:2]
-        assert gt_instance.min() == 0, "ID 0 of gt_instance must be background"
-        pred_segmentation = (pred_instance > 0).long()
-        gt_segmentation = (gt_instance > 0).long()
-        for b in range(batch_size):
-            unique_id_mapping = {}
-            for t in range(sequence_length):
-                result = self.panoptic_metrics(pred_segmentation[b, t].detach(), pred_instance[b, t].detach(), gt_segmentation[b, t],
-                                               gt_instance[b, t], unique_id_mapping)
-                for k in self.keys:
-                    getattr(self, k).add_(result[k].to(getattr(self, k).device))
+        if pred_instance.shape != gt_instance.shape or gt_instance.dim() != 4:
+            raise ValueError("expected two [batch, time, H, W] id tensors of the same shape")
+        batch, steps = gt_instance.shape[:2]
+        top = torch.stack([pred_instance.max(), gt_instance.max(), -gt_instance.min()]).cpu()
+        assert int(top[2]) == 0, "ID 0 of gt_instance must be background"
+        K = int(max(top[0], top[1])) + 1
+        hist, flag = frame_confusions(pred_instance, gt_instance, batch * steps, K)
+        hist = hist.cpu().numpy().reshape(batch, steps, K, K)          # the one device -> host copy of this update
+        if int(flag.item()):
+            raise ValueError("negative instance id")
+        tally = {k: np.zeros(self.n_classes, dtype=np.float64) for k in self.keys}
+        for b in range(batch):
+            partner = {}            # ground-truth vehicle id -> predicted id of its latest match (id switches)
+            for t in range(steps):
+                self._score_frame(hist[b, t], partner, tally)
+        dev = pred_instance.device
+        for k in self.keys:
+            self._accumulate(k, torch.from_numpy(tally[k]).to(dev))
+
+    def _score_frame(self, joint, partner, tally):
+        """joint[g, p]: pixels with ground-truth id g and predicted id p in one frame."""
+        area_gt, area_pred = joint.sum(1), joint.sum(0)
+        union = (area_gt[:, None] + area_pred[None, :] - joint).astype(np.float32)
+        iou = np.where(union > 0, (joint.astype(np.float32) + np.float32(1e-9)) / (union + np.float32(1e-9)), np.float32(0))
+        hits = iou > 0.5
+        if hits[0, 0]:                                   # the background segment is scored as a class-0 match only
+            tally["true_positive"][0] += 1
+            tally["iou"][0] += iou[0, 0]
+        gt_ids, pred_ids = np.nonzero(hits[1:, 1:])      # thing <-> thing matches, ascending ground-truth id
+        gt_ids, pred_ids = gt_ids + 1, pred_ids + 1
+        track = self.temporally_consistent and THING_CLASS == self.vehicles_id
+        for g, p in zip(gt_ids.tolist(), pred_ids.tolist()):
+            switched = track and g in partner and partner[g] != p
+            partner[g] = p
+            if switched:
+                tally["false_negative"][THING_CLASS] += 1
+                tally["false_positive"][THING_CLASS] += 1
+            else:
+                tally["true_positive"][THING_CLASS] += 1
+                tally["iou"][THING_CLASS] += iou[g, p]
+        present_gt, present_pred = area_gt[1:] > 0, area_pred[1:] > 0
+        matched_gt, matched_pred = hits[1:, 1:].any(1), hits[1:, 1:].any(0)
+        tally["false_negative"][THING_CLASS] += int(np.count_nonzero(present_gt & ~matched_gt))
+        tally["false_positive"][THING_CLASS] += int(np.count_nonzero(present_pred & ~matched_pred))
 
     def compute(self):
-        denominator = torch.maximum(self.true_positive + self.false_positive / 2 + self.false_negative / 2,
-                                    torch.ones_like(self.true_positive))
-        pq = self.iou / denominator
-        sq = self.iou / torch.maximum(self.true_positive, torch.ones_like(self.true_positive))
-        rq = self.true_positive / denominator
-        return {"pq": pq, "sq": sq, "rq": rq}
-
-    def panoptic_metrics(self, pred_segmentation, pred_instance, gt_segmentation, gt_instance, unique_id_mapping):
-        """metrics.py:143-226: the joint histogram runs on the device, the (small) matching on the host."""
-        n_classes = self.n_classes
-        assert pred_segmentation.dim() == 2
-        assert pred_segmentation.shape == pred_instance.shape == gt_segmentation.shape == gt_instance.shape
-        n_instances = int(torch.cat([pred_instance, gt_instance]).max().item())
-        n_all_things = n_instances + n_classes
-        n_things_and_void = n_all_things + 1
-        prediction, pred_to_cls = self.combine_mask(pred_segmentation, pred_instance, n_classes, n_all_things)
-        target, target_to_cls = self.combine_mask(gt_segmentation, gt_instance, n_classes, n_all_things)
-        conf, bad = confusion(prediction, target, n_things_and_void)        # [target][prediction]
-        conf = conf.cpu()
-        if int(bad.item()):
-            raise ValueError("Incorrect bincount size.")
-        pred_to_cls, target_to_cls = pred_to_cls.cpu(), target_to_cls.cpu()
-        result = {key: torch.zeros(n_classes, dtype=torch.float32) for key in self.keys}
-        conf = conf[1:, 1:]                                                  # drop the void class
-        union = conf.sum(0).unsqueeze(0) + conf.sum(1).unsqueeze(1) - conf
-        iou = torch.where(union > 0, (conf.float() + 1e-9) / (union.float() + 1e-9), torch.zeros_like(union).float())
-        mapping = (iou > 0.5).nonzero(as_tuple=False)
-        is_matching = pred_to_cls[mapping[:, 1]] == target_to_cls[mapping[:, 0]]
-        mapping = mapping[is_matching]
-        tp_mask = torch.zeros_like(conf, dtype=torch.bool)
-        tp_mask[mapping[:, 0], mapping[:, 1]] = True
-        for target_id, pred_id in mapping:
-            cls_id = pred_to_cls[pred_id]
-            if self.temporally_consistent and cls_id == self.vehicles_id:
-                if target_id.item() in unique_id_mapping and unique_id_mapping[target_id.item()] != pred_id.item():
-                    result["false_negative"][target_to_cls[target_id]] += 1
-                    result["false_positive"][pred_to_cls[pred_id]] += 1
-                    unique_id_mapping[target_id.item()] = pred_id.item()
-                    continue
-            result["true_positive"][cls_id] += 1
-            result["iou"][cls_id] += iou[target_id][pred_id]
-            unique_id_mapping[target_id.item()] = pred_id.item()
-        for target_id in range(n_classes, n_all_things):
-            if tp_mask[target_id, n_classes:].any():
-                continue
-            if target_to_cls[target_id] != -1:
-                result["false_negative"][target_to_cls[target_id]] += 1
-        for pred_id in range(n_classes, n_all_things):
-            if tp_mask[n_classes:, pred_id].any():
-                continue
-            if pred_to_cls[pred_id] != -1 and (conf[:, pred_id] > 0).any():
-                result["false_positive"][pred_to_cls[pred_id]] += 1
-        return result
-
-    def combine_mask(self, segmentation, instance, n_classes, n_all_things):
-        """metrics.py:228-261 (tensor plumbing, unchanged semantics)."""
-        instance = instance.view(-1)
-        instance_mask = instance > 0
-        instance = instance - 1 + n_classes
-        segmentation = segmentation.clone().view(-1)
-        segmentation_mask = segmentation < n_classes
-        keep = instance_mask & segmentation_mask
-        tuples = torch.cat((instance[keep].unsqueeze(1), segmentation[keep].unsqueeze(1)), dim=1)
-        instance_id_to_class = -tuples.new_ones((n_all_things,))
-        instance_id_to_class[tuples[:, 0]] = tuples[:, 1]
-        instance_id_to_class[torch.arange(n_classes, device=segmentation.device)] = torch.arange(n_classes, device=segmentation.device)
-        segmentation[instance_mask] = instance[instance_mask]
-        segmentation += 1
-        segmentation[~segmentation_mask] = 0
-        return segmentation, instance_id_to_class
+        one = torch.ones_like(self.true_positive)
+        denominator = torch.maximum(self.true_positive + 0.5 * self.false_positive + 0.5 * self.false_negative, one)
+        return {"pq": self.iou / denominator, "sq": self.iou / torch.maximum(self.true_positive, one),
+                "rq": self.true_positive / denominator}
