@@ -10,13 +10,18 @@ sample at a time; here samples with the same schedule structure go through the k
 ``value`` = ODE steps integrated per second over all ranks = n_ode_steps * batch * K * N / t;
 the single-sample (batch 1) latency of the same forward is reported next to it.
 
-N > 1: one process per GPU (torchrun), every rank runs its own sample (the reference is batch-1,
-samples shard with no data-path collective: weak scaling); barrier + synchronize on both sides of
-the timed region, max over ranks.
+N > 1: one process per GPU (torchrun, backend nccl = RCCL over xGMI), every rank runs its own samples (the
+reference is batch-1, samples shard with no data-path collective: weak scaling); barrier + synchronize on both sides
+of the timed region, max over ranks.  What the north star names for the multi-GPU case — the all-gather of per-sample
+BEV grids — runs INSIDE the timed region: after every forward each rank hands one sample's [T, C, H, W] grid to
+``streamingflow_amd.dist.gather_predictions`` on a side stream, overlapped with the next forward (``--no-gather`` to
+leave it out); its stand-alone time, byte count and the RCCL world size are reported (``multi_gpu``).
 
-Extra objects on the JSON line: ``roofline`` (dominant kernel, per-launch hipEvent timing in a
-dedicated pass of the same workload through libsfnative's profiler) and ``cpu_baseline`` (the
-oracle — a torch-CPU port of the reference path — on the host cores, rank 0, N=1 only).
+Extra objects on the JSON line: ``roofline`` (dominant kernel of the forward, per-launch hipEvent timing in a dedicated
+pass of the same workload through libsfnative's profiler), ``roofline_ode_step`` (the kernel group of ONE GRU-ODE
+step — the unit SURVEY.md §8d defines: 728 C^2 h w FLOP, 16 C h w + eps + weights bytes — from >= 20 individually timed
+hipGraph replays: median and p95), ``batch1_forward`` (the same forward at the reference's own batch size) and
+``cpu_baseline`` (the oracle — a torch-CPU port of the reference path — on the host cores, rank 0, N=1 only).
 """
 import argparse
 import ctypes
@@ -44,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary sections (next-row components, ODE step alone)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the all-gather of per-sample BEV grids out of the timed region")
     return ap.parse_args()
 
 
@@ -64,6 +70,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend, rank=rank, world_size=world)
+        if a.gpus != world:
+            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE is {world}")
+        assert dist.get_world_size() == world and dist.get_backend() == backend
 
     import streamingflow_amd as sfa
     from streamingflow_amd import _lib, schedule as S
@@ -94,12 +103,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from streamingflow_amd import dist as sfd
+    do_gather = world > 1 and not a.no_gather and backend == "nccl"
+    side = torch.cuda.Stream(device=dev) if do_gather else None
+    gathered = [None]
+
+    def gather(y):
+        """one sample's BEV grid per rank -> every rank (RCCL all_gather_into_tensor on a side stream, overlapped with the
+        next forward; sample index = rank, so each rank owns exactly one slot)"""
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            y[0].record_stream(side)
+            gathered[0] = sfd.gather_predictions({rank: y[0]}, world)
+
     for _ in range(a.warmup):
-        forward()
+        y, _ = forward()
+        if do_gather:
+            gather(y)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         y, _ = forward()
+        if do_gather:
+            gather(y)
     fence()
     el = time.perf_counter() - t0
     if world > 1:
@@ -108,6 +134,30 @@ def main():
         el = float(t.item())
     ms_per_step = 1e3 * el / a.steps
     value = n_ode * B * a.steps * world / el
+
+    multi = None
+    if world > 1:
+        grid = y[0]
+        gbytes = grid.numel() * 4
+        gms = None
+        if do_gather:
+            ts = []
+            for _ in range(5):
+                fence()
+                tg = time.perf_counter()
+                sfd.gather_predictions({rank: grid}, world)
+                torch.cuda.synchronize()
+                ts.append(1e3 * (time.perf_counter() - tg))
+            gms = sorted(ts)[2]
+            ok = all(g.shape == grid.shape for g in gathered[0]) and torch.equal(gathered[0][rank], grid)
+            assert ok, "all-gather returned a wrong slot"
+        cnt = torch.ones(8, device=dev if backend == "nccl" else "cpu")
+        sfd.reduce_counters(cnt)
+        assert float(cnt[0]) == world
+        multi = {"rccl_world": dist.get_world_size(), "backend": dist.get_backend(), "gather_in_timed_region": do_gather,
+                 "gather_bytes_per_rank": gbytes, "gather_bytes_total": gbytes * world, "gather_ms_standalone": gms,
+                 "gather_estimate_ms": gbytes / 153e9 * 1e3,      # one xGMI hop at ~153 GB/s per link
+                 "what": "all_gather_into_tensor of one sample's [T, C, H, W] fp32 BEV grid per rank (streamingflow_amd.dist.gather_predictions), side stream, overlapped with the next forward; metric counters: all_reduce(SUM)"}
 
     # ---- single-sample latency of the same forward (batch 1) -----------------------------------------
     def forward1():
@@ -120,98 +170,187 @@ def main():
     torch.cuda.synchronize()
     single_ms = 1e3 * (time.perf_counter() - t0) / 3
 
-    # ---- ODE rollout alone (the serial chain the north star names), same stream, hipEvents -------
     L = _lib.lib()
-    ode = net.gru_ode
-    hx = torch.randn((len(times), H // 4, W // 4, C), device=dev) * 0.5
-    eps = torch.randn((sc.n_draws, H // 4, W // 4, C), device=dev)
-    for _ in range(2):
-        ode.rollout_nhwc(hx, sc, eps)
-    torch.cuda.synchronize()
-    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
-    L.sf_event_create(ctypes.byref(e0)); L.sf_event_create(ctypes.byref(e1))
-    from streamingflow_amd import runtime
-    reps = 10
-    L.sf_event_record(e0, runtime.stream_ptr(dev))
-    for _ in range(reps):
-        ode.rollout_nhwc(hx, sc, eps)
-    L.sf_event_record(e1, runtime.stream_ptr(dev))
-    ms = ctypes.c_float()
-    L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
-    rollout_ms = ms.value / reps
-    # the same rollout replayed as one captured hipGraph
-    ode.use_graph = True
-    for _ in range(2):
-        ode.rollout_nhwc(hx, sc, eps)
-    torch.cuda.synchronize()
-    L.sf_event_record(e0, runtime.stream_ptr(dev))
-    for _ in range(reps):
-        ode.rollout_nhwc(hx, sc, eps)
-    L.sf_event_record(e1, runtime.stream_ptr(dev))
-    L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
-    rollout_graph_ms = ms.value / reps
-    ode.use_graph = False
-    flops_step = 728.0 * C * C * (H // 4) * (W // 4)          # Euler step, algorithmic
-    flops_jump = flops_step
-    rollout = {"ms": rollout_ms, "hipgraph_replay_ms": rollout_graph_ms, "batch": 1, "ode_steps": sc.n_steps, "jumps": sc.n_jumps,
-               "ode_steps_per_s_single_sample_graph": sc.n_steps / (rollout_graph_ms * 1e-3),
-               "us_per_op": 1e3 * rollout_ms / max(1, len(sc.ops)),
-               "ops_per_s": len(sc.ops) / (rollout_ms * 1e-3),
-               "tflops": (sc.n_steps * flops_step + sc.n_jumps * flops_jump) / (rollout_ms * 1e-3) / 1e12}
-
-    # ---- one fused GRU-ODE step alone (SURVEY §8d unit of work), hipEvents on the launch stream -----
-    def time_step(Bs, h, w, reps):
-        s_in = torch.randn((Bs, h, w, C), device=dev) * 0.5
-        p_in = torch.randn((Bs, h, w, C), device=dev) * 0.5
-        e_in = torch.randn((S.DRAWS_PER_STEP[a.solver], Bs, h, w, C), device=dev)
-        s_o, p_o = torch.empty_like(s_in), torch.empty_like(p_in)
-        coef = torch.from_numpy(S.Schedule(dts=[float(dt)]).coef_array()).to(dev)
-        wsb = L.sf_ode_step_ws_bytes(C, Bs, h, w)
-        ws = runtime.workspace(wsb, dev)
-        pr = runtime.ptr
-
-        def one():
-            _lib.check(L.sf_ode_step_fwd(ode.gru_c.packed().struct, ode.p_model.packed().struct, _lib.SOLVER[a.solver], 1,
-                                         pr(s_in), pr(p_in), pr(coef), pr(e_in), pr(s_o), pr(p_o), Bs, h, w, pr(ws),
-                                         ws.numel() * 4, runtime.stream_ptr(dev)), "ode_step")
-        for _ in range(3):
-            one()
+    rollout = step_only = roof_step = None
+    if world == 1:      # secondary sections: single-GPU runs only (at N > 1 no rank may lag behind the others)
+        # ---- ODE rollout alone (the serial chain the north star names), same stream, hipEvents -------
+        ode = net.gru_ode
+        hx = torch.randn((len(times), H // 4, W // 4, C), device=dev) * 0.5
+        eps = torch.randn((sc.n_draws, H // 4, W // 4, C), device=dev)
+        for _ in range(2):
+            ode.rollout_nhwc(hx, sc, eps)
+        torch.cuda.synchronize()
+        e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+        L.sf_event_create(ctypes.byref(e0)); L.sf_event_create(ctypes.byref(e1))
+        from streamingflow_amd import runtime
+        reps = 10
+        L.sf_event_record(e0, runtime.stream_ptr(dev))
+        for _ in range(reps):
+            ode.rollout_nhwc(hx, sc, eps)
+        L.sf_event_record(e1, runtime.stream_ptr(dev))
+        ms = ctypes.c_float()
+        L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+        rollout_ms = ms.value / reps
+        # the same rollout replayed as one captured hipGraph
+        ode.use_graph = True
+        for _ in range(2):
+            ode.rollout_nhwc(hx, sc, eps)
         torch.cuda.synchronize()
         L.sf_event_record(e0, runtime.stream_ptr(dev))
         for _ in range(reps):
-            one()
+            ode.rollout_nhwc(hx, sc, eps)
         L.sf_event_record(e1, runtime.stream_ptr(dev))
         L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
-        t = ms.value / reps * 1e-3
-        mult = {"euler": 1, "midpoint": 2, "rk4": 4}[a.solver]
-        fl = mult * 728.0 * C * C * h * w * Bs
-        nparam = sum(v.numel() for k, v in sd.items() if k.startswith(("gru_ode.gru_c.", "gru_ode.p_model."))
-                     and "num_batches" not in k)
-        by = (16.0 + 4.0 * S.DRAWS_PER_STEP[a.solver]) * C * h * w * Bs + 4.0 * nparam
-        return {"batch": Bs, "latent": f"{h}x{w}x{C}", "us_per_step": t * 1e6, "steps_per_s": Bs / t,
-                "tflops": fl / t / 1e12, "mfma_frac": fl / t / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                "algorithmic_bytes_per_step": by / Bs, "algorithmic_gbs": by / t / 1e9,
-                "hbm_frac": by / t / 1e9 / PEAK_HBM_GBS}
-    step_only = {"single_sample": time_step(1, H // 4, W // 4, 50), "batch8": time_step(8, H // 4, W // 4, 20),
-                 "stress_latent_200x200": time_step(1, H, W, 5)}
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:      # the same unit of work on the host cores (oracle, 16 threads)
-        from oracle import ref_torch as R
-        torch.set_num_threads(min(os.cpu_count() or 1, 16))
-        s_c, p_c = torch.randn((1, C, H // 4, W // 4)) * 0.5, torch.randn((1, C, H // 4, W // 4)) * 0.5
-        with torch.no_grad():
-            R.ode_step(sd, "gru_ode", s_c, p_c, dt, a.solver, True, hashfill.HashedNoise(0))
-            t0 = time.perf_counter()
-            for _ in range(5):
-                R.ode_step(sd, "gru_ode", s_c, p_c, dt, a.solver, True, hashfill.HashedNoise(0))
-            tc = (time.perf_counter() - t0) / 5
-        step_only["cpu_baseline"] = {"value": 1.0 / tc, "unit": "ODE-steps/s", "cores": min(os.cpu_count() or 1, 16), "kind": "port",
-                                     "sample": f"5 single-sample {a.solver} steps at latent 50x50x64, oracle/ref_torch.py:ode_step, {tc * 1e3:.1f} ms each"}
-    pmc_step = os.path.join(ROOT, "profiles", "pmc_ode_step.json")
-    if os.path.exists(pmc_step):
+        rollout_graph_ms = ms.value / reps
+        ode.use_graph = False
+        # BASELINE config 5: streaming 0.05 s x 40 targets -> 46 ODE steps + 8 jumps, the whole rollout one hipGraph
+        stream40 = None
         try:
-            step_only["rocprof_hbm"] = json.load(open(pmc_step))
-        except Exception:
-            pass
+            c5, l5, t5, dt5 = cases.timeset("stream40")
+            tm5, _ = S.merge_observations(c5[0].tolist(), l5[0].tolist())
+            sc5 = S.build_schedule(tm5, t5[0].tolist(), dt5, True, a.solver)
+            eps5 = torch.randn((sc5.n_draws, H // 4, W // 4, C), device=dev)
+            ode.use_graph = True
+            for _ in range(2):
+                ode.rollout_nhwc(hx, sc5, eps5)
+            torch.cuda.synchronize()
+            L.sf_event_record(e0, runtime.stream_ptr(dev))
+            for _ in range(reps):
+                ode.rollout_nhwc(hx, sc5, eps5)
+            L.sf_event_record(e1, runtime.stream_ptr(dev))
+            L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+            ode.use_graph = False
+            m5 = ms.value / reps
+            stream40 = {"hipgraph_replay_ms": m5, "ode_steps": sc5.n_steps, "jumps": sc5.n_jumps, "solver": a.solver,
+                        "us_per_op": 1e3 * m5 / len(sc5.ops), "ode_steps_per_s": sc5.n_steps / (m5 * 1e-3)}
+        except Exception as ex:
+            stream40 = {"error": repr(ex)}
+        flops_step = 728.0 * C * C * (H // 4) * (W // 4)          # Euler step, algorithmic
+        flops_jump = flops_step
+        rollout = {"ms": rollout_ms, "hipgraph_replay_ms": rollout_graph_ms, "batch": 1, "ode_steps": sc.n_steps, "jumps": sc.n_jumps,
+                   "ode_steps_per_s_single_sample_graph": sc.n_steps / (rollout_graph_ms * 1e-3),
+                   "us_per_op": 1e3 * rollout_ms / max(1, len(sc.ops)),
+                   "ops_per_s": len(sc.ops) / (rollout_ms * 1e-3),
+                   "tflops": (sc.n_steps * flops_step + sc.n_jumps * flops_jump) / (rollout_ms * 1e-3) / 1e12,
+                   "config5_stream40": stream40}
+
+        # ---- one fused GRU-ODE step alone (SURVEY §8d unit of work), hipEvents on the launch stream -----
+        def time_step(Bs, h, w, reps):
+            s_in = torch.randn((Bs, h, w, C), device=dev) * 0.5
+            p_in = torch.randn((Bs, h, w, C), device=dev) * 0.5
+            e_in = torch.randn((S.DRAWS_PER_STEP[a.solver], Bs, h, w, C), device=dev)
+            s_o, p_o = torch.empty_like(s_in), torch.empty_like(p_in)
+            coef = torch.from_numpy(S.Schedule(dts=[float(dt)]).coef_array()).to(dev)
+            wsb = L.sf_ode_step_ws_bytes(C, Bs, h, w)
+            ws = runtime.workspace(wsb, dev)
+            pr = runtime.ptr
+
+            def one():
+                _lib.check(L.sf_ode_step_fwd(ode.gru_c.packed().struct, ode.p_model.packed().struct, _lib.SOLVER[a.solver], 1,
+                                             pr(s_in), pr(p_in), pr(coef), pr(e_in), pr(s_o), pr(p_o), Bs, h, w, pr(ws),
+                                             ws.numel() * 4, runtime.stream_ptr(dev)), "ode_step")
+            for _ in range(3):
+                one()
+            torch.cuda.synchronize()
+            L.sf_event_record(e0, runtime.stream_ptr(dev))
+            for _ in range(reps):
+                one()
+            L.sf_event_record(e1, runtime.stream_ptr(dev))
+            L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+            t = ms.value / reps * 1e-3
+            mult = {"euler": 1, "midpoint": 2, "rk4": 4}[a.solver]
+            fl = mult * 728.0 * C * C * h * w * Bs
+            nparam = sum(v.numel() for k, v in sd.items() if k.startswith(("gru_ode.gru_c.", "gru_ode.p_model."))
+                         and "num_batches" not in k)
+            by = (16.0 + 4.0 * S.DRAWS_PER_STEP[a.solver]) * C * h * w * Bs + 4.0 * nparam
+            return {"batch": Bs, "latent": f"{h}x{w}x{C}", "us_per_step": t * 1e6, "steps_per_s": Bs / t,
+                    "tflops": fl / t / 1e12, "mfma_frac": fl / t / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                    "algorithmic_bytes_per_step": by / Bs, "algorithmic_gbs": by / t / 1e9,
+                    "hbm_frac": by / t / 1e9 / PEAK_HBM_GBS}
+        step_only = {"single_sample": time_step(1, H // 4, W // 4, 50), "batch8": time_step(8, H // 4, W // 4, 20),
+                     "stress_latent_200x200": time_step(1, H, W, 5)}
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:      # the same unit of work on the host cores (oracle, 16 threads)
+            from oracle import ref_torch as R
+            torch.set_num_threads(min(os.cpu_count() or 1, 16))
+            s_c, p_c = torch.randn((1, C, H // 4, W // 4)) * 0.5, torch.randn((1, C, H // 4, W // 4)) * 0.5
+            with torch.no_grad():
+                R.ode_step(sd, "gru_ode", s_c, p_c, dt, a.solver, True, hashfill.HashedNoise(0))
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    R.ode_step(sd, "gru_ode", s_c, p_c, dt, a.solver, True, hashfill.HashedNoise(0))
+                tc = (time.perf_counter() - t0) / 5
+            step_only["cpu_baseline"] = {"value": 1.0 / tc, "unit": "ODE-steps/s", "cores": min(os.cpu_count() or 1, 16), "kind": "port",
+                                         "sample": f"5 single-sample {a.solver} steps at latent 50x50x64, oracle/ref_torch.py:ode_step, {tc * 1e3:.1f} ms each"}
+        pmc_step = os.path.join(ROOT, "profiles", "pmc_ode_step.json")
+        pmc_step_data = None
+        if os.path.exists(pmc_step):
+            try:
+                pmc_step_data = json.load(open(pmc_step))
+                step_only["rocprof_hbm"] = pmc_step_data
+            except Exception:
+                pass
+
+        # ---- roofline object of the ODE-step kernel group: ONE Euler step of one sample at latent 50x50x64
+        # captured into a hipGraph, >= 20 replays timed one by one with hipEvents on the launch stream: median and p95
+        def graph_step_times(h, w, n=25):
+            s_in = torch.randn((1, h, w, C), device=dev) * 0.5
+            p_in = torch.randn((1, h, w, C), device=dev) * 0.5
+            e_in = torch.randn((S.DRAWS_PER_STEP[a.solver], 1, h, w, C), device=dev)
+            s_o, p_o = torch.empty_like(s_in), torch.empty_like(p_in)
+            coef = torch.from_numpy(S.Schedule(dts=[float(dt)]).coef_array()).to(dev)
+            ws = torch.empty(L.sf_ode_step_ws_bytes(C, 1, h, w) // 4 + 1024, dtype=torch.float32, device=dev)
+            pr = runtime.ptr
+
+            def one(sp):
+                _lib.check(L.sf_ode_step_fwd(ode.gru_c.packed().struct, ode.p_model.packed().struct, _lib.SOLVER[a.solver], 1,
+                                             pr(s_in), pr(p_in), pr(coef), pr(e_in), pr(s_o), pr(p_o), 1, h, w, pr(ws), ws.numel() * 4, sp), "ode_step")
+            one(runtime.stream_ptr(dev))
+            torch.cuda.synchronize()
+            cap = torch.cuda.Stream(device=dev)
+            ex = ctypes.c_void_p()
+            with torch.cuda.stream(cap):
+                sp = runtime.stream_ptr(dev)
+                _lib.check(L.sf_graph_begin(sp), "graph_begin")
+                try:
+                    one(sp)
+                finally:
+                    _lib.check(L.sf_graph_end(sp, ctypes.byref(ex)), "graph_end")
+            sp = runtime.stream_ptr(dev)
+            for _ in range(3):
+                L.sf_graph_launch(ex, sp)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(n):
+                L.sf_event_record(e0, sp)
+                L.sf_graph_launch(ex, sp)
+                L.sf_event_record(e1, sp)
+                L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+                ts.append(ms.value * 1e3)
+            L.sf_graph_destroy(ex)
+            ts.sort()
+            return ts[len(ts) // 2], ts[min(len(ts) - 1, int(round(0.95 * (len(ts) - 1))))], n
+        roof_step = None
+        try:
+            hh, ww = H // 4, W // 4
+            med_us, p95_us, nrep = graph_step_times(hh, ww)
+            mult = {"euler": 1, "midpoint": 2, "rk4": 4}[a.solver]
+            fl = mult * 728.0 * C * C * hh * ww
+            nparam = sum(v.numel() for k, v in sd.items() if k.startswith(("gru_ode.gru_c.", "gru_ode.p_model.")) and "num_batches" not in k)
+            by = (16.0 + 4.0 * S.DRAWS_PER_STEP[a.solver]) * C * hh * ww + 4.0 * nparam
+            tr = None
+            if pmc_step_data:
+                tr = pmc_step_data.get("cases", {}).get("1_50_50", {}).get("hbm_bytes_per_step_launch")
+            roof_step = {"bound": "mfma", "achieved": fl / (med_us * 1e-6) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fl / (med_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": tr,
+                         "traffic_source": {"file": "profiles/pmc_ode_step.json", "measured_in_this_run": False,
+                                            "commit": (pmc_step_data or {}).get("commit")},
+                         "kernel": f"ode_step kernel group ({a.solver}, one sample, latent {hh}x{ww}x{C}): sf_ode_step_fwd as one hipGraph",
+                         "us_per_step_median": med_us, "us_per_step_p95": p95_us, "graph_replays_timed": nrep,
+                         "flops_per_step": fl, "algorithmic_bytes_per_step": by,
+                         "hbm_frac_if_bytes_bound": by / (med_us * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                         "steps_per_s": 1e6 / med_us}
+        except Exception as ex:      # secondary object: never lose the headline line over it
+            roof_step = {"error": repr(ex)}
 
     # ---- roofline of the dominant kernel: per-launch hipEvents in a dedicated pass ---------------
     roof = None
@@ -228,15 +367,19 @@ def main():
         tot = sum(pms)
         k = max(range(NK), key=lambda i: pms[i])
         achieved = pfl[k] / (pms[k] * 1e-3) / 1e12
-        traffic = None
+        traffic, traffic_commit = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic, traffic_commit = pj.get("hbm_bytes_per_launch"), pj.get("commit")
             except Exception:
                 traffic = None
         roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                # PMC counters need their own rocprofv3 passes: the figure is the committed summary of the same command,
+                # never a measurement of this run
+                "traffic_source": {"file": "profiles/pmc_dominant.json", "measured_in_this_run": False, "commit": traffic_commit},
                 "kernel": _lib.KERNEL_NAMES.get(k, str(k)), "launches_per_forward": calls[k] // 2,
                 "avg_launch_us": 1e3 * pms[k] / max(1, calls[k]),
                 "flops_per_launch": pfl[k] / max(1, calls[k]),
@@ -309,9 +452,13 @@ def main():
                "config": {"workload": f"BASELINE config 2: C=64, BEV 200x200 (latent 50x50), timeset '{a.timeset}' "
                                       f"({len(times)} observations, {tts.shape[1]} targets), variable-step {a.solver}: "
                                       f"{n_ode} ODE steps + {sc.n_jumps} jumps per sample, {B} sample(s) per forward per GPU",
-                          "parallelism": f"replicas x{world} (sample sharding, no data-path collective)"},
+                          "batch_per_gpu": B,
+                          "parallelism": f"replicas x{world} (sample sharding; " + ("RCCL all-gather of one BEV grid per rank per forward on a side stream)" if do_gather else "no data-path collective)")},
                "samples_per_s": B * a.steps * world / el, "batch_per_gpu": B, "ms_per_sample": ms_per_step / B,
+               "batch1_forward": {"what": "the same FuturePredictionODE.forward at the reference's own batch size (evaluate.py:46: one sample per call)",
+                                  "ms_per_forward": single_ms, "ode_steps_per_s": n_ode / (single_ms * 1e-3), "samples_per_s": 1e3 / single_ms},
                "single_sample_forward_ms": single_ms, "single_sample_ode_steps_per_s": n_ode / (single_ms * 1e-3),
+               "roofline_ode_step": roof_step, "multi_gpu": multi,
                "ode_rollout_only": rollout, "ode_step_only": step_only, "lift_splat": lift, "lidar_voxelize": vox, "bev_decoder": dec, "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:

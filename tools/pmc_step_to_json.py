@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-out = {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/stepbench.py B h w %d; "
+out = {"commit": __import__("os").environ.get("SF_COMMIT"), "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/stepbench.py B h w %d; "
                  "sum over the sf:: kernels / steps; FETCH_SIZE x2 (gfx950), KiB" % N, "cases": {}}
 for tag in ("1_50_50", "8_50_50", "1_200_200"):
     tot = {}

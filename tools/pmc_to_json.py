@@ -33,6 +33,7 @@ def main():
     want = sys.argv[1] if len(sys.argv) > 1 else "conv_glds_kernel<4, 2, 2, 4, 0"   # 128x128 tiles, affine epilogue
     dom = next((r for r in rows if want in r["kernel"]), rows[0])
     out = {"kernel": dom["kernel"], "hbm_bytes_per_launch": dom["hbm_bytes_per_launch"],
+           "commit": os.environ.get("SF_COMMIT"),
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --steps 1 --warmup 1; "
                      "KiB counters, FETCH_SIZE doubled (gfx950), averaged over the kernel's launches",
            "all_conv_kernels": rows}
