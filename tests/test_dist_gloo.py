@@ -37,6 +37,18 @@ def _worker(rank, world, port, q):
         full = sfd.gather_predictions(local, n)
         want = [fn(s) for s in samples]
     ok = all(torch.equal(a, b) for a, b in zip(full, want))
+    # padded shards: 3 samples over 2 ranks (2 + 1), and 1 sample (rank 1 owns nothing and passes `like`)
+    with torch.no_grad():
+        for m in (3, 1):
+            loc = sfd.run_sharded(fn, samples[:m])
+            got = sfd.gather_predictions(loc, m, like=torch.empty(1, 8, 6, 6))
+            ok = ok and len(got) == m and all(torch.equal(a, b) for a, b in zip(got, want[:m]))
+    if rank == 1:
+        try:
+            sfd.gather_predictions({}, 0)       # nothing to infer the shape from and no `like`
+            ok = False
+        except ValueError:
+            pass
     cnt = sfd.reduce_counters(torch.tensor([float(len(local)), 1.0]))
     ok = ok and cnt.tolist() == [float(n), float(world)]
     q.put((rank, ok))
