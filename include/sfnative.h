@@ -57,6 +57,22 @@ typedef struct sf_conv_w {
   int32_t cout, cout_pad, c0, c1, cin_pad, kh, kw, dil, stride, pad, act;
 } sf_conv_w;
 
+/* ---- weight packing on the device (load time) ---------------------------------------------------------------------
+ * sf_pack_conv packs ONE reference convolution into `blob` (device memory of at least sf_pack_conv_bytes) and fills
+ * `out` with pointers into it:
+ *   weight     Conv2d weight [cout][cin][kh][kw] fp32 (device); with SF_PACK_TRANSPOSED a ConvTranspose2d(k, s1, p=(k-1)/2)
+ *              weight [cin][cout][kh][kw], stored as the equivalent convolution; with SF_PACK_FOLD_DUP a weight
+ *              [cout][2*cin][kh][kw] of a layer that reads cat[s, s], folded to W[:, :cin] + W[:, cin:]
+ *              (temporal_ode_bayes.py:148-161: gru_cell_2(s, s)); with SF_PACK_INTERLEAVE the output rows of the last
+ *              p_model convolution are interleaved (loc, loc, raw, raw) for the sampling epilogue
+ *   affine     either eval-mode BatchNorm2d buffers (bn_weight / bn_bias / bn_mean / bn_var, bn_eps: scale = w / sqrt(var + eps),
+ *              bias = b - mean * scale + conv_bias * scale) or a plain per-channel `scale` (LayerNorm weight; NULL = 1) and
+ *              `conv_bias` (NULL = 0)
+ *   c0 + c1 = cin: channels read from the first / second input tensor; pad < 0 = "same" ((kh-1)*dil/2).
+ * The composite structs below (sf_gru_w ... sf_deeplab_w) are assembled from packed convolutions by plain struct
+ * assignment; [update ; reset] gate pairs are packed from the two weights stored one after the other (cout = 2*hidden). */
+enum { SF_PACK_TRANSPOSED = 1, SF_PACK_FOLD_DUP = 2, SF_PACK_INTERLEAVE = 4 };
+
 /* conv-GRU cell: SpatialGRU.gru_cell (streamingflow/layers/temporal.py:44-57) */
 typedef struct sf_gru_w {
   sf_conv_w gates;    /* [conv_update ; conv_reset] stacked on cout (2*hidden), sigmoid */
@@ -383,6 +399,11 @@ int sf_event_destroy(void* ev);
 #define SF_PROF_KEYS 120
 int sf_prof_enable(int on);
 int sf_prof_collect(int32_t* calls, double* ms, double* flops, double* bytes);
+
+size_t sf_pack_conv_bytes(int cout, int cin, int kh, int kw, int flags);
+int sf_pack_conv(const float* weight, const float* conv_bias, const float* scale, const float* bn_weight, const float* bn_bias,
+                 const float* bn_mean, const float* bn_var, float bn_eps, int cout, int cin, int kh, int kw, int c0, int c1, int act,
+                 int dil, int stride, int pad, int flags, void* blob, size_t blob_bytes, sf_conv_w* out, void* stream);
 
 /* Diagnostic builds of the library only (hipcc -DSF_STAMP; the product build returns SF_ERR_UNSUPPORTED): `buf` is a
  * device buffer of 64 slots x 4096 workgroups x 8 uint64; every implicit-GEMM launch then takes the next slot (mod 64)

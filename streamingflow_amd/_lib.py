@@ -14,6 +14,7 @@ i32p = C.POINTER(C.c_int32)
 
 SF_COEF_STRIDE = 12
 SF_PROF_KEYS = 120
+PACK_TRANSPOSED, PACK_FOLD_DUP, PACK_INTERLEAVE = 1, 2, 4      # SF_PACK_* of sfnative.h
 ACT = {"none": 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4, "gelu": 5}
 SOLVER = {"euler": 0, "midpoint": 1, "rk4": 2}
 OP_JUMP, OP_STEP = 0, 1
@@ -149,6 +150,8 @@ SIGNATURES = {
     "sf_prof_enable": (_i, [_i]),
     "sf_prof_collect": (_i, [i32p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sf_debug_stamps": (_i, [_vp]),
+    "sf_pack_conv_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "sf_pack_conv": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, C.POINTER(ConvW), _vp]),
 }
 
 # kernel key = tile_config*8 + epilogue  (csrc/conv_igemm.hip launch_conv; configs 10..13: the LDS-DMA kernel conv_glds_kernel)

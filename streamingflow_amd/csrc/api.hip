@@ -38,6 +38,35 @@ using namespace sf;
 
 namespace {
 
+// Zero fill as a KERNEL (16-byte stores): inside a captured rollout these are kernel nodes of the graph like everything
+// around them.  (With hipMemsetAsync nodes the replayed 46-step RK4 rollout differed from eager by ~3e-6 from the third
+// replay on — tools/r02, profiles/README.md "graph memset nodes" — while eager never did.)
+__global__ void zero_fill_kernel(float4* __restrict__ p, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ void copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// device-to-device copy as a kernel node, for the same reason (n floats, a multiple of 4; both pointers 16-byte aligned)
+hipError_t copy_floats(const float* src, float* dst, size_t n, hipStream_t st) {
+  const size_t n4 = n / 4;
+  if (n4 == 0 || (n & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15))
+    return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n4);
+  return hipGetLastError();
+}
+hipError_t zero_fill(void* p, size_t bytes, hipStream_t st) {     // p 16-byte aligned, bytes a multiple of 16 (arena blocks are)
+  const size_t n4 = bytes / 16;
+  if (n4 == 0) return hipSuccess;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<float4*>(p), n4);
+  return hipGetLastError();
+}
+
 #define SF_TRY(expr)                                   \
   do {                                                 \
     int _st = (expr);                                  \
@@ -456,7 +485,7 @@ struct SplitScope {
     ctx.slab_floats = SPLIT_SLAB_FLOATS;
     ctx.ncounters = SPLIT_COUNTERS;
     if (!A.ok() || !ctx.slab || !ctx.counters) return;
-    if (hipMemsetAsync(ctx.counters, 0, SPLIT_COUNTERS * sizeof(unsigned), st) != hipSuccess) return;
+    if (zero_fill(ctx.counters, SPLIT_COUNTERS * sizeof(unsigned), st) != hipSuccess) return;
     g_split = &ctx;
     active = true;
   }
@@ -917,7 +946,7 @@ int sf_ode_step_fwd(const sf_dual_w* gru_c, const sf_pmodel_w* pm, int solver, i
   const size_t PC = (size_t)n_img * H * W * gru_c->C;
   float* zeros = A.take(PC);
   if (!A.ok()) return SF_ERR_WORKSPACE;
-  if (!impute) SF_HIP(hipMemsetAsync(zeros, 0, PC * sizeof(float), st));
+  if (!impute) SF_HIP(zero_fill(zeros, al(PC) * sizeof(float), st));
   return ode_step(*gru_c, *pm, solver, impute, state_in, p_in, coef, 0, eps, state_out, p_out, zeros, 0, n_img, H, W, A, st);
 }
 
@@ -949,7 +978,7 @@ int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const fl
     if (g.op_end >= 0)
       for (int t = 0; t < n_targets; ++t)
         if (sel_nops[t] == g.op_end + 1)
-          SF_HIP(hipMemcpyAsync(out_states + (size_t)t * PC, g.out, PC * sizeof(float), hipMemcpyDeviceToDevice, st));
+          SF_HIP(copy_floats(g.out, out_states + (size_t)t * PC, PC, st));
     if (g.infer_after) {
       Arena Ai = A;
       SF_TRY(infer_state(pm, g.out, eps + (size_t)g.draw * PC, g.p_out, nullptr, B, H, W, Ai, st));
@@ -979,9 +1008,9 @@ int sf_nnfo_rollout_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const 
   float* s3 = A.take(PC);
   if (!A.ok()) return SF_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  SF_HIP(hipMemsetAsync(zeros, 0, PC * sizeof(float), st));
-  SF_HIP(hipMemsetAsync(sbuf[0], 0, PC * sizeof(float), st));   // state = zeros  (temporal_ode_bayes.py:507)
-  SF_HIP(hipMemsetAsync(pbuf[0], 0, PC * sizeof(float), st));   // input: overwritten by the first jump (:565,574)
+  SF_HIP(zero_fill(zeros, al(PC) * sizeof(float), st));
+  SF_HIP(zero_fill(sbuf[0], al(PC) * sizeof(float), st));   // state = zeros  (temporal_ode_bayes.py:507)
+  SF_HIP(zero_fill(pbuf[0], al(PC) * sizeof(float), st));   // input: overwritten by the first jump (:565,574)
   int si = 0, pi = 0, draw = 0;
   const int cstride = coef_per_image ? SF_COEF_STRIDE : 0;
   const size_t step_stride = (size_t)SF_COEF_STRIDE * (coef_per_image ? B : 1);
@@ -1029,7 +1058,7 @@ int sf_nnfo_rollout_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const 
     }
   }
   SF_TRY(run_stages(stages, *pm, eps, cstride, sel_nops, n_targets, out_states, B, H, W, A, st));
-  if (final_state) SF_HIP(hipMemcpyAsync(final_state, sbuf[si], PC * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (final_state) SF_HIP(copy_floats(sbuf[si], final_state, PC, st));
   return SF_OK;
 }
 

@@ -58,6 +58,12 @@ constexpr int sp_lds_bytes(bool scale) { return (SpGeo<NT>::RING + SP_MISC + (sc
 
 typedef __attribute__((address_space(3))) void sp_lds_void;
 
+#ifdef SP_EXP_FRESH      // experiment: small per-call tables written by the previous kernel are read past the CU's vector L1
+#define SP_FRESH_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define SP_FRESH_LOAD(p) (*(p))
+#endif
+
 __device__ __forceinline__ f32x4 sp_lds_read128(const float* p) {
   typedef const __attribute__((address_space(3))) f32x4 lds_f4;
   return *(lds_f4*)p;   // explicit LDS address space: ds_read_b128
@@ -303,12 +309,16 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
       const float* const in_scale = P.in_scale;
       for (int idx = tid; idx < SP_SC_IMGS * cin_pad; idx += SP_THREADS) {
         const int si = idx / cin_pad, ch = idx - si * cin_pad;
-        sc_lds[idx] = (in_scale && img0 + si < P.n_img && ch < P.c0) ? in_scale[(size_t)(img0 + si) * P.c0 + ch] : (in_scale ? 0.f : 1.f);
+        sc_lds[idx] = (in_scale && img0 + si < P.n_img && ch < P.c0) ? SP_FRESH_LOAD(in_scale + (size_t)(img0 + si) * P.c0 + ch) : (in_scale ? 0.f : 1.f);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   };
   SF_STAMP_AT(L, 0);
+#ifdef SP_EXP_ZERO_LDS     // experiment: no LDS word is read before this kernel wrote it
+  for (int i = tid; i < G::RING + SP_MISC + (SCALE ? SP_SC_FLOATS : 0); i += SP_THREADS) smem[i] = 0.f;
+  __syncthreads();
+#endif
 
   if (wave >= 8) {
     // ================================= loader =================================================================

@@ -2,6 +2,8 @@
 the packed device layout of include/sfnative.h.  Runs once per (module, parameter version); uses
 torch tensor ops on the parameters' own device as plumbing — nothing here is on the hot path.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -40,54 +42,33 @@ def bn_fold(bn, conv_bias=None):
 
 def conv_w(holder, weight, c0, c1=0, scale=None, bias=None, act="none", dil=1, stride=1, pad=None,
            transposed=False, fold_dup=False, interleave=False):
-    """Pack one convolution.  weight: Conv2d [cout][cin][kh][kw] (or ConvTranspose2d [cin][cout][kh][kw]
-    with transposed=True, k3/s1/p1 only).  Returns a filled _lib.ConvW whose tensors `holder` owns."""
-    w = weight.detach().to(torch.float32)
+    """Pack one convolution with ``sf_pack_conv`` (csrc/pack.hip: layout change, ConvTranspose flip, duplicate-input
+    fold, row interleave, zero padding — all on the device).  weight: Conv2d [cout][cin][kh][kw] (or ConvTranspose2d
+    [cin][cout][kh][kw] with transposed=True, k3/s1/p1 only).  Returns a filled _lib.ConvW whose blob `holder` owns."""
+    w = weight.detach().to(torch.float32).contiguous()
+    if not w.is_cuda:
+        raise RuntimeError("weights are packed on the MI355X: move the module to the GPU first (no CPU fallback)")
     if transposed:
-        w = w.permute(1, 0, 2, 3).flip(2, 3)
-    if fold_dup:   # layer reads cat[s, s]: W[:, :C] + W[:, C:] applied to s once
-        half = w.shape[1] // 2
-        w = w[:, :half] + w[:, half:]
-    cout, cin, kh, kw = w.shape
+        cin, cout, kh, kw = w.shape
+    else:
+        cout, cin, kh, kw = w.shape
+        if fold_dup:
+            cin //= 2
     assert cin == c0 + c1, (cin, c0, c1)
-    cin_pad, cout_pad = _round_up(cin, 32), _round_up(cout, 16)
-    dev = w.device
-
-    def pad_vec(v):
-        if v is None:
-            return None
-        out = torch.zeros(cout_pad, device=dev, dtype=torch.float32)
-        out[:cout] = v.detach().to(torch.float32)
-        return out
-
-    packed = torch.zeros(cout_pad, kh, kw, cin_pad, device=dev, dtype=torch.float32)
-    packed[:cout, :, :, :cin] = w.permute(0, 2, 3, 1)
-    scale, bias = pad_vec(scale), pad_vec(bias)
-    if interleave:
-        # row 16T+4g+r <- (r<2: loc channel 8T+2g+r) / (r>=2: raw channel C+8T+2g+r-2)
-        Ch = cout // 2
-        cout_pad = _round_up(_round_up(Ch, 8) * 2, 16)
-        idx = torch.full((cout_pad,), -1, dtype=torch.long)
-        for row in range(cout_pad):
-            T, g, r = row // 16, (row % 16) // 4, row % 4
-            c = 8 * T + 2 * g + (r & 1)
-            if c < Ch:
-                idx[row] = c if r < 2 else Ch + c
-        sel = idx.clamp(min=0).to(dev)
-        mask = (idx >= 0).to(dev)
-        packed = packed[sel] * mask[:, None, None, None]
-        if scale is not None:
-            scale = scale[sel] * mask
-        if bias is not None:
-            bias = bias[sel] * mask
+    flags = (_lib.PACK_TRANSPOSED if transposed else 0) | (_lib.PACK_FOLD_DUP if fold_dup else 0) | (_lib.PACK_INTERLEAVE if interleave else 0)
+    L = _lib.lib()
+    nbytes = L.sf_pack_conv_bytes(cout, cin, kh, kw, flags)
+    if nbytes == 0:
+        raise ValueError(f"cannot pack a {tuple(w.shape)} convolution")
+    blob = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+    vec = lambda v: None if v is None else v.detach().to(device=w.device, dtype=torch.float32).contiguous()
+    sc, bi = vec(scale), vec(bias)
     s = _lib.ConvW()
-    s.w = holder.hold(packed.reshape(cout_pad, kh * kw * cin_pad))
-    s.scale = holder.hold(scale)
-    s.bias = holder.hold(bias)
-    s.cout, s.cout_pad, s.c0, s.c1, s.cin_pad = cout, cout_pad, c0, c1, cin_pad
-    s.kh, s.kw, s.dil, s.stride = kh, kw, dil, stride
-    s.pad = (dil * (kh - 1)) // 2 if pad is None else pad
-    s.act = _lib.ACT[act]
+    from . import runtime
+    _lib.check(L.sf_pack_conv(runtime.ptr(w), runtime.ptr(bi), runtime.ptr(sc), None, None, None, None, 0.0, cout, cin, kh, kw, c0, c1,
+                              _lib.ACT[act], dil, stride, -1 if pad is None else pad, flags, runtime.ptr(blob), nbytes,
+                              ctypes.byref(s), runtime.stream_ptr(w.device)), "pack_conv")
+    holder.keep.extend([blob, w, sc, bi])      # the launch reads w / sc / bi asynchronously: keep them until the pack dies
     return s
 
 
