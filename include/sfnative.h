@@ -209,6 +209,19 @@ int sf_nnfo_rollout_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const 
                         const float* coef, int coef_per_image, const int32_t* sel_nops, int n_targets,
                         float* out_states, float* final_state, int n_img, int H, int W, float* ws,
                         size_t ws_bytes, void* stream);
+/* Throughput mode: the Gaussian noise of every infer_state is generated inside the sampling epilogue instead of being read
+ * from an eps tensor (Philox4x32-10, Box-Muller; csrc/sf_math.h).  philox_state: device record {uint64 seed, uint64 offset};
+ * the draw of an element is a function of (seed, offset, draw index, pixel, channel) only, so results do not depend on the
+ * kernel / tile / batch, and a captured graph gives fresh noise when the host rewrites the 16-byte record between replays.
+ * Same distribution as the reference's Normal.rsample (temporal_ode_bayes.py:474-476), different stream: parity tests use
+ * the eps-fed entry points above. */
+int sf_nnfo_rollout_philox_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const sf_pmodel_w* pm, int solver, int impute,
+                               const int32_t* ops, int n_ops, const float* hx_obs, const uint64_t* philox_state, const float* coef,
+                               int coef_per_image, const int32_t* sel_nops, int n_targets, float* out_states, float* final_state,
+                               int n_img, int H, int W, float* ws, size_t ws_bytes, void* stream);
+int sf_infer_state_philox_fwd(const sf_pmodel_w* w, const float* s, const uint64_t* philox_state, int draw, float* p_out, float* q_out,
+                              int n_img, int H, int W, float* ws, size_t ws_bytes, void* stream);
+
 size_t sf_nnfo_rollout_ws_bytes(int C, int n_img, int H, int W);
 
 /* SmallEncoder.forward — res_models.py:98-109: [n][H][W][C] -> [n][H/4][W/4][C] */

@@ -98,6 +98,9 @@ SIGNATURES = {
     "sf_ode_step_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "sf_nnfo_rollout_fwd": (_i, [C.POINTER(DualW), C.POINTER(DualW), C.POINTER(PModelW), _i, _i, i32p, _i, _vp, _vp,
                                  _vp, _i, i32p, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_nnfo_rollout_philox_fwd": (_i, [C.POINTER(DualW), C.POINTER(DualW), C.POINTER(PModelW), _i, _i, i32p, _i, _vp, _vp,
+                                        _vp, _i, i32p, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_infer_state_philox_fwd": (_i, [C.POINTER(PModelW), _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sf_nnfo_rollout_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "sf_small_encoder_fwd": (_i, [C.POINTER(EncoderW), _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sf_small_encoder_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),

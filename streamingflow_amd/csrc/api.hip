@@ -594,7 +594,8 @@ size_t infer_ws_floats(int C, int P) {
 // the producing conv's epilogue writes; B > 1 (16-pixel tiles straddle images) sums per-image
 // slabs with one extra small launch.  Both are fixed-order.
 int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p_out, float* q_out, int B, int H, int W,
-                Arena& A, hipStream_t st) {
+                Arena& A, hipStream_t st, const unsigned long long* philox = nullptr, int draw = 0) {
+  if (!eps && !philox) return SF_ERR_INVALID;
   const int C = w.C, C2 = 2 * C, HW = H * W, P = B * HW;
   if (B < 1 || B > 64) return SF_ERR_UNSUPPORTED;
   const bool tiles = (B == 1);
@@ -638,7 +639,7 @@ int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p
   c4.add = y1; c4.add_scale = sc1; c4.chansum = tiles ? cs2 : nullptr;
   SF_TRY(run1(c4, EPI_AFFINE, st));
   ConvProblem c5 = problem(w.last, y2, nullptr, p_out, B, H, W);
-  c5.e0 = eps; c5.out2 = q_out;
+  c5.e0 = eps; c5.out2 = q_out; c5.philox = philox; c5.draw = draw;
   if (fuse_se) {
     c5.se_sum = cs2; c5.se_fc0 = w.se1_fc0; c5.se_fc2 = w.se1_fc2; c5.se_out = nullptr; c5.se_nt = nt2; c5.se_cr = C2 / 8;
     c5.se_inv_hw = 1.f / (float)HW;
@@ -969,8 +970,8 @@ size_t rollout_ws_floats(int C, int P) {
   return (cellw > inf ? cellw : inf) + 9 * al((size_t)P * C) + SPLIT_WS_FLOATS + 256;
 }
 
-int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const float* eps, int coef_stride, const int32_t* sel_nops,
-               int n_targets, float* out_states, int B, int H, int W, Arena& A, hipStream_t st) {
+int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const float* eps, const unsigned long long* philox, int coef_stride,
+               const int32_t* sel_nops, int n_targets, float* out_states, int B, int H, int W, Arena& A, hipStream_t st) {
   const size_t PC = (size_t)B * H * W * pm.C;
   for (const Stage& g : stages) {
     Arena Ac = A;
@@ -981,18 +982,18 @@ int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const fl
           SF_HIP(copy_floats(g.out, out_states + (size_t)t * PC, PC, st));
     if (g.infer_after) {
       Arena Ai = A;
-      SF_TRY(infer_state(pm, g.out, eps + (size_t)g.draw * PC, g.p_out, nullptr, B, H, W, Ai, st));
+      SF_TRY(infer_state(pm, g.out, eps ? eps + (size_t)g.draw * PC : nullptr, g.p_out, nullptr, B, H, W, Ai, st, philox, g.draw));
     }
   }
   return SF_OK;
 }
 
 size_t sf_nnfo_rollout_ws_bytes(int C, int n_img, int H, int W) { return rollout_ws_floats(C, n_img * H * W) * sizeof(float); }
-int sf_nnfo_rollout_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const sf_pmodel_w* pm, int solver, int impute,
-                        const int32_t* ops, int n_ops, const float* hx_obs, const float* eps, const float* coef,
-                        int coef_per_image, const int32_t* sel_nops, int n_targets, float* out_states,
+static int rollout_core(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const sf_pmodel_w* pm, int solver, int impute,
+                        const int32_t* ops, int n_ops, const float* hx_obs, const float* eps, const unsigned long long* philox,
+                        const float* coef, int coef_per_image, const int32_t* sel_nops, int n_targets, float* out_states,
                         float* final_state, int n_img, int H, int W, float* ws, size_t ws_bytes, void* stream) {
-  if (!gru_c || !gru_obs || !pm || !ops || !hx_obs || !eps || !sel_nops || !out_states || n_img < 1) return SF_ERR_INVALID;
+  if (!gru_c || !gru_obs || !pm || !ops || !hx_obs || (!eps && !philox) || !sel_nops || !out_states || n_img < 1) return SF_ERR_INVALID;
   if (gru_c->C > 64 || (gru_c->C % 8)) return SF_ERR_UNSUPPORTED;
   if (solver != SF_SOLVER_EULER && solver != SF_SOLVER_MIDPOINT && solver != SF_SOLVER_RK4) return SF_ERR_INVALID;
   const int C = gru_c->C, B = n_img;
@@ -1057,9 +1058,33 @@ int sf_nnfo_rollout_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const 
       return SF_ERR_INVALID;
     }
   }
-  SF_TRY(run_stages(stages, *pm, eps, cstride, sel_nops, n_targets, out_states, B, H, W, A, st));
+  SF_TRY(run_stages(stages, *pm, eps, philox, cstride, sel_nops, n_targets, out_states, B, H, W, A, st));
   if (final_state) SF_HIP(copy_floats(sbuf[si], final_state, PC, st));
   return SF_OK;
+}
+int sf_nnfo_rollout_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const sf_pmodel_w* pm, int solver, int impute,
+                        const int32_t* ops, int n_ops, const float* hx_obs, const float* eps, const float* coef,
+                        int coef_per_image, const int32_t* sel_nops, int n_targets, float* out_states,
+                        float* final_state, int n_img, int H, int W, float* ws, size_t ws_bytes, void* stream) {
+  if (!eps) return SF_ERR_INVALID;
+  return rollout_core(gru_c, gru_obs, pm, solver, impute, ops, n_ops, hx_obs, eps, nullptr, coef, coef_per_image, sel_nops, n_targets,
+                      out_states, final_state, n_img, H, W, ws, ws_bytes, stream);
+}
+// the same with the Gaussian noise of infer_state generated in the sampling epilogue (Philox4x32-10, csrc/sf_math.h)
+int sf_nnfo_rollout_philox_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const sf_pmodel_w* pm, int solver, int impute,
+                               const int32_t* ops, int n_ops, const float* hx_obs, const uint64_t* philox_state, const float* coef,
+                               int coef_per_image, const int32_t* sel_nops, int n_targets, float* out_states, float* final_state,
+                               int n_img, int H, int W, float* ws, size_t ws_bytes, void* stream) {
+  if (!philox_state) return SF_ERR_INVALID;
+  return rollout_core(gru_c, gru_obs, pm, solver, impute, ops, n_ops, hx_obs, nullptr, reinterpret_cast<const unsigned long long*>(philox_state),
+                      coef, coef_per_image, sel_nops, n_targets, out_states, final_state, n_img, H, W, ws, ws_bytes, stream);
+}
+int sf_infer_state_philox_fwd(const sf_pmodel_w* w, const float* s, const uint64_t* philox_state, int draw, float* p_out, float* q_out,
+                              int n_img, int H, int W, float* ws, size_t ws_bytes, void* stream) {
+  if (!w || !s || !philox_state || !p_out || w->C <= 0 || (w->C % 8) || n_img < 1 || draw < 0) return SF_ERR_INVALID;
+  Arena A(ws, ws_bytes);
+  SplitScope sp(A, (hipStream_t)stream);
+  return infer_state(*w, s, nullptr, p_out, q_out, n_img, H, W, A, (hipStream_t)stream, reinterpret_cast<const unsigned long long*>(philox_state), draw);
 }
 
 // ---- SmallEncoder / SmallDecoder ------------------------------------------------------------------

@@ -17,7 +17,7 @@
 // * Accumulator layout (16x16x4): lane l holds D[cout = 4*(l>>4)+r][pixel = l&15] in register r,
 //   i.e. four consecutive channels of one pixel => NHWC float4 stores, and per-pixel channel
 //   reductions (LayerNorm, 1x1->2 logits) are in-register sums + two xor-shuffles (16, 32).
-#include "sf_device.h"
+#include "sf_math.h"
 #include <cstdlib>
 
 namespace sf {
@@ -307,7 +307,8 @@ __device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[
           float4 bi = P.bias ? ld4(P.bias + row) : zero4();
           float q0 = act_apply(acc[m][n][0] + bi.x, P.act), q1 = act_apply(acc[m][n][1] + bi.y, P.act);
           float q2 = act_apply(acc[m][n][2] + bi.z, P.act), q3 = act_apply(acc[m][n][3] + bi.w, P.act);
-          float2 e = *reinterpret_cast<const float2*>(P.e0 + (size_t)gp * Chalf + c);
+          const float2 e = P.e0 ? *reinterpret_cast<const float2*>(P.e0 + (size_t)gp * Chalf + c)
+                                : spm_philox_normal2(P.philox, P.draw, (unsigned)gp, (unsigned)c);
           float2 o;
           o.x = q0 + e.x * (softplus_f(q2) + 1e-8f);     // model_utils.py:84,107-108
           o.y = q1 + e.y * (softplus_f(q3) + 1e-8f);

@@ -198,7 +198,8 @@ __device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, cons
     const bool ok = on && ch < Chalf;
     const int chz = ok ? ch : 0;
     const float4 bi = P.bias ? spm_ld4(P.bias + cz) : spm_zero4();
-    const float2 e = *reinterpret_cast<const float2*>(P.e0 + (ok ? gpz : 0) * Chalf + chz);
+    const float2 e = P.e0 ? *reinterpret_cast<const float2*>(P.e0 + (ok ? gpz : 0) * Chalf + chz)
+                          : spm_philox_normal2(P.philox, P.draw, (unsigned)gpz, (unsigned)chz);      // block-uniform choice
     const float q0 = spm_act(v.x + bi.x, P.act), q1 = spm_act(v.y + bi.y, P.act);
     const float q2 = spm_act(v.z + bi.z, P.act), q3 = spm_act(v.w + bi.w, P.act);
     if (ok) {

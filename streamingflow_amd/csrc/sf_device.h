@@ -67,6 +67,9 @@ struct ConvProblem {
   // small-P kernel, one image: the SE gate of the input (res_models.py:161-165) is computed in the consuming layer's
   // prologue from the per-tile channel sums the producer wrote: scale = sigmoid(fc2 relu(fc0 mean)), every workgroup
   // for itself; workgroup 0 also stores it to se_out (the residual of the next layer is scaled by it)
+  // SAMPLE epilogue without an eps tensor (e0 == null): {seed, offset} record on the device + the draw index of this call
+  const unsigned long long* philox;
+  int draw;
   const float* se_sum;    // [se_nt][c0] per-tile channel sums (null: in_scale holds the gate, or no gate)
   const float* se_fc0;    // [se_cr][c0]
   const float* se_fc2;    // [c0][se_cr]

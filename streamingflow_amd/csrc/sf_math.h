@@ -25,4 +25,31 @@ __device__ __forceinline__ float4 spm_ld4(const float* p) { return *reinterpret_
 __device__ __forceinline__ void spm_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 spm_zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// ---- in-kernel Gaussian noise (throughput mode of infer_state: no eps tensor) -------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11), counter = (pixel, channel, draw, offset low), key = (seed low, seed high ^ offset
+// high): the noise of an element depends only on (seed, offset, draw, pixel, channel) — not on the kernel, the tiling or the
+// batch the pixel sits in — so one captured graph serves every call (the host bumps `offset` in a 16-byte device record).
+__device__ __forceinline__ void spm_philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, const unsigned k0, const unsigned k1) {
+  const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+  c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
+}
+// two independent N(0, 1) draws for channels ch, ch + 1 of pixel gp (Box-Muller on two of the four 32-bit words)
+__device__ __forceinline__ float2 spm_philox_normal2(const unsigned long long* state, const int draw, const unsigned gp, const unsigned ch) {
+  const unsigned long long seed = state[0], offset = state[1];
+  unsigned c0 = gp, c1 = ch, c2 = (unsigned)draw, c3 = (unsigned)offset;
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32) ^ (unsigned)(offset >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    spm_philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const float u1 = ((float)c0 + 1.0f) * 2.3283064365386963e-10f;        // (0, 1]
+  const float u2 = (float)c1 * 2.3283064365386963e-10f;                 // [0, 1]
+  const float r = sqrtf(-2.0f * logf(u1));
+  float sn, cs;
+  sincosf(6.28318530717958647692f * u2, &sn, &cs);
+  return make_float2(r * cs, r * sn);
+}
+
 }  // namespace sf

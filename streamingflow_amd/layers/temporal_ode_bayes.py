@@ -202,6 +202,11 @@ class NNFOwithBayesianJumps(nn.Module):
         assert self.solver in ["euler", "midpoint", "rk4"], "Solver must be 'euler', 'midpoint' (reference) or 'rk4' (build-defined)."
         self.input_size, self.hidden_size, self.logvar, self.mixing = input_size, hidden_size, logvar, mixing
         self.noise = None    # None: torch.randn on the device; else callable(shape, dtype, device) -> NCHW eps per draw
+        # throughput mode: the noise of infer_state is generated inside the sampling epilogue (Philox4x32-10 keyed by
+        # (noise_seed, call counter)); no eps tensor exists.  Same distribution, its own stream; ignored when eps is given
+        self.in_kernel_noise = False
+        self.noise_seed = 0x5EED5F10
+        self._noise_calls = 0
         self.use_graph = False   # capture the rollout of each schedule structure into a hipGraph and replay it
         self._graphs = {}
         self._graph_gens = None
@@ -264,10 +269,17 @@ class NNFOwithBayesianJumps(nn.Module):
                 torch.tensor([0], device=dev, dtype=torch.float64), torch.tensor([0], device=dev, dtype=torch.float32))
 
     # ---- the rollout ----------------------------------------------------------------------------
-    def _enqueue_rollout(self, s0, per_image, hx_obs, eps, coef, out, final, ws, B, h, w):
+    def _enqueue_rollout(self, s0, per_image, hx_obs, eps, coef, out, final, ws, B, h, w, philox=None):
         ops = s0.ops_array()
         sel = np.asarray(s0.sel_nops, dtype=np.int32)
         L = _lib.lib()
+        if philox is not None:
+            _lib.check(L.sf_nnfo_rollout_philox_fwd(
+                self.gru_c.packed().struct, self.gru_obs.gru_d.packed().struct, self.p_model.packed().struct,
+                _lib.SOLVER[self.solver], int(bool(self.impute)), ops.ctypes.data_as(_lib.i32p), len(s0.ops),
+                ptr(hx_obs), ptr(philox), ptr(coef), int(per_image), sel.ctypes.data_as(_lib.i32p), len(sel), ptr(out),
+                ptr(final), B, h, w, ptr(ws), ws.numel() * 4, runtime.stream_ptr(hx_obs.device)), "nnfo_rollout_philox")
+            return
         _lib.check(L.sf_nnfo_rollout_fwd(
             self.gru_c.packed().struct, self.gru_obs.gru_d.packed().struct, self.p_model.packed().struct,
             _lib.SOLVER[self.solver], int(bool(self.impute)), ops.ctypes.data_as(_lib.i32p), len(s0.ops),
@@ -303,11 +315,16 @@ class NNFOwithBayesianJumps(nn.Module):
         # draws the kernels will read: one per jump, DRAWS_PER_STEP[solver] per step (a schedule built for another solver
         # would make them read past the end of eps)
         need = s0.n_jumps + sched.DRAWS_PER_STEP[self.solver] * s0.n_steps
-        if eps is None:
+        philox = None
+        if eps is None and self.in_kernel_noise and self.noise is None:
+            self._noise_calls += 1
+            philox = torch.tensor([self.noise_seed, self._noise_calls], dtype=torch.int64, device=dev)
+            eps = torch.empty((0, B, h, w, C), dtype=torch.float32, device=dev)      # placeholder (shape key of the graph cache)
+        elif eps is None:
             eps = self._draw_eps(need, B, h, w, dev)
         elif eps.dim() == 4:
             eps = eps[:, None]
-        if eps.shape[0] < need or tuple(eps.shape[1:]) != (B, h, w, C):
+        if philox is None and (eps.shape[0] < need or tuple(eps.shape[1:]) != (B, h, w, C)):
             raise ValueError(f"eps must be [{need}, {B}, {h}, {w}, {C}] for solver {self.solver!r}, got {tuple(eps.shape)}")
         coef_np = np.stack([x.coef_array() for x in scs], axis=1) if per_image else s0.coef_array()
         coef = torch.from_numpy(np.ascontiguousarray(coef_np)).to(dev)
@@ -317,7 +334,7 @@ class NNFOwithBayesianJumps(nn.Module):
             out = torch.empty((len(s0.sel_nops), B, h, w, C), dtype=torch.float32, device=dev)
             final = torch.empty((B, h, w, C), dtype=torch.float32, device=dev)
             ws = runtime.workspace(nbytes, dev)
-            self._enqueue_rollout(s0, per_image, hx_obs, eps, coef, out, final, ws, B, h, w)
+            self._enqueue_rollout(s0, per_image, hx_obs, eps, coef, out, final, ws, B, h, w, philox)
         else:
             # a captured graph holds raw pointers into the packed weights: when any of the three packs was rebuilt
             # (load_state_dict, .to(), in-place update) every cached graph is stale — destroy them and their buffers
@@ -325,29 +342,34 @@ class NNFOwithBayesianJumps(nn.Module):
             if self._graph_gens != gens:
                 self.drop_graphs()
                 self._graph_gens = gens
-            key = (s0.key(), per_image, tuple(hx_obs.shape), tuple(eps.shape), str(dev), self.solver, bool(self.impute))
+            key = (s0.key(), per_image, tuple(hx_obs.shape), tuple(eps.shape), str(dev), self.solver, bool(self.impute), philox is not None)
             g = self._graphs.get(key)
             if g is None:
                 g = {"hx": torch.empty_like(hx_obs), "eps": torch.empty_like(eps), "coef": torch.empty_like(coef),
                      "out": torch.empty((len(s0.sel_nops), B, h, w, C), dtype=torch.float32, device=dev),
                      "final": torch.empty((B, h, w, C), dtype=torch.float32, device=dev),
-                     "ws": torch.empty(nbytes // 4 + 1024, dtype=torch.float32, device=dev)}
+                     "ws": torch.empty(nbytes // 4 + 1024, dtype=torch.float32, device=dev),
+                     "philox": torch.empty_like(philox) if philox is not None else None}
                 g["hx"].copy_(hx_obs); g["eps"].copy_(eps); g["coef"].copy_(coef)
+                if philox is not None:
+                    g["philox"].copy_(philox)
                 # eager warm-up (sets kernel attributes, packs weights), then capture on a side stream
-                self._enqueue_rollout(s0, per_image, g["hx"], g["eps"], g["coef"], g["out"], g["final"], g["ws"], B, h, w)
+                self._enqueue_rollout(s0, per_image, g["hx"], g["eps"], g["coef"], g["out"], g["final"], g["ws"], B, h, w, g["philox"])
                 torch.cuda.synchronize(dev)
                 side = torch.cuda.Stream(device=dev)
                 with torch.cuda.stream(side):
                     sp = runtime.stream_ptr(dev)
                     _lib.check(L.sf_graph_begin(sp), "graph_begin")
                     try:
-                        self._enqueue_rollout(s0, per_image, g["hx"], g["eps"], g["coef"], g["out"], g["final"], g["ws"], B, h, w)
+                        self._enqueue_rollout(s0, per_image, g["hx"], g["eps"], g["coef"], g["out"], g["final"], g["ws"], B, h, w, g["philox"])
                     finally:
                         ex = ctypes.c_void_p()
                         _lib.check(L.sf_graph_end(sp, ctypes.byref(ex)), "graph_end")
                 g["exec"] = ex
                 self._graphs[key] = g
             g["hx"].copy_(hx_obs); g["eps"].copy_(eps); g["coef"].copy_(coef)
+            if philox is not None:
+                g["philox"].copy_(philox)
             _lib.check(L.sf_graph_launch(g["exec"], runtime.stream_ptr(dev)), "graph_launch")
             out, final = g["out"], g["final"]      # valid until the next replay of this graph
         return (out[:, 0], final[0]) if one else (out, final)
