@@ -297,6 +297,9 @@ SPARSE_CASES = {
     "conv_module": (dict(sparse_shape=[24, 24, 41], block_type="conv_module", base_channels=16, output_channels=32,
                          encoder_channels=[[16], [32, 32, 32], [64, 64, 64], [64, 64, 64]],
                          encoder_paddings=[[1], [1, 1, 1], [1, 1, 1], [[0, 1, 1], 1, 1]]), 140, 1),
+    # the shipped channel widths / depth (41 z cells) on an x-y crop of the shipped 1600 x 1600 grid that the dense
+    # conv3d formulation can still hold: 12 000 voxels in two samples
+    "crop96_shipped_widths": (dict(sparse_shape=[96, 96, 41]), 6000, 2),
 }
 
 

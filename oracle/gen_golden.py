@@ -76,6 +76,28 @@ def gen_ops(m):
     print("ops_c8.npz", {k: v.shape for k, v in out.items()})
 
 
+def gen_gate_bias(m):
+    """gru_bias_init != 0 (a constant added to the gate pre-activations, temporal.py:50-51, temporal_ode_bayes.py:54-55,
+    :139-140, :154-155): the reference's own cells with hashed weights -> tests/golden/gate_bias.npz."""
+    C, h, w = 8, 12, 12
+    x = hashfill.normal("gb_x", (1, C, h, w), 21)
+    s = hashfill.normal("gb_s", (1, C, h, w), 22) * 0.5
+    out = {}
+    with torch.no_grad():
+        for tag, gb in (("pos", 0.7), ("neg", -1.3)):
+            cell = m.temporal.SpatialGRU(C, C, gru_bias_init=gb).eval()
+            cell.load_state_dict(hashfill.fill_state_dict(cell.state_dict(), seed=31, gain=0.6))
+            out[f"spatial_gru_cell_{tag}"] = _np(cell.gru_cell(x, s))
+            dual = m.tob.DualGRUODECell(C, C, gru_bias_init=gb).eval()
+            dual.load_state_dict(hashfill.fill_state_dict(dual.state_dict(), seed=32, gain=0.6))
+            out[f"dual_ode_cell_{tag}"] = _np(dual(x, s))
+            obs = m.tob.DualGRUCell(C, C, gru_bias_init=gb).eval()
+            obs.load_state_dict(hashfill.fill_state_dict(obs.state_dict(), seed=33, gain=0.6))
+            out[f"dual_cell_{tag}"] = _np(obs(x, s))
+    np.savez_compressed(os.path.join(OUT, "gate_bias.npz"), **out)
+    print("gate_bias.npz", list(out))
+
+
 def gen_fpode(m, table=None, fname="fpode.npz", keep_decoded=True):
     out = {}
     for name, (C, H, W, ts, solver, impute, variable, eps0) in (table or cases.FPODE_CASES).items():
@@ -453,6 +475,8 @@ def main():
         gen_schedules(m)
     if "beverse" in todo:
         gen_beverse(m)
+    if "gate_bias" in todo:
+        gen_gate_bias(m)
     if "fpode_stream" in todo:
         gen_fpode(m, cases.FPODE_STREAM_CASES, "fpode_stream.npz", keep_decoded=False)
     if a.big or "big" in todo:

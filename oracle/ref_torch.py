@@ -128,11 +128,11 @@ def gru_cell(sd, p, x, state, suffix="", gru_bias_init=0.0):
     return (1.0 - u) * state + u * cand
 
 
-def dual_cell(sd, p, x, state, derivative):
+def dual_cell(sd, p, x, state, derivative, gru_bias_init=0.0):
     """layers/temporal_ode_bayes.py:92-131 (``DualGRUODECell``, derivative=True: returns cur - s)
     and :239-275 (``DualGRUCell``, derivative=False: returns cur).  4-D inputs, n_present = 1."""
-    r1 = gru_cell(sd, p, x, state, "_1")
-    h2 = gru_cell(sd, p, state, state, "_2")
+    r1 = gru_cell(sd, p, x, state, "_1", gru_bias_init)
+    h2 = gru_cell(sd, p, state, state, "_2", gru_bias_init)
     r2 = _conv(sd, p + ".conv_decoder_2", h2, padding=1)
     t = bottleblock(sd, p + ".trusting_gate.0", torch.cat([r1, r2], dim=1))
     g = torch.softmax(_conv(sd, p + ".trusting_gate.1", t), dim=1)

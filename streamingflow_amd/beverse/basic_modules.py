@@ -33,12 +33,10 @@ class SpatialGRU(PackedModule):
     def _pack(self):
         if self.training:
             raise RuntimeError("streamingflow_amd is inference-only: call .eval()")
-        if self.gru_bias_init != 0.0:
-            raise NotImplementedError("gru_bias_init != 0")
         pk = packing.Pack(_lib.GruW())
         s = pk.struct
         wg = torch.cat([self.conv_update.weight, self.conv_reset.weight], 0)
-        bg = torch.cat([self.conv_update.bias, self.conv_reset.bias], 0)
+        bg = torch.cat([self.conv_update.bias, self.conv_reset.bias], 0) + float(self.gru_bias_init)
         s.gates = packing.conv_w(pk, wg, self.input_size, self.hidden_size, bias=bg, act="sigmoid")
         sc, bi = packing.bn_fold(self.conv_state_tilde.norm)
         s.cand = packing.conv_w(pk, self.conv_state_tilde.conv.weight, self.input_size, self.hidden_size, scale=sc,

@@ -12,11 +12,13 @@ from .. import _lib, packing, runtime
 from ..runtime import PackedModule, ptr
 
 
-def pack_gru(pk, update, reset, tilde, cx, ch, decoder=None, fold_dup=False):
-    """Pack a conv-GRU cell: gates = [update; reset] stacked on the output-channel axis."""
+def pack_gru(pk, update, reset, tilde, cx, ch, decoder=None, fold_dup=False, gate_bias=0.0):
+    """Pack a conv-GRU cell: gates = [update; reset] stacked on the output-channel axis.  ``gate_bias`` is the
+    reference's ``gru_bias_init`` — a constant added to both gate pre-activations (temporal.py:50-51) — folded into the
+    gates' bias."""
     s = _lib.GruW()
     wg = torch.cat([update.weight, reset.weight], 0)
-    bg = torch.cat([update.bias, reset.bias], 0)
+    bg = torch.cat([update.bias, reset.bias], 0) + float(gate_bias)
     if fold_dup:
         s.gates = packing.conv_w(pk, wg, ch, 0, bias=bg, act="sigmoid", fold_dup=True)
     else:
@@ -38,11 +40,9 @@ class SpatialGRU(PackedModule):
         self.conv_decoder = nn.Conv2d(hidden_size, input_size, kernel_size=1, bias=False)
 
     def _pack(self):
-        if self.gru_bias_init != 0.0:
-            raise NotImplementedError("gru_bias_init != 0")
         pk = packing.Pack(None)
         pk.struct = pack_gru(pk, self.conv_update, self.conv_reset, self.conv_state_tilde, self.input_size,
-                             self.hidden_size, self.conv_decoder)
+                             self.hidden_size, self.conv_decoder, gate_bias=self.gru_bias_init)
         return pk
 
     def forward_nhwc(self, x, state):

@@ -45,12 +45,10 @@ class _SingleGRU(PackedModule):
     def _pack(self):
         if self.training:
             raise RuntimeError("streamingflow_amd is inference-only: call .eval()")
-        if self.gru_bias_init != 0.0:
-            raise NotImplementedError("gru_bias_init != 0")
         pk = packing.Pack(_lib.GruW())
         s = pk.struct
         wg = torch.cat([self.conv_update.weight, self.conv_reset.weight], 0)
-        bg = torch.cat([self.conv_update.bias, self.conv_reset.bias], 0)
+        bg = torch.cat([self.conv_update.bias, self.conv_reset.bias], 0) + float(self.gru_bias_init)     # :54-55
         s.gates = packing.conv_w(pk, wg, self.input_size, self.hidden_size, bias=bg, act="sigmoid")
         sc, bi = packing.bn_fold(self.conv_state_tilde.norm)
         s.cand = packing.conv_w(pk, self.conv_state_tilde.conv.weight, self.input_size, self.hidden_size, scale=sc,
@@ -98,14 +96,13 @@ class _DualCell(PackedModule):
                                            nn.Conv2d(hidden_size, 2, kernel_size=1, bias=False))
 
     def _pack(self):
-        if self.gru_bias_init != 0.0:
-            raise NotImplementedError("gru_bias_init != 0")
         C = self.hidden_size
         pk = packing.Pack(_lib.DualW())
         s = pk.struct
-        g1 = pack_gru(pk, self.conv_update_1, self.conv_reset_1, self.conv_state_tilde_1, C, C)
+        gb = self.gru_bias_init       # added to the gate pre-activations of both cells (:139-140, :154-155)
+        g1 = pack_gru(pk, self.conv_update_1, self.conv_reset_1, self.conv_state_tilde_1, C, C, gate_bias=gb)
         # gru_cell_2 is called as gru_cell_2(s, s): its gates see cat[s, s] -> duplicate input folded
-        g2 = pack_gru(pk, self.conv_update_2, self.conv_reset_2, self.conv_state_tilde_2, C, C, fold_dup=True)
+        g2 = pack_gru(pk, self.conv_update_2, self.conv_reset_2, self.conv_state_tilde_2, C, C, fold_dup=True, gate_bias=gb)
         s.gates1, s.cand1, s.gates2, s.cand2 = g1.gates, g1.cand, g2.gates, g2.cand
         s.dec2 = packing.conv_w(pk, self.conv_decoder_2.weight, C, bias=self.conv_decoder_2.bias)
         bb = self.trusting_gate[0]

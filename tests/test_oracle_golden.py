@@ -97,3 +97,20 @@ def test_config1_full_size_oracle_vs_reference_stats():
     flat = y.reshape(-1).double()
     assert float((flat[torch.tensor(st["sample_idx"])] - torch.tensor(st["samples"])).abs().max()) <= 1e-5
     assert abs(flat.mean().item() - st["mean"]) <= 1e-6
+
+
+def test_gate_bias_cells():
+    """gru_bias_init != 0: the oracle against the reference's own cells (tests/golden/gate_bias.npz)."""
+    g = gold("gate_bias.npz")
+    C, h, w = 8, 12, 12
+    x = hashfill.normal("gb_x", (1, C, h, w), 21)
+    s = hashfill.normal("gb_s", (1, C, h, w), 22) * 0.5
+    import streamingflow_amd as sfa
+    from streamingflow_amd.layers import temporal_ode_bayes as tob
+    with torch.no_grad():
+        for tag, gb in (("pos", 0.7), ("neg", -1.3)):
+            sd = {"c." + k: v for k, v in hashfill.fill_state_dict(sfa.layers.temporal.SpatialGRU(C, C).state_dict(), seed=31, gain=0.6).items()}
+            assert maxabs(R.gru_cell(sd, "c", x, s, "", gb), g[f"spatial_gru_cell_{tag}"]) <= TOL
+            for key, cls, seed, deriv in (("dual_ode_cell", tob.DualGRUODECell, 32, True), ("dual_cell", tob.DualGRUCell, 33, False)):
+                sd = {"c." + k: v for k, v in hashfill.fill_state_dict(cls(C, C).state_dict(), seed=seed, gain=0.6).items()}
+                assert maxabs(R.dual_cell(sd, "c", x, s, deriv, gb), g[f"{key}_{tag}"]) <= TOL, (key, tag)

@@ -87,3 +87,56 @@ def test_gpu_index_kernels_exact():
     tab2 = m._table(cd, oc, B, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], False)
     want2 = SR.neighbour_table(c.numpy(), shape, wc, [3, 3, 3], [2, 2, 2], [1, 1, 1], False)
     assert np.array_equal(tab2.cpu().numpy(), want2.astype(np.int32))
+
+
+@pytest.mark.gpu
+def test_gpu_shipped_size_properties():
+    """The shipped LiDAR configuration (1600 x 1600 x 41 cells, 350 000-point cloud -> 160 000-voxel cap, the reference's
+    channel widths): what can be checked without a buildable spconv.  (1) the index kernels are exact against the numpy
+    restatement at this size: neighbour table of the first submanifold layer and the output sites / table of the first
+    strided layer; (2) the forward is invariant under a permutation of the input rows; (3) every output value is finite
+    and the occupied BEV cells are exactly the cells under an active site of the last layer."""
+    import os
+    import sys
+    from util import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import voxelbench
+    from streamingflow_amd.models.sparse_encoder import SparseEncoder
+    from streamingflow_amd.voxelize import Voxelization, voxelize
+    cfg = SR.default_cfg()
+    m = SparseEncoder(cfg["in_channels"], cfg["sparse_shape"], base_channels=cfg["base_channels"], output_channels=cfg["output_channels"],
+                      encoder_channels=cfg["encoder_channels"], encoder_paddings=cfg["encoder_paddings"], block_type="basicblock").eval()
+    from util import hashfill
+    m.load_state_dict(hashfill.fill_state_dict(m.state_dict(), seed=83, gain=1.6))
+    m = m.cuda()
+    vox = Voxelization(voxel_size=[0.0625, 0.0625, 0.2], point_cloud_range=[-50.0, -50.0, -5.0, 50.0, 50.0, 3.0], max_num_points=10,
+                       max_voxels=(160000, 160000))
+    pts = voxelbench.cloud(350000, seed=7).cuda()
+    feats, coords, _ = voxelize([pts], vox, True)
+    n = coords.shape[0]
+    assert 100000 <= n <= 160000 and feats.shape == (n, 5)
+    shape = cfg["sparse_shape"]
+    cn = coords.cpu().numpy()
+    # (1) integer work, exact
+    tab = m._table(coords.int().contiguous(), coords.int().contiguous(), 1, shape, [3, 3, 3], [1, 1, 1], [0, 0, 0], True)
+    assert np.array_equal(tab.cpu().numpy(), SR.neighbour_table(cn, shape, cn, [3, 3, 3], [1, 1, 1], [0, 0, 0], True).astype(np.int32))
+    oc, so = m._out_sites(coords.int().contiguous(), 1, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    wc, wso = SR.down_sites(cn, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    assert so == wso and np.array_equal(oc.cpu().numpy(), wc)
+    tab2 = m._table(coords.int().contiguous(), oc, 1, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], False)
+    assert np.array_equal(tab2.cpu().numpy(), SR.neighbour_table(cn, shape, wc, [3, 3, 3], [2, 2, 2], [1, 1, 1], False).astype(np.int32))
+    # (2) permutation invariance of the whole forward
+    out = m(feats, coords, 1)
+    assert out.shape == (1, 256, 200, 200) and torch.isfinite(out).all()
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(11)).cuda()
+    out2 = m(feats[perm], coords[perm], 1)
+    assert maxabs(out2, out) <= 2e-5
+    # (3) occupancy: a BEV cell is non-zero only under an active site of the last layer (site sets are exact integer work)
+    sites = cn
+    sh = list(shape)
+    for k, s, p in (([3, 3, 3], [2, 2, 2], [1, 1, 1]), ([3, 3, 3], [2, 2, 2], [1, 1, 1]), ([3, 3, 3], [2, 2, 2], [1, 1, 0]), ([1, 1, 3], [1, 1, 2], [0, 0, 0])):
+        sites, sh = SR.down_sites(sites, sh, k, s, p)
+    occ = np.zeros((200, 200), bool)
+    occ[sites[:, 1], sites[:, 2]] = True
+    nz = (out[0].abs().sum(0) > 0).cpu().numpy()
+    assert not (nz & ~occ).any() and nz.sum() >= 0.95 * occ.sum()
