@@ -292,19 +292,22 @@ def main():
 
         # ---- roofline object of the ODE-step kernel group: ONE Euler step of one sample at latent 50x50x64
         # captured into a hipGraph, >= 20 replays timed one by one with hipEvents on the launch stream: median and p95
+        STEPS_PER_GRAPH = 10      # one replay = 10 chained steps (state / input ping-pong): the 10-16 us host-side floor of a
+                                  # graph replay (MI355X_MICROARCH.md, graph-replay-floor) is not kernel time
+
         def graph_step_times(h, w, n=25):
-            s_in = torch.randn((1, h, w, C), device=dev) * 0.5
-            p_in = torch.randn((1, h, w, C), device=dev) * 0.5
+            bufs = [torch.randn((1, h, w, C), device=dev) * 0.5 for _ in range(4)]      # s_a, p_a, s_b, p_b
             e_in = torch.randn((S.DRAWS_PER_STEP[a.solver], 1, h, w, C), device=dev)
-            s_o, p_o = torch.empty_like(s_in), torch.empty_like(p_in)
             coef = torch.from_numpy(S.Schedule(dts=[float(dt)]).coef_array()).to(dev)
             ws = torch.empty(L.sf_ode_step_ws_bytes(C, 1, h, w) // 4 + 1024, dtype=torch.float32, device=dev)
             pr = runtime.ptr
 
-            def one(sp):
-                _lib.check(L.sf_ode_step_fwd(ode.gru_c.packed().struct, ode.p_model.packed().struct, _lib.SOLVER[a.solver], 1,
-                                             pr(s_in), pr(p_in), pr(coef), pr(e_in), pr(s_o), pr(p_o), 1, h, w, pr(ws), ws.numel() * 4, sp), "ode_step")
-            one(runtime.stream_ptr(dev))
+            def chain(sp):
+                for i in range(STEPS_PER_GRAPH):
+                    si, pi, so, po = (bufs[0], bufs[1], bufs[2], bufs[3]) if i % 2 == 0 else (bufs[2], bufs[3], bufs[0], bufs[1])
+                    _lib.check(L.sf_ode_step_fwd(ode.gru_c.packed().struct, ode.p_model.packed().struct, _lib.SOLVER[a.solver], 1,
+                                                 pr(si), pr(pi), pr(coef), pr(e_in), pr(so), pr(po), 1, h, w, pr(ws), ws.numel() * 4, sp), "ode_step")
+            chain(runtime.stream_ptr(dev))
             torch.cuda.synchronize()
             cap = torch.cuda.Stream(device=dev)
             ex = ctypes.c_void_p()
@@ -312,7 +315,7 @@ def main():
                 sp = runtime.stream_ptr(dev)
                 _lib.check(L.sf_graph_begin(sp), "graph_begin")
                 try:
-                    one(sp)
+                    chain(sp)
                 finally:
                     _lib.check(L.sf_graph_end(sp, ctypes.byref(ex)), "graph_end")
             sp = runtime.stream_ptr(dev)
@@ -325,7 +328,7 @@ def main():
                 L.sf_graph_launch(ex, sp)
                 L.sf_event_record(e1, sp)
                 L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
-                ts.append(ms.value * 1e3)
+                ts.append(ms.value * 1e3 / STEPS_PER_GRAPH)
             L.sf_graph_destroy(ex)
             ts.sort()
             return ts[len(ts) // 2], ts[min(len(ts) - 1, int(round(0.95 * (len(ts) - 1))))], n
@@ -344,7 +347,7 @@ def main():
                          "frac": fl / (med_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": tr,
                          "traffic_source": {"file": "profiles/pmc_ode_step.json", "measured_in_this_run": False,
                                             "commit": (pmc_step_data or {}).get("commit")},
-                         "kernel": f"ode_step kernel group ({a.solver}, one sample, latent {hh}x{ww}x{C}): sf_ode_step_fwd as one hipGraph",
+                         "kernel": f"ode_step kernel group ({a.solver}, one sample, latent {hh}x{ww}x{C}): {STEPS_PER_GRAPH} chained sf_ode_step_fwd per hipGraph replay, time / {STEPS_PER_GRAPH}",
                          "us_per_step_median": med_us, "us_per_step_p95": p95_us, "graph_replays_timed": nrep,
                          "flops_per_step": fl, "algorithmic_bytes_per_step": by,
                          "hbm_frac_if_bytes_bound": by / (med_us * 1e-6) / 1e9 / PEAK_HBM_GBS,
