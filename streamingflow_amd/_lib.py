@@ -13,7 +13,7 @@ f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
 
 SF_COEF_STRIDE = 12
-SF_PROF_KEYS = 120
+SF_PROF_KEYS = 128
 PACK_TRANSPOSED, PACK_FOLD_DUP, PACK_INTERLEAVE = 1, 2, 4      # SF_PACK_* of sfnative.h
 ACT = {"none": 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4, "gelu": 5}
 SOLVER = {"euler": 0, "midpoint": 1, "rk4": 2}
@@ -160,7 +160,7 @@ SIGNATURES = {
 # kernel key = tile_config*8 + epilogue  (csrc/conv_igemm.hip launch_conv; configs 10..13: the LDS-DMA kernel conv_glds_kernel)
 KERNEL_NAMES = {c * 8 + e: (f"conv_glds<{cn[3:]},{en}>" if cn.startswith("dma") else f"conv_sp<{cn[2:]},{en}>" if cn.startswith("sp") else f"conv_igemm<{cn},{en}>")
                 for c, cn in enumerate(("S16x64k4", "L64x64", "LN64x128", "direct16px", "T64x64splitK", "L128x64", "L64x128", "L128x128w4", "L64x128w8", "L128x128w8",
-                                        "dma128x128w8", "dma64x64", "dma64x128w8", "dmaLN64x128", "sp64x32"))
+                                        "dma128x128w8", "dma64x64", "dma64x128w8", "dmaLN64x128", "sp64x32", "dmaT64x64splitK"))
                 for e, en in enumerate(("affine", "blend", "ln_gelu", "trust", "sample"))}
 
 _LIB = None

@@ -161,14 +161,14 @@ const Tune& tune() {
     x.chunks_per_wave = geti("SF_DIRECT_CPW", 5);
     if (x.chunks_per_wave < 1) x.chunks_per_wave = 1;
     x.split = geti("SF_SPLIT", 1);                 // cross-workgroup split-K on 64x64 tiles (small P)
-    x.split_target = geti("SF_SPLIT_WGS", 512);    // aim for this many workgroups per launch
+    x.split_target = geti("SF_SPLIT_WGS", 1024);   // round 2 (sc1 hand-off): 512 -> 1024, batch-8 step 754 -> 701 us    // aim for this many workgroups per launch
     x.split_min_chunks = geti("SF_SPLIT_MINCH", 2);
-    x.mid_tiles = geti("SF_MID_TILES", 640);
+    x.mid_tiles = geti("SF_MID_TILES", 1300);      // round 2: 640 -> 1300 (the 200x200 latent splits its 7x7 too: 1364 -> 1311 us)
     x.glds = geti("SF_GLDS", 15);                  // LDS-DMA staging for large plain layers: bit 0 = 128-cout tiles, bit 1 = 64-cout tiles, bit 2 = LayerNorm-epilogue tiles, bit 3 = cross-workgroup split-K launches (0: register staging everywhere)
     x.glds_var = geti("SF_GLDS_VAR", -1);          // -1: shipped choice; 0..8: force a variant of launch_conv_glds (experiments)
     x.small_dma = geti("SF_SMALL_DMA", 1);         // >= 0: plain layers below LARGE_P run on the LDS-DMA kernel (32x32 tiles); bit 0: GRU candidates too (pre-gated state)
     x.narrow = geti("SF_NARROW", 9);             // tile variant for layers with <= 32 output channels (32 cout x 128 px; -1: the 64-row tiles)
-    x.large_p = geti("SF_LARGE_P", 12288);      // measured: a 4-sample rollout (10000 px) is 18 % faster on the small-P kernels, 8 samples (20000 px) on the large tiles
+    x.large_p = geti("SF_LARGE_P", 8192);      // measured: a 4-sample rollout (10000 px) is 18 % faster on the small-P kernels, 8 samples (20000 px) on the large tiles
     x.split_cfg = geti("SF_SPLIT_CFG", 4);         // tile config of the mid-P split-K launches without a LayerNorm epilogue (4 | 1)
     x.split_from = geti("SF_SPLIT_FROM", 100);     // only layers with at least this many K chunks (the 7x7)
     return x;
@@ -425,12 +425,15 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   // (profiles/r01_v_sweep_glds_wide_tiles.txt; single-sample rollout 5.10 -> 4.64 ms with the pre-gated candidates).
   // SF_SMALL_DMA=-1 switches it off, 0 keeps the reset gate in the candidate's staging.  LayerNorm epilogues on
   // 64x32 tiles were slower than the direct kernel and stay there.
-  if ((tune().glds & 8) && cfg == 4 && epi != EPI_SAMPLE) {   // cross-workgroup split-K launches (the slab hand-off is shared)
+  if ((tune().glds & 8) && cfg == 4) {   // cross-workgroup split-K launches (the slab hand-off is shared); SE-scaled layers on the SCALE instantiation
     bool ok = true;
+    int nscaled = 0;
+    for (int i = 0; i < n; ++i) nscaled += L.p[i].in_scale != nullptr;
+    ok = (nscaled == 0 && epi != EPI_SAMPLE) || (nscaled == n && (epi == EPI_AFFINE || epi == EPI_SAMPLE));
     for (int i = 0; i < n; ++i) {
       const ConvProblem& q = L.p[i];
       const double span = (256.0 / ((double)q.Hout * q.Wout) + 2.0) * q.Hin * q.Win * 4.0;
-      ok = ok && !q.gate && !q.in_scale && !q.gather && one_source_per_chunk(q) && span * q.in0_cs < 2147483648.0 &&
+      ok = ok && !q.gate && scale_ok(q) && !q.gather && one_source_per_chunk(q) && span * q.in0_cs < 2147483648.0 &&
            span * q.in1_cs < 2147483648.0 && 4.0 * q.cout_pad * q.ktot < 2147483648.0;
     }
     if (ok) glds_tile = 4;
@@ -455,7 +458,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     return SF_OK;
   }
   ProfRec r;
-  r.key = (glds_tile < 0 || glds_tile == 4 ? cfg : glds_tile == 0 ? 10 : glds_tile == 2 ? 13 : glds_var == 6 ? 12 : 11) * 8 + epi; r.flops = 0; r.bytes = 0;
+  r.key = (glds_tile < 0 ? cfg : glds_tile == 4 ? 15 : glds_tile == 0 ? 10 : glds_tile == 2 ? 13 : glds_var == 6 ? 12 : 11) * 8 + epi; r.flops = 0; r.bytes = 0;
   for (int i = 0; i < n; ++i) {
     const ConvProblem& q = ps[i];
     const double Pi = (double)q.n_img * q.Hout * q.Wout;
@@ -598,7 +601,7 @@ int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p
   if (!eps && !philox) return SF_ERR_INVALID;
   const int C = w.C, C2 = 2 * C, HW = H * W, P = B * HW;
   if (B < 1 || B > 64) return SF_ERR_UNSUPPORTED;
-  const bool tiles = (B == 1);
+  const bool tiles = (B == 1) && P < 8192;      // a large single latent: thousands of per-tile rows would be summed by ONE workgroup (32 us at 200x200)
   // rows of per-tile channel sums each SE producer writes (its kernel's pixel tile), or per-image slab sums
   ConvProblem probe1 = problem(w.rb0.conv2, s, nullptr, nullptr, B, H, W), probe2 = problem(w.rb1.conv2, s, nullptr, nullptr, B, H, W);
   const int tpx1 = chansum_tile_px(probe1, EPI_AFFINE), tpx2 = chansum_tile_px(probe2, EPI_AFFINE);

@@ -324,38 +324,36 @@ __device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[
 }
 
 // ---- cross-workgroup split-K: slab publish, ticket, last arriver reduces in slice order ------
-// (cdna_hip_programming.md "In-launch split-K reduction": plain slab stores, every wave drains,
-// barrier, ONE agent-scope release + ticket; the last arriver does ONE agent-scope acquire, then
-// plain loads.  Placement independent; fixed summation order => bitwise reproducible.)
+// Round 2: the partial tiles leave with sc1 (write-through) 16-byte stores, every wave drains, barrier, ONE agent-scope
+// ticket per workgroup; the workgroup whose ticket is the last re-reads ALL slices with sc1 loads in slice order
+// (MI355X_MICROARCH.md, hand-off table row 1).  No release / acquire fence: the round-1 form (plain stores + agent
+// release + acquire) cost 5-14 us per launch in the fences (tools/r02/stamps.py); placement independent either way;
+// fixed summation order => bitwise reproducible.
 // Returns false for the workgroups that are done (not the last arriver of their tile).
 template <int MT, int NT, int NW>
 __device__ __forceinline__ bool splitk_handoff(const ConvProblem& P, f32x4 (&acc)[MT][NT], const int nsplit, const int tile,
                                                const int wave, const int lane, const int tid, float* smem) {
   constexpr int PER_WAVE = MT * NT * 4 * 64;
-  float* tile_slab = P.slab + (size_t)tile * nsplit * NW * PER_WAVE;
-  {
-    float* my = tile_slab + ((size_t)blockIdx.z * NW + wave) * PER_WAVE + lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+  float* const tile_slab = P.slab + (size_t)tile * nsplit * NW * PER_WAVE;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tile_slab, (short)0, nsplit * NW * PER_WAVE * 4, 0x00020000);
+  const int lane_off = (wave * PER_WAVE + lane * 4) * 4;      // bytes: [slice][wave][m*NT+n][lane][4]
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) my[((m * NT + n) * 4 + q) * 64] = acc[m][n][q];
-  }
+    for (int n = 0; n < NT; ++n)
+      __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(acc[m][n][0]), __float_as_uint(acc[m][n][1]), __float_as_uint(acc[m][n][2]),
+                                                     __float_as_uint(acc[m][n][3])},
+                                             rs, lane_off + (m * NT + n) * 1024, (int)blockIdx.z * (NW * PER_WAVE * 4), 16);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int* flag = reinterpret_cast<int*>(smem);
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned* cnt = P.counters + tile;
     const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (t == (unsigned)(nsplit - 1));
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    }
+    if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     *flag = last;
   }
   __syncthreads();
@@ -364,16 +362,21 @@ __device__ __forceinline__ bool splitk_handoff(const ConvProblem& P, f32x4 (&acc
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int z = 0; z < nsplit; ++z) {
-    const float* r = tile_slab + ((size_t)z * NW + wave) * PER_WAVE + lane;
+  for (int z = 0; z < nsplit; ++z) {      // slice order, own slice included: the sum does not depend on who arrives last
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[m][n][q] += r[((m * NT + n) * 4 + q) * 64];
+      for (int n = 0; n < NT; ++n) {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off + (m * NT + n) * 1024, z * (NW * PER_WAVE * 4), 16);
+        acc[m][n][0] += __uint_as_float(t[0]); acc[m][n][1] += __uint_as_float(t[1]);
+        acc[m][n][2] += __uint_as_float(t[2]); acc[m][n][3] += __uint_as_float(t[3]);
+      }
   }
   return true;
+#else
+  (void)P; (void)acc; (void)nsplit; (void)tile; (void)wave; (void)lane; (void)tid; (void)smem;
+  return true;
+#endif
 }
 
 template <int MT, int NT, int WM, int WN, int KS, int EPI, int KB = 32, bool SWZ = false>
@@ -1064,6 +1067,7 @@ hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant,
   if (scaled || epi == EPI_SAMPLE) {     // 64x64 tiles (large P), 32x32 (one latent)
     if (tile == 3) return launch_glds_s<1, 1, 2, 2>(L, epi, stream);
     if (tile == 1 || tile == 0) return launch_glds_s<2, 2, 2, 2>(L, epi, stream);
+    if (tile == 4) return launch_glds_s<4, 1, 1, 4>(L, epi, stream);      // cross-workgroup split-K launches (a few batched samples)
     return hipErrorInvalidValue;
   }
   if (tile == 2) {   // LayerNorm epilogues: one wave holds all (<= 64) output channels of its pixels; 64 cout x 128 px, 4 waves
