@@ -590,7 +590,7 @@ constexpr int SE_SLABS = 64;
 size_t infer_ws_floats(int C, int P) {
   int nt = (P + 15) / 16;
   if (nt < SE_SLABS * 64) nt = SE_SLABS * 64;   // room for [B<=64][SE_SLABS] slab sums as well
-  return al((size_t)P * C) + 4 * al((size_t)P * 2 * C) + 2 * al((size_t)nt * 2 * C) + 2 * al((size_t)64 * 2 * C);
+  return al((size_t)P * C) + 4 * al((size_t)P * 2 * C) + 2 * al((size_t)nt * 2 * C) + 3 * al((size_t)64 * 2 * C);
 }
 
 // temporal_ode_bayes.py:463-477 on B images.  SE channel means: B == 1 uses the per-16-pixel sums
@@ -601,12 +601,16 @@ int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p
   if (!eps && !philox) return SF_ERR_INVALID;
   const int C = w.C, C2 = 2 * C, HW = H * W, P = B * HW;
   if (B < 1 || B > 64) return SF_ERR_UNSUPPORTED;
-  const bool tiles = (B == 1) && P < 8192;      // a large single latent: thousands of per-tile rows would be summed by ONE workgroup (32 us at 200x200)
-  // rows of per-tile channel sums each SE producer writes (its kernel's pixel tile), or per-image slab sums
+  // SE channel means.  One sample: the producing conv's epilogue writes per-tile channel sums ("rows"); a small latent sums
+  // them in the consuming layer's prologue (small-P kernel) or in the gate kernel; a large one (thousands of rows) first
+  // reduces the rows to SE_SLABS slab sums (two short launches instead of a pass over the whole tensor: 22 -> ~10 us per
+  // gate at 200x200).  Several samples (tiles straddle images): per-image slab sums of the tensor.  All fixed-order.
+  const bool tiles = (B == 1);
+  const bool two_level = tiles && P >= 8192;
+  // rows of per-tile channel sums each SE producer writes (its kernel's pixel tile)
   ConvProblem probe1 = problem(w.rb0.conv2, s, nullptr, nullptr, B, H, W), probe2 = problem(w.rb1.conv2, s, nullptr, nullptr, B, H, W);
   const int tpx1 = chansum_tile_px(probe1, EPI_AFFINE), tpx2 = chansum_tile_px(probe2, EPI_AFFINE);
   const int nt1 = tiles ? (P + tpx1 - 1) / tpx1 : SE_SLABS, nt2 = tiles ? (P + tpx2 - 1) / tpx2 : SE_SLABS;
-
   float* a = A.take((size_t)P * C);
   float* pr = A.take((size_t)P * C2);
   float* y1 = A.take((size_t)P * C2);
@@ -616,8 +620,21 @@ int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p
   float* cs2 = A.take(tiles ? (size_t)nt2 * C2 : (size_t)B * SE_SLABS * C2);
   float* sc1 = A.take((size_t)B * C2);
   float* sc2 = A.take((size_t)B * C2);
+  float* slabs = A.take((size_t)SE_SLABS * C2);
   if (!A.ok()) return SF_ERR_WORKSPACE;
   if (!w.rb0.proj.w || w.rb1.proj.w) return SF_ERR_INVALID;
+  auto gate = [&](const float* y, const float* rows, int nrows, const float* fc0, const float* fc2, float* scale) -> int {
+    if (!tiles) {
+      SF_HIP(launch_chan_partial(y, const_cast<float*>(rows), B, HW, C2, SE_SLABS, st));
+      SF_HIP(launch_se_fc(rows, SE_SLABS, C2, C2 / 8, HW, fc0, fc2, scale, B, st));
+    } else if (two_level) {
+      SF_HIP(launch_chan_partial(rows, slabs, 1, nrows, C2, SE_SLABS, st));      // the [nrows][C2] sums as a one-image "tensor"
+      SF_HIP(launch_se_fc(slabs, SE_SLABS, C2, C2 / 8, HW, fc0, fc2, scale, 1, st));
+    } else {
+      SF_HIP(launch_se_fc(rows, nrows, C2, C2 / 8, HW, fc0, fc2, scale, B, st));
+    }
+    return SF_OK;
+  };
   ConvProblem ps[2];
   ps[0] = problem(w.rb0.conv1, s, nullptr, a, B, H, W);
   ps[1] = problem(w.rb0.proj, s, nullptr, pr, B, H, W);
@@ -633,8 +650,7 @@ int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p
   const bool fuse_se = tiles && tune().sp_fuse_se && sp_takes(&c3, 1, EPI_AFFINE);
   if (!fuse_se) {
     c3.se_sum = nullptr;
-    if (!tiles) SF_HIP(launch_chan_partial(y1, cs1, B, HW, C2, SE_SLABS, st));
-    SF_HIP(launch_se_fc(cs1, nt1, C2, C2 / 8, HW, w.se0_fc0, w.se0_fc2, sc1, B, st));
+    SF_TRY(gate(y1, cs1, nt1, w.se0_fc0, w.se0_fc2, sc1));
     c3.in_scale = sc1;
   }
   SF_TRY(run1(c3, EPI_AFFINE, st));
@@ -649,8 +665,7 @@ int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p
   }
   if (!fuse_se || !sp_takes(&c5, 1, EPI_SAMPLE)) {
     c5.se_sum = nullptr;
-    if (!tiles) SF_HIP(launch_chan_partial(y2, cs2, B, HW, C2, SE_SLABS, st));
-    SF_HIP(launch_se_fc(cs2, nt2, C2, C2 / 8, HW, w.se1_fc0, w.se1_fc2, sc2, B, st));
+    SF_TRY(gate(y2, cs2, nt2, w.se1_fc0, w.se1_fc2, sc2));
     c5.in_scale = sc2;
   }
   return run1(c5, EPI_SAMPLE, st);
