@@ -82,37 +82,79 @@ __device__ __forceinline__ float sp_reduce16(float v) {   // sum over the 16 lan
   return v;
 }
 
+// Epilogue operands of one (pixel, channel quad) item.  They are loaded by the consumer waves BEFORE the K loop (every one of
+// them was written by an earlier launch), so that the epilogue is arithmetic + stores only: measured 1.1-2.8 us per launch
+// when the loads sat behind the reduction (tools/r02/stamps.py).
+struct SpOps {
+  float4 a[10];
+  float2 e;
+  float c0f, c1f;
+};
+// `on`: the lane owns a real element (consumer wave, pixel < P, channel < cout); lanes that are not `on` load from safe
+// addresses and store nothing.
+template <int EPI>
+__device__ __forceinline__ void sp_epi_load(const ConvProblem& P, const int gp, const int c, const bool on, const int HWout, SpOps& o) {
+  const int img = on ? gp / HWout : 0;
+  const size_t gpz = on ? (size_t)gp : 0;
+  const int cz = on ? c : 0;
+  if constexpr (EPI == EPI_AFFINE || EPI == EPI_BLEND) {
+    o.a[0] = P.scale ? spm_ld4(P.scale + cz) : make_float4(1.f, 1.f, 1.f, 1.f);
+    o.a[1] = P.bias ? spm_ld4(P.bias + (P.bias_per_img ? (size_t)img * P.cout : 0) + cz) : spm_zero4();
+    if constexpr (EPI == EPI_AFFINE) {
+      o.a[2] = P.add ? spm_ld4(P.add + gpz * P.add_cs + cz) : spm_zero4();
+      o.a[3] = (P.add && P.add_scale) ? spm_ld4(P.add_scale + (size_t)img * P.cout + cz) : make_float4(1.f, 1.f, 1.f, 1.f);
+      const int cg = (P.out2 && cz >= P.gate_from) ? cz - P.gate_from : 0;
+      o.a[4] = P.out2 ? spm_ld4(P.e1 + gpz * P.e1_cs + cg) : spm_zero4();
+    } else {
+      o.a[2] = spm_ld4(P.e0 + gpz * P.e0_cs + cz);
+      o.a[3] = spm_ld4(P.e1 + gpz * P.e1_cs + cz);
+    }
+  }
+  if constexpr (EPI == EPI_LNG || EPI == EPI_TRUST) {
+    const size_t po = gpz * P.cout + cz;
+    const bool do_ln = (EPI == EPI_TRUST) || (P.mode & 1);      // a plain GELU layer (the gate's 1x1 projection) has no LayerNorm parameters
+    o.a[0] = do_ln ? spm_ld4(P.scale + cz) : spm_zero4();
+    o.a[1] = do_ln ? spm_ld4(P.bias + cz) : spm_zero4();
+    o.c0f = 0.f; o.c1f = 0.f;
+    if constexpr (EPI == EPI_TRUST) {
+      o.a[2] = spm_ld4(P.e0 + po);
+      o.a[3] = spm_ld4(P.e1 + cz); o.a[4] = spm_ld4(P.e1 + P.cout + cz);
+      o.a[5] = spm_ld4(P.e2 + po); o.a[6] = spm_ld4(P.e3 + po);
+      const bool deriv = (P.mode & 1) != 0;
+      o.a[7] = deriv ? spm_ld4(P.e4 + po) : spm_zero4();
+      o.a[8] = deriv ? spm_ld4(P.e5 + po) : spm_zero4();
+      o.a[9] = (P.out2 && (P.mode & 2)) ? spm_ld4(P.out2 + po) : spm_zero4();
+      const float* cf = P.coef ? P.coef + (size_t)img * P.coef_stride : nullptr;
+      o.c0f = cf ? cf[0] : 0.f;
+      o.c1f = (cf && P.out2) ? cf[1] : 0.f;
+    }
+  }
+  if constexpr (EPI == EPI_SAMPLE) {
+    const int Chalf = P.cout >> 1;
+    const int ch = ((c >> 4) << 3) + 2 * ((c >> 2) & 3);
+    const bool ok = on && ch < Chalf;
+    o.a[0] = P.bias ? spm_ld4(P.bias + cz) : spm_zero4();
+    o.e = P.e0 ? *reinterpret_cast<const float2*>(P.e0 + (ok ? gpz : 0) * Chalf + (ok ? ch : 0)) : make_float2(0.f, 0.f);
+  }
+}
+
 // ---- epilogues in the (pixel, channel-quad) layout -------------------------------------------------------------------
 // v: the lane's four consecutive output channels c..c+3 of pixel gp (pre-activation accumulator sums).
-// `on`: the lane owns a real element (consumer wave, pixel < P, channel < cout); lanes that are not `on` load from safe
-// addresses and store nothing.  y_out (AFFINE): the stored value, zero where not `on` (for the SE channel sums).
+// y_out (AFFINE): the stored value, zero where not `on` (for the SE channel sums).
 template <int EPI>
 __device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, const int gp, const int c, const bool on,
-                                            const int HWout, float4& y_out) {
-  const int img = on ? gp / HWout : 0;
+                                            const SpOps& o, float4& y_out) {
   const size_t gpz = on ? (size_t)gp : 0;
   const int cz = on ? c : 0;
 
   if constexpr (EPI == EPI_AFFINE || EPI == EPI_BLEND) {
-    // all operands first (one round trip), arithmetic after
-    const float4 sc = P.scale ? spm_ld4(P.scale + cz) : make_float4(1.f, 1.f, 1.f, 1.f);
-    const float4 bi = P.bias ? spm_ld4(P.bias + (P.bias_per_img ? (size_t)img * P.cout : 0) + cz) : spm_zero4();
-    float4 ad = spm_zero4(), as = make_float4(1.f, 1.f, 1.f, 1.f), u = spm_zero4(), s = spm_zero4(), sv = spm_zero4();
-    bool gate_out = false;
-    int cg = 0;
-    if constexpr (EPI == EPI_AFFINE) {
-      if (P.add) ad = spm_ld4(P.add + gpz * P.add_cs + cz);
-      if (P.add && P.add_scale) as = spm_ld4(P.add_scale + (size_t)img * P.cout + cz);
-      gate_out = P.out2 && cz >= P.gate_from;
-      cg = gate_out ? cz - P.gate_from : 0;
-      if (P.out2) sv = spm_ld4(P.e1 + gpz * P.e1_cs + cg);
-    } else {
-      u = spm_ld4(P.e0 + gpz * P.e0_cs + cz);
-      s = spm_ld4(P.e1 + gpz * P.e1_cs + cz);
-    }
+    const float4 sc = o.a[0], bi = o.a[1];
     v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
     float4 y;
     if constexpr (EPI == EPI_AFFINE) {
+      const float4 ad = o.a[2], as = o.a[3], sv = o.a[4];
+      const bool gate_out = P.out2 && cz >= P.gate_from;
+      const int cg = gate_out ? cz - P.gate_from : 0;
       const bool act_last = (P.mode & 2) != 0;
       y = act_last ? v : spm_act4(v, P.act);
       if (P.clamp_from >= 0) {
@@ -126,6 +168,7 @@ __device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, cons
       if (on && gate_out)   // GRU gates, reset half: also emit (1 - r) * s, the candidate conv's input
         spm_st4(P.out2 + gpz * P.out2_cs + cg, make_float4(sv.x * (1.f - y.x), sv.y * (1.f - y.y), sv.z * (1.f - y.z), sv.w * (1.f - y.w)));
     } else {
+      const float4 u = o.a[2], s = o.a[3];
       v = spm_act4(v, P.act);
       if (P.mode & 1) y = make_float4(u.x * (v.x - s.x), u.y * (v.y - s.y), u.z * (v.z - s.z), u.w * (v.w - s.w));
       else y = make_float4((1.f - u.x) * s.x + u.x * v.x, (1.f - u.y) * s.y + u.y * v.y, (1.f - u.z) * s.z + u.z * v.z, (1.f - u.w) * s.w + u.w * v.w);
@@ -139,19 +182,7 @@ __device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, cons
     const bool cv = c < P.cout;
     const float inv_c = 1.f / (float)P.cout;
     const size_t po = gpz * P.cout + cz;
-    const float4 lw = spm_ld4(P.scale + cz), lb = spm_ld4(P.bias + cz);
-    float4 sk = spm_zero4(), w0 = spm_zero4(), w1 = spm_zero4(), r2 = spm_zero4(), r1 = spm_zero4(), st = spm_zero4(), base = spm_zero4(), b2in = spm_zero4();
-    float c0f = 0.f, c1f = 0.f;
-    if constexpr (EPI == EPI_TRUST) {
-      sk = spm_ld4(P.e0 + po);
-      w0 = spm_ld4(P.e1 + cz); w1 = spm_ld4(P.e1 + P.cout + cz);
-      r2 = spm_ld4(P.e2 + po); r1 = spm_ld4(P.e3 + po);
-      if (P.mode & 1) { st = spm_ld4(P.e4 + po); base = spm_ld4(P.e5 + po); }
-      if (P.out2 && (P.mode & 2)) b2in = spm_ld4(P.out2 + po);
-      const float* cf = P.coef ? P.coef + (size_t)img * P.coef_stride : nullptr;
-      c0f = cf ? cf[0] : 0.f;
-      c1f = (cf && P.out2) ? cf[1] : 0.f;
-    }
+    const float4 lw = o.a[0], lb = o.a[1];
     const bool do_ln = (EPI == EPI_TRUST) || (P.mode & 1);
     if (do_ln) {   // convolutions.py:303-308 (channels_first LayerNorm over the pixel's channels)
       const float mean = sp_reduce16(cv ? (v.x + v.y) + (v.z + v.w) : 0.f) * inv_c;
@@ -166,6 +197,8 @@ __device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, cons
       if (on) spm_st4(P.out + gpz * P.out_cs + P.out_co + c, v);
     } else {
       // trusting gate tail (temporal_ode_bayes.py:124-131 / :268-275, convolutions.py:375-380)
+      const float4 sk = o.a[2], w0 = o.a[3], w1 = o.a[4], r2 = o.a[5], r1 = o.a[6], st = o.a[7], base = o.a[8], b2in = o.a[9];
+      const float c0f = o.c0f, c1f = o.c1f;
       const float b0 = v.x + sk.x, b1 = v.y + sk.y, b2 = v.z + sk.z, b3 = v.w + sk.w;
       const float z0 = sp_reduce16(cv ? (w0.x * b0 + w0.y * b1) + (w0.z * b2 + w0.w * b3) : 0.f);
       const float z1 = sp_reduce16(cv ? (w1.x * b0 + w1.y * b1) + (w1.z * b2 + w1.w * b3) : 0.f);
@@ -197,16 +230,15 @@ __device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, cons
     const int ch = ((c >> 4) << 3) + 2 * ((c >> 2) & 3);
     const bool ok = on && ch < Chalf;
     const int chz = ok ? ch : 0;
-    const float4 bi = P.bias ? spm_ld4(P.bias + cz) : spm_zero4();
-    const float2 e = P.e0 ? *reinterpret_cast<const float2*>(P.e0 + (ok ? gpz : 0) * Chalf + chz)
-                          : spm_philox_normal2(P.philox, P.draw, (unsigned)gpz, (unsigned)chz);      // block-uniform choice
+    const float4 bi = o.a[0];
+    const float2 e = P.e0 ? o.e : spm_philox_normal2(P.philox, P.draw, (unsigned)gpz, (unsigned)chz);      // block-uniform choice
     const float q0 = spm_act(v.x + bi.x, P.act), q1 = spm_act(v.y + bi.y, P.act);
     const float q2 = spm_act(v.z + bi.z, P.act), q3 = spm_act(v.w + bi.w, P.act);
     if (ok) {
-      float2 o;
-      o.x = q0 + e.x * (spm_softplus(q2) + 1e-8f);     // model_utils.py:84,107-108
-      o.y = q1 + e.y * (spm_softplus(q3) + 1e-8f);
-      *reinterpret_cast<float2*>(P.out + gpz * Chalf + ch) = o;
+      float2 r;
+      r.x = q0 + e.x * (spm_softplus(q2) + 1e-8f);     // model_utils.py:84,107-108
+      r.y = q1 + e.y * (spm_softplus(q3) + 1e-8f);
+      *reinterpret_cast<float2*>(P.out + gpz * Chalf + ch) = r;
       if (P.out2) {   // raw q parameters, reference channel order [loc | raw]
         *reinterpret_cast<float2*>(P.out2 + gpz * P.cout + ch) = make_float2(q0, q1);
         *reinterpret_cast<float2*>(P.out2 + gpz * P.cout + Chalf + ch) = make_float2(q2, q3);
@@ -315,6 +347,19 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   };
+  // epilogue items of this lane — lane (pixel, channel quad): pixels 4*wave + lane/16 (+ 32 i), channels 4*(lane%16) .. +3 —
+  // and their operands, fetched now (consumer waves) and used after the K loop
+  const int quad = lane & 15;
+  const int c_out = m_tile * SP_BM + 4 * quad;
+  int px[G::NPX];
+  bool on_item[G::NPX];
+  SpOps ops[G::NPX];
+#pragma unroll
+  for (int i = 0; i < G::NPX; ++i) {
+    px[i] = (wave < 8 ? 4 * wave : 0) + (lane >> 4) + 32 * i;
+    on_item[i] = (wave < 8) && (p_tile * BN + px[i]) < Ptot && c_out < P.cout;
+    if (wave < 8) sp_epi_load<EPI>(P, p_tile * BN + px[i], c_out, on_item[i], HWout, ops[i]);
+  }
   SF_STAMP_AT(L, 0);
 #ifdef SP_EXP_ZERO_LDS     // experiment: no LDS word is read before this kernel wrote it
   for (int i = tid; i < G::RING + SP_MISC + (SCALE ? SP_SC_FLOATS : 0); i += SP_THREADS) smem[i] = 0.f;
@@ -556,13 +601,9 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
                 make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]));
   }
   __syncthreads();
-  // lane (pixel, channel quad): pixels 4*wave + lane/16 (+ 32 i), channels 4*(lane%16) .. +3
-  const int quad = lane & 15;
-  int px[G::NPX];
   float4 v[G::NPX];
 #pragma unroll
   for (int i = 0; i < G::NPX; ++i) {
-    px[i] = (wave < 8 ? 4 * wave : 0) + (lane >> 4) + 32 * i;
     v[i] = spm_zero4();
     if (wave < 8) {
 #pragma unroll
@@ -609,14 +650,12 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
 #endif
   }
   SF_STAMP_AT(L, 4);
-  const int c = m_tile * SP_BM + 4 * quad;
+  const int c = c_out;
   float4 ysum = spm_zero4();
 #pragma unroll
   for (int i = 0; i < G::NPX; ++i) {
-    const int gp = p_tile * BN + px[i];
-    const bool on = (wave < 8) && gp < Ptot && c < P.cout;
     float4 y = spm_zero4();
-    sp_epilogue<EPI>(P, v[i], gp, c, on, HWout, y);
+    sp_epilogue<EPI>(P, v[i], p_tile * BN + px[i], c, on_item[i], ops[i], y);
     ysum.x += y.x; ysum.y += y.y; ysum.z += y.z; ysum.w += y.w;
   }
   if constexpr (EPI == EPI_AFFINE) {
