@@ -259,26 +259,46 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       work_total += (double)tiles * ((ps[i].KH * ps[i].KW * (ps[i].cin_pad / 32) + 1) / 2);
     }
     const double per_wg = work_total / tune().sp_split_wgs;      // chunks per workgroup at the target
+    int ns_of[SF_MAX_GROUP], tiles_of[SF_MAX_GROUP], nch_of[SF_MAX_GROUP];
+    int wgs = 0;
+    const bool may_split = g_split && tune().split && bn == 64;
+    for (int i = 0; i < n; ++i) {
+      const ConvProblem& q = ps[i];
+      tiles_of[i] = ((q.n_img * q.Hout * q.Wout + bn - 1) / bn) * ((q.cout_pad + 63) / 64);
+      nch_of[i] = (q.KH * q.KW * (q.cin_pad / 32) + 1) / 2;
+      int ns = (may_split && per_wg > 0) ? (int)(nch_of[i] / per_wg + 0.5) : 1;
+      if (ns > nch_of[i] / 3) ns = nch_of[i] / 3;      // at least 3 chunks per slice
+      if (ns > 8) ns = 8;
+      if (ns < 1) ns = 1;
+      ns_of[i] = ns;
+      wgs += tiles_of[i] * ns;
+    }
+    // one workgroup owns a whole CU: a launch of more than 256 of them runs a second round for the few that are left
+    // (measured: the 7x7 + projection launch at 280 workgroups took 54 us for 26 us of work per workgroup)
+    while (may_split && wgs > 256) {
+      int k = -1;
+      for (int i = 0; i < n; ++i)
+        if (ns_of[i] > 1 && (k < 0 || tiles_of[i] * ns_of[i] > tiles_of[k] * ns_of[k])) k = i;
+      if (k < 0) break;
+      wgs -= tiles_of[k];
+      --ns_of[k];
+    }
     size_t slab_off = 0;
     int cnt_off = 0;
-    for (int i = 0; i < n && g_split && tune().split && bn == 64; ++i) {
+    for (int i = 0; i < n && may_split; ++i) {
       ConvProblem& q = L.p[i];
-      const int tiles = ((q.n_img * q.Hout * q.Wout + bn - 1) / bn) * ((q.cout_pad + 63) / 64);
-      const int nch = (q.KH * q.KW * (q.cin_pad / 32) + 1) / 2;
-      int ns = per_wg > 0 ? (int)(nch / per_wg + 0.5) : 1;
-      if (ns > nch / 3) ns = nch / 3;      // at least 3 chunks per slice
-      if (ns > 8) ns = 8;
+      int ns = ns_of[i];
       if (ns < 2) continue;
-      const int cps = (nch + ns - 1) / ns;
-      ns = (nch + cps - 1) / cps;      // every slice non-empty
+      const int cps = (nch_of[i] + ns - 1) / ns;
+      ns = (nch_of[i] + cps - 1) / cps;      // every slice non-empty
       if (ns < 2) continue;
       const size_t per = (size_t)64 * bn;
-      if (slab_off + (size_t)tiles * ns * per > g_split->slab_floats || cnt_off + tiles > g_split->ncounters) continue;
+      if (slab_off + (size_t)tiles_of[i] * ns * per > g_split->slab_floats || cnt_off + tiles_of[i] > g_split->ncounters) continue;
       q.nsplit = ns;
       q.slab = g_split->slab + slab_off;
       q.counters = g_split->counters + cnt_off;
-      slab_off += (size_t)tiles * ns * per;
-      cnt_off += tiles;
+      slab_off += (size_t)tiles_of[i] * ns * per;
+      cnt_off += tiles_of[i];
     }
     L.stamp_slot = g_stamp_slot;
     if (g_stamp_on) g_stamp_slot = (g_stamp_slot + 1) % 64;

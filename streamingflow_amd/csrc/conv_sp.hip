@@ -416,9 +416,15 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
     int sc = 2 * cb;
     int cur_kc = sc % kcpt, cur_ty = (sc / kcpt) / KW, cur_tx = (sc / kcpt) % KW;
     bool tap_fresh = true;
-    int tap_off0[G::NBI], tap_off1[G::NBI];
+    // Per tap and pixel row block: byte offset of the gathered pixel in either source (channel slot of this lane included),
+    // or 0x80000000 outside the image: adding the sub-chunk's channel offset keeps it beyond any buffer (< 2^31 bytes), so the
+    // range check zero-fills.  Per sub-chunk the loader then needs ONE vector add per DMA: its instruction stream shares the
+    // SIMD's issue with two MFMA streams, and every VALU instruction in it was measured to cost ~8 cycles there.
+    int vb0[G::NBI], vb1[G::NBI];
 #pragma unroll
-    for (int i = 0; i < G::NBI; ++i) { tap_off0[i] = -1; tap_off1[i] = 0; }
+    for (int i = 0; i < G::NBI; ++i) { vb0[i] = (int)0x80000000; vb1[i] = (int)0x80000000; }
+    const bool whole_chunks = (c0 % 32 == 0) && (c01 % 32 == 0) && c01 == cin_pad;      // block-uniform: no channel padding inside a sub-chunk
+    const int minus1 = -1;
     auto issue_chunk = [&](const int buf) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -429,28 +435,37 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
             const int iy = iy0[i] + cur_ty * dil, ix = ix0[i] + cur_tx * dil;
             const bool in = (iy >= 0) & (iy < Hlog) & (ix >= 0) & (ix < Wlog);
             const int px = in ? pbase[i] + (iy >> in_up) * Win + (ix >> in_up) : 0;
-            tap_off0[i] = in ? px * in0_cs : -1;
-            tap_off1[i] = px * in1_cs - c0;
+            vb0[i] = in ? (px * in0_cs + b_c4[i]) * 4 : (int)0x80000000;
+            vb1[i] = in ? (px * in1_cs - c0 + b_c4[i]) * 4 : (int)0x80000000;
           }
         }
         const bool from1 = cur_kc * 32 >= c0;                   // wave-uniform: the whole sub-chunk reads in1
-        const int soff = live ? sc * 128 : 0;
+        const int koff = cur_kc * 128;                          // bytes
         float* const blk = smem + buf * G::BUFF + s2 * G::SUBF;
 #if defined(__HIP_DEVICE_COMPILE__)
-        // offset -1 fails the buffer range check: the DMA writes 0 (zero padding, channels past cin, the odd last half)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * lw) * 32), 16, live ? a_voff[0] : -1, soff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * (lw + 4)) * 32), 16, live ? a_voff[1] : -1, soff, 0, 0);
+        if (live) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * lw) * 32), 16, a_voff[0], sc * 128, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * (lw + 4)) * 32), 16, a_voff[1], sc * 128, 0, 0);
 #pragma unroll
-        for (int i = 0; i < G::NBI; ++i) {
-          const int c = cur_kc * 32 + b_c4[i];
-          const bool ok = live & (tap_off0[i] >= 0) & (c < c01);
-          const int vob = ok ? (c + (from1 ? tap_off1[i] : tap_off0[i])) * 4 : -1;
-          float* const dB = blk + (SP_BM + 8 * (lw + 4 * i)) * 32;
-          if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (sp_lds_void*)dB, 16, vob, 0, 0, 0);
-          else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (sp_lds_void*)dB, 16, vob, 0, 0, 0);
+          for (int i = 0; i < G::NBI; ++i) {
+            float* const dB = blk + (SP_BM + 8 * (lw + 4 * i)) * 32;
+            int vob = (from1 ? vb1[i] : vb0[i]) + koff;
+            if (!whole_chunks) {                                 // channels past cin inside the sub-chunk: zero
+              const int c = cur_kc * 32 + b_c4[i];
+              vob = (c < c01) ? vob : -1;
+            }
+            if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (sp_lds_void*)dB, 16, vob, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (sp_lds_void*)dB, 16, vob, 0, 0, 0);
+          }
+        } else {      // offset -1 fails the buffer range check: the DMA writes zeros
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * lw) * 32), 16, minus1, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * (lw + 4)) * 32), 16, minus1, 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < G::NBI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (sp_lds_void*)(blk + (SP_BM + 8 * (lw + 4 * i)) * 32), 16, minus1, 0, 0, 0);
         }
 #else
-        (void)blk; (void)soff; (void)from1; (void)live;
+        (void)blk; (void)koff; (void)from1; (void)live; (void)whole_chunks; (void)minus1;
 #endif
         ++sc;
         ++cur_kc;
