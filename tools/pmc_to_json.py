@@ -19,19 +19,34 @@ def load(d):
     return agg
 
 
+def durations(d):
+    """total ns per kernel name from the kernel trace written beside the counters"""
+    fs = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", d, "*", "*kernel_trace.csv")))
+    tot = collections.defaultdict(float)
+    if fs:
+        for r in csv.DictReader(open(fs[-1])):
+            tot[r["Kernel_Name"]] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return tot
+
+
 def main():
     fetch, write = load("pmcb_fetch"), load("pmcb_write")
     rows = []
     for k in fetch:
-        if "conv_igemm" not in k and "conv_direct" not in k and "conv_glds" not in k:
+        if not any(t in k for t in ("conv_igemm", "conv_direct", "conv_glds", "conv_sp")):
             continue
         f, w = fetch[k], write.get(k, [0.0])
         rows.append({"kernel": k, "launches": len(f), "fetch_kib_avg_raw": sum(f) / len(f), "write_kib_avg": sum(w) / len(w),
                      "hbm_bytes_per_launch": (2.0 * sum(f) / len(f) + sum(w) / len(w)) * 1024.0,
                      "total_hbm_bytes": (2.0 * sum(f) + sum(w)) * 1024.0})
     rows.sort(key=lambda r: -r["total_hbm_bytes"])
-    want = sys.argv[1] if len(sys.argv) > 1 else "conv_glds_kernel<4, 2, 2, 4, 0"   # 128x128 tiles, affine epilogue
-    dom = next((r for r in rows if want in r["kernel"]), rows[0])
+    dur = durations("pmcb_write")
+    for r in rows:
+        r["total_ms_under_pmc"] = dur.get(r["kernel"], 0.0) / 1e6
+    if len(sys.argv) > 1:
+        dom = next((r for r in rows if sys.argv[1] in r["kernel"]), rows[0])
+    else:       # the kernel template that takes the most time in the forward (bench.py's `roofline.kernel` groups by tile shape)
+        dom = max(rows, key=lambda r: r["total_ms_under_pmc"]) if dur else rows[0]
     out = {"kernel": dom["kernel"], "hbm_bytes_per_launch": dom["hbm_bytes_per_launch"],
            "commit": os.environ.get("SF_COMMIT"),
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --steps 1 --warmup 1; "
