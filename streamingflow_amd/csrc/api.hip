@@ -144,12 +144,13 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int sp, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
     Tune x;
     x.sp = geti("SF_SP", 1);                       // small pixel counts: the loader / consumer kernel of conv_sp.hip (0: the round-1 kernels)
+    x.sp_xcd = geti("SF_SP_XCD", 1);               // ... bit 0: compact 1-D grid (no idle workgroups: step 198 -> 195 us); bit 1: XCD-contiguous logical ids (measured: fabric traffic 156 -> 144 MB per step but 195 -> 203 us; tile-major 133 MB and 218 us — the round-robin spread of a layer's workgroups over the XCDs is the fast one)
     x.sp_split_wgs = geti("SF_SP_SPLIT_WGS", 240); // ... K ranges are split across about this many workgroups per launch
     x.sp_bn = geti("SF_SP_BN", 0);                 // ... pixels per tile (0: by the amount of work, see sp_bn)
     x.sp_max_p = geti("SF_SP_MAX_P", 4096);        // ... used below this many pixels (one 50x50 latent; measured: from two samples on the round-1 kernels are as fast or faster)
@@ -302,6 +303,17 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     }
     L.stamp_slot = g_stamp_slot;
     if (g_stamp_on) g_stamp_slot = (g_stamp_slot + 1) % 64;
+    // compact 1-D grid: problem i owns logical workgroups [wg_base[i], wg_base[i + 1]); bit 0 of sp_xcd: compact grid,
+    // bit 1: XCD-contiguous logical ids
+    if (tune().sp_xcd & 1) {
+      int base = 0;
+      for (int i = 0; i < n; ++i) {
+        L.wg_base[i] = base;
+        base += tiles_of[i] * (L.p[i].nsplit > 1 ? L.p[i].nsplit : 1);
+      }
+      for (int i = n; i <= SF_MAX_GROUP; ++i) L.wg_base[i] = base;
+      L.xcd_shift = (tune().sp_xcd >> 1) & 1;
+    }
     bool scaled = false;
     for (int i = 0; i < n; ++i) scaled = scaled || (ps[i].in_scale != nullptr) || (ps[i].se_sum != nullptr);
     if (!g_prof.on) {

@@ -84,6 +84,9 @@ struct ConvLaunch {
   int nprob;
   int xcd_shift;   // LDS-DMA kernel, large launches: log2 of the XCD tile chunk + 1 (0: workgroup b computes tile b)
   int stamp_slot;  // diagnostic builds (-DSF_STAMP): launch slot of the in-kernel time stamps
+  // small-P kernel, compact 1-D grid: problem i owns the logical workgroups [wg_base[i], wg_base[i + 1]), K slice major,
+  // then cout tile, then pixel tile (wg_base[nprob] = grid size; all zero: the 3-D grid of tiles x problems x slices)
+  int wg_base[SF_MAX_GROUP + 1];
 };
 
 // Diagnostic builds only (-DSF_STAMP, tools/r02/stamps.py): wave 0 of every workgroup records s_memrealtime (100 MHz)
