@@ -181,6 +181,24 @@ int sf_dual_cell_fwd(const sf_dual_w* w, const float* x, const float* s, float* 
                      float* ws, size_t ws_bytes, void* stream);
 size_t sf_dual_cell_ws_bytes(int C, int n_img, int H, int W);
 
+/* The tail of both dual cells on given branch states — temporal_ode_bayes.py:122-131 / :266-275 and the loop body of
+ * Dual_GRU.forward (layers/temporal.py:118-124): gate = softmax(trusting_gate(cat[r1, r2])); cur = r2*gate0 + r1*gate1;
+ * derivative != 0: out = base + coef[0]*(cur - s), else out = cur (s, base, coef may then be NULL).
+ * Workspace: sf_dual_cell_ws_bytes. */
+int sf_trust_mix_fwd(const sf_dual_w* w, const float* r1, const float* r2, const float* s, float* out, int derivative,
+                     const float* base, const float* coef, int n_img, int H, int W, float* ws, size_t ws_bytes, void* stream);
+
+/* Bottleblock.forward — convolutions.py:348-380 on cat[x0, x1] (x1 may be NULL): 7x7 + LN + GELU -> 1x1 + LN + GELU ->
+ * 3x3 + LN + GELU, plus projection(x) (1x1 + GELU) or x itself when in == out (then x1 must be NULL).
+ * Channel counts of the LayerNorm layers <= 64. */
+typedef struct sf_bottle_w {
+  sf_conv_w c7, c1, c3; /* layers.0 / .3 / .6 with the LayerNorm weight / bias in scale / bias */
+  sf_conv_w proj;       /* projection.0; proj.w == NULL when in == out */
+} sf_bottle_w;
+int sf_bottleblock_fwd(const sf_bottle_w* w, const float* x0, const float* x1, float* out, int n_img, int H, int W,
+                       float* ws, size_t ws_bytes, void* stream);
+size_t sf_bottleblock_ws_bytes(int cin, int cout, int n_img, int H, int W);
+
 /* NNFOwithBayesianJumps.infer_state — temporal_ode_bayes.py:463-477: p = loc + eps*(softplus(raw)+1e-8).
  * q_out (raw p_model output, [P][2C], reference channel order) may be NULL.  n_img <= 64. */
 int sf_infer_state_fwd(const sf_pmodel_w* w, const float* s, const float* eps, float* p_out, float* q_out,

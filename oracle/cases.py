@@ -383,3 +383,23 @@ def label_batch(seed=0, b=2, T=7, h=64, w=64):
     return {"segmentation": labels["segmentation"], "instance": labels["instance"], "centerness": out["instance_center"],
             "offset": out["instance_offset"], "flow": out["instance_flow"], "future_egomotion": ego,
             "depths": torch.rand((b, T, 2, 32, 48), generator=g) * 60.0}
+
+
+# ---- a16: modules the reference defines but never constructs (tests/golden/unused_cells.npz) ------------------------
+def unused_cell_inputs():
+    """Hashed inputs of tests/golden/unused_cells.npz (shared by the generator and the GPU test)."""
+    C, h, w = 8, 12, 12
+    return {
+        "x1": hashfill.normal("uc_x1", (2, 1, C, h, w), 41),
+        "x1w": hashfill.normal("uc_x1w", (2, 1, 2 * C, h, w), 42),
+        "st1": hashfill.normal("uc_st1", (2, 1, C, h, w), 43) * 0.5,
+        "st3": hashfill.normal("uc_st3", (2, 3, C, h, w), 44) * 0.5,
+        "seq": hashfill.normal("uc_seq", (2, 3, C, h, w), 45) * 0.5,
+        "x1b1": hashfill.normal("uc_x1b1", (1, 1, C, h, w), 46),
+        "st2b1": hashfill.normal("uc_st2b1", (1, 2, C, h, w), 47) * 0.5,
+    }
+
+
+UNUSED_CELL_SEEDS = {"dual_gru": 51, "dual_gru_wide": 52, "bigru": 53, "dual_ode": 54, "dual_obs": 55}
+
+

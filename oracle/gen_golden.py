@@ -11,6 +11,7 @@ Only outputs (data) are stored; weights / inputs / eps are regenerated from thei
                   control flow (temporal_ode_bayes.py:508-620) with its numerics stubbed out
   big_stats.json  G7: statistics of the C=64, 200x200 forward (tensors are 72 MB)
   voxelize.npz    N2: mmdet3d Voxelization (hard voxelisation) outputs from the reference's C++ CPU kernel
+  unused_cells.npz a16: Dual_GRU / BiGRU (layers/temporal.py:59-249) and the dual cells with several present frames
   lift_splat.npz  N1: streamingflow.bev_pool / projection_to_birds_eye_view / get_geometry /
                   create_frustum / pose_vec2mat / mmdet3d bev_pool (+ QuickCumsum) outputs
 """
@@ -444,6 +445,39 @@ def gen_labels():
     np.savez_compressed(os.path.join(OUT, "labels.npz"), **out)
 
 
+def gen_unused_cells(m):
+    """The recurrent modules the reference defines but never constructs (layers/temporal.py:59-249) and the dual cells'
+    several-present-frames path (temporal_ode_bayes.py:101-109, :248-256): the reference's own classes, hashed weights."""
+    C = 8
+    I = cases.unused_cell_inputs()
+    out = {}
+    fill = lambda mod, key: mod.load_state_dict(hashfill.fill_state_dict(mod.state_dict(), seed=cases.UNUSED_CELL_SEEDS[key], gain=0.6))
+    with torch.no_grad():
+        for mix in (True, False):
+            net = m.temporal.Dual_GRU(C, C, n_future=3, mixture=mix, gru_bias_init=0.3).eval()
+            fill(net, "dual_gru")
+            out[f"dual_gru_mix{int(mix)}_p1"] = _np(net(I["x1"], I["st1"]))
+            out[f"dual_gru_mix{int(mix)}_p3"] = _np(net(I["x1"], I["st3"]))
+        net = m.temporal.Dual_GRU(2 * C, C, n_future=2, mixture=True).eval()       # input wider than the state
+        fill(net, "dual_gru_wide")
+        out["dual_gru_wide"] = _np(net(I["x1w"], I["st1"]))
+        net = m.temporal.BiGRU(C, gru_bias_init=-0.2).eval()
+        fill(net, "bigru")
+        out["bigru"] = _np(net(I["seq"]))
+        net = m.tob.DualGRUODECell(C, C).eval()
+        fill(net, "dual_ode")
+        out["dual_ode_p2"] = _np(net(I["x1b1"], I["st2b1"]))
+        net = m.tob.DualGRUCell(C, C).eval()
+        fill(net, "dual_obs")
+        out["dual_obs_p3"] = _np(net(I["x1"], I["st3"]))
+    np.savez_compressed(os.path.join(OUT, "unused_cells.npz"), **out)
+    print("unused_cells.npz", {k: v.shape for k, v in out.items()})
+    keys = {"Dual_GRU(16, 8, 2)": m.temporal.Dual_GRU(2 * C, C, n_future=2), "BiGRU(8)": m.temporal.BiGRU(C),
+            "Bottleblock(16, 8)": m.convolutions.Bottleblock(2 * C, C), "Bottleblock(8)": m.convolutions.Bottleblock(C)}
+    json.dump({k: {n: list(t.shape) for n, t in mod.state_dict().items()} for k, mod in keys.items()},
+              open(os.path.join(OUT, "unused_cells_keys.json"), "w"), indent=0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also generate the C=64 200x200 statistics (slow)")
@@ -477,6 +511,8 @@ def main():
         gen_beverse(m)
     if "gate_bias" in todo:
         gen_gate_bias(m)
+    if "unused_cells" in todo:
+        gen_unused_cells(m)
     if "fpode_stream" in todo:
         gen_fpode(m, cases.FPODE_STREAM_CASES, "fpode_stream.npz", keep_decoded=False)
     if a.big or "big" in todo:

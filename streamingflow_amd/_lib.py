@@ -37,6 +37,10 @@ class DualW(C.Structure):
                 ("w_logit", C.c_void_p), ("C", C.c_int32)]
 
 
+class BottleW(C.Structure):
+    _fields_ = [("c7", ConvW), ("c1", ConvW), ("c3", ConvW), ("proj", ConvW)]
+
+
 class ResW(C.Structure):
     _fields_ = [("conv1", ConvW), ("conv2", ConvW), ("proj", ConvW)]
 
@@ -91,6 +95,9 @@ SIGNATURES = {
     "sf_spatial_gru_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "sf_dual_cell_fwd": (_i, [C.POINTER(DualW), _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sf_dual_cell_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "sf_trust_mix_fwd": (_i, [C.POINTER(DualW), _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_bottleblock_fwd": (_i, [C.POINTER(BottleW), _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_bottleblock_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "sf_infer_state_fwd": (_i, [C.POINTER(PModelW), _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sf_infer_state_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "sf_ode_step_fwd": (_i, [C.POINTER(DualW), C.POINTER(PModelW), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,

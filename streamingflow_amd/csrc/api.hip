@@ -971,6 +971,56 @@ int sf_dual_cell_fwd(const sf_dual_w* w, const float* x, const float* s, float* 
   return dual_cell(*w, x, s, out, derivative, base, coef, 0, out2, acc2, n_img, H, W, A, (hipStream_t)stream);
 }
 
+// trusting gate + mix of two given branch states (the tail of both dual cells; the recurrent Dual_GRU calls it per step)
+int sf_trust_mix_fwd(const sf_dual_w* w, const float* r1, const float* r2, const float* s, float* out, int derivative,
+                     const float* base, const float* coef, int n_img, int H, int W, float* ws, size_t ws_bytes, void* stream) {
+  if (!w || !r1 || !r2 || !out || w->C <= 0 || (w->C % 8) || n_img < 1) return SF_ERR_INVALID;
+  if (derivative && (!s || !coef)) return SF_ERR_INVALID;
+  if (w->C > 64) return SF_ERR_UNSUPPORTED;
+  Arena A(ws, ws_bytes);
+  SplitScope sp(A, (hipStream_t)stream);
+  CellBufs b;
+  if (!b.take(A, w->C, n_img * H * W)) return SF_ERR_WORKSPACE;
+  b.h1 = const_cast<float*>(r1);      // read only from here on
+  b.r2 = const_cast<float*>(r2);
+  return cell_tail(*w, s ? s : r1, out, derivative, base, coef, 0, nullptr, 0, b, n_img, H, W, (hipStream_t)stream);
+}
+
+// Bottleblock (convolutions.py:348-380) on cat[x0, x1]: out = layers(x) + (projection(x) | x)
+size_t sf_bottleblock_ws_bytes(int cin, int cout, int n_img, int H, int W) {
+  const size_t P = (size_t)n_img * H * W;
+  return (2 * al(P * (size_t)(cin / 2 > 0 ? cin / 2 : 1)) + al(P * (size_t)cout) + SPLIT_WS_FLOATS) * sizeof(float);
+}
+int sf_bottleblock_fwd(const sf_bottle_w* w, const float* x0, const float* x1, float* out, int n_img, int H, int W, float* ws,
+                       size_t ws_bytes, void* stream) {
+  if (!w || !x0 || !out || n_img < 1 || !valid_w(w->c7) || !valid_w(w->c1) || !valid_w(w->c3)) return SF_ERR_INVALID;
+  const bool has_proj = w->proj.w != nullptr;
+  if (!has_proj && (x1 || w->c7.c1 != 0 || w->c3.cout != w->c7.c0)) return SF_ERR_INVALID;      // the residual is x itself
+  if (w->c7.cout_pad > 64 || w->c3.cout_pad > 64) return SF_ERR_UNSUPPORTED;                      // LayerNorm epilogue: all channels of a pixel in one wave
+  hipStream_t st = (hipStream_t)stream;
+  Arena A(ws, ws_bytes);
+  SplitScope sp(A, st);
+  const size_t P = (size_t)n_img * H * W;
+  float* t1 = A.take(P * w->c7.cout);
+  float* t2 = A.take(P * w->c1.cout);
+  float* sk = has_proj ? A.take(P * w->proj.cout) : nullptr;
+  if (!A.ok()) return SF_ERR_WORKSPACE;
+  ConvProblem ps[2];
+  ps[0] = problem(w->c7, x0, x1, t1, n_img, H, W); ps[0].mode = 1;        // 7x7 + LN + GELU
+  if (has_proj) {
+    ps[1] = problem(w->proj, x0, x1, sk, n_img, H, W); ps[1].mode = 0;   // 1x1 + GELU
+    SF_TRY(run(ps, 2, EPI_LNG, st));
+  } else {
+    SF_TRY(run1(ps[0], EPI_LNG, st));
+  }
+  ConvProblem q = problem(w->c1, t1, nullptr, t2, n_img, H, W); q.mode = 1;
+  SF_TRY(run1(q, EPI_LNG, st));
+  ConvProblem f = problem(w->c3, t2, nullptr, out, n_img, H, W); f.mode = 1;
+  f.add = has_proj ? sk : x0;
+  f.add_cs = has_proj ? w->proj.cout : w->c7.c0;
+  return run1(f, EPI_LNG, st);
+}
+
 size_t sf_infer_state_ws_bytes(int C, int n_img, int H, int W) {
   return (infer_ws_floats(C, n_img * H * W) + SPLIT_WS_FLOATS) * sizeof(float);
 }

@@ -235,7 +235,12 @@ __device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[
           for (int m = 0; m < MT; ++m)
             if (cvm[m]) {
               const int c = m0 + m * 16 + 4 * g;
-              st4(P.out + (size_t)gp * P.out_cs + P.out_co + c, make_float4(v[m][0], v[m][1], v[m][2], v[m][3]));
+              float4 y = make_float4(v[m][0], v[m][1], v[m][2], v[m][3]);
+              if (P.add) {   // Bottleblock residual (convolutions.py:375-380): layers(x) + x | projection(x)
+                const float4 ad = ld4(P.add + (size_t)gp * P.add_cs + c);
+                y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w;
+              }
+              st4(P.out + (size_t)gp * P.out_cs + P.out_co + c, y);
             }
         }
       } else {

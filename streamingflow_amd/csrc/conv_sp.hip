@@ -116,6 +116,7 @@ __device__ __forceinline__ void sp_epi_load(const ConvProblem& P, const int gp, 
     o.a[0] = do_ln ? spm_ld4(P.scale + cz) : spm_zero4();
     o.a[1] = do_ln ? spm_ld4(P.bias + cz) : spm_zero4();
     o.c0f = 0.f; o.c1f = 0.f;
+    if constexpr (EPI == EPI_LNG) o.a[2] = P.add ? spm_ld4(P.add + gpz * P.add_cs + cz) : spm_zero4();
     if constexpr (EPI == EPI_TRUST) {
       o.a[2] = spm_ld4(P.e0 + po);
       o.a[3] = spm_ld4(P.e1 + cz); o.a[4] = spm_ld4(P.e1 + P.cout + cz);
@@ -194,7 +195,8 @@ __device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, cons
     }
     v.x = spm_gelu(v.x); v.y = spm_gelu(v.y); v.z = spm_gelu(v.z); v.w = spm_gelu(v.w);
     if constexpr (EPI == EPI_LNG) {
-      if (on) spm_st4(P.out + gpz * P.out_cs + P.out_co + c, v);
+      const float4 ad = o.a[2];      // Bottleblock residual (zero without one)
+      if (on) spm_st4(P.out + gpz * P.out_cs + P.out_co + c, make_float4(v.x + ad.x, v.y + ad.y, v.z + ad.z, v.w + ad.w));
     } else {
       // trusting gate tail (temporal_ode_bayes.py:124-131 / :268-275, convolutions.py:375-380)
       const float4 sk = o.a[2], w0 = o.a[3], w1 = o.a[4], r2 = o.a[5], r1 = o.a[6], st = o.a[7], base = o.a[8], b2in = o.a[9];

@@ -99,8 +99,9 @@ class Block(PackedModule):
 
     def __init__(self, dim, drop_path=0., layer_scale_init_value=1e-6):
         super().__init__()
-        if drop_path > 0.:
-            raise NotImplementedError("inference-only: DropPath is the identity")
+        # drop_path: stochastic depth is the identity at inference (timm's DropPath returns its input when not training);
+        # accepted for signature compatibility — BiGRU passes Block(C, C) — and otherwise unused
+        self.drop_path_rate = drop_path
         self.dwconv = nn.Conv2d(dim, dim, kernel_size=7, padding=3, groups=dim)
         self.norm = LayerNorm(dim, eps=1e-6)
         self.pwconv1 = nn.Linear(dim, 4 * dim)
@@ -134,9 +135,11 @@ class Block(PackedModule):
         return runtime.to_nchw(self.forward_nhwc(runtime.to_nhwc(x)))
 
 
-class Bottleblock(nn.Module):
-    """Parameter container for the trusting-gate body (convolutions.py:348-380); executed inside
-    the dual GRU cells (layers/temporal_ode_bayes.py)."""
+class Bottleblock(PackedModule):
+    """7x7 + LN + GELU -> 1x1 + LN + GELU -> 3x3 + LN + GELU with a residual (the input itself, or a 1x1 + GELU projection
+    of it when the channel count changes) — convolutions.py:348-380.  The trusting-gate body of the dual GRU cells (which
+    run it fused with the gate's softmax / mix, layers/temporal_ode_bayes.py) and a block of ``BiGRU``; ``forward`` is the
+    stand-alone form (``sf_bottleblock_fwd``: four launches, the residual added in the last epilogue)."""
 
     def __init__(self, in_channels, out_channels=None):
         super().__init__()
@@ -149,6 +152,42 @@ class Bottleblock(nn.Module):
             nn.Conv2d(mid, out_channels, kernel_size=3, bias=False, padding=1), LayerNorm(out_channels, **cf), nn.GELU())
         self.projection = None if out_channels == in_channels else _seq(
             nn.Conv2d(in_channels, out_channels, kernel_size=1, bias=False), nn.GELU())
+        self.in_channels, self.out_channels = in_channels, out_channels
+
+    def _pack(self):
+        pk = packing.Pack(_lib.BottleW())
+        s, L, cin = pk.struct, self.layers, self.in_channels
+        mid = L[0].out_channels
+        s.c7 = packing.conv_w(pk, L[0].weight, cin, 0, scale=L[1].weight, bias=L[1].bias)
+        s.c1 = packing.conv_w(pk, L[3].weight, mid, scale=L[4].weight, bias=L[4].bias)
+        s.c3 = packing.conv_w(pk, L[6].weight, mid, scale=L[7].weight, bias=L[7].bias)
+        if self.projection is not None:
+            s.proj = packing.conv_w(pk, self.projection[0].weight, cin, 0)
+        return pk
+
+    def forward_nhwc(self, x0, x1=None):
+        """x0 [n, h, w, c0] (and x1 [n, h, w, c1]: the block then reads cat[x0, x1] without materialising it)."""
+        n, h, w, c0 = x0.shape
+        c1 = 0 if x1 is None else x1.shape[-1]
+        if c0 + c1 != self.in_channels:
+            raise ValueError(f"Bottleblock({self.in_channels}) got {c0 + c1} input channels")
+        st = self.packed().struct
+        if c1:      # same packed weights, the channel split of this call
+            if self.projection is None:
+                raise ValueError("a Bottleblock without projection adds its input: pass one tensor")
+            st = _lib.BottleW.from_buffer_copy(st)
+            st.c7.c0, st.c7.c1, st.proj.c0, st.proj.c1 = c0, c1, c0, c1
+        L = _lib.lib()
+        ws = runtime.workspace(L.sf_bottleblock_ws_bytes(self.in_channels, self.out_channels, n, h, w), x0.device)
+        out = torch.empty((n, h, w, self.out_channels), dtype=torch.float32, device=x0.device)
+        _lib.check(L.sf_bottleblock_fwd(st, ptr(x0), ptr(x1), ptr(out), n, h, w, ptr(ws), ws.numel() * 4,
+                                        runtime.stream_ptr(x0.device)), "bottleblock")
+        return out
+
+    def forward(self, *args):
+        (x,) = args
+        runtime.require_cuda(x)
+        return runtime.to_nchw(self.forward_nhwc(runtime.to_nhwc(x)))
 
 
 class ASPP(nn.Module):

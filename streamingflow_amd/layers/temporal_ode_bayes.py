@@ -125,11 +125,52 @@ class _DualCell(PackedModule):
                                       runtime.stream_ptr(s.device)), "dual_cell")
         return out
 
+    def _general_pack(self):
+        """Second packed copy for calls with several present frames: cell 2 then sees two different tensors, so its gate
+        convolution keeps both input halves (the main copy folds them, `_pack`)."""
+        sig = self._param_signature()
+        cache = self.__dict__.get("_sf_general")
+        if cache is None or cache[0] != sig:
+            C, gb = self.hidden_size, self.gru_bias_init
+            pk = packing.Pack(None)
+            with torch.no_grad():
+                g1 = pack_gru(pk, self.conv_update_1, self.conv_reset_1, self.conv_state_tilde_1, C, C, gate_bias=gb)
+                g2 = pack_gru(pk, self.conv_update_2, self.conv_reset_2, self.conv_state_tilde_2, C, C, gate_bias=gb)
+                dec2 = packing.conv_w(pk, self.conv_decoder_2.weight, C, bias=self.conv_decoder_2.bias)
+            pk.struct = (g1, g2, dec2)
+            self.__dict__["_sf_general"] = cache = (sig, pk)
+        return cache[1].struct
+
+    def _forward_frames(self, x, state):
+        """state [b, n_present > 1, C, h, w] (temporal_ode_bayes.py:101-131 / :248-275): branch 2's hidden state starts from
+        the first frame (the ODE cell warms it up over the present frames), both branches start from the last one.
+        Unused by the reference's forward path."""
+        from .temporal import conv_nhwc, gru_cell_nhwc, trust_mix_nhwc
+        g1, g2, dec2 = self._general_pack()
+        n = state.shape[1]
+        frames = [runtime.to_nhwc(state[:, t]) for t in range(n)]
+        hid = frames[0]
+        if self.derivative:               # only the ODE cell warms branch 2 up (:106-109); the observation cell keeps state[:, 0] (:252)
+            for t in range(n - 1):
+                hid = gru_cell_nhwc(g2, frames[t], hid)
+        r1 = gru_cell_nhwc(g1, runtime.to_nhwc(x[:, 0]), frames[-1])
+        hid = gru_cell_nhwc(g2, frames[-1], hid)
+        r2 = conv_nhwc(dec2, hid)
+        cur = runtime.to_nchw(trust_mix_nhwc(self.packed().struct, r1, r2))
+        if not self.derivative:
+            return cur
+        # the reference returns `cur_state - state.squeeze(1)`: with several frames the squeeze is a no-op and the
+        # difference broadcasts over them (one sample)
+        if state.shape[0] != 1:
+            raise ValueError("DualGRUODECell with n_present > 1: one sample per call (the reference's broadcast)")
+        return cur[:, None] - state
+
     def forward(self, x, state):
         runtime.require_cuda(x, state)
         if x.dim() == 5:
-            if x.shape[1] != 1 or state.shape[1] != 1:
-                raise NotImplementedError("n_present > 1 warm-up is unused by the reference forward path")
+            assert x.shape[2] == self.input_size, f'feature sizes must match, got input {x.shape[2]} for layer with size {self.input_size}'
+            if state.shape[1] != 1:
+                return self._forward_frames(x, state)
             x, state = x[:, 0], state[:, 0]
         assert x.shape[1] == self.input_size, f'feature sizes must match, got input {x.shape[1]} for layer with size {self.input_size}'
         # note: the reference mis-broadcasts for batch > 1 (SURVEY.md §0); here every sample of the
