@@ -212,7 +212,7 @@ bool sp_takes(const ConvProblem* ps, int n, int epi) {
     if (q.in_scale || q.se_sum) {
       ++scaled;
       if (q.c1 != 0 || q.cin_pad > 256 || (long)q.Hout * q.Wout < 32) return false;   // a 64-pixel tile touches <= 4 images
-      if (q.se_sum && (q.n_img != 1 || q.c0 > 128 || q.c0 < 1 || q.se_cr < 1 || q.se_cr > 16 || q.c0 != q.cin_pad)) return false;
+      if (q.se_sum && (q.n_img != 1 || q.c0 > 128 || q.c0 < 64 || q.se_cr < 1 || q.se_cr > 16 || q.c0 != q.cin_pad || q.se_nt > 20 * (512 / q.c0))) return false;
     }
     const double span = (64.0 / ((double)q.Hout * q.Wout) + 2.0) * q.Hin * q.Win * 4.0;
     if (span * q.in0_cs >= 2147483648.0 || span * q.in1_cs >= 2147483648.0 || 4.0 * q.cout_pad * q.ktot >= 2147483648.0) return false;

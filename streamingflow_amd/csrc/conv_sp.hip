@@ -24,6 +24,8 @@
 //     (MI355X_MICROARCH.md, hand-off table row 1): no release / acquire fence.  Bitwise reproducible.
 #include "sf_math.h"
 
+#include <type_traits>
+
 namespace sf {
 
 #ifdef SF_STAMP
@@ -73,6 +75,24 @@ __device__ __forceinline__ void sp_barrier() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+}
+// Sum over the 64 lanes of a wave, the same value in every lane.  DPP within the 16-lane rows (quad swaps, half mirror, row
+// mirror: VALU, no LDS round trips — six ds_bpermute steps cost ~1500 cycles in the SE prologue), v_readlane across the rows.
+__device__ __forceinline__ float sp_wave_sum(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1, 0, 3, 2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2, 3, 0, 1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror: the other quad of each half row
+  v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror: the other half row
+  const int b = __float_as_int(v);
+  return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
+#else
+  return v;
+#endif
 }
 __device__ __forceinline__ float sp_reduce16(float v) {   // sum over the 16 lanes (channel quads) of a pixel
   v += __shfl_xor(v, 1);
@@ -315,49 +335,79 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
   // tile touches go to LDS; the consumers multiply their pixel fragments by them.  Published by the first barrier.
   auto fill_scale_rows = [&]() {
     if (SCALE && P.se_sum) {   // block-uniform: compute the gate here (one image; fixed summation order; host: C <= 128, Cr <= 16)
+      // Only the 8 consumer waves work (the loaders' loads would queue behind their first DMAs); every global operand is
+      // requested up front and each thread's partial rows are all in flight together (before: four dependent round trips
+      // for the rows, three barriers, the loader waves' loads queued behind their DMAs).  What remains, ~3 us over a layer
+      // without a gate, is the miss latency of rows another XCD wrote a moment ago plus two barrier / LDS round trips.
       const int C = P.c0, Cr = P.se_cr, nt = P.se_nt;
-      float* const part = sc_lds + SP_SC_IMGS * 256;    // [G][C]
-      float* const mean = part + 768;                   // [C]
-      float* const hid = mean + 256;                    // [Cr]
-      const int G = SP_THREADS / C;                     // tile rows summed in parallel
+      float* const part = sc_lds + SP_SC_IMGS * 256;    // [G][C] partial row sums (<= 512 floats)
+      float* const hid = part + 1024;                   // [Cr]
+      constexpr int SE_Q = 20;                          // rows per thread (host: nt <= SE_Q * G)
+      const int G = 512 / C;                            // row groups summed in parallel
       const int ch = tid % C, grp = tid / C;
-      // every global operand up front: one round trip instead of three
       float f2[16];
+      float f0a = 0.f, f0b = 0.f, f0c = 0.f, f0d = 0.f;
+      if (wave < 8) {
+        const bool mine = tid < C;                      // the thread that produces the gate of channel tid
 #pragma unroll
-      for (int h = 0; h < 16; ++h) f2[h] = (tid < C && h < Cr) ? P.se_fc2[tid * Cr + h] : 0.f;
-      const int hrow = wave < Cr ? wave : 0;
-      const float f0a = (lane < C) ? P.se_fc0[hrow * C + lane] : 0.f;
-      const float f0b = (lane + 64 < C) ? P.se_fc0[hrow * C + lane + 64] : 0.f;
-      const float f0c = (wave + 12 < Cr && lane < C) ? P.se_fc0[(wave + 12) * C + lane] : 0.f;
-      const float f0d = (wave + 12 < Cr && lane + 64 < C) ? P.se_fc0[(wave + 12) * C + lane + 64] : 0.f;
-      if (grp < G) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int t = grp;
-        for (; t + 3 * G < nt; t += 4 * G) {
-          s0 += P.se_sum[(size_t)t * C + ch]; s1 += P.se_sum[(size_t)(t + G) * C + ch];
-          s2 += P.se_sum[(size_t)(t + 2 * G) * C + ch]; s3 += P.se_sum[(size_t)(t + 3 * G) * C + ch];
+        for (int h = 0; h < 16; ++h) {
+          f2[h] = P.se_fc2[min(tid, C - 1) * Cr + min(h, Cr - 1)];      // clamped, never predicated (selected after the pins below)
         }
-        for (; t < nt; t += G) s0 += P.se_sum[(size_t)t * C + ch];
-        part[grp * C + ch] = (s0 + s1) + (s2 + s3);
+        // hidden units `wave` and `wave + 8`: their fc0 rows, channels lane and lane + 64
+        const int h0 = min(wave, Cr - 1), h1 = min(wave + 8, Cr - 1);
+        const int l0 = min(lane, C - 1), l1 = min(lane + 64, C - 1);
+        float a0 = P.se_fc0[h0 * C + l0], b0 = P.se_fc0[h0 * C + l1], c0v = P.se_fc0[h1 * C + l0], d0 = P.se_fc0[h1 * C + l1];
+        float r[SE_Q];
+#pragma unroll
+        for (int q = 0; q < SE_Q; ++q) {                // rows grp, grp + G, ...: unconditional loads, selected afterwards
+          const int t = grp + q * G;
+          r[q] = P.se_sum[(size_t)min(t, nt - 1) * C + ch];
+        }
+        // hipcc sinks a load whose value is only needed under a lane mask into that region and drains vmcnt(0) behind it:
+        // every value is "used" here, unconditionally, after ALL the loads were issued -> one wait for the lot
+        asm volatile("" : "+v"(a0), "+v"(b0), "+v"(c0v), "+v"(d0));
+#pragma unroll
+        for (int h = 0; h < 16; h += 4) asm volatile("" : "+v"(f2[h]), "+v"(f2[h + 1]), "+v"(f2[h + 2]), "+v"(f2[h + 3]));
+#pragma unroll
+        for (int q = 0; q < SE_Q; q += 4) asm volatile("" : "+v"(r[q]), "+v"(r[q + 1]), "+v"(r[q + 2]), "+v"(r[q + 3]));
+#pragma unroll
+        for (int h = 0; h < 16; ++h) f2[h] = (mine && h < Cr) ? f2[h] : 0.f;
+#pragma unroll
+        for (int q = 0; q < SE_Q; ++q) r[q] = (grp + q * G < nt && grp < G) ? r[q] : 0.f;
+        f0a = (wave < Cr && lane < C) ? a0 : 0.f;
+        f0b = (wave < Cr && lane + 64 < C) ? b0 : 0.f;
+        f0c = (wave + 8 < Cr && lane < C) ? c0v : 0.f;
+        f0d = (wave + 8 < Cr && lane + 64 < C) ? d0 : 0.f;
+        float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < SE_Q; ++q) acc4[q & 3] += r[q];
+        if (grp < G) part[grp * C + ch] = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
       }
       __syncthreads();
-      if (tid < C) {
-        float s = 0.f;
-        for (int q = 0; q < G; ++q) s += part[q * C + tid];
-        mean[tid] = s * P.se_inv_hw;
-      }
-      __syncthreads();
-      {   // hidden units wave and wave + 12 (12 waves, Cr <= 16)
-        float s = f0a * (lane < C ? mean[lane] : 0.f) + f0b * (lane + 64 < C ? mean[lane + 64] : 0.f);
-        float u = f0c * (lane < C ? mean[lane] : 0.f) + f0d * (lane + 64 < C ? mean[lane + 64] : 0.f);
-        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); u += __shfl_xor(u, o); }
+      if (wave < 8) {
+        // channel means of lane and lane + 64: the G <= 8 partial sums are read together (clamped, selected afterwards —
+        // a dependent LDS round trip per partial cost ~300 cycles each)
+        float pl[8], ph[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          pl[q] = part[min(q, G - 1) * C + min(lane, C - 1)];
+          ph[q] = part[min(q, G - 1) * C + min(lane + 64, C - 1)];
+        }
+        float m_lo = 0.f, m_hi = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          m_lo += (q < G && lane < C) ? pl[q] : 0.f;
+          m_hi += (q < G && lane + 64 < C) ? ph[q] : 0.f;
+        }
+        m_lo *= P.se_inv_hw; m_hi *= P.se_inv_hw;
+        const float s = sp_wave_sum(f0a * m_lo + f0b * m_hi), u = sp_wave_sum(f0c * m_lo + f0d * m_hi);
         if (lane == 0 && wave < Cr) hid[wave] = s > 0.f ? s : 0.f;
-        if (lane == 0 && wave + 12 < Cr) hid[wave + 12] = u > 0.f ? u : 0.f;
+        if (lane == 0 && wave + 8 < Cr) hid[wave + 8] = u > 0.f ? u : 0.f;
       }
       __syncthreads();
       for (int idx = tid; idx < SP_SC_IMGS * cin_pad; idx += SP_THREADS) {
         float sv = 0.f;
-        if (idx < C) {      // idx == tid here (C <= 128 < SP_THREADS)
+        if (idx < C) {      // idx == tid here (C <= 128: consumer waves 0 and 1, which hold f2)
           float s = 0.f;
 #pragma unroll
           for (int h = 0; h < 16; ++h) s += f2[h] * (h < Cr ? hid[h] : 0.f);
