@@ -144,7 +144,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -170,6 +170,7 @@ const Tune& tune() {
     x.small_dma = geti("SF_SMALL_DMA", 1);         // >= 0: plain layers below LARGE_P run on the LDS-DMA kernel (32x32 tiles); bit 0: GRU candidates too (pre-gated state)
     x.narrow = geti("SF_NARROW", 9);             // tile variant for layers with <= 32 output channels (32 cout x 128 px; -1: the 64-row tiles)
     x.large_p = geti("SF_LARGE_P", 8192);      // measured: a 4-sample rollout (10000 px) is 18 % faster on the small-P kernels, 8 samples (20000 px) on the large tiles
+    x.mid_minch_ln = geti("SF_MID_MINCH_LN", 1);   // LayerNorm-epilogue layers at mid P take the 64x64 tiles from this many K chunks (the 1x1 of the trusting gate: 4-sample step 415 -> 408 us; 8: the round-1 rule, 64x128 tiles for short K)
     x.split_cfg = geti("SF_SPLIT_CFG", 4);         // tile config of the mid-P split-K launches without a LayerNorm epilogue (4 | 1)
     x.split_from = geti("SF_SPLIT_FROM", 100);     // only layers with at least this many K chunks (the 7x7)
     return x;
@@ -390,7 +391,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   const bool split_small = (cfg == 0 || cfg == 3) && chunks_max >= tune().split_from;
   // a few batched samples (P = 8k..40k pixels): the large-tile kernels would have too few tiles,
   // each walking the whole K range; split the K range instead (also keeps LayerNorm layers on 64x64)
-  const bool split_mid = (cfg == 1 || cfg == 2) && tiles_total < tune().mid_tiles && chunks_max >= 8;
+  const bool split_mid = (cfg == 1 || cfg == 2) && tiles_total < tune().mid_tiles && chunks_max >= (cfg == 2 ? tune().mid_minch_ln : 8);
   if ((split_small || split_mid) && tune().split && g_split) {
     // workgroup budget shared in proportion to each problem's work (tiles x chunks)
     double work_total = 0;
