@@ -206,3 +206,25 @@ def test_split_k_handoff_is_stable_under_repetition(pair64):
             cell.run_nhwc(x, s, out, True, s, one)
             if i % 10 == 9:
                 assert torch.equal(out, ref), (B, i)
+
+
+@pytest.mark.parametrize("B", [2, 3, 9])
+def test_infer_state_of_batched_samples_equals_per_sample_calls(pair64, B):
+    """Several 50x50 samples share one pixel space; the SE gates are per sample.  With 2500 pixels per image the 16-pixel
+    groups whose channel sums feed the gates straddle the image borders (the producers split those sums at the border):
+    the batched call must reproduce the per-sample calls (same kernels at B = 1 and the oracle-checked path)."""
+    net, _ = pair64
+    ode = net.gru_ode
+    s = (hashfill.normal("bs_s", (B, 64, 50, 50), 71) * 0.5).cuda()
+    eps = hashfill.normal("bs_e", (B, 64, 50, 50), 72)
+    try:
+        ode.noise = lambda shape, dtype, device: eps.clone()
+        with torch.no_grad():
+            y, q = ode.infer_state(s)
+        for i in range(B):
+            ode.noise = lambda shape, dtype, device, i=i: eps[i:i + 1].clone()
+            with torch.no_grad():
+                yi, qi = ode.infer_state(s[i:i + 1])
+            assert maxabs(q[i:i + 1], qi) <= 2e-5 and maxabs(y[i:i + 1], yi) <= 2e-5, i
+    finally:
+        ode.noise = None
