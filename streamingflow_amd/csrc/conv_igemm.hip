@@ -56,13 +56,7 @@ __device__ __forceinline__ float pix_allreduce(float v) {
   return v;
 }
 // sum over the 16 pixels (lanes with equal l>>4) of a wave tile
-__device__ __forceinline__ float tile_px_reduce(float v) {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
-  return v;
-}
+__device__ __forceinline__ float tile_px_reduce(float v) { return spm_row16_sum(v); }
 
 // One ds_read_b64 per fragment.  The 36-float row pitch is conflict-free for ds_read_b64 (banks
 // (a/4) mod 64 over 32-lane halves) but 2-way conflicting for the ds_read2_b64 hipcc would merge

@@ -80,13 +80,7 @@ __device__ __forceinline__ void sp_barrier() {
 // mirror: VALU, no LDS round trips — six ds_bpermute steps cost ~1500 cycles in the SE prologue), v_readlane across the rows.
 __device__ __forceinline__ float sp_wave_sum(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  auto dpp = [](float x, auto ctrl) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true));
-  };
-  v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1, 0, 3, 2]
-  v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2, 3, 0, 1]
-  v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror: the other quad of each half row
-  v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror: the other half row
+  v = spm_row16_sum(v);
   const int b = __float_as_int(v);
   return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
          (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
@@ -94,13 +88,7 @@ __device__ __forceinline__ float sp_wave_sum(float v) {
   return v;
 #endif
 }
-__device__ __forceinline__ float sp_reduce16(float v) {   // sum over the 16 lanes (channel quads) of a pixel
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
-  return v;
-}
+__device__ __forceinline__ float sp_reduce16(float v) { return spm_row16_sum(v); }   // sum over the 16 lanes (channel quads) of a pixel
 
 // Epilogue operands of one (pixel, channel quad) item.  They are loaded by the consumer waves BEFORE the K loop (every one of
 // them was written by an earlier launch), so that the epilogue is arithmetic + stores only: measured 1.1-2.8 us per launch

@@ -25,6 +25,19 @@ __device__ __forceinline__ float4 spm_ld4(const float* p) { return *reinterpret_
 __device__ __forceinline__ void spm_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 spm_zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// Sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), the result in every lane of the row: quad swaps, half-row
+// mirror, row mirror — four VALU instructions, no LDS round trips (the ds_bpermute butterfly they replace adds the same
+// operands in the same order: bitwise identical).
+__device__ __forceinline__ float spm_row16_sum(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1, 0, 3, 2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2, 3, 0, 1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
+#endif
+  return v;
+}
+
 // ---- in-kernel Gaussian noise (throughput mode of infer_state: no eps tensor) -------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11), counter = (pixel, channel, draw, offset low), key = (seed low, seed high ^ offset
 // high): the noise of an element depends only on (seed, offset, draw, pixel, channel) — not on the kernel, the tiling or the
