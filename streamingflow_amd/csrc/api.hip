@@ -239,17 +239,31 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   std::memset(&L, 0, sizeof(L));
   if (n < 1 || n > SF_MAX_GROUP) return SF_ERR_INVALID;
   int P = 0;
+  bool wide_ln = false;      // a LayerNorm / trust epilogue over 65..128 channels (hidden sizes above every shipped config)
   for (int i = 0; i < n; ++i) {
     L.p[i] = ps[i];
     int Pi = ps[i].n_img * ps[i].Hout * ps[i].Wout;
     if (Pi > P) P = Pi;
-    if ((epi == EPI_LNG || epi == EPI_TRUST) && ps[i].cout_pad > 64) return SF_ERR_UNSUPPORTED;
+    if ((epi == EPI_LNG || epi == EPI_TRUST) && ps[i].cout_pad > 128) return SF_ERR_UNSUPPORTED;
+    wide_ln = wide_ln || ((epi == EPI_LNG || epi == EPI_TRUST) && ps[i].cout_pad > 64);
   }
   L.nprob = n;
   if (P <= 0) return SF_OK;
   for (int i = 0; i < n; ++i) {   // the staged kernels keep per-tap element offsets (relative to the tile's first image) in 32 bits
     const double e0 = 2.0 * ps[i].Hin * ps[i].Win * ps[i].in0_cs, e1 = 2.0 * ps[i].Hin * ps[i].Win * ps[i].in1_cs;
     if (!ps[i].gather && (e0 >= 2147483648.0 || e1 >= 2147483648.0)) return SF_ERR_UNSUPPORTED;
+  }
+  if (wide_ln) {
+    // all channels of a pixel must sit in one wave: 128 cout x 64 px tiles of the LDS-DMA kernel, whatever the pixel count
+    for (int i = 0; i < n; ++i) {
+      const ConvProblem& q = ps[i];
+      const double span = (256.0 / ((double)q.Hout * q.Wout) + 2.0) * q.Hin * q.Win * 4.0;
+      if (q.gate || q.gather || q.in_scale || q.se_sum || !one_source_per_chunk(q) || span * q.in0_cs >= 2147483648.0 ||
+          span * q.in1_cs >= 2147483648.0 || 4.0 * q.cout_pad * q.ktot >= 2147483648.0)
+        return SF_ERR_UNSUPPORTED;
+    }
+    SF_HIP(launch_conv_glds(L, epi, 5, 0, st));
+    return SF_OK;
   }
   if (sp_takes(ps, n, epi)) {
     // K ranges are split across workgroups (sc1 slab hand-off) so that the launch has about sp_split_wgs workgroups of
@@ -966,7 +980,7 @@ int sf_dual_cell_fwd(const sf_dual_w* w, const float* x, const float* s, float* 
                      const float* coef, float* out2, int acc2, int n_img, int H, int W, float* ws, size_t ws_bytes,
                      void* stream) {
   if (!w || !x || !s || !out || w->C <= 0 || (w->C % 8) || n_img < 1) return SF_ERR_INVALID;
-  if (w->C > 64) return SF_ERR_UNSUPPORTED;
+  if (w->C > 128) return SF_ERR_UNSUPPORTED;
   Arena A(ws, ws_bytes);
   SplitScope sp(A, (hipStream_t)stream);
   return dual_cell(*w, x, s, out, derivative, base, coef, 0, out2, acc2, n_img, H, W, A, (hipStream_t)stream);
@@ -977,7 +991,7 @@ int sf_trust_mix_fwd(const sf_dual_w* w, const float* r1, const float* r2, const
                      const float* base, const float* coef, int n_img, int H, int W, float* ws, size_t ws_bytes, void* stream) {
   if (!w || !r1 || !r2 || !out || w->C <= 0 || (w->C % 8) || n_img < 1) return SF_ERR_INVALID;
   if (derivative && (!s || !coef)) return SF_ERR_INVALID;
-  if (w->C > 64) return SF_ERR_UNSUPPORTED;
+  if (w->C > 128) return SF_ERR_UNSUPPORTED;
   Arena A(ws, ws_bytes);
   SplitScope sp(A, (hipStream_t)stream);
   CellBufs b;
@@ -997,7 +1011,7 @@ int sf_bottleblock_fwd(const sf_bottle_w* w, const float* x0, const float* x1, f
   if (!w || !x0 || !out || n_img < 1 || !valid_w(w->c7) || !valid_w(w->c1) || !valid_w(w->c3)) return SF_ERR_INVALID;
   const bool has_proj = w->proj.w != nullptr;
   if (!has_proj && (x1 || w->c7.c1 != 0 || w->c3.cout != w->c7.c0)) return SF_ERR_INVALID;      // the residual is x itself
-  if (w->c7.cout_pad > 64 || w->c3.cout_pad > 64) return SF_ERR_UNSUPPORTED;                      // LayerNorm epilogue: all channels of a pixel in one wave
+  if (w->c7.cout_pad > 128 || w->c3.cout_pad > 128) return SF_ERR_UNSUPPORTED;                    // LayerNorm epilogue: all channels of a pixel in one wave
   hipStream_t st = (hipStream_t)stream;
   Arena A(ws, ws_bytes);
   SplitScope sp(A, st);
@@ -1041,7 +1055,7 @@ int sf_ode_step_fwd(const sf_dual_w* gru_c, const sf_pmodel_w* pm, int solver, i
                     const float* p_in, const float* coef, const float* eps, float* state_out, float* p_out, int n_img,
                     int H, int W, float* ws, size_t ws_bytes, void* stream) {
   if (!gru_c || !pm || !state_in || !p_in || !coef || !eps || !state_out || !p_out || n_img < 1) return SF_ERR_INVALID;
-  if (gru_c->C > 64 || (gru_c->C % 8)) return SF_ERR_UNSUPPORTED;
+  if (gru_c->C > 128 || (gru_c->C % 8)) return SF_ERR_UNSUPPORTED;
   Arena A(ws, ws_bytes);
   hipStream_t st = (hipStream_t)stream;
   SplitScope sp(A, st);
@@ -1095,7 +1109,7 @@ static int rollout_core(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const 
                         const float* coef, int coef_per_image, const int32_t* sel_nops, int n_targets, float* out_states,
                         float* final_state, int n_img, int H, int W, float* ws, size_t ws_bytes, void* stream) {
   if (!gru_c || !gru_obs || !pm || !ops || !hx_obs || (!eps && !philox) || !sel_nops || !out_states || n_img < 1) return SF_ERR_INVALID;
-  if (gru_c->C > 64 || (gru_c->C % 8)) return SF_ERR_UNSUPPORTED;
+  if (gru_c->C > 128 || (gru_c->C % 8)) return SF_ERR_UNSUPPORTED;
   if (solver != SF_SOLVER_EULER && solver != SF_SOLVER_MIDPOINT && solver != SF_SOLVER_RK4) return SF_ERR_INVALID;
   const int C = gru_c->C, B = n_img;
   const size_t PC = (size_t)B * H * W * C;

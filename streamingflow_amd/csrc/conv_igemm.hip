@@ -1074,6 +1074,11 @@ hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant,
     if (epi == EPI_TRUST) return launch_glds_t<4, 2, 1, 4, EPI_TRUST>(L, stream);
     return hipErrorInvalidValue;
   }
+  if (tile == 5) {   // LayerNorm epilogues over 65..128 output channels (hidden sizes no shipped config uses): 128 cout x 64 px, 4 waves of 128x16
+    if (epi == EPI_LNG) return launch_glds_t<8, 1, 1, 4, EPI_LNG>(L, stream);
+    if (epi == EPI_TRUST) return launch_glds_t<8, 1, 1, 4, EPI_TRUST>(L, stream);
+    return hipErrorInvalidValue;
+  }
   if (tile == 4) {   // cross-workgroup split-K launches: 64 cout x 64 px, 4 waves of 64x16 (all channels of a pixel in one wave)
     switch (epi) {
       case EPI_AFFINE: return launch_glds_t<4, 1, 1, 4, EPI_AFFINE>(L, stream);

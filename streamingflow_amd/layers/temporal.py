@@ -136,8 +136,8 @@ class Dual_GRU(PackedModule):
     def __init__(self, in_channels, latent_dim, n_future, mixture=True, gru_bias_init=0.0):
         super().__init__()
         from .convolutions import Bottleblock
-        if latent_dim % 8 or latent_dim > 64 or in_channels % 4:
-            raise NotImplementedError("Dual_GRU: latent_dim a multiple of 8, <= 64 (the gate's LayerNorm layers keep a pixel's channels in one wave)")
+        if latent_dim % 8 or latent_dim > 128 or in_channels % 4:
+            raise NotImplementedError("Dual_GRU: latent_dim a multiple of 8, <= 128 (the gate's LayerNorm layers keep a pixel's channels in one wave)")
         self.n_future, self.mixture = n_future, mixture
         self.input_size, self.hidden_size, self.gru_bias_init = in_channels, latent_dim, gru_bias_init
         for tag, cx in (("1", in_channels), ("2", latent_dim)):
@@ -190,8 +190,8 @@ class BiGRU(PackedModule):
     def __init__(self, in_channels, gru_bias_init=0.0):
         super().__init__()
         from .convolutions import Block, Bottleblock
-        if in_channels % 8 or in_channels > 64:
-            raise NotImplementedError("BiGRU: in_channels a multiple of 8, <= 64")
+        if in_channels % 8 or in_channels > 128:
+            raise NotImplementedError("BiGRU: in_channels a multiple of 8, <= 128")
         self.input_size = self.hidden_size = in_channels
         self.gru_bias_init = gru_bias_init
         for tag in ("1", "2"):

@@ -84,8 +84,8 @@ class _DualCell(PackedModule):
 
     def __init__(self, input_size, hidden_size, gru_bias_init=0.0, norm='bn', activation='relu', bias=True):
         super().__init__()
-        if input_size != hidden_size or hidden_size % 8 or hidden_size > 64:
-            raise NotImplementedError("dual GRU cell: input_size == hidden_size, multiple of 8, <= 64")
+        if input_size != hidden_size or hidden_size % 8 or hidden_size > 128:
+            raise NotImplementedError("dual GRU cell: input_size == hidden_size, multiple of 8, <= 128")
         self.input_size, self.hidden_size, self.gru_bias_init = input_size, hidden_size, gru_bias_init
         c2 = input_size + hidden_size
         for tag in ("1", "2"):

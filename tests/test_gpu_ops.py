@@ -228,3 +228,24 @@ def test_infer_state_of_batched_samples_equals_per_sample_calls(pair64, B):
             assert maxabs(q[i:i + 1], qi) <= 2e-5 and maxabs(y[i:i + 1], yi) <= 2e-5, i
     finally:
         ode.noise = None
+
+
+@pytest.mark.parametrize("C", [96, 128])
+def test_hidden_sizes_above_64_vs_oracle(C):
+    """Hidden sizes no shipped config uses (65..128 channels): the LayerNorm / trusting-gate epilogues then run on
+    128-channel tiles (all channels of a pixel in one wave).  Dual cells and one Euler step against the oracle."""
+    net, sd = build_pair(C)
+    h, w = 16, 20
+    x = hashfill.normal("xw", (1, C, h, w), 81)
+    s = hashfill.normal("sw", (1, C, h, w), 82) * 0.5
+    ode = net.gru_ode
+    try:
+        with torch.no_grad():
+            assert maxabs(ode.gru_c(x.cuda(), s.cuda()), R.dual_cell(sd, "gru_ode.gru_c", x, s, True)) <= TOL
+            assert maxabs(ode.gru_obs(s.cuda(), None, x.cuda())[0], R.dual_cell(sd, "gru_ode.gru_obs.gru_d", x, s, False)) <= TOL
+            ode.noise = _noise()
+            st, inp, *_ = ode.ode_step(s.cuda(), x.cuda(), 0.3, 0.0)
+            sr, ir = R.ode_step(sd, "gru_ode", s, x, 0.3, "euler", True, _noise())
+        assert maxabs(st, sr) <= TOL and maxabs(inp, ir) <= TOL
+    finally:
+        ode.noise = None
