@@ -1,27 +1,31 @@
-// Small-pixel-count implicit-GEMM convolution for the GRU-ODE latent (one to four 50x50 samples): the kernel behind
-// every layer of ode_step / the Bayesian jump when P = n_img*Hout*Wout < 12288.  gfx950 only.
+// Small-pixel-count implicit-GEMM convolution for the GRU-ODE latent: the kernel behind every layer of ode_step / the
+// Bayesian jump of ONE 50x50 sample (P = n_img*Hout*Wout < 4096; from two samples on the large-tile kernels of
+// conv_igemm.hip are as fast or faster).  gfx950 only.
 //
-// Why a second kernel.  In-kernel time stamps of the round-1 small-P kernels (tools/r02/stamps.py, profiles/r02_*)
-// showed where a 2500-pixel layer loses its time: every wave issued its own LDS-DMAs (~550 cycles of address
-// arithmetic + issue per 32-deep chunk at one wave per SIMD), owned ONE 16x16 accumulator (LDS-read latency + the
-// 40-cycle dependent MFMA latency exposed: ~750 cycles for 8 MFMAs), one wave ran the whole epilogue behind a chain of
-// dependent global loads (4-7 us for the LayerNorm / trusting-gate tails), and a cross-workgroup split-K hand-off cost
-// 5-14 us in the agent-scope release fence.  Structure here, one 768-thread workgroup per CU:
+// Why a second kernel.  A 2500-pixel layer has 40-80 tiles, fewer than the chip has CUs, and a step is a chain of eleven
+// such layers: what counts is the latency of one workgroup on one CU.  In-kernel time stamps of the round-1 small-P kernels
+// (tools/r02/stamps.py) showed where that went: every wave issued its own LDS-DMAs (~550 cycles of address arithmetic +
+// issue per 32-deep chunk), owned ONE 16x16 accumulator, one wave ran the whole epilogue behind a chain of dependent
+// global loads (4-7 us for the LayerNorm / trusting-gate tails), and a cross-workgroup split-K hand-off cost 5-14 us in
+// the agent-scope release fence.  Structure here, one 768-thread workgroup per CU:
 //   * roles: waves 8-11 are LOADERS (all im2col address arithmetic + buffer_load ... lds issue), waves 0-7 CONSUMERS
-//     (ds_read_b128 + MFMA only).  Two consumers and one loader share each SIMD, so the matrix pipe has two
-//     instruction streams to draw from and the DMA issue runs beside them instead of in front of them.
-//   * tile 64 cout x 32 px; a K chunk is 64 deep (two 32-deep sub-chunks in the packed K order, each a [96 rows][32]
-//     block with the 16-B slots XOR-swizzled by (row>>1)&7 through the DMA's per-lane SOURCE address); ring of 3 chunk
-//     buffers, 2 chunks in flight, one s_barrier per chunk placed between a chunk's fragment reads and its MFMAs.
+//     (ds_read_b128 + MFMA only).  Two consumers and one loader share each SIMD.
+//   * tile 64 cout x 32 px (NT = 2) or 64 x 64 px (NT = 4); a K chunk is 64 deep (two 32-deep sub-chunks in the packed K
+//     order, each a [64 + BN rows][32] block with the 16-B slots XOR-swizzled by (row>>1)&7 through the DMA's per-lane
+//     SOURCE address); ring of 3 chunk buffers, 2 chunks in flight, one s_barrier per chunk placed between a chunk's
+//     fragment reads and its MFMAs.
 //   * consumer (mh, kq): cout half mh, K quarter kq of every chunk (16 K values = one ds_read_b128 per 16-row
-//     fragment): 4 fragment reads feed 16 MFMAs on 4 accumulators.  In-workgroup split-K over the 4 quarters, reduced
-//     through LDS in a fixed order.
+//     fragment): 2 + NT fragment reads feed 8 NT MFMAs.  In-workgroup split-K over the 4 quarters, reduced through LDS in
+//     a fixed order.
 //   * distributed epilogue: after the reduction lane (pixel, channel quad) of the 512 consumer lanes owns ONE float4 of
-//     the tile; LayerNorm / softmax statistics are 16-lane shuffles; every epilogue operand is loaded up front in one
-//     round trip.
-//   * cross-workgroup split-K (long K: the 7x7 trusting-gate conv): partial tiles leave with sc1 (write-through)
-//     stores, one agent-scope ticket per workgroup, the last arriver re-reads all slices with sc1 loads in slice order
-//     (MI355X_MICROARCH.md, hand-off table row 1): no release / acquire fence.  Bitwise reproducible.
+//     the tile; LayerNorm / softmax statistics are DPP sums over 16-lane rows; every epilogue operand is requested before
+//     the K loop.
+//   * cross-workgroup split-K (NT = 4): partial tiles leave with sc1 (write-through) stores, one agent-scope ticket per
+//     workgroup, the last arriver re-reads all slices with sc1 loads in slice order (MI355X_MICROARCH.md, hand-off table
+//     row 1): no release / acquire fence.  Bitwise reproducible.  Compact 1-D grid of at most 256 workgroups.
+//   * the SE gate of the input (one image) is computed in the prologue from the producer's per-tile channel sums.
+// What bounds it: the fp32 MFMA shares the vector ALU — every DMA instruction costs ~60 cycles of matrix
+// time, every VALU instruction 4-8; the shipped loop runs at ~70 % of the MFMA rate on 64x64 tiles.
 #include "sf_math.h"
 
 #include <type_traits>
@@ -60,11 +64,6 @@ constexpr int sp_lds_bytes(bool scale) { return (SpGeo<NT>::RING + SP_MISC + (sc
 
 typedef __attribute__((address_space(3))) void sp_lds_void;
 
-#ifdef SP_EXP_FRESH      // experiment: small per-call tables written by the previous kernel are read past the CU's vector L1
-#define SP_FRESH_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#else
-#define SP_FRESH_LOAD(p) (*(p))
-#endif
 
 __device__ __forceinline__ f32x4 sp_lds_read128(const float* p) {
   typedef const __attribute__((address_space(3))) f32x4 lds_f4;
@@ -409,7 +408,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
       const float* const in_scale = P.in_scale;
       for (int idx = tid; idx < SP_SC_IMGS * cin_pad; idx += SP_THREADS) {
         const int si = idx / cin_pad, ch = idx - si * cin_pad;
-        sc_lds[idx] = (in_scale && img0 + si < P.n_img && ch < P.c0) ? SP_FRESH_LOAD(in_scale + (size_t)(img0 + si) * P.c0 + ch) : (in_scale ? 0.f : 1.f);
+        sc_lds[idx] = (in_scale && img0 + si < P.n_img && ch < P.c0) ? in_scale[(size_t)(img0 + si) * P.c0 + ch] : (in_scale ? 0.f : 1.f);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -428,10 +427,6 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
     if (wave < 8) sp_epi_load<EPI>(P, p_tile * BN + px[i], c_out, on_item[i], HWout, ops[i]);
   }
   SF_STAMP_AT(L, 0);
-#ifdef SP_EXP_ZERO_LDS     // experiment: no LDS word is read before this kernel wrote it
-  for (int i = tid; i < G::RING + SP_MISC + (SCALE ? SP_SC_FLOATS : 0); i += SP_THREADS) smem[i] = 0.f;
-  __syncthreads();
-#endif
 
   if (wave >= 8) {
     // ================================= loader =================================================================
