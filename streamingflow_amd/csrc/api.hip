@@ -144,7 +144,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -171,6 +171,7 @@ const Tune& tune() {
     x.narrow = geti("SF_NARROW", 9);             // tile variant for layers with <= 32 output channels (32 cout x 128 px; -1: the 64-row tiles)
     x.large_p = geti("SF_LARGE_P", 8192);      // measured: a 4-sample rollout (10000 px) is 18 % faster on the small-P kernels, 8 samples (20000 px) on the large tiles
     x.mid_minch_ln = geti("SF_MID_MINCH_LN", 1);   // LayerNorm-epilogue layers at mid P take the 64x64 tiles from this many K chunks (the 1x1 of the trusting gate: 4-sample step 415 -> 408 us; 8: the round-1 rule, 64x128 tiles for short K)
+    x.sp_fuse_1x1 = geti("SF_SP_FUSE_1X1", 1);     // small-P kernel: the trusting gate's 1x1 layer runs inside the 7x7 layer's launch
     x.split_cfg = geti("SF_SPLIT_CFG", 4);         // tile config of the mid-P split-K launches without a LayerNorm epilogue (4 | 1)
     x.split_from = geti("SF_SPLIT_FROM", 100);     // only layers with at least this many K chunks (the 7x7)
     return x;
@@ -606,9 +607,18 @@ int cell_tail(const sf_dual_w& w, const float* s, float* out, int derivative, co
   ConvProblem ps[2];
   ps[0] = problem(w.tg7, b.h1, b.r2, b.t1, B, H, W); ps[0].mode = 1;       // 7x7 + LN + GELU
   ps[1] = problem(w.tgproj, b.h1, b.r2, b.sk, B, H, W); ps[1].mode = 0;   // 1x1 projection + GELU
-  SF_TRY(run(ps, 2, EPI_LNG, st));
   ConvProblem q = problem(w.tg1, b.t1, nullptr, b.t2, B, H, W); q.mode = 1;
-  SF_TRY(run1(q, EPI_LNG, st));
+  // one latent on the small-P kernel: the 1x1 + LN + GELU layer is applied to the 7x7 layer's tile before it leaves the
+  // workgroup (one launch and one 0.64-MB round trip fewer per cell evaluation)
+  const bool fuse_1x1 = tune().sp_fuse_1x1 && sp_takes(ps, 2, EPI_LNG) && sp_takes(&q, 1, EPI_LNG) && w.tg1.kh == 1 && w.tg1.kw == 1 &&
+                        w.tg1.c1 == 0 && w.tg1.cin_pad <= 64 && w.tg1.cout_pad <= 64 && w.tg7.cout_pad <= 64 && w.tg1.scale && w.tg1.bias;
+  if (fuse_1x1) {
+    ps[0].out = nullptr;
+    ps[0].fuse_w = w.tg1.w; ps[0].fuse_scale = w.tg1.scale; ps[0].fuse_bias = w.tg1.bias; ps[0].fuse_out = b.t2;
+    ps[0].fuse_cout = w.tg1.cout; ps[0].fuse_cout_pad = w.tg1.cout_pad; ps[0].fuse_kpad = w.tg1.cin_pad;
+  }
+  SF_TRY(run(ps, 2, EPI_LNG, st));
+  if (!fuse_1x1) SF_TRY(run1(q, EPI_LNG, st));
   ConvProblem f = problem(w.tg3, b.t2, nullptr, out, B, H, W);
   f.e0 = b.sk; f.e1 = w.w_logit; f.e2 = b.r2; f.e3 = b.h1; f.e4 = s; f.e5 = base ? base : s;
   f.coef = coef; f.coef_stride = coef_stride; f.out2 = out2; f.mode = (derivative ? 1 : 0) | (acc2 ? 2 : 0);

@@ -203,7 +203,9 @@ __device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, cons
     v.x = spm_gelu(v.x); v.y = spm_gelu(v.y); v.z = spm_gelu(v.z); v.w = spm_gelu(v.w);
     if constexpr (EPI == EPI_LNG) {
       const float4 ad = o.a[2];      // Bottleblock residual (zero without one)
-      if (on) spm_st4(P.out + gpz * P.out_cs + P.out_co + c, make_float4(v.x + ad.x, v.y + ad.y, v.z + ad.z, v.w + ad.w));
+      const float4 y = make_float4(v.x + ad.x, v.y + ad.y, v.z + ad.z, v.w + ad.w);
+      if (on && P.out) spm_st4(P.out + gpz * P.out_cs + P.out_co + c, y);      // no `out`: the tile feeds the fused 1x1 layer only
+      y_out = on ? y : spm_zero4();
     } else {
       // trusting gate tail (temporal_ode_bayes.py:124-131 / :268-275, convolutions.py:375-380)
       const float4 sk = o.a[2], w0 = o.a[3], w1 = o.a[4], r2 = o.a[5], r1 = o.a[6], st = o.a[7], base = o.a[8], b2in = o.a[9];
@@ -426,6 +428,16 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
     on_item[i] = (wave < 8) && (p_tile * BN + px[i]) < Ptot && c_out < P.cout;
     if (wave < 8) sp_epi_load<EPI>(P, p_tile * BN + px[i], c_out, on_item[i], HWout, ops[i]);
   }
+  // fused 1x1 layer (LNG launches, block-uniform): its weights and this tile's output meet in a chunk-shaped buffer behind
+  // the ring — [2 sub-chunks][64 weight rows | BN pixel rows][32] — and run through the consumers' fragment / MFMA code once more
+  const bool fuse = (EPI == EPI_LNG) && P.fuse_w != nullptr;
+  float* const fz = misc + SP_MISC + (SCALE ? SP_SC_FLOATS : 0);
+  float4 fuse_lw = spm_zero4(), fuse_lb = spm_zero4();
+  if (fuse && wave < 8) {
+    const int cz = c_out < P.fuse_cout ? c_out : 0;
+    fuse_lw = spm_ld4(P.fuse_scale + cz);
+    fuse_lb = spm_ld4(P.fuse_bias + cz);
+  }
   SF_STAMP_AT(L, 0);
 
   if (wave >= 8) {
@@ -473,6 +485,21 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
     const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(in1 ? in1 : in0, in1 ? imgs_left * P.Hin * P.Win * in1_cs * sizeof(float) : 0);
 #else
     (void)in0; (void)in1;
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (fuse) {      // the fused layer's weights: 2 sub-chunks x 64 rows, this loader's row blocks lw and lw + 4 (zeros past its K)
+      const __amdgpu_buffer_rsrc_t rsrc_f = make_rsrc(P.fuse_w, (size_t)P.fuse_cout_pad * P.fuse_kpad * sizeof(float));
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = 8 * (lw + 4 * i) + (lane >> 3);
+          const int k4 = (lane & 7) ^ ((r >> 1) & 7);
+          const int grow = r < P.fuse_cout_pad ? r : P.fuse_cout_pad - 1;
+          const int vo = (s2 * 32 < P.fuse_kpad) ? (grow * P.fuse_kpad + s2 * 32 + k4 * 4) * (int)sizeof(float) : -1;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_f, (sp_lds_void*)(fz + s2 * G::SUBF + (8 * (lw + 4 * i)) * 32), 16, vo, 0, 0, 0);
+        }
+    }
 #endif
     // cursor of the next sub-chunk to fetch
     int sc = 2 * cb;
@@ -729,11 +756,82 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
   SF_STAMP_AT(L, 4);
   const int c = c_out;
   float4 ysum = spm_zero4();
+  if (!fuse) {
 #pragma unroll
-  for (int i = 0; i < G::NPX; ++i) {
-    float4 y = spm_zero4();
-    sp_epilogue<EPI>(P, v[i], p_tile * BN + px[i], c, on_item[i], ops[i], y);
-    ysum.x += y.x; ysum.y += y.y; ysum.z += y.z; ysum.w += y.w;
+    for (int i = 0; i < G::NPX; ++i) {
+      float4 y = spm_zero4();
+      sp_epilogue<EPI>(P, v[i], p_tile * BN + px[i], c, on_item[i], ops[i], y);
+      ysum.x += y.x; ysum.y += y.y; ysum.z += y.z; ysum.w += y.w;
+    }
+  }
+  if constexpr (EPI == EPI_LNG) {
+    if (fuse) {      // block-uniform; only the workgroup that owns the finished tile gets here
+      // this lane's four channels of its pixels are one 16-B slot of the pixel rows (K = channel: sub-chunk c / 32)
+      // (the loaders' DMAs of the fused weights landed long ago: their K loop ended with vmcnt(0))
+#pragma unroll
+      for (int i = 0; i < G::NPX; ++i) {
+        float4 y = spm_zero4();
+        sp_epilogue<EPI>(P, v[i], p_tile * BN + px[i], c, on_item[i], ops[i], y);
+        if (wave < 8) {
+          const int row = SP_BM + px[i];
+          spm_st4(fz + (quad >> 3) * G::SUBF + row * 32 + (((quad & 7) ^ ((row >> 1) & 7)) << 2), y);
+        }
+      }
+      __syncthreads();
+      if (wave < 8) {
+        const int mh = wave & 1, kq = wave >> 1, j = lane & 15, g = lane >> 4;
+        const int slot4 = ((((kq & 1) << 2) + g) ^ ((j >> 1) & 7)) * 4;
+        const float* const base = fz + (kq >> 1) * G::SUBF;
+        f32x4 fa2[2], fb2[NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) fa2[m] = sp_lds_read128(base + (32 * mh + 16 * m + j) * 32 + slot4);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) fb2[n] = sp_lds_read128(base + (SP_BM + 16 * n + j) * 32 + slot4);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa2[m][e], fb2[n][e], acc[m][n], 0, 0, 0);
+        // K quarters through the reduction buffer once more (every read of the first pass is behind two barriers)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            spm_st4(red + ((kq * BN) + 16 * n + j) * SP_RED_PITCH + 32 * mh + 16 * m + 4 * g,
+                    make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]));
+      }
+      __syncthreads();
+      if (wave < 8) {
+        const bool cv = c < P.fuse_cout;
+        const float inv_c = 1.f / (float)P.fuse_cout;
+#pragma unroll
+        for (int i = 0; i < G::NPX; ++i) {
+          float4 t = spm_zero4();
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq) {
+            const float4 u = spm_ld4(red + (kq * BN + px[i]) * SP_RED_PITCH + 4 * quad);
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+          }
+          // channels-first LayerNorm over the pixel's channels + GELU (convolutions.py:303-308, :359-360)
+          const float mean = sp_reduce16(cv ? (t.x + t.y) + (t.z + t.w) : 0.f) * inv_c;
+          const float dx = t.x - mean, dy = t.y - mean, dz = t.z - mean, dw = t.w - mean;
+          const float var = sp_reduce16(cv ? (dx * dx + dy * dy) + (dz * dz + dw * dw) : 0.f) * inv_c;
+          const float rstd = 1.f / sqrtf(var + P.eps);
+          float4 y;
+          y.x = spm_gelu(fuse_lw.x * (dx * rstd) + fuse_lb.x); y.y = spm_gelu(fuse_lw.y * (dy * rstd) + fuse_lb.y);
+          y.z = spm_gelu(fuse_lw.z * (dz * rstd) + fuse_lb.z); y.w = spm_gelu(fuse_lw.w * (dw * rstd) + fuse_lb.w);
+          const int gp = p_tile * BN + px[i];
+          if (gp < Ptot && cv) spm_st4(P.fuse_out + (size_t)gp * P.fuse_cout + c, y);
+        }
+      }
+      return;
+    }
   }
   if constexpr (EPI == EPI_AFFINE) {
     if (P.chansum) {   // block-uniform: per-tile channel sums of `out` for the next SE gate, fixed order
@@ -768,24 +866,27 @@ static hipError_t launch_sp_t(const ConvLaunch& L, hipStream_t stream) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
   if (!attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, sp_lds_bytes<NT>(SCALE));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, sp_lds_bytes<NT>(SCALE) + SpGeo<NT>::BUFF * 4);
     if (e != hipSuccess) return e;
     attr_done[dev] = true;
   }
   int maxblocks = 0, zs = 1;
+  bool fused = false;
   for (int i = 0; i < L.nprob; ++i) {
     const ConvProblem& P = L.p[i];
+    fused = fused || P.fuse_w != nullptr;
     const int Ptot = P.n_img * P.Hout * P.Wout;
     const int nb = ((Ptot + 16 * NT - 1) / (16 * NT)) * ((P.cout_pad + SP_BM - 1) / SP_BM);
     maxblocks = nb > maxblocks ? nb : maxblocks;
     zs = P.nsplit > zs ? P.nsplit : zs;
   }
   if (maxblocks == 0) return hipSuccess;
+  const int lds = sp_lds_bytes<NT>(SCALE) + (fused ? SpGeo<NT>::BUFF * 4 : 0);      // + the fused 1x1 layer's chunk buffer
   if (L.wg_base[L.nprob] > 0) {      // compact 1-D grid (the host filled wg_base for this tile size)
-    hipLaunchKernelGGL(kern, dim3(L.wg_base[L.nprob], 1, 1), dim3(SP_THREADS), sp_lds_bytes<NT>(SCALE), stream, L);
+    hipLaunchKernelGGL(kern, dim3(L.wg_base[L.nprob], 1, 1), dim3(SP_THREADS), lds, stream, L);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(kern, dim3(maxblocks, L.nprob, zs), dim3(SP_THREADS), sp_lds_bytes<NT>(SCALE), stream, L);
+  hipLaunchKernelGGL(kern, dim3(maxblocks, L.nprob, zs), dim3(SP_THREADS), lds, stream, L);
   return hipGetLastError();
 }
 

@@ -76,6 +76,14 @@ struct ConvProblem {
   float* se_out;          // [c0] (may be null)
   int se_nt, se_cr;
   float se_inv_hw;
+  // small-P kernel, LNG epilogue: a following 1x1 + LayerNorm + GELU layer (the middle layer of the trusting-gate body,
+  // convolutions.py:358-360) applied to the tile before it leaves the workgroup: out2 = GELU(LN(fuse_w . GELU(LN(conv)))).
+  // fuse_w: packed [fuse_cout_pad <= 64][fuse_kpad <= 64] (K = this layer's cout); the first layer's own output is not stored
+  const float* fuse_w;
+  const float* fuse_scale;   // LayerNorm weight / bias of the fused layer
+  const float* fuse_bias;
+  float* fuse_out;           // [P][fuse_cout]
+  int fuse_cout, fuse_cout_pad, fuse_kpad;
 };
 
 #define SF_MAX_GROUP 4
