@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary sections (next-row components, ODE step alone)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the all-gather of per-sample BEV grids out of the timed region")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed workload and its roofline pass (profiling aid: the rocprofv3 "
+                    "kernel statistics of such a run average over exactly the launches the roofline object describes)")
     return ap.parse_args()
 
 
@@ -162,17 +164,19 @@ def main():
     # ---- single-sample latency of the same forward (batch 1) -----------------------------------------
     def forward1():
         return net(x_in[:1], cam_d[:1], lid_d[:1], cts, lts, tts)
-    forward1()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
+    single_ms = None
+    if not a.headline_only:
         forward1()
-    torch.cuda.synchronize()
-    single_ms = 1e3 * (time.perf_counter() - t0) / 3
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            forward1()
+        torch.cuda.synchronize()
+        single_ms = 1e3 * (time.perf_counter() - t0) / 3
 
     L = _lib.lib()
     rollout = step_only = roof_step = None
-    if world == 1:      # secondary sections: single-GPU runs only (at N > 1 no rank may lag behind the others)
+    if world == 1 and not a.headline_only:      # secondary sections: single-GPU runs only (at N > 1 no rank may lag behind the others)
         # ---- ODE rollout alone (the serial chain the north star names), same stream, hipEvents -------
         ode = net.gru_ode
         hx = torch.randn((len(times), H // 4, W // 4, C), device=dev) * 0.5
@@ -396,7 +400,7 @@ def main():
 
     # ---- camera lift-splat voxel pooling feeding the BEV tensor (HBM-bound gather) ----
     lift = None
-    if rank == 0 and world == 1 and not a.no_extras:     # secondary figures: single-GPU runs only (no rank may lag behind the others at N > 1)
+    if rank == 0 and world == 1 and not a.no_extras and not a.headline_only:     # secondary figures: single-GPU runs only (no rank may lag behind the others at N > 1)
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import liftbench
@@ -408,7 +412,7 @@ def main():
             lift = {"error": repr(ex)}
 
     vox = None
-    if rank == 0 and world == 1 and not a.no_extras:
+    if rank == 0 and world == 1 and not a.no_extras and not a.headline_only:
         try:
             import voxelbench
             vox = voxelbench.run(reps=10, cpu=(world == 1 and not a.no_cpu_baseline), dev=dev)
@@ -418,7 +422,7 @@ def main():
             vox = {"error": repr(ex)}
 
     dec = None
-    if rank == 0 and world == 1 and not a.no_extras:
+    if rank == 0 and world == 1 and not a.no_extras and not a.headline_only:
         try:
             import decoderbench
             dec = decoderbench.run(reps=5, cpu=(world == 1 and not a.no_cpu_baseline), dev=dev)
@@ -431,7 +435,7 @@ def main():
 
     # ---- CPU baseline: the oracle (torch-CPU port of the reference path) on the host cores --------
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.headline_only:
         from oracle import ref_torch as R
         cores = min(os.cpu_count() or 1, 16)   # more threads only thrash on these small convs
         torch.set_num_threads(cores)
@@ -458,9 +462,11 @@ def main():
                           "batch_per_gpu": B,
                           "parallelism": f"replicas x{world} (sample sharding; " + ("RCCL all-gather of one BEV grid per rank per forward on a side stream)" if do_gather else "no data-path collective)")},
                "samples_per_s": B * a.steps * world / el, "batch_per_gpu": B, "ms_per_sample": ms_per_step / B,
-               "batch1_forward": {"what": "the same FuturePredictionODE.forward at the reference's own batch size (evaluate.py:46: one sample per call)",
-                                  "ms_per_forward": single_ms, "ode_steps_per_s": n_ode / (single_ms * 1e-3), "samples_per_s": 1e3 / single_ms},
-               "single_sample_forward_ms": single_ms, "single_sample_ode_steps_per_s": n_ode / (single_ms * 1e-3),
+               "batch1_forward": None if single_ms is None else {
+                   "what": "the same FuturePredictionODE.forward at the reference's own batch size (evaluate.py:46: one sample per call)",
+                   "ms_per_forward": single_ms, "ode_steps_per_s": n_ode / (single_ms * 1e-3), "samples_per_s": 1e3 / single_ms},
+               "single_sample_forward_ms": single_ms,
+               "single_sample_ode_steps_per_s": None if single_ms is None else n_ode / (single_ms * 1e-3),
                "roofline_ode_step": roof_step, "multi_gpu": multi,
                "ode_rollout_only": rollout, "ode_step_only": step_only, "lift_splat": lift, "lidar_voxelize": vox, "bev_decoder": dec, "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
