@@ -601,6 +601,20 @@ void cell_cand_problems(const sf_dual_w& w, const float* x, const float* s, cons
     c2.gate = b.g2; c2.gate_cs = 2 * C; c2.gate_co = C;
   }
 }
+// Small-P kernel: a 1x1 + LayerNorm + GELU layer `q` (weights w1) that follows the LayerNorm layer ps[0] is applied to ps[0]'s
+// tile before it leaves the workgroup (conv_sp.hip, ConvProblem::fuse_*); ps[0]'s own output is then not stored.  Returns
+// whether the launch of ps carries q.
+bool fuse_following_1x1(ConvProblem* ps, int n, const ConvProblem& q, const sf_conv_w& w1, float* out) {
+  if (!tune().sp_fuse_1x1 || !sp_takes(ps, n, EPI_LNG) || !sp_takes(&q, 1, EPI_LNG)) return false;
+  if (w1.kh != 1 || w1.kw != 1 || w1.c1 != 0 || w1.cin_pad > 64 || w1.cout_pad > 64 || ps[0].cout_pad > 64 || !w1.scale || !w1.bias ||
+      w1.c0 != ps[0].cout || q.add)
+    return false;
+  ps[0].out = nullptr;
+  ps[0].fuse_w = w1.w; ps[0].fuse_scale = w1.scale; ps[0].fuse_bias = w1.bias; ps[0].fuse_out = out;
+  ps[0].fuse_cout = w1.cout; ps[0].fuse_cout_pad = w1.cout_pad; ps[0].fuse_kpad = w1.cin_pad;
+  return true;
+}
+
 // trusting gate + mix + integrator update   (:124-131, convolutions.py:348-380)
 int cell_tail(const sf_dual_w& w, const float* s, float* out, int derivative, const float* base, const float* coef,
               int coef_stride, float* out2, int acc2, const CellBufs& b, int B, int H, int W, hipStream_t st) {
@@ -610,13 +624,7 @@ int cell_tail(const sf_dual_w& w, const float* s, float* out, int derivative, co
   ConvProblem q = problem(w.tg1, b.t1, nullptr, b.t2, B, H, W); q.mode = 1;
   // one latent on the small-P kernel: the 1x1 + LN + GELU layer is applied to the 7x7 layer's tile before it leaves the
   // workgroup (one launch and one 0.64-MB round trip fewer per cell evaluation)
-  const bool fuse_1x1 = tune().sp_fuse_1x1 && sp_takes(ps, 2, EPI_LNG) && sp_takes(&q, 1, EPI_LNG) && w.tg1.kh == 1 && w.tg1.kw == 1 &&
-                        w.tg1.c1 == 0 && w.tg1.cin_pad <= 64 && w.tg1.cout_pad <= 64 && w.tg7.cout_pad <= 64 && w.tg1.scale && w.tg1.bias;
-  if (fuse_1x1) {
-    ps[0].out = nullptr;
-    ps[0].fuse_w = w.tg1.w; ps[0].fuse_scale = w.tg1.scale; ps[0].fuse_bias = w.tg1.bias; ps[0].fuse_out = b.t2;
-    ps[0].fuse_cout = w.tg1.cout; ps[0].fuse_cout_pad = w.tg1.cout_pad; ps[0].fuse_kpad = w.tg1.cin_pad;
-  }
+  const bool fuse_1x1 = fuse_following_1x1(ps, 2, q, w.tg1, b.t2);
   SF_TRY(run(ps, 2, EPI_LNG, st));
   if (!fuse_1x1) SF_TRY(run1(q, EPI_LNG, st));
   ConvProblem f = problem(w.tg3, b.t2, nullptr, out, B, H, W);
@@ -1032,14 +1040,11 @@ int sf_bottleblock_fwd(const sf_bottle_w* w, const float* x0, const float* x1, f
   if (!A.ok()) return SF_ERR_WORKSPACE;
   ConvProblem ps[2];
   ps[0] = problem(w->c7, x0, x1, t1, n_img, H, W); ps[0].mode = 1;        // 7x7 + LN + GELU
-  if (has_proj) {
-    ps[1] = problem(w->proj, x0, x1, sk, n_img, H, W); ps[1].mode = 0;   // 1x1 + GELU
-    SF_TRY(run(ps, 2, EPI_LNG, st));
-  } else {
-    SF_TRY(run1(ps[0], EPI_LNG, st));
-  }
   ConvProblem q = problem(w->c1, t1, nullptr, t2, n_img, H, W); q.mode = 1;
-  SF_TRY(run1(q, EPI_LNG, st));
+  if (has_proj) { ps[1] = problem(w->proj, x0, x1, sk, n_img, H, W); ps[1].mode = 0; }   // 1x1 + GELU
+  const bool fused = fuse_following_1x1(ps, has_proj ? 2 : 1, q, w->c1, t2);
+  SF_TRY(run(ps, has_proj ? 2 : 1, EPI_LNG, st));
+  if (!fused) SF_TRY(run1(q, EPI_LNG, st));
   ConvProblem f = problem(w->c3, t2, nullptr, out, n_img, H, W); f.mode = 1;
   f.add = has_proj ? sk : x0;
   f.add_cs = has_proj ? w->proj.cout : w->c7.c0;
