@@ -222,7 +222,7 @@ bool sp_takes(const ConvProblem* ps, int n, int epi) {
   if (scaled && (scaled != n || (epi != EPI_AFFINE && epi != EPI_SAMPLE))) return false;
   return true;
 }
-// pixels per tile of the small-P kernel.  Measured on the 11 conv launches of an Euler step at 50x50 (profiles/r02_*):
+// pixels per tile of the small-P kernel.  Measured on the conv launches of an Euler step at 50x50 (profiles/r02_*):
 // 64-pixel tiles with the K range split across workgroups win where a launch has a lot of work (both gate / candidate
 // pairs, the 128 -> 128 layers of p_model, the 7x7), 32-pixel tiles without a hand-off elsewhere
 int sp_bn(const ConvProblem* ps, int n) {

@@ -2,7 +2,7 @@
 // Bayesian jump of ONE 50x50 sample (P = n_img*Hout*Wout < 4096; from two samples on the large-tile kernels of
 // conv_igemm.hip are as fast or faster).  gfx950 only.
 //
-// Why a second kernel.  A 2500-pixel layer has 40-80 tiles, fewer than the chip has CUs, and a step is a chain of eleven
+// Why a second kernel.  A 2500-pixel layer has 40-80 tiles, fewer than the chip has CUs, and a step is a chain of ten
 // such layers: what counts is the latency of one workgroup on one CU.  In-kernel time stamps of the round-1 small-P kernels
 // (tools/r02/stamps.py) showed where that went: every wave issued its own LDS-DMAs (~550 cycles of address arithmetic +
 // issue per 32-deep chunk), owned ONE 16x16 accumulator, one wave ran the whole epilogue behind a chain of dependent
