@@ -414,3 +414,72 @@ def single_gru_cell(sd, x, state, ode, p=""):
     cand = torch.cat([x, (1.0 - r) * state], dim=1)
     cand = F.relu(_bn(sd, p + "conv_state_tilde.norm", _conv(sd, p + "conv_state_tilde.conv", cand, padding=1)))
     return u * (cand - state) if ode else (1.0 - u) * state + u * cand
+
+
+# ---- modules the reference defines but never constructs ------------------------------------------------
+
+def _dual_branches(sd, p, x, r1, r2, hid, gru_bias_init=0.0):
+    """One pass of the two branches + trusting gate shared by Dual_GRU (layers/temporal.py:112-122) and the dual cells
+    (temporal_ode_bayes.py:116-129): returns (cur, new hidden state of branch 2)."""
+    r1 = gru_cell(sd, p, x, r1, "_1", gru_bias_init)
+    hid = gru_cell(sd, p, r2, hid, "_2", gru_bias_init)
+    r2 = _conv(sd, p + ".conv_decoder_2", hid, padding=1)
+    t = bottleblock(sd, p + ".trusting_gate.0", torch.cat([r1, r2], dim=1))
+    g = torch.softmax(_conv(sd, p + ".trusting_gate.1", t), dim=1)
+    return r2 * g[:, 0:1] + r1 * g[:, 1:], hid
+
+
+def dual_gru(sd, x, state, n_future, mixture=True, gru_bias_init=0.0):
+    """layers/temporal.py:88-126 (``Dual_GRU.forward``) on a bare state_dict: x [b, 1, Cin, h, w],
+    state [b, n_present, C, h, w] -> [b, n_future, C, h, w]."""
+    m = _prefixed(sd)
+    hid = state[:, 0]
+    for t in range(state.shape[1] - 1):                  # warm-up of branch 2 over the present frames
+        hid = gru_cell(m, "m", state[:, t], hid, "_2", gru_bias_init)
+    r1 = r2 = state[:, -1]
+    out = []
+    for _ in range(n_future):
+        r1n = gru_cell(m, "m", x[:, 0], r1, "_1", gru_bias_init)
+        hid = gru_cell(m, "m", r2, hid, "_2", gru_bias_init)
+        r2n = _conv(m, "m.conv_decoder_2", hid, padding=1)
+        t = bottleblock(m, "m.trusting_gate.0", torch.cat([r1n, r2n], dim=1))
+        g = torch.softmax(_conv(m, "m.trusting_gate.1", t), dim=1)
+        cur = r2n * g[:, 0:1] + r1n * g[:, 1:]
+        out.append(cur)
+        r1, r2 = (cur, cur) if mixture else (r1n, r2n)
+    return torch.stack(out, dim=1)
+
+
+def _prefixed(sd, name="m"):
+    """The functions above address parameters as '<prefix>.<key>'; a bare module state_dict gets a prefix."""
+    return {name + "." + k: v for k, v in sd.items()}
+
+
+def bigru(sd, x, gru_bias_init=0.0):
+    """layers/temporal.py:183-213 (``BiGRU.forward``) on a bare state_dict: x [b, s, C, h, w]."""
+    m = _prefixed(sd)
+    b, s, c, h, w = x.shape
+    r1, r2 = x[:, 0], x[:, -1]
+    fwd, bwd = [], []
+    for t in range(s):
+        r1 = gru_cell(m, "m", x[:, t], r1, "_1", gru_bias_init)
+        r2 = gru_cell(m, "m", x[:, s - t - 1], r2, "_2", gru_bias_init)
+        fwd.append(bottleblock(m, "m.conv_decoder_1", r1))
+        bwd.append(bottleblock(m, "m.conv_decoder_2", r2))
+    states = torch.cat([torch.stack(fwd, dim=1), torch.stack(bwd[::-1], dim=1)], dim=2).view(b * s, 2 * c, h, w)
+    y = bottleblock(m, "m.res_blocks.0", states)
+    y = convnext_block(m, "m.res_blocks.2", convnext_block(m, "m.res_blocks.1", y))
+    return y.view(b, s, c, h, w)
+
+
+def dual_cell_frames(sd, x, state, derivative, gru_bias_init=0.0):
+    """The dual cells with several present frames (temporal_ode_bayes.py:101-131 / :248-275) on a bare state_dict:
+    x [b, 1, C, h, w], state [b, n, C, h, w].  Only the ODE cell warms branch 2 up; its result is ``cur - state`` broadcast
+    over the frames (the reference's ``squeeze(1)`` is a no-op for n > 1)."""
+    m = _prefixed(sd)
+    hid = state[:, 0]
+    if derivative:
+        for t in range(state.shape[1] - 1):
+            hid = gru_cell(m, "m", state[:, t], hid, "_2", gru_bias_init)
+    cur, _ = _dual_branches(m, "m", x[:, 0], state[:, -1], state[:, -1], hid, gru_bias_init)
+    return cur - state if derivative else cur

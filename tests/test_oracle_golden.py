@@ -114,3 +114,26 @@ def test_gate_bias_cells():
             for key, cls, seed, deriv in (("dual_ode_cell", tob.DualGRUODECell, 32, True), ("dual_cell", tob.DualGRUCell, 33, False)):
                 sd = {"c." + k: v for k, v in hashfill.fill_state_dict(cls(C, C).state_dict(), seed=seed, gain=0.6).items()}
                 assert maxabs(R.dual_cell(sd, "c", x, s, deriv, gb), g[f"{key}_{tag}"]) <= TOL, (key, tag)
+
+
+def test_unused_recurrent_modules():
+    """the oracle's Dual_GRU / BiGRU / several-present-frames dual cells against the fixtures produced by
+    the reference classes (tests/golden/unused_cells.npz)."""
+    g = gold("unused_cells.npz")
+    I = cases.unused_cell_inputs()
+    fill = lambda shapes, key: hashfill.fill_state_dict(shapes, seed=cases.UNUSED_CELL_SEEDS[key], gain=0.6)
+    from streamingflow_amd.layers.temporal import BiGRU, Dual_GRU
+    from streamingflow_amd.layers.temporal_ode_bayes import DualGRUCell, DualGRUODECell
+    with torch.no_grad():
+        for mix in (True, False):
+            sd = fill(Dual_GRU(8, 8, n_future=3, mixture=mix, gru_bias_init=0.3).state_dict(), "dual_gru")
+            assert maxabs(R.dual_gru(sd, I["x1"], I["st1"], 3, mix, 0.3), g[f"dual_gru_mix{int(mix)}_p1"]) <= TOL
+            assert maxabs(R.dual_gru(sd, I["x1"], I["st3"], 3, mix, 0.3), g[f"dual_gru_mix{int(mix)}_p3"]) <= TOL
+        sd = fill(Dual_GRU(16, 8, n_future=2).state_dict(), "dual_gru_wide")
+        assert maxabs(R.dual_gru(sd, I["x1w"], I["st1"], 2), g["dual_gru_wide"]) <= TOL
+        sd = fill(BiGRU(8, gru_bias_init=-0.2).state_dict(), "bigru")
+        assert maxabs(R.bigru(sd, I["seq"], -0.2), g["bigru"]) <= 2 * TOL
+        sd = fill(DualGRUODECell(8, 8).state_dict(), "dual_ode")
+        assert maxabs(R.dual_cell_frames(sd, I["x1b1"], I["st2b1"], True), g["dual_ode_p2"]) <= TOL
+        sd = fill(DualGRUCell(8, 8).state_dict(), "dual_obs")
+        assert maxabs(R.dual_cell_frames(sd, I["x1"], I["st3"], False), g["dual_obs_p3"]) <= TOL
