@@ -171,7 +171,7 @@ const Tune& tune() {
     x.narrow = geti("SF_NARROW", 9);             // tile variant for layers with <= 32 output channels (32 cout x 128 px; -1: the 64-row tiles)
     x.large_p = geti("SF_LARGE_P", 8192);      // measured: a 4-sample rollout (10000 px) is 18 % faster on the small-P kernels, 8 samples (20000 px) on the large tiles
     x.mid_minch_ln = geti("SF_MID_MINCH_LN", 1);   // LayerNorm-epilogue layers at mid P take the 64x64 tiles from this many K chunks (the 1x1 of the trusting gate: 4-sample step 415 -> 408 us; 8: the round-1 rule, 64x128 tiles for short K)
-    x.sp_fuse_1x1 = geti("SF_SP_FUSE_1X1", 3);     // the trusting gate's 1x1 layer runs inside the 7x7 layer's launch: bit 0 small-P kernel, bit 1 the other kernels
+    x.sp_fuse_1x1 = geti("SF_SP_FUSE_1X1", 1);     // small-P kernel: the trusting gate's 1x1 layer runs inside the 7x7 layer's launch
     x.split_cfg = geti("SF_SPLIT_CFG", 4);         // tile config of the mid-P split-K launches without a LayerNorm epilogue (4 | 1)
     x.split_from = geti("SF_SPLIT_FROM", 100);     // only layers with at least this many K chunks (the 7x7)
     return x;
@@ -605,17 +605,10 @@ void cell_cand_problems(const sf_dual_w& w, const float* x, const float* s, cons
 // tile before it leaves the workgroup (conv_sp.hip, ConvProblem::fuse_*); ps[0]'s own output is then not stored.  Returns
 // whether the launch of ps carries q.
 bool fuse_following_1x1(ConvProblem* ps, int n, const ConvProblem& q, const sf_conv_w& w1, float* out) {
-  if (!tune().sp_fuse_1x1) return false;
-  if (w1.kh != 1 || w1.kw != 1 || w1.c1 != 0 || !w1.scale || !w1.bias || w1.c0 != ps[0].cout || q.add || ps[0].add) return false;
-  if (sp_takes(ps, n, EPI_LNG)) {
-    // small-P kernel: second GEMM through a chunk-shaped LDS buffer (64-channel tiles)
-    if (!sp_takes(&q, 1, EPI_LNG) || w1.cin_pad > 64 || w1.cout_pad > 64 || ps[0].cout_pad > 64) return false;
-  } else {
-    // the other kernels (bit 1 of the knob): the tile is the MFMA B operand as it sits in the registers of the LayerNorm
-    // epilogue; both layers must fit the wave tile that holds all channels of a pixel (64, or 128 on the wide tiles)
-    const int wave_rows = ps[0].cout_pad > 64 ? 128 : 64;
-    if (!(tune().sp_fuse_1x1 & 2) || w1.cout_pad > wave_rows || w1.cin_pad > ((wave_rows + 31) / 32) * 32 || ps[0].gather) return false;
-  }
+  if (!tune().sp_fuse_1x1 || !sp_takes(ps, n, EPI_LNG) || !sp_takes(&q, 1, EPI_LNG)) return false;
+  if (w1.kh != 1 || w1.kw != 1 || w1.c1 != 0 || w1.cin_pad > 64 || w1.cout_pad > 64 || ps[0].cout_pad > 64 || !w1.scale || !w1.bias ||
+      w1.c0 != ps[0].cout || q.add)
+    return false;
   ps[0].out = nullptr;
   ps[0].fuse_w = w1.w; ps[0].fuse_scale = w1.scale; ps[0].fuse_bias = w1.bias; ps[0].fuse_out = out;
   ps[0].fuse_cout = w1.cout; ps[0].fuse_cout_pad = w1.cout_pad; ps[0].fuse_kpad = w1.cin_pad;

@@ -224,59 +224,7 @@ __device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[
         for (int q = 0; q < 4; ++q) v[m][q] = gelu_f(v[m][q]);
 
       if constexpr (EPI == EPI_LNG) {
-        if (P.fuse_w) {      // block-uniform
-          // A following 1x1 + LayerNorm + GELU layer (ConvProblem::fuse_*) on the tile while it is in registers: lane (j, g)
-          // holds channels 16 m + 4 g + q of pixel j — exactly the B operand of v_mfma_f32_16x16x4 for the K step (m, q) —
-          // and the 16 x 4 weight fragment of output block mo is one float4 per lane straight from the packed [cout][K] rows.
-          f32x4 acc2[MT];
-#pragma unroll
-          for (int mo = 0; mo < MT; ++mo) acc2[mo] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            if (16 * m < P.fuse_kpad) {      // block-uniform
-#pragma unroll
-              for (int mo = 0; mo < MT; ++mo) {
-                if (16 * mo < P.fuse_cout_pad) {      // block-uniform
-                  const float4 wf = ld4(P.fuse_w + (size_t)(16 * mo + j) * P.fuse_kpad + 16 * m + 4 * g);
-                  const float bz0 = (pv && cvm[m]) ? v[m][0] : 0.f, bz1 = (pv && cvm[m]) ? v[m][1] : 0.f;
-                  const float bz2 = (pv && cvm[m]) ? v[m][2] : 0.f, bz3 = (pv && cvm[m]) ? v[m][3] : 0.f;
-                  acc2[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.x, bz0, acc2[mo], 0, 0, 0);
-                  acc2[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.y, bz1, acc2[mo], 0, 0, 0);
-                  acc2[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.z, bz2, acc2[mo], 0, 0, 0);
-                  acc2[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.w, bz3, acc2[mo], 0, 0, 0);
-                }
-              }
-            }
-          }
-          // channels-first LayerNorm over the fused layer's channels + GELU, same lane layout as the first layer
-          const float inv_c2 = 1.f / (float)P.fuse_cout;
-          bool cv2[MT];
-          float s2 = 0.f;
-#pragma unroll
-          for (int mo = 0; mo < MT; ++mo) {
-            cv2[mo] = (16 * mo + 4 * g) < P.fuse_cout;
-            if (cv2[mo]) s2 += (acc2[mo][0] + acc2[mo][1]) + (acc2[mo][2] + acc2[mo][3]);
-          }
-          const float mean2 = pix_allreduce(s2) * inv_c2;
-          float sq2 = 0.f;
-#pragma unroll
-          for (int mo = 0; mo < MT; ++mo)
-            if (cv2[mo]) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { const float d = acc2[mo][q] - mean2; sq2 += d * d; }
-            }
-          const float rstd2 = 1.f / sqrtf(pix_allreduce(sq2) * inv_c2 + P.eps);
-#pragma unroll
-          for (int mo = 0; mo < MT; ++mo)
-            if (pv && cv2[mo]) {
-              const int c = 16 * mo + 4 * g;
-              const float4 w2 = ld4(P.fuse_scale + c), b2 = ld4(P.fuse_bias + c);
-              float4 y;
-              y.x = gelu_f(w2.x * ((acc2[mo][0] - mean2) * rstd2) + b2.x); y.y = gelu_f(w2.y * ((acc2[mo][1] - mean2) * rstd2) + b2.y);
-              y.z = gelu_f(w2.z * ((acc2[mo][2] - mean2) * rstd2) + b2.z); y.w = gelu_f(w2.w * ((acc2[mo][3] - mean2) * rstd2) + b2.w);
-              st4(P.fuse_out + (size_t)gp * P.fuse_cout + c, y);
-            }
-        } else if (pv) {
+        if (pv) {
 #pragma unroll
           for (int m = 0; m < MT; ++m)
             if (cvm[m]) {
