@@ -249,3 +249,29 @@ def test_hidden_sizes_above_64_vs_oracle(C):
         assert maxabs(st, sr) <= TOL and maxabs(inp, ir) <= TOL
     finally:
         ode.noise = None
+
+
+@pytest.mark.parametrize("C,h,w,B", [(8, 5, 7, 1), (16, 13, 9, 2), (24, 31, 17, 1), (32, 50, 50, 1), (48, 23, 40, 1), (64, 37, 41, 1),
+                                     (64, 63, 64, 1), (64, 64, 65, 1), (40, 19, 21, 3), (64, 8, 8, 5)])
+def test_cells_and_step_at_odd_latent_sizes(C, h, w, B):
+    """Latent sizes and widths no config ships (ragged last tiles, 1..5 samples in one pixel space, channel counts that pad
+    to the next 32): dual ODE cell, observation cell, infer_state and one Euler step against the oracle, sample by sample."""
+    net, sd = build_pair(C)
+    ode = net.gru_ode
+    x = hashfill.normal("xo", (B, C, h, w), 91)
+    s = hashfill.normal("so", (B, C, h, w), 92) * 0.5
+    eps = hashfill.normal("eo", (B, C, h, w), 93)
+    try:
+        with torch.no_grad():
+            d = ode.gru_c(x.cuda(), s.cuda())
+            o = ode.gru_obs(s.cuda(), None, x.cuda())[0]
+            ode.noise = lambda shape, dtype, device: eps.clone()
+            st, inp, *_ = ode.ode_step(s.cuda(), x.cuda(), 0.25, 0.0)
+            for i in range(B):
+                xi, si = x[i:i + 1], s[i:i + 1]
+                assert maxabs(d[i:i + 1], R.dual_cell(sd, "gru_ode.gru_c", xi, si, True)) <= TOL
+                assert maxabs(o[i:i + 1], R.dual_cell(sd, "gru_ode.gru_obs.gru_d", xi, si, False)) <= TOL
+                sr, ir = R.ode_step(sd, "gru_ode", si, xi, 0.25, "euler", True, lambda shape, dtype, device, i=i: eps[i:i + 1].clone())
+                assert maxabs(st[i:i + 1], sr) <= TOL and maxabs(inp[i:i + 1], ir) <= TOL
+    finally:
+        ode.noise = None
