@@ -52,14 +52,106 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the all-gather of per-sample BEV grids out of the timed region")
     ap.add_argument("--headline-only", action="store_true", help="only the timed workload and its roofline pass (profiling aid: the rocprofv3 "
                     "kernel statistics of such a run average over exactly the launches the roofline object describes)")
+    ap.add_argument("--dry", action="store_true", help="no GPU: the launcher, the rendezvous, the sample sharding, the timed-region collectives "
+                    "and the JSON relay on the gloo backend with a stub forward (tests/test_bench_launcher.py); the line says \"dry\": true")
     return ap.parse_args()
+
+
+def launch_ranks(a, argv):
+    """``python bench.py --gpus N`` (N > 1) outside torchrun: start the N ranks as children — one process per GPU through
+    ``python -m torch.distributed.run`` on 127.0.0.1 — BEFORE this process touches the GPU (it never does: it only relays
+    the children's output and exits with their return code; no exec)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["SF_BENCH_LAUNCHED_BY"] = "bench.py"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line_ok = False
+    for line in p.stdout:                      # relay as it comes; the JSON line of rank 0 must report all N ranks
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        if line.startswith("{"):
+            try:
+                line_ok = line_ok or json.loads(line).get("n_gpus") == a.gpus
+            except ValueError:
+                pass
+    rc = p.wait()
+    if rc == 0 and not line_ok:
+        sys.stderr.write(f"bench.py: the {a.gpus} ranks exited 0 without a JSON line for n_gpus={a.gpus}\n")
+        rc = 3
+    return rc
+
+
+def dry_run(a, world):
+    """The N > 1 control flow without a GPU (gloo, CPU tensors): rendezvous, sample sharding, barrier-bracketed timed
+    region with the all-gather inside, MAX over ranks, counters all-reduce, one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    from streamingflow_amd import dist as sfd
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, n_ode = max(1, a.batch), 10
+    grid = torch.full((2, 4, 8, 8), float(rank))
+
+    def forward():
+        time.sleep(0.002)
+        return [grid]
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+    got = None
+    for _ in range(a.warmup):
+        forward()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        y = forward()
+        if world > 1:
+            got = sfd.gather_predictions({rank: y[0]}, world)
+    fence()
+    el = time.perf_counter() - t0
+    multi = None
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        assert all(float(g.flatten()[0]) == r for r, g in enumerate(got)), "all-gather returned a wrong slot"
+        cnt = sfd.reduce_counters(torch.ones(8))
+        assert float(cnt[0]) == world
+        multi = {"rccl_world": dist.get_world_size(), "backend": dist.get_backend(), "gather_in_timed_region": True,
+                 "gather_bytes_per_rank": grid.numel() * 4, "gather_bytes_total": grid.numel() * 4 * world, "gather_ms_standalone": None}
+    if rank == 0:
+        print(json.dumps({"metric": "ODE-steps/s (DRY RUN: stub forward, no GPU)", "dry": True, "value": n_ode * B * a.steps * world / el,
+                          "unit": "ODE-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
+                          "launched_by": os.environ.get("SF_BENCH_LAUNCHED_BY", "torchrun"), "multi_gpu": multi}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:      # not under torchrun: be the launcher (nothing below runs in this process)
+        sys.exit(launch_ranks(a, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:                                     # never fall through to a different rank count than asked for
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE is {world}")
+    if a.dry:
+        return dry_run(a, world)
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # SF_BENCH_BACKEND=gloo + SF_BENCH_ONE_DEVICE=1: exercise the multi-rank path on a 1-GPU box
@@ -72,8 +164,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend, rank=rank, world_size=world)
-        if a.gpus != world:
-            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE is {world}")
         assert dist.get_world_size() == world and dist.get_backend() == backend
 
     import streamingflow_amd as sfa
@@ -290,7 +380,7 @@ def main():
         if os.path.exists(pmc_step):
             try:
                 pmc_step_data = json.load(open(pmc_step))
-                step_only["rocprof_hbm"] = pmc_step_data
+                step_only["rocprof_fabric_traffic"] = pmc_step_data
             except Exception:
                 pass
 
@@ -346,7 +436,7 @@ def main():
             by = (16.0 + 4.0 * S.DRAWS_PER_STEP[a.solver]) * C * hh * ww + 4.0 * nparam
             tr = None
             if pmc_step_data:
-                tr = pmc_step_data.get("cases", {}).get("1_50_50", {}).get("hbm_bytes_per_step_launch")
+                tr = pmc_step_data.get("cases", {}).get("1_50_50", {}).get("fabric_bytes_per_step_launch")
             roof_step = {"bound": "mfma", "achieved": fl / (med_us * 1e-6) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": fl / (med_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": tr,
                          "traffic_source": {"file": "profiles/pmc_ode_step.json", "measured_in_this_run": False,
@@ -397,6 +487,16 @@ def main():
                 "per_kernel": {_lib.KERNEL_NAMES.get(i, str(i)): {
                     "calls_per_forward": calls[i] // 2, "ms_per_forward": pms[i] / 2,
                     "tflops": pfl[i] / (pms[i] * 1e-3) / 1e12} for i in range(NK) if calls[i]}}
+
+    # flat scalars of the GRU-ODE step inside `roofline` (the driver's record keeps the scalar members of that object)
+    if roof is not None and isinstance(roof_step, dict) and "error" not in roof_step:
+        roof["ode_step_us_median"] = roof_step["us_per_step_median"]
+        roof["ode_step_us_p95"] = roof_step["us_per_step_p95"]
+        roof["ode_step_frac"] = roof_step["frac"]
+        roof["ode_step_launches"] = roof_step.get("launches_per_step")
+        roof["ode_step_traffic_ratio"] = (roof_step["traffic"] / roof_step["algorithmic_bytes_per_step"]) if roof_step.get("traffic") else None
+    if roof is not None:
+        roof["batch1_forward_ms"] = single_ms
 
     # ---- camera lift-splat voxel pooling feeding the BEV tensor (HBM-bound gather) ----
     lift = None
