@@ -144,11 +144,12 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
     Tune x;
+    x.pipe = geti("SF_PIPE", 1);                   // one latent: branch 2 of the NEXT dual cell (gates2 -> cand2, functions of the state only) rides in the launches of infer_state, its conv_decoder_2 in the candidate launch (0: every cell on its own, 5 launches)
     x.sp = geti("SF_SP", 1);                       // small pixel counts: the loader / consumer kernel of conv_sp.hip (0: the round-1 kernels)
     x.sp_xcd = geti("SF_SP_XCD", 1);               // ... bit 0: compact 1-D grid (no idle workgroups: step 198 -> 195 us); bit 1: XCD-contiguous logical ids (measured: fabric traffic 156 -> 144 MB per step but 195 -> 203 us; tile-major 133 MB and 218 us — the round-robin spread of a layer's workgroups over the XCDs is the fast one)
     x.sp_split_wgs = geti("SF_SP_SPLIT_WGS", 240); // ... K ranges are split across about this many workgroups per launch
@@ -233,7 +234,8 @@ int sp_bn(const ConvProblem* ps, int n) {
   return work >= tune().sp_wide_work ? 64 : 32;
 }
 // pixels per SE partial-sum row the producing conv's epilogue writes (the SE gate kernel sums ceil(P / this) rows)
-int chansum_tile_px(const ConvProblem& producer, int epi) { return sp_takes(&producer, 1, epi) ? sp_bn(&producer, 1) : 16; }
+// (the producer's whole launch group decides its tile)
+int chansum_tile_px(const ConvProblem* group, int n, int epi) { return sp_takes(group, n, epi) ? sp_bn(group, n) : 16; }
 
 int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   ConvLaunch L;
@@ -634,15 +636,58 @@ int cell_tail(const sf_dual_w& w, const float* s, float* out, int derivative, co
   return run1(f, EPI_TRUST, st);
 }
 
+// Branch 2 of a dual cell — gru_cell_2(s, s) and conv_decoder_2 (temporal_ode_bayes.py:112-119 / :256-263) — is a function of
+// the state alone.  In a rollout the state of cell j+1 is the output of cell j, so while infer_state(state) runs (five
+// launches that only the NEXT cell's branch 1 waits for) branch 2 of the next cell is computed beside it: its gate and
+// candidate convolutions ride in infer_state's first two launches (`Side`), its decoder convolution in the next cell's
+// candidate launch.  One latent on the small-P kernel only (every launch there leaves CUs idle); same arithmetic, same
+// summation orders as the cell on its own.
+struct Carry {
+  float *g2, *rs2, *h2;      // gates2 output [P][2C], (1 - r2) * s [P][C], blended hidden state of cell 2 [P][C]
+};
+struct Side {                // extra problems for infer_state's launches (AFFINE): [0] with conv1 + projection, [1] with conv2
+  ConvProblem p[2];
+  int n;
+};
+bool carry_ok(const sf_dual_w& w, int B, int H, int W) {
+  const long P = (long)B * H * W;
+  return tune().pipe && B == 1 && P < tune().sp_max_p && tune().sp && pregate(P, w.cand1) && pregate(P, w.cand2);
+}
+// the two side problems of cell `w` on state `s` (= the output of the cell before it)
+void side_problems(const sf_dual_w& w, const float* s, const Carry& c, int B, int H, int W, Side& sd) {
+  const int C = w.C;
+  ConvProblem& g2 = sd.p[0];
+  g2 = problem(w.gates2, s, nullptr, c.g2, B, H, W);
+  g2.out2 = c.rs2; g2.out2_cs = C; g2.e1 = s; g2.e1_cs = C; g2.gate_from = C;
+  ConvProblem& c2 = sd.p[1];
+  c2 = problem(w.cand2, s, c.rs2, c.h2, B, H, W);
+  c2.e0 = c.g2; c2.e0_cs = 2 * C; c2.e1 = s; c2.e1_cs = C;
+  c2.mode = 4;               // blend inside an AFFINE launch
+  sd.n = 2;
+}
+
 // B images (samples) are processed as one pixel space; coef_stride = floats between the
-// coefficient records of consecutive images (0: one record shared by all)
+// coefficient records of consecutive images (0: one record shared by all).  `carry`: gates2 / cand2 of this cell were
+// computed beside the previous infer_state (see Carry).
 int dual_cell(const sf_dual_w& w, const float* x, const float* s, float* out, int derivative, const float* base,
-              const float* coef, int coef_stride, float* out2, int acc2, int B, int H, int W, Arena& A, hipStream_t st) {
+              const float* coef, int coef_stride, float* out2, int acc2, int B, int H, int W, Arena& A, hipStream_t st,
+              const Carry* carry = nullptr) {
   const int C = w.C, P = B * H * W;
   CellBufs b;
   if (!b.take(A, C, P)) return SF_ERR_WORKSPACE;
   const bool pre = pregate(P, w.cand1) && pregate(P, w.cand2);
   ConvProblem ps[2];
+  if (carry) {
+    if (!pre) return SF_ERR_INVALID;
+    ConvProblem unused;
+    cell_gate_problems(w, x, s, b, pre, B, H, W, ps[0], unused);
+    SF_TRY(run(ps, 1, EPI_AFFINE, st));                             // gates of cell 1
+    cell_cand_problems(w, x, s, b, pre, B, H, W, ps[0], unused);
+    ps[0].mode = 4;                                                 // candidate of cell 1 + blend ...
+    ps[1] = problem(w.dec2, carry->h2, nullptr, b.r2, B, H, W);     // ... beside rnn_state2 = conv_decoder_2(h2)
+    SF_TRY(run(ps, 2, EPI_AFFINE, st));
+    return cell_tail(w, s, out, derivative, base, coef, coef_stride, out2, acc2, b, B, H, W, st);
+  }
   cell_gate_problems(w, x, s, b, pre, B, H, W, ps[0], ps[1]);     // gates of both cells in one launch
   SF_TRY(run(ps, 2, EPI_AFFINE, st));
   cell_cand_problems(w, x, s, b, pre, B, H, W, ps[0], ps[1]);     // candidates + blend
@@ -662,7 +707,7 @@ size_t infer_ws_floats(int C, int P) {
 // the producing conv's epilogue writes; B > 1 (16-pixel tiles straddle images) sums per-image
 // slabs with one extra small launch.  Both are fixed-order.
 int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p_out, float* q_out, int B, int H, int W,
-                Arena& A, hipStream_t st, const unsigned long long* philox = nullptr, int draw = 0) {
+                Arena& A, hipStream_t st, const unsigned long long* philox = nullptr, int draw = 0, const Side* side = nullptr) {
   if (!eps && !philox) return SF_ERR_INVALID;
   const int C = w.C, C2 = 2 * C, HW = H * W, P = B * HW;
   if (B < 1 || B > 64) return SF_ERR_UNSUPPORTED;
@@ -673,8 +718,9 @@ int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p
   const bool tiles = (B == 1);
   const bool two_level = tiles && P >= 8192;
   // rows of per-tile channel sums each SE producer writes (its kernel's pixel tile)
-  ConvProblem probe1 = problem(w.rb0.conv2, s, nullptr, nullptr, B, H, W), probe2 = problem(w.rb1.conv2, s, nullptr, nullptr, B, H, W);
-  const int tpx1 = chansum_tile_px(probe1, EPI_AFFINE), tpx2 = chansum_tile_px(probe2, EPI_AFFINE);
+  ConvProblem probe1[2] = {problem(w.rb0.conv2, s, nullptr, nullptr, B, H, W), ConvProblem()}, probe2 = problem(w.rb1.conv2, s, nullptr, nullptr, B, H, W);
+  if (side) probe1[1] = side->p[1];      // rides in rb0.conv2's launch
+  const int tpx1 = chansum_tile_px(probe1, side ? 2 : 1, EPI_AFFINE), tpx2 = chansum_tile_px(&probe2, 1, EPI_AFFINE);
   const int nt1 = tiles ? (P + tpx1 - 1) / tpx1 : SE_SLABS, nt2 = tiles ? (P + tpx2 - 1) / tpx2 : SE_SLABS;
   float* a = A.take((size_t)P * C);
   float* pr = A.take((size_t)P * C2);
@@ -700,13 +746,16 @@ int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p
     }
     return SF_OK;
   };
-  ConvProblem ps[2];
+  ConvProblem ps[3];
   ps[0] = problem(w.rb0.conv1, s, nullptr, a, B, H, W);
   ps[1] = problem(w.rb0.proj, s, nullptr, pr, B, H, W);
-  SF_TRY(run(ps, 2, EPI_AFFINE, st));
+  if (side) ps[2] = side->p[0];
+  SF_TRY(run(ps, side ? 3 : 2, EPI_AFFINE, st));
   ConvProblem c2 = problem(w.rb0.conv2, a, nullptr, y1, B, H, W);
   c2.add = pr; c2.chansum = tiles ? cs1 : nullptr;
-  SF_TRY(run1(c2, EPI_AFFINE, st));
+  ps[0] = c2;
+  if (side) ps[1] = side->p[1];
+  SF_TRY(run(ps, side ? 2 : 1, EPI_AFFINE, st));
   // SE gates.  One sample on the small-P kernel: the consuming layer computes the gate in its prologue from the
   // producer's per-tile channel sums (two launches fewer per infer_state); otherwise the gate kernel
   ConvProblem c3 = problem(w.rb1.conv1, y1, nullptr, b, B, H, W);
@@ -1097,22 +1146,34 @@ struct Stage {
 
 size_t rollout_ws_floats(int C, int P) {
   const size_t cellw = dual_ws_floats(C, P), inf = infer_ws_floats(C, P);
-  return (cellw > inf ? cellw : inf) + 9 * al((size_t)P * C) + SPLIT_WS_FLOATS + 256;
+  return (cellw > inf ? cellw : inf) + 13 * al((size_t)P * C) + SPLIT_WS_FLOATS + 256;
 }
 
 int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const float* eps, const unsigned long long* philox, int coef_stride,
                const int32_t* sel_nops, int n_targets, float* out_states, int B, int H, int W, Arena& A, hipStream_t st) {
   const size_t PC = (size_t)B * H * W * pm.C;
-  for (const Stage& g : stages) {
+  // buffers of the carried branch 2 (outside the per-stage arenas: written during one stage's infer_state, read by the next cell)
+  Carry cb;
+  cb.g2 = A.take(2 * PC); cb.rs2 = A.take(PC); cb.h2 = A.take(PC);
+  if (!A.ok()) return SF_ERR_WORKSPACE;
+  bool carried = false;
+  for (size_t j = 0; j < stages.size(); ++j) {
+    const Stage& g = stages[j];
     Arena Ac = A;
-    SF_TRY(dual_cell(*g.w, g.x, g.s, g.out, g.derivative, g.base, g.coef, coef_stride, g.out2, g.acc2, B, H, W, Ac, st));
+    SF_TRY(dual_cell(*g.w, g.x, g.s, g.out, g.derivative, g.base, g.coef, coef_stride, g.out2, g.acc2, B, H, W, Ac, st, carried ? &cb : nullptr));
+    carried = false;
     if (g.op_end >= 0)
       for (int t = 0; t < n_targets; ++t)
         if (sel_nops[t] == g.op_end + 1)
           SF_HIP(copy_floats(g.out, out_states + (size_t)t * PC, PC, st));
     if (g.infer_after) {
       Arena Ai = A;
-      SF_TRY(infer_state(pm, g.out, eps ? eps + (size_t)g.draw * PC : nullptr, g.p_out, nullptr, B, H, W, Ai, st, philox, g.draw));
+      Side sd;
+      const Stage* nx = j + 1 < stages.size() ? &stages[j + 1] : nullptr;
+      const bool pipe = nx && nx->s == g.out && carry_ok(*nx->w, B, H, W);
+      if (pipe) side_problems(*nx->w, g.out, cb, B, H, W, sd);
+      SF_TRY(infer_state(pm, g.out, eps ? eps + (size_t)g.draw * PC : nullptr, g.p_out, nullptr, B, H, W, Ai, st, philox, g.draw, pipe ? &sd : nullptr));
+      carried = pipe;
     }
   }
   return SF_OK;

@@ -108,8 +108,13 @@ __device__ __forceinline__ void sp_epi_load(const ConvProblem& P, const int gp, 
     o.a[0] = P.scale ? spm_ld4(P.scale + cz) : make_float4(1.f, 1.f, 1.f, 1.f);
     o.a[1] = P.bias ? spm_ld4(P.bias + (P.bias_per_img ? (size_t)img * P.cout : 0) + cz) : spm_zero4();
     if constexpr (EPI == EPI_AFFINE) {
-      o.a[2] = P.add ? spm_ld4(P.add + gpz * P.add_cs + cz) : spm_zero4();
-      o.a[3] = (P.add && P.add_scale) ? spm_ld4(P.add_scale + (size_t)img * P.cout + cz) : make_float4(1.f, 1.f, 1.f, 1.f);
+      if (P.mode & 4) {      // block-uniform: conv-GRU blend inside an AFFINE launch (a candidate grouped with plain layers)
+        o.a[2] = spm_ld4(P.e0 + gpz * P.e0_cs + cz);
+        o.a[3] = spm_ld4(P.e1 + gpz * P.e1_cs + cz);
+      } else {
+        o.a[2] = P.add ? spm_ld4(P.add + gpz * P.add_cs + cz) : spm_zero4();
+        o.a[3] = (P.add && P.add_scale) ? spm_ld4(P.add_scale + (size_t)img * P.cout + cz) : make_float4(1.f, 1.f, 1.f, 1.f);
+      }
       const int cg = (P.out2 && cz >= P.gate_from) ? cz - P.gate_from : 0;
       o.a[4] = P.out2 ? spm_ld4(P.e1 + gpz * P.e1_cs + cg) : spm_zero4();
     } else {
@@ -171,7 +176,9 @@ __device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, cons
         if (c + 2 >= P.clamp_from) y.z = fminf(fmaxf(y.z, P.clamp_lo), P.clamp_hi);
         if (c + 3 >= P.clamp_from) y.w = fminf(fmaxf(y.w, P.clamp_lo), P.clamp_hi);
       }
-      if (P.add) { y.x += ad.x * as.x; y.y += ad.y * as.y; y.z += ad.z * as.z; y.w += ad.w * as.w; }
+      if (P.mode & 4) {      // (1 - u) * s + u * h~ with u = e0 (in a[2]), s = e1 (in a[3]): temporal.py:55-57
+        y = make_float4((1.f - ad.x) * as.x + ad.x * y.x, (1.f - ad.y) * as.y + ad.y * y.y, (1.f - ad.z) * as.z + ad.z * y.z, (1.f - ad.w) * as.w + ad.w * y.w);
+      } else if (P.add) { y.x += ad.x * as.x; y.y += ad.y * as.y; y.z += ad.z * as.z; y.w += ad.w * as.w; }
       if (act_last) y = spm_act4(y, P.act);
       if (on && gate_out)   // GRU gates, reset half: also emit (1 - r) * s, the candidate conv's input
         spm_st4(P.out2 + gpz * P.out2_cs + cg, make_float4(sv.x * (1.f - y.x), sv.y * (1.f - y.y), sv.z * (1.f - y.z), sv.w * (1.f - y.w)));
