@@ -426,10 +426,40 @@ def main():
             L.sf_graph_destroy(ex)
             ts.sort()
             return ts[len(ts) // 2], ts[min(len(ts) - 1, int(round(0.95 * (len(ts) - 1))))], n
+        def rollout_step_times(h, w, n1=10, n2=30, n=25):
+            """the same step inside a rollout (what FuturePredictionODE.forward runs): hipGraph replays of rollouts with one jump +
+            N Euler steps for N = n1 and n2; per-step time = (t(n2) - median t(n1)) / (n2 - n1).  Inside a rollout branch 2 of the
+            next cell and the state half of its gates ride in infer_state's launches (csrc/api.hip: Carry): 9 launches per step."""
+            per = S.DRAWS_PER_STEP[a.solver]
+            hx1 = torch.randn((1, h, w, C), device=dev) * 0.5
+            out = {}
+            for nn_ in (n1, n2):
+                scn = S.Schedule(ops=[(_lib.OP_JUMP, 0)] + [(_lib.OP_STEP, i) for i in range(nn_)], dts=[float(dt)] * nn_, sel_nops=[nn_ + 1],
+                                 n_draws=1 + per * nn_)
+                en = torch.randn((scn.n_draws, h, w, C), device=dev)
+                ode.use_graph = True
+                for _ in range(3):
+                    ode.rollout_nhwc(hx1, scn, en)
+                torch.cuda.synchronize()
+                ts = []
+                sp = runtime.stream_ptr(dev)
+                for _ in range(n):
+                    L.sf_event_record(e0, sp)
+                    ode.rollout_nhwc(hx1, scn, en)
+                    L.sf_event_record(e1, sp)
+                    L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+                    ts.append(ms.value * 1e3)
+                ode.use_graph = False
+                ts.sort()
+                out[nn_] = ts
+            base = out[n1][len(out[n1]) // 2]
+            per_step = sorted((t - base) / (n2 - n1) for t in out[n2])
+            return per_step[len(per_step) // 2], per_step[min(len(per_step) - 1, int(round(0.95 * (len(per_step) - 1))))], n
         roof_step = None
         try:
             hh, ww = H // 4, W // 4
-            med_us, p95_us, nrep = graph_step_times(hh, ww)
+            alone_us, alone_p95, _ = graph_step_times(hh, ww)
+            med_us, p95_us, nrep = rollout_step_times(hh, ww)
             mult = {"euler": 1, "midpoint": 2, "rk4": 4}[a.solver]
             fl = mult * 728.0 * C * C * hh * ww
             nparam = sum(v.numel() for k, v in sd.items() if k.startswith(("gru_ode.gru_c.", "gru_ode.p_model.")) and "num_batches" not in k)
@@ -441,8 +471,12 @@ def main():
                          "frac": fl / (med_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": tr,
                          "traffic_source": {"file": "profiles/pmc_ode_step.json", "measured_in_this_run": False,
                                             "commit": (pmc_step_data or {}).get("commit")},
-                         "kernel": f"ode_step kernel group ({a.solver}, one sample, latent {hh}x{ww}x{C}): {STEPS_PER_GRAPH} chained sf_ode_step_fwd per hipGraph replay, time / {STEPS_PER_GRAPH}",
-                         "us_per_step_median": med_us, "us_per_step_p95": p95_us, "graph_replays_timed": nrep,
+                         "kernel": f"ode_step kernel group ({a.solver}, one sample, latent {hh}x{ww}x{C}) inside sf_nnfo_rollout_fwd: hipGraph replays of "
+                                   f"one jump + N steps, (t(N=30) - t(N=10)) / 20 (steady state: 9 launches per step, branch 2 of the next cell beside infer_state)",
+                         "us_per_step_median": med_us, "us_per_step_p95": p95_us, "graph_replays_timed": nrep, "launches_per_step": 9 if a.solver == "euler" else None,
+                         "standalone_call": {"what": f"{STEPS_PER_GRAPH} chained sf_ode_step_fwd calls per hipGraph replay, time / {STEPS_PER_GRAPH} (no cross-call pipelining: 10 launches per step; the round-1/2 figure)",
+                                             "us_per_step_median": alone_us, "us_per_step_p95": alone_p95,
+                                             "frac": fl / (alone_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS},
                          "flops_per_step": fl, "algorithmic_bytes_per_step": by,
                          "hbm_frac_if_bytes_bound": by / (med_us * 1e-6) / 1e9 / PEAK_HBM_GBS,
                          "steps_per_s": 1e6 / med_us}

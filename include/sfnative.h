@@ -89,6 +89,10 @@ typedef struct sf_dual_w {
   sf_conv_w tg1, tg3;        /* .layers.3 (1x1 + LN), .layers.6 (3x3 + LN) */
   const float* w_logit;      /* trusting_gate.1: [2][C] */
   int32_t C;
+  /* optional (w == NULL: unused): the two input halves of gates1 packed on their own — gates1_x = W[:, :C] on x with the
+   * bias and the sigmoid, gates1_s = W[:, C:] on s with neither.  In a rollout the s half is accumulated beside the
+   * previous infer_state (the state is known five launches before x is) and added to the x half's sums. */
+  sf_conv_w gates1_x, gates1_s;
 } sf_dual_w;
 
 /* ResBlock (streamingflow/layers/res_models.py:52-79) */

@@ -34,7 +34,7 @@ class GruW(C.Structure):
 class DualW(C.Structure):
     _fields_ = [("gates1", ConvW), ("cand1", ConvW), ("gates2", ConvW), ("cand2", ConvW), ("dec2", ConvW),
                 ("tg7", ConvW), ("tgproj", ConvW), ("tg1", ConvW), ("tg3", ConvW),
-                ("w_logit", C.c_void_p), ("C", C.c_int32)]
+                ("w_logit", C.c_void_p), ("C", C.c_int32), ("gates1_x", ConvW), ("gates1_s", ConvW)]
 
 
 class BottleW(C.Structure):

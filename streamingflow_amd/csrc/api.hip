@@ -149,7 +149,7 @@ const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
     Tune x;
-    x.pipe = geti("SF_PIPE", 1);                   // one latent: branch 2 of the NEXT dual cell (gates2 -> cand2, functions of the state only) rides in the launches of infer_state, its conv_decoder_2 in the candidate launch (0: every cell on its own, 5 launches)
+    x.pipe = geti("SF_PIPE", 2);                   // one latent: branch 2 of the NEXT dual cell (gates2 -> cand2, functions of the state only) rides in the launches of infer_state, its conv_decoder_2 in the candidate launch (0: every cell on its own, 5 launches)
     x.sp = geti("SF_SP", 1);                       // small pixel counts: the loader / consumer kernel of conv_sp.hip (0: the round-1 kernels)
     x.sp_xcd = geti("SF_SP_XCD", 1);               // ... bit 0: compact 1-D grid (no idle workgroups: step 198 -> 195 us); bit 1: XCD-contiguous logical ids (measured: fabric traffic 156 -> 144 MB per step but 195 -> 203 us; tile-major 133 MB and 218 us — the round-robin spread of a layer's workgroups over the XCDs is the fast one)
     x.sp_split_wgs = geti("SF_SP_SPLIT_WGS", 240); // ... K ranges are split across about this many workgroups per launch
@@ -256,6 +256,9 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     const double e0 = 2.0 * ps[i].Hin * ps[i].Win * ps[i].in0_cs, e1 = 2.0 * ps[i].Hin * ps[i].Win * ps[i].in1_cs;
     if (!ps[i].gather && (e0 >= 2147483648.0 || e1 >= 2147483648.0)) return SF_ERR_UNSUPPORTED;
   }
+  bool has_acc = false;
+  for (int i = 0; i < n; ++i) has_acc = has_acc || ps[i].acc_in != nullptr;
+  if (has_acc && (wide_ln || !sp_takes(ps, n, epi))) return SF_ERR_UNSUPPORTED;      // K-partial inputs: small-P kernel only
   if (wide_ln) {
     // all channels of a pixel must sit in one wave: 128 cout x 64 px tiles of the LDS-DMA kernel, whatever the pixel count
     for (int i = 0; i < n; ++i) {
@@ -644,10 +647,11 @@ int cell_tail(const sf_dual_w& w, const float* s, float* out, int derivative, co
 // summation orders as the cell on its own.
 struct Carry {
   float *g2, *rs2, *h2;      // gates2 output [P][2C], (1 - r2) * s [P][C], blended hidden state of cell 2 [P][C]
+  float* g1s;                // state half of gates1, raw sums [P][2C] (null: not carried)
 };
-struct Side {                // extra problems for infer_state's launches (AFFINE): [0] with conv1 + projection, [1] with conv2
-  ConvProblem p[2];
-  int n;
+struct Side {                // extra problems for infer_state's launches (AFFINE): [0] with conv1 + projection, [1], [2] with conv2
+  ConvProblem p[3];
+  int n;                     // 2 or 3
 };
 bool carry_ok(const sf_dual_w& w, int B, int H, int W) {
   const long P = (long)B * H * W;
@@ -664,6 +668,10 @@ void side_problems(const sf_dual_w& w, const float* s, const Carry& c, int B, in
   c2.e0 = c.g2; c2.e0_cs = 2 * C; c2.e1 = s; c2.e1_cs = C;
   c2.mode = 4;               // blend inside an AFFINE launch
   sd.n = 2;
+  if (c.g1s && w.gates1_x.w && w.gates1_s.w && tune().pipe >= 2) {      // gates1 = sigmoid(W_x x + [W_s s] + b): the bracket now, raw
+    sd.p[2] = problem(w.gates1_s, s, nullptr, c.g1s, B, H, W);
+    sd.n = 3;
+  }
 }
 
 // B images (samples) are processed as one pixel space; coef_stride = floats between the
@@ -681,6 +689,12 @@ int dual_cell(const sf_dual_w& w, const float* x, const float* s, float* out, in
     if (!pre) return SF_ERR_INVALID;
     ConvProblem unused;
     cell_gate_problems(w, x, s, b, pre, B, H, W, ps[0], unused);
+    if (carry->g1s) {                                               // x half only; the state half is carried
+      ConvProblem gx = problem(w.gates1_x, x, nullptr, b.g1, B, H, W);
+      gx.out2 = ps[0].out2; gx.out2_cs = ps[0].out2_cs; gx.e1 = ps[0].e1; gx.e1_cs = ps[0].e1_cs; gx.gate_from = ps[0].gate_from;
+      gx.acc_in = carry->g1s; gx.acc_cs = 2 * C;
+      ps[0] = gx;
+    }
     SF_TRY(run(ps, 1, EPI_AFFINE, st));                             // gates of cell 1
     cell_cand_problems(w, x, s, b, pre, B, H, W, ps[0], unused);
     ps[0].mode = 4;                                                 // candidate of cell 1 + blend ...
@@ -718,9 +732,9 @@ int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p
   const bool tiles = (B == 1);
   const bool two_level = tiles && P >= 8192;
   // rows of per-tile channel sums each SE producer writes (its kernel's pixel tile)
-  ConvProblem probe1[2] = {problem(w.rb0.conv2, s, nullptr, nullptr, B, H, W), ConvProblem()}, probe2 = problem(w.rb1.conv2, s, nullptr, nullptr, B, H, W);
-  if (side) probe1[1] = side->p[1];      // rides in rb0.conv2's launch
-  const int tpx1 = chansum_tile_px(probe1, side ? 2 : 1, EPI_AFFINE), tpx2 = chansum_tile_px(&probe2, 1, EPI_AFFINE);
+  ConvProblem probe1[3] = {problem(w.rb0.conv2, s, nullptr, nullptr, B, H, W), ConvProblem(), ConvProblem()}, probe2 = problem(w.rb1.conv2, s, nullptr, nullptr, B, H, W);
+  if (side) { probe1[1] = side->p[1]; probe1[2] = side->p[2]; }      // they ride in rb0.conv2's launch
+  const int tpx1 = chansum_tile_px(probe1, side ? side->n : 1, EPI_AFFINE), tpx2 = chansum_tile_px(&probe2, 1, EPI_AFFINE);
   const int nt1 = tiles ? (P + tpx1 - 1) / tpx1 : SE_SLABS, nt2 = tiles ? (P + tpx2 - 1) / tpx2 : SE_SLABS;
   float* a = A.take((size_t)P * C);
   float* pr = A.take((size_t)P * C2);
@@ -754,8 +768,8 @@ int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p
   ConvProblem c2 = problem(w.rb0.conv2, a, nullptr, y1, B, H, W);
   c2.add = pr; c2.chansum = tiles ? cs1 : nullptr;
   ps[0] = c2;
-  if (side) ps[1] = side->p[1];
-  SF_TRY(run(ps, side ? 2 : 1, EPI_AFFINE, st));
+  if (side) { ps[1] = side->p[1]; ps[2] = side->p[2]; }
+  SF_TRY(run(ps, side ? side->n : 1, EPI_AFFINE, st));
   // SE gates.  One sample on the small-P kernel: the consuming layer computes the gate in its prologue from the
   // producer's per-tile channel sums (two launches fewer per infer_state); otherwise the gate kernel
   ConvProblem c3 = problem(w.rb1.conv1, y1, nullptr, b, B, H, W);
@@ -1146,21 +1160,21 @@ struct Stage {
 
 size_t rollout_ws_floats(int C, int P) {
   const size_t cellw = dual_ws_floats(C, P), inf = infer_ws_floats(C, P);
-  return (cellw > inf ? cellw : inf) + 13 * al((size_t)P * C) + SPLIT_WS_FLOATS + 256;
+  return (cellw > inf ? cellw : inf) + 15 * al((size_t)P * C) + SPLIT_WS_FLOATS + 256;
 }
 
 int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const float* eps, const unsigned long long* philox, int coef_stride,
                const int32_t* sel_nops, int n_targets, float* out_states, int B, int H, int W, Arena& A, hipStream_t st) {
   const size_t PC = (size_t)B * H * W * pm.C;
   // buffers of the carried branch 2 (outside the per-stage arenas: written during one stage's infer_state, read by the next cell)
-  Carry cb;
-  cb.g2 = A.take(2 * PC); cb.rs2 = A.take(PC); cb.h2 = A.take(PC);
+  Carry cb, cnow;
+  cb.g2 = A.take(2 * PC); cb.rs2 = A.take(PC); cb.h2 = A.take(PC); cb.g1s = A.take(2 * PC);
   if (!A.ok()) return SF_ERR_WORKSPACE;
   bool carried = false;
   for (size_t j = 0; j < stages.size(); ++j) {
     const Stage& g = stages[j];
     Arena Ac = A;
-    SF_TRY(dual_cell(*g.w, g.x, g.s, g.out, g.derivative, g.base, g.coef, coef_stride, g.out2, g.acc2, B, H, W, Ac, st, carried ? &cb : nullptr));
+    SF_TRY(dual_cell(*g.w, g.x, g.s, g.out, g.derivative, g.base, g.coef, coef_stride, g.out2, g.acc2, B, H, W, Ac, st, carried ? &cnow : nullptr));
     carried = false;
     if (g.op_end >= 0)
       for (int t = 0; t < n_targets; ++t)
@@ -1168,10 +1182,14 @@ int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const fl
           SF_HIP(copy_floats(g.out, out_states + (size_t)t * PC, PC, st));
     if (g.infer_after) {
       Arena Ai = A;
-      Side sd;
+      Side sd = {};
       const Stage* nx = j + 1 < stages.size() ? &stages[j + 1] : nullptr;
       const bool pipe = nx && nx->s == g.out && carry_ok(*nx->w, B, H, W);
-      if (pipe) side_problems(*nx->w, g.out, cb, B, H, W, sd);
+      if (pipe) {
+        side_problems(*nx->w, g.out, cb, B, H, W, sd);
+        cnow = cb;
+        if (sd.n < 3) cnow.g1s = nullptr;
+      }
       SF_TRY(infer_state(pm, g.out, eps ? eps + (size_t)g.draw * PC : nullptr, g.p_out, nullptr, B, H, W, Ai, st, philox, g.draw, pipe ? &sd : nullptr));
       carried = pipe;
     }

@@ -94,6 +94,7 @@ __device__ __forceinline__ float sp_reduce16(float v) { return spm_row16_sum(v);
 // when the loads sat behind the reduction (tools/r02/stamps.py).
 struct SpOps {
   float4 a[10];
+  float4 pre;      // K-partial sum an earlier launch left (ConvProblem::acc_in), zero without one
   float2 e;
   float c0f, c1f;
 };
@@ -104,6 +105,7 @@ __device__ __forceinline__ void sp_epi_load(const ConvProblem& P, const int gp, 
   const int img = on ? gp / HWout : 0;
   const size_t gpz = on ? (size_t)gp : 0;
   const int cz = on ? c : 0;
+  o.pre = P.acc_in ? spm_ld4(P.acc_in + gpz * P.acc_cs + cz) : spm_zero4();
   if constexpr (EPI == EPI_AFFINE || EPI == EPI_BLEND) {
     o.a[0] = P.scale ? spm_ld4(P.scale + cz) : make_float4(1.f, 1.f, 1.f, 1.f);
     o.a[1] = P.bias ? spm_ld4(P.bias + (P.bias_per_img ? (size_t)img * P.cout : 0) + cz) : spm_zero4();
@@ -761,6 +763,8 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
 #endif
   }
   SF_STAMP_AT(L, 4);
+#pragma unroll
+  for (int i = 0; i < G::NPX; ++i) { v[i].x += ops[i].pre.x; v[i].y += ops[i].pre.y; v[i].z += ops[i].pre.z; v[i].w += ops[i].pre.w; }
   const int c = c_out;
   float4 ysum = spm_zero4();
   if (!fuse) {

@@ -84,6 +84,11 @@ struct ConvProblem {
   const float* fuse_bias;
   float* fuse_out;           // [P][fuse_cout]
   int fuse_cout, fuse_cout_pad, fuse_kpad;
+  // small-P kernel: a K-partial sum of this layer that an EARLIER launch left as a plain [P][acc_cs] tensor (the half of
+  // a two-input layer whose operand was known early, computed beside other work): added to the accumulator sums before
+  // the epilogue.  Fixed order (own K range summed first, then + acc_in): bitwise reproducible.
+  const float* acc_in;
+  int acc_cs;
 };
 
 #define SF_MAX_GROUP 4

@@ -104,6 +104,11 @@ class _DualCell(PackedModule):
         # gru_cell_2 is called as gru_cell_2(s, s): its gates see cat[s, s] -> duplicate input folded
         g2 = pack_gru(pk, self.conv_update_2, self.conv_reset_2, self.conv_state_tilde_2, C, C, fold_dup=True, gate_bias=gb)
         s.gates1, s.cand1, s.gates2, s.cand2 = g1.gates, g1.cand, g2.gates, g2.cand
+        # the two input halves of gates1 on their own (rollout: the state half is accumulated beside the previous infer_state)
+        wg = torch.cat([self.conv_update_1.weight, self.conv_reset_1.weight], 0)
+        bg = torch.cat([self.conv_update_1.bias, self.conv_reset_1.bias], 0) + float(gb)
+        s.gates1_x = packing.conv_w(pk, wg[:, :C], C, bias=bg, act="sigmoid")
+        s.gates1_s = packing.conv_w(pk, wg[:, C:], C)
         s.dec2 = packing.conv_w(pk, self.conv_decoder_2.weight, C, bias=self.conv_decoder_2.bias)
         bb = self.trusting_gate[0]
         L = bb.layers

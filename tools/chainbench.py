@@ -46,7 +46,7 @@ def main():
     net, _ = build_pair(C, solver, True, True, 0.05)
     ode = net.gru_ode
     t1, t2 = time_chain(ode, n1, solver, h, w, C), time_chain(ode, n2, solver, h, w, C)
-    print(f"chain {solver} {h}x{w} SF_PIPE={os.environ.get('SF_PIPE', '1')}: {n1} steps {t1:.1f} us, {n2} steps {t2:.1f} us -> {(t2 - t1) / (n2 - n1):.2f} us per step (steady state)", flush=True)
+    print(f"chain {solver} {h}x{w} SF_PIPE={os.environ.get('SF_PIPE', 'default')}: {n1} steps {t1:.1f} us, {n2} steps {t2:.1f} us -> {(t2 - t1) / (n2 - n1):.2f} us per step (steady state)", flush=True)
 
 
 if __name__ == "__main__":

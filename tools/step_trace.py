@@ -9,7 +9,10 @@ def main():
     rows = [r for r in csv.DictReader(open(path)) if r["Kernel_Name"].startswith(("void sf::", "sf::"))]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     n = len(rows) // per
-    rows = rows[(n - 1) * per:n * per] if n > 1 else rows   # the last full step (warm)
+    if len(sys.argv) > 3 and sys.argv[3] == "tail":        # a rollout trace: the last 2 steps' worth of launches before the final copies
+        rows = rows[-(2 * per + 4):]
+    else:
+        rows = rows[(n - 1) * per:n * per] if n > 1 else rows   # the last full step (warm)
     t0 = int(rows[0]["Start_Timestamp"])
     prev_end = t0
     busy = 0
