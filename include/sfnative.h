@@ -55,6 +55,12 @@ typedef struct sf_conv_w {
   const float* scale; /* may be NULL (= 1) */
   const float* bias;  /* may be NULL (= 0) */
   int32_t cout, cout_pad, c0, c1, cin_pad, kh, kw, dil, stride, pad, act;
+  int32_t reserved;
+  /* optional, NULL unless packed with SF_PACK_BF16X3: the same packed weights split into bf16 pieces for the opt-in
+   * "bf16x3" math mode (a = hi + lo; a*b ~ hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16, fp32 accumulators).  Layers
+   * whose struct carries it run the split-bf16 K loop where a kernel has one; results then differ from the exact-fp32
+   * path by ~1e-5 (profiles/r03_bf16x3_*).  The default build of every module leaves it NULL: exact fp32. */
+  const void* w_bf16x3;
 } sf_conv_w;
 
 /* ---- weight packing on the device (load time) ---------------------------------------------------------------------
@@ -71,7 +77,7 @@ typedef struct sf_conv_w {
  *   c0 + c1 = cin: channels read from the first / second input tensor; pad < 0 = "same" ((kh-1)*dil/2).
  * The composite structs below (sf_gru_w ... sf_deeplab_w) are assembled from packed convolutions by plain struct
  * assignment; [update ; reset] gate pairs are packed from the two weights stored one after the other (cout = 2*hidden). */
-enum { SF_PACK_TRANSPOSED = 1, SF_PACK_FOLD_DUP = 2, SF_PACK_INTERLEAVE = 4 };
+enum { SF_PACK_TRANSPOSED = 1, SF_PACK_FOLD_DUP = 2, SF_PACK_INTERLEAVE = 4, SF_PACK_BF16X3 = 8 };
 
 /* conv-GRU cell: SpatialGRU.gru_cell (streamingflow/layers/temporal.py:44-57) */
 typedef struct sf_gru_w {

@@ -14,7 +14,7 @@ i32p = C.POINTER(C.c_int32)
 
 SF_COEF_STRIDE = 12
 SF_PROF_KEYS = 128
-PACK_TRANSPOSED, PACK_FOLD_DUP, PACK_INTERLEAVE = 1, 2, 4      # SF_PACK_* of sfnative.h
+PACK_TRANSPOSED, PACK_FOLD_DUP, PACK_INTERLEAVE, PACK_BF16X3 = 1, 2, 4, 8      # SF_PACK_* of sfnative.h
 ACT = {"none": 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4, "gelu": 5}
 SOLVER = {"euler": 0, "midpoint": 1, "rk4": 2}
 OP_JUMP, OP_STEP = 0, 1
@@ -24,7 +24,7 @@ class ConvW(C.Structure):
     _fields_ = [("w", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p),
                 ("cout", C.c_int32), ("cout_pad", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
                 ("cin_pad", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("dil", C.c_int32),
-                ("stride", C.c_int32), ("pad", C.c_int32), ("act", C.c_int32)]
+                ("stride", C.c_int32), ("pad", C.c_int32), ("act", C.c_int32), ("reserved", C.c_int32), ("w_bf16x3", C.c_void_p)]
 
 
 class GruW(C.Structure):

@@ -106,7 +106,7 @@ ConvProblem problem(const sf_conv_w& w, const float* in0, const float* in1, floa
                     int Win, int in_up = 0) {
   ConvProblem p;
   std::memset(&p, 0, sizeof(p));
-  p.in0 = in0; p.in1 = in1; p.w = w.w; p.scale = w.scale; p.bias = w.bias; p.out = out;
+  p.in0 = in0; p.in1 = in1; p.w = w.w; p.w3 = w.w_bf16x3; p.scale = w.scale; p.bias = w.bias; p.out = out;
   p.c0 = w.c0; p.c1 = w.c1; p.in0_cs = w.c0; p.in1_cs = w.c1;
   p.n_img = n_img; p.Hin = Hin; p.Win = Win; p.in_up = in_up;
   const int Hl = Hin << in_up, Wl = Win << in_up;
@@ -144,11 +144,12 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
     Tune x;
+    x.b3 = geti("SF_BF16X3", 1);                   // layers packed with split-bf16 weights (opt-in at pack time) run the bf16x3 K loop where a kernel has one (0: exact fp32 even then)
     x.pipe = geti("SF_PIPE", 2);                   // one latent: branch 2 of the NEXT dual cell (gates2 -> cand2, functions of the state only) rides in the launches of infer_state, its conv_decoder_2 in the candidate launch (0: every cell on its own, 5 launches)
     x.sp = geti("SF_SP", 1);                       // small pixel counts: the loader / consumer kernel of conv_sp.hip (0: the round-1 kernels)
     x.sp_xcd = geti("SF_SP_XCD", 1);               // ... bit 0: compact 1-D grid (no idle workgroups: step 198 -> 195 us); bit 1: XCD-contiguous logical ids (measured: fabric traffic 156 -> 144 MB per step but 195 -> 203 us; tile-major 133 MB and 218 us — the round-robin spread of a layer's workgroups over the XCDs is the fast one)
@@ -267,6 +268,11 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       if (q.gate || q.gather || q.in_scale || q.se_sum || !one_source_per_chunk(q) || span * q.in0_cs >= 2147483648.0 ||
           span * q.in1_cs >= 2147483648.0 || 4.0 * q.cout_pad * q.ktot >= 2147483648.0)
         return SF_ERR_UNSUPPORTED;
+    }
+    if (tune().b3) {
+      bool all3 = true;
+      for (int i = 0; i < n; ++i) all3 = all3 && L.p[i].w3 != nullptr;
+      for (int i = 0; i < n; ++i) L.p[i].use_w3 = all3 ? 1 : 0;
     }
     SF_HIP(launch_conv_glds(L, epi, 5, 0, st));
     return SF_OK;
@@ -502,6 +508,11 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   }
   L.stamp_slot = g_stamp_slot;
   if (g_stamp_on) g_stamp_slot = (g_stamp_slot + 1) % 64;
+  if (glds_tile >= 0 && tune().b3) {      // opt-in math mode: every problem of the launch was packed with split-bf16 weights
+    bool all3 = true;
+    for (int i = 0; i < n; ++i) all3 = all3 && L.p[i].w3 != nullptr;
+    for (int i = 0; i < n; ++i) L.p[i].use_w3 = all3 ? 1 : 0;
+  }
   auto launch = [&]() -> hipError_t {
     if (glds_tile >= 0) return launch_conv_glds(L, epi, glds_tile, glds_var, st);
     return cfg == 3 ? launch_conv_direct(L, epi, mt, ks, st) : launch_conv(L, epi, cfg, st);

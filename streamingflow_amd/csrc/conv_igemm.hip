@@ -18,6 +18,8 @@
 //   i.e. four consecutive channels of one pixel => NHWC float4 stores, and per-pixel channel
 //   reductions (LayerNorm, 1x1->2 logits) are in-register sums + two xor-shuffles (16, 32).
 #include "sf_math.h"
+
+#include <type_traits>
 #include <cstdlib>
 
 namespace sf {
@@ -66,6 +68,39 @@ __device__ __forceinline__ float2 lds_read_b64(const float* p) {
   typedef const volatile __attribute__((address_space(3))) unsigned long long lds_u64;
   const unsigned long long u = *(lds_u64*)p;   // explicit LDS address space: ds_read_b64, not flat_load
   return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+}
+
+// ---- split-bf16 operands (opt-in math mode "bf16x3", never the default) --------------------------------------------------
+// a = hi + lo with hi = bf16(a), lo = bf16(a - hi) (round to nearest even): a * b ~ hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulators — products of bf16 values are exact in fp32, the dropped lo*lo term and
+// the residual of the split are ~2^-17 relative (profiles/r03_bf16x3_accuracy_study.json: <= 5e-5 max-abs on the BEV logits
+// of the full-size forward, against 2e-2 for plain bf16).  Weights are split once by sf_pack_conv (SF_PACK_BF16X3: every
+// aligned group of 8 K values is stored as [8 x bf16 hi][8 x bf16 lo], the same 32 bytes, so the staging DMAs do not
+// change); activations stay fp32 in memory and in LDS and are split in registers after the fragment read.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
+__device__ __forceinline__ f32x4 lds_read_b128(const float* p) {
+  typedef const __attribute__((address_space(3))) f32x4 lds_f4;
+  return *(lds_f4*)p;
+}
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {      // v_cvt_pk_bf16_f32: a in the low half
+  const bf16x2 t = __builtin_convertvector((f32x2){a, b}, bf16x2);
+  return __builtin_bit_cast(unsigned, t);
+}
+// eight consecutive K values (two float4) -> their bf16 hi and lo pieces, K ascending from the low half of word 0
+__device__ __forceinline__ void split_bf16x8(const f32x4 x0, const f32x4 x1, bf16x8& hi, bf16x8& lo) {
+  u32x4v h, l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = i < 2 ? x0[2 * i] : x1[2 * i - 4], b = i < 2 ? x0[2 * i + 1] : x1[2 * i - 3];
+    const unsigned pk = pk_bf16(a, b);
+    h[i] = pk;
+    l[i] = pk_bf16(a - __uint_as_float(pk << 16), b - __uint_as_float(pk & 0xffff0000u));
+  }
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
 }
 
 #ifndef SF_SETPRIO
@@ -691,7 +726,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
 // fragments after the LDS read.  A reset-gate multiply is not: the GRU gates launch writes (1 - r) * s instead.
 // (tools/experiments/diag_loop.sh: without its staging the register-staged loop runs at 134 instead of 115 TFLOP/s on a
 // 7-frame 128->128 layer — global loads cost 10 %, the LDS writes 6 %; this kernel reaches 126, 134 at 224 frames.)
-template <int MT, int NT, int WM, int WN, int EPI, int NB, bool SCALE>
+template <int MT, int NT, int WM, int WN, int EPI, int NB, bool SCALE, bool B3 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunch L) {
   constexpr int NWV = WM * WN;
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
@@ -778,7 +813,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (int)nrec, 0x00020000);
   };
   const size_t imgs_left = (size_t)(P.n_img - img0);
-  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(P.w, (size_t)P.cout_pad * P.ktot * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(B3 ? static_cast<const float*>(P.w3) : P.w, (size_t)P.cout_pad * P.ktot * sizeof(float));
   const __amdgpu_buffer_rsrc_t rsrc0 = make_rsrc(in0, imgs_left * P.Hin * P.Win * in0_cs * sizeof(float));
   const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(in1 ? in1 : in0, in1 ? imgs_left * P.Hin * P.Win * in1_cs * sizeof(float) : 0);
 #endif
@@ -886,6 +921,94 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
   };
 
   const int sx = (j >> 1) & 7;
+  if constexpr (B3) {
+    // ---- split-bf16 K loop: one v_mfma_f32_16x16x32_bf16 per (tile pair, product) and 32-deep chunk.  Lane (j, g) holds the
+    // 8 K values 8g .. 8g+7 of its row: the 16-byte slots 2g and 2g+1 (weights: hi and lo pieces; pixels: two float4).
+    // Software pipeline over the two staging buffers: after the barrier that publishes chunk c+1 its fragments are read into
+    // the other register set while the third product (lo x hi) of chunk c is still being multiplied.
+    static_assert(NB == 2, "bf16x3 loop: two staging buffers");
+    const int o0 = 4 * ((2 * g) ^ sx), o1 = 4 * ((2 * g + 1) ^ sx);
+    f32x4 wa[2][MT][2], xb[2][NT][2], xs[2][NT][2];
+    int kc_cmp = cb % kcpt;
+    auto read3 = [&](int buf, auto SET) {
+      constexpr int st = decltype(SET)::value;
+      const float* a = smem + buf * BUF + (wm * MT * 16 + j) * 32;
+      const float* b = smem + buf * BUF + (BM + wn * NT * 16 + j) * 32;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { wa[st][m][0] = lds_read_b128(a + m * 16 * 32 + o0); wa[st][m][1] = lds_read_b128(a + m * 16 * 32 + o1); }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { xb[st][n][0] = lds_read_b128(b + n * 16 * 32 + o0); xb[st][n][1] = lds_read_b128(b + n * 16 * 32 + o1); }
+      if (SCALE && in_scale) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          xs[st][n][0] = lds_read_b128(sc_lds + simg[n] + kc_cmp * BK + 8 * g);
+          xs[st][n][1] = lds_read_b128(sc_lds + simg[n] + kc_cmp * BK + 8 * g + 4);
+        }
+      }
+    };
+    SF_STAMP_AT(L, 1);
+    if (nchunks > 0) {
+#pragma unroll
+      for (int q = 0; q < G; ++q) issue_one(cb, 0, q);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    SF_STAMP_AT(L, 2);
+    read3(0, std::integral_constant<int, 0>());
+    auto step = [&](const int c, auto SET) {
+      constexpr int st = decltype(SET)::value;
+      const bool more = c + 1 < nchunks;
+      if (more) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) issue_one(cb + c + 1, st ^ 1, q);
+      }
+      bf16x8 bh[NT], bl[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        f32x4 x0 = xb[st][n][0], x1 = xb[st][n][1];
+        if (SCALE && in_scale) { x0 = x0 * xs[st][n][0]; x1 = x1 * xs[st][n][1]; }
+        split_bf16x8(x0, x1, bh[n], bl[n]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[st][m][0]), bl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[st][m][0]), bh[n], acc[m][n], 0, 0, 0);
+      if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      kc_cmp = kc_cmp + 1 == kcpt ? 0 : kc_cmp + 1;
+      if (more) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read3(st ^ 1, std::integral_constant<int, st ^ 1>());
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[st][m][1]), bh[n], acc[m][n], 0, 0, 0);
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+      step(c, std::integral_constant<int, 0>());
+      if (c + 1 < nchunks) step(c + 1, std::integral_constant<int, 1>());
+    }
+    SF_STAMP_AT(L, 3);
+    if (nsplit > 1) {      // block-uniform
+      __syncthreads();
+      if (!splitk_handoff<MT, NT, NWV>(P, acc, nsplit, bid, wave, lane, tid, smem)) return;
+    }
+    SF_STAMP_AT(L, 4);
+    run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
+    return;
+  }
   auto koff = [&](int t4) { return 4 * ((2 * t4 + (g >> 1)) ^ sx) + ((2 * g) & 3); };
   // Barrier in the middle of the MFMA stream (two buffers): the last k-group of chunk c is multiplied AFTER the
   // barrier that publishes chunk c+1, from fragments read before it, and the first fragments of chunk c+1 are read
@@ -1009,11 +1132,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
 #endif
 }
 
+template <int MT, int NT, int WM, int WN, int EPI, bool SCALE, bool B3>
+static hipError_t launch_glds_tb(const ConvLaunch& L, hipStream_t stream);
+// bf16x3 (opt-in math mode): every problem of the launch carries split weights (api.hip decides); block-uniform host switch
 template <int MT, int NT, int WM, int WN, int EPI, bool SCALE = false, int NB = 2>
 static hipError_t launch_glds_t(const ConvLaunch& L, hipStream_t stream) {
+  static_assert(NB == 2, "two staging buffers");
+  bool b3 = L.nprob > 0;
+  for (int i = 0; i < L.nprob; ++i) b3 = b3 && L.p[i].w3 != nullptr && L.p[i].use_w3;
+  return b3 ? launch_glds_tb<MT, NT, WM, WN, EPI, SCALE, true>(L, stream) : launch_glds_tb<MT, NT, WM, WN, EPI, SCALE, false>(L, stream);
+}
+template <int MT, int NT, int WM, int WN, int EPI, bool SCALE, bool B3>
+static hipError_t launch_glds_tb(const ConvLaunch& L, hipStream_t stream) {
+  constexpr int NB = 2;
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   constexpr int lds = NB * (BM + BN) * 32 * 4 + (SCALE ? 4 * 256 * 4 : 0);   // staging buffers (+ the SE scale rows of up to 4 images x 256 channels)
-  auto kern = conv_glds_kernel<MT, NT, WM, WN, EPI, NB, SCALE>;
+  auto kern = conv_glds_kernel<MT, NT, WM, WN, EPI, NB, SCALE, B3>;
   // the attribute is per device (a process may touch more than one GPU); one process per GPU and one launching
   // thread per device are the documented use (include/sfnative.h), so the flag needs no lock
   static bool attr_done[64] = {};

@@ -48,6 +48,32 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int cout, int c
   out[idx] = v;
 }
 
+// opt-in math mode bf16x3: the packed fp32 weights split into bf16 pieces, a = hi + lo (round to nearest even both times).
+// One thread per aligned group of 8 K values of a packed row: [8 x fp32] (32 bytes) -> [8 x bf16 hi][8 x bf16 lo] (32 bytes).
+__device__ __forceinline__ unsigned pack_bf16_rne(float v) {
+  unsigned u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);      // finite weights only
+  return u >> 16;
+}
+__global__ void pack_split_bf16_kernel(const float* __restrict__ packed, long groups, unsigned* __restrict__ out) {
+  const long gi = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= groups) return;
+  const float* src = packed + gi * 8;
+  unsigned hi[8], lo[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float a = src[i];
+    hi[i] = pack_bf16_rne(a);
+    lo[i] = pack_bf16_rne(a - __uint_as_float(hi[i] << 16));
+  }
+  unsigned* dst = out + gi * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    dst[i] = hi[2 * i] | (hi[2 * i + 1] << 16);
+    dst[4 + i] = lo[2 * i] | (lo[2 * i + 1] << 16);
+  }
+}
+
 // per-output-channel affine: eval-mode BatchNorm folded onto the accumulator (+ conv bias), or the plain conv bias
 __global__ void pack_affine_kernel(const float* __restrict__ conv_bias, const float* __restrict__ bn_w, const float* __restrict__ bn_b,
                                    const float* __restrict__ bn_mean, const float* __restrict__ bn_var, float eps,
@@ -90,7 +116,7 @@ static int packed_dims(int cout, int cin, int flags, int* cout_pad, int* cin_pad
 size_t sf_pack_conv_bytes(int cout, int cin, int kh, int kw, int flags) {
   int cp = 0, ip = 0;
   if (packed_dims(cout, cin, flags, &cp, &ip) != SF_OK || kh < 1 || kw < 1) return 0;
-  return (a64((size_t)cp * kh * kw * ip) + 2 * a64((size_t)cp)) * sizeof(float);
+  return (a64((size_t)cp * kh * kw * ip) * ((flags & SF_PACK_BF16X3) ? 2 : 1) + 2 * a64((size_t)cp)) * sizeof(float);
 }
 
 int sf_pack_conv(const float* weight, const float* conv_bias, const float* scale, const float* bn_weight, const float* bn_bias,
@@ -114,9 +140,16 @@ int sf_pack_conv(const float* weight, const float* conv_bias, const float* scale
   const bool has_scale = bn_weight || scale, has_bias = bn_weight || conv_bias;
   hipLaunchKernelGGL(pack_affine_kernel, dim3((cp + 255) / 256), dim3(256), 0, st, conv_bias, bn_weight, bn_bias, bn_mean, bn_var, bn_eps, scale,
                      cout, cp, flags & SF_PACK_INTERLEAVE, has_scale ? sp : nullptr, has_bias ? bp : nullptr);
+  float* w3 = nullptr;
+  if (flags & SF_PACK_BF16X3) {      // ip is a multiple of 32: every row is a whole number of 8-value groups
+    w3 = bp + a64((size_t)cp);
+    const long groups = total / 8;
+    hipLaunchKernelGGL(pack_split_bf16_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, wp, groups, reinterpret_cast<unsigned*>(w3));
+  }
   if (hipGetLastError() != hipSuccess) return SF_ERR_LAUNCH;
   std::memset(out, 0, sizeof(*out));
   out->w = wp;
+  out->w_bf16x3 = w3;
   out->scale = has_scale ? sp : nullptr;
   out->bias = has_bias ? bp : nullptr;
   out->cout = cout; out->cout_pad = cp; out->c0 = c0; out->c1 = c1; out->cin_pad = ip;

@@ -89,6 +89,10 @@ struct ConvProblem {
   // the epilogue.  Fixed order (own K range summed first, then + acc_in): bitwise reproducible.
   const float* acc_in;
   int acc_cs;
+  // opt-in math mode bf16x3: the packed weights split into bf16 pieces ([8 hi][8 lo] per aligned group of 8 K values, same
+  // bytes and row pitch as `w`); use_w3 is set by the host when the launch runs on a kernel that has the split-bf16 K loop
+  int use_w3;
+  const void* w3;
 };
 
 #define SF_MAX_GROUP 4

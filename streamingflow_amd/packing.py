@@ -8,6 +8,23 @@ import torch
 
 from . import _lib
 
+# Math mode of the convolutions, decided when a module packs its weights:
+#   "fp32"    exact fp32 on v_mfma_f32_16x16x4_f32 (default; every parity figure and the bench headline)
+#   "bf16x3"  opt-in: operands split into two bf16 pieces, three v_mfma_f32_16x16x32_bf16 products, fp32 accumulators
+#             (~1e-5 from the exact path; profiles/r03_bf16x3_*).  set_math_mode() re-packs modules on their next call.
+_MATH_MODE = ["fp32"]
+
+
+def set_math_mode(mode):
+    if mode not in ("fp32", "bf16x3"):
+        raise ValueError("math mode must be 'fp32' or 'bf16x3'")
+    _MATH_MODE[0] = mode
+
+
+def math_mode():
+    return _MATH_MODE[0]
+
+
 def _round_up(v, m):
     return (v + m - 1) // m * m
 
@@ -56,6 +73,8 @@ def conv_w(holder, weight, c0, c1=0, scale=None, bias=None, act="none", dil=1, s
             cin //= 2
     assert cin == c0 + c1, (cin, c0, c1)
     flags = (_lib.PACK_TRANSPOSED if transposed else 0) | (_lib.PACK_FOLD_DUP if fold_dup else 0) | (_lib.PACK_INTERLEAVE if interleave else 0)
+    if _MATH_MODE[0] == "bf16x3":
+        flags |= _lib.PACK_BF16X3
     L = _lib.lib()
     nbytes = L.sf_pack_conv_bytes(cout, cin, kh, kw, flags)
     if nbytes == 0:

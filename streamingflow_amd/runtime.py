@@ -69,7 +69,8 @@ class PackedModule(torch.nn.Module):
     (captured hipGraphs): it changes exactly when ``packed()`` returns a new copy and is never reused."""
 
     def _param_signature(self):
-        sig = []
+        from . import packing
+        sig = [packing.math_mode()]
         for t in list(self.parameters()) + list(self.buffers()):
             sig.append((t.data_ptr(), t._version, t.device))
         return tuple(sig)

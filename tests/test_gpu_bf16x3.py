@@ -1,0 +1,51 @@
+"""GPU: the opt-in "bf16x3" math mode (split-bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulators).
+Never the default: every other test and the bench headline run exact fp32.  Checked here: the mode is live (results differ
+from the exact path), stays within the exact path's own tolerance on every LDS-DMA layer shape, reproduces bit for bit, and
+holds the north-star tolerance (1e-3 max-abs on the BEV logits) on a full-size forward with a wide margin."""
+import pytest
+import torch
+
+import test_gpu_conv_random as RC
+from util import build_pair, cases, hashfill, maxabs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def bf16x3():
+    import streamingflow_amd as sfa
+    sfa.set_math_mode("bf16x3")
+    yield
+    sfa.set_math_mode("fp32")
+
+
+@pytest.mark.parametrize("i", range(len(RC._DMA)))
+def test_dma_layers_in_bf16x3(i, bf16x3):
+    import streamingflow_amd as sfa
+    c = dict(act=["none", "relu", "lrelu", "tanh"][i % 4], add=i % 3 != 0, after=i % 2 == 0, in_slack=8 * (i % 2), out_slack=[0, 4, 16][i % 3])
+    c.update(RC._DMA[i])
+    got3 = RC._run(c, 100 + i)                 # the exact path's own tolerance (2e-4 against torch CPU fp32)
+    again = RC._run(c, 100 + i)
+    assert torch.equal(got3, again)            # fixed summation order here too
+    sfa.set_math_mode("fp32")
+    got = RC._run(c, 100 + i)
+    assert not torch.equal(got3, got), "bf16x3 mode was not used"
+    assert maxabs(got3, got) <= 5e-5
+
+
+def test_full_size_forward_in_bf16x3(bf16x3):
+    """BASELINE config 2 (C=64, BEV 200x200, 10 Euler steps + 8 jumps) with every LDS-DMA layer in bf16x3 against the oracle."""
+    from oracle import ref_torch as R
+    C, H, W = 64, 200, 200
+    cts, lts, tts, dt = cases.timeset("shipped")
+    net, sd = build_pair(C, "euler", True, True, dt)
+    cam, lid = cases.bev_inputs(C, H, W, cts.shape[1], lts.shape[1])
+    net.gru_ode.noise = hashfill.HashedNoise(cases.EPS_SEED)
+    y, _ = net(cases.present_input(cam, lid).cuda(), cam.cuda(), lid.cuda(), cts, lts, tts)
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        yr, _ = R.future_prediction_ode_forward(sd, cases.present_input(cam, lid), cam, lid, cts, lts, tts, dt, 2, "euler", True, True,
+                                                hashfill.HashedNoise(cases.EPS_SEED))
+    err = maxabs(y, yr)
+    print("bf16x3 full-size forward max-abs vs oracle", err)
+    assert err <= 2e-4      # north-star tolerance 1e-3; measured ~5e-5

@@ -79,7 +79,7 @@ def test_dma_conv(i):
     assert used and all(u.startswith("conv_glds") for u in used), used   # the case really ran on the LDS-DMA kernel
 
 
-def _run(c, i):
+def _run(c, i, tol=2e-4):
     from streamingflow_amd import _lib, packing, runtime
     k, n, H, W, c0, c1, cout = c["k"], c["n"], c["H"], c["W"], c["c0"], c["c1"], c["cout"]
     up = c.get("in_up", 0)
@@ -116,11 +116,12 @@ def _run(c, i):
                                   int(c["after"]), ctypes.c_void_p(out.data_ptr()), ocs, oco, n, H, W, up, runtime.ptr(ws), ws.numel() * 4,
                                   runtime.stream_ptr()), "conv2d_ex")
     got = out[..., oco:oco + cout].permute(0, 3, 1, 2)
-    assert maxabs(got, want) <= 2e-4, c
+    assert maxabs(got, want) <= tol, c
     # nothing outside the output slice was touched
     if ocs > cout:
         rest = torch.cat([out[..., :oco], out[..., oco + cout:]], -1)
         assert float((rest - 7.0).abs().max()) == 0.0
+    return got.clone()
 
 
 @pytest.mark.parametrize("i", [0, 1, 3, 8])
