@@ -446,6 +446,13 @@ int sf_pack_conv(const float* weight, const float* conv_bias, const float* scale
                  const float* bn_mean, const float* bn_var, float bn_eps, int cout, int cin, int kh, int kw, int c0, int c1, int act,
                  int dil, int stride, int pad, int flags, void* blob, size_t blob_bytes, sf_conv_w* out, void* stream);
 
+/* The BatchNorm fold of sf_pack_conv on its own (the same device code): scale[i] = w[i] / sqrt(var[i] + eps),
+ * bias[i] = b[i] - mean[i] * scale[i] (+ conv_bias[i] * scale[i]), i < n.  For callers that stack or zero-pad the folded
+ * vectors of several layers before packing them as one convolution (streamingflow/models/decoder.py heads,
+ * streamingflow/layers/temporal.py blocks).  There is no second implementation of the fold on the host side. */
+int sf_bn_fold(const float* conv_bias, const float* bn_weight, const float* bn_bias, const float* bn_mean, const float* bn_var,
+               float bn_eps, int n, float* scale, float* bias, void* stream);
+
 /* Diagnostic builds of the library only (hipcc -DSF_STAMP; the product build returns SF_ERR_UNSUPPORTED): `buf` is a
  * device buffer of 64 slots x 4096 workgroups x 8 uint64; every implicit-GEMM launch then takes the next slot (mod 64)
  * and wave 0 of each workgroup records s_memrealtime (100 MHz) at entry / prologue done / first chunk landed / K loop

@@ -144,11 +144,12 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
     Tune x;
+    x.fenced = geti("SF_HANDOFF_FENCED", 0);       // 1: split-K hand-offs also run the agent-scope release / acquire fences of round 1 (known-good reference for the fence-free sc1 form; gfx950 only either way)
     x.b3 = geti("SF_BF16X3", 1);                   // layers packed with split-bf16 weights (opt-in at pack time) run the bf16x3 K loop where a kernel has one (0: exact fp32 even then)
     x.pipe = geti("SF_PIPE", 2);                   // one latent: branch 2 of the NEXT dual cell (gates2 -> cand2, functions of the state only) rides in the launches of infer_state, its conv_decoder_2 in the candidate launch (0: every cell on its own, 5 launches)
     x.sp = geti("SF_SP", 1);                       // small pixel counts: the loader / consumer kernel of conv_sp.hip (0: the round-1 kernels)
@@ -246,6 +247,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   bool wide_ln = false;      // a LayerNorm / trust epilogue over 65..128 channels (hidden sizes above every shipped config)
   for (int i = 0; i < n; ++i) {
     L.p[i] = ps[i];
+    L.p[i].fenced = tune().fenced;
     int Pi = ps[i].n_img * ps[i].Hout * ps[i].Wout;
     if (Pi > P) P = Pi;
     if ((epi == EPI_LNG || epi == EPI_TRUST) && ps[i].cout_pad > 128) return SF_ERR_UNSUPPORTED;

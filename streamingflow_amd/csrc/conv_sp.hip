@@ -742,7 +742,15 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
     int* const flag = reinterpret_cast<int*>(misc);
     if (tid == 0) {
       unsigned* cnt = P.counters + bx;
+      if (P.fenced) {      // reference form (SF_HANDOFF_FENCED=1): agent-scope release before the ticket, acquire behind it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (P.fenced) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       const int last = (t == (unsigned)(nsplit - 1));
       if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
       *flag = last;

@@ -159,4 +159,12 @@ int sf_pack_conv(const float* weight, const float* conv_bias, const float* scale
   return SF_OK;
 }
 
+int sf_bn_fold(const float* conv_bias, const float* bn_weight, const float* bn_bias, const float* bn_mean, const float* bn_var,
+               float bn_eps, int n, float* scale, float* bias, void* stream) {
+  if (!bn_weight || !bn_bias || !bn_mean || !bn_var || !scale || !bias || n < 1) return SF_ERR_INVALID;
+  hipLaunchKernelGGL(pack_affine_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), conv_bias, bn_weight, bn_bias,
+                     bn_mean, bn_var, bn_eps, nullptr, n, n, 0, scale, bias);
+  return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
+}
+
 }  // extern "C"

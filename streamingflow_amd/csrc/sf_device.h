@@ -93,6 +93,9 @@ struct ConvProblem {
   // bytes and row pitch as `w`); use_w3 is set by the host when the launch runs on a kernel that has the split-bf16 K loop
   int use_w3;
   const void* w3;
+  // split-K hand-off: 1 = the round-1 form as a known-good reference (SF_HANDOFF_FENCED=1): an agent-scope release fence
+  // before the arrival ticket and an acquire fence behind it, on top of the sc1 stores / loads (tests/test_gpu_splitk_stress.py)
+  int fenced;
 };
 
 #define SF_MAX_GROUP 4

@@ -49,11 +49,20 @@ class Pack:
 
 
 def bn_fold(bn, conv_bias=None):
-    """eval-mode BatchNorm2d after a conv -> per-channel (scale, bias) on the accumulator."""
-    sc = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
-    bi = bn.bias.detach() - bn.running_mean.detach() * sc
-    if conv_bias is not None:
-        bi = bi + conv_bias.detach() * sc
+    """eval-mode BatchNorm after a conv -> per-channel (scale, bias) on the accumulator, computed by the library
+    (``sf_bn_fold``: the device code sf_pack_conv itself folds with — the only implementation of the fold)."""
+    from . import runtime
+    f = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+    w, b, m, v, cb = f(bn.weight), f(bn.bias), f(bn.running_mean), f(bn.running_var), f(conv_bias)
+    if not w.is_cuda:
+        raise RuntimeError("weights are packed on the MI355X: move the module to the GPU first (no CPU fallback)")
+    n = w.numel()
+    sc, bi = torch.empty(n, dtype=torch.float32, device=w.device), torch.empty(n, dtype=torch.float32, device=w.device)
+    _lib.check(_lib.lib().sf_bn_fold(runtime.ptr(cb), runtime.ptr(w), runtime.ptr(b), runtime.ptr(m), runtime.ptr(v), float(bn.eps), n,
+                                     runtime.ptr(sc), runtime.ptr(bi), runtime.stream_ptr(w.device)), "bn_fold")
+    for t in (w, b, m, v, cb):
+        if t is not None:
+            t.record_stream(torch.cuda.current_stream(w.device))      # a temporary (dtype cast) must outlive the launch
     return sc, bi
 
 
@@ -87,7 +96,13 @@ def conv_w(holder, weight, c0, c1=0, scale=None, bias=None, act="none", dil=1, s
     _lib.check(L.sf_pack_conv(runtime.ptr(w), runtime.ptr(bi), runtime.ptr(sc), None, None, None, None, 0.0, cout, cin, kh, kw, c0, c1,
                               _lib.ACT[act], dil, stride, -1 if pad is None else pad, flags, runtime.ptr(blob), nbytes,
                               ctypes.byref(s), runtime.stream_ptr(w.device)), "pack_conv")
-    holder.keep.extend([blob, w, sc, bi])      # the launch reads w / sc / bi asynchronously: keep them until the pack dies
+    holder.keep.append(blob)
+    # the pack kernels read w / sc / bi asynchronously: a temporary among them (torch.cat of heads, a slice, a dtype cast) is
+    # handed to the caching allocator only after the launches are ordered on this stream — it is NOT kept for the life of
+    # the pack (a second resident copy of every such weight)
+    for t in (w, sc, bi):
+        if t is not None:
+            t.record_stream(torch.cuda.current_stream(w.device))
     return s
 
 
