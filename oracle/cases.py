@@ -108,6 +108,17 @@ BIG_CASES = {
 }
 
 
+# BASELINE config 5 at full size (C=64, BEV 200x200, the 46-step streaming schedule, 43 decoded frames): statistics only —
+# euler / midpoint from the real reference, rk4 (build-defined solver) from the oracle (big_stats.json "cases" / "oracle_cases")
+BIG_STREAM_CASES = {
+    "config5_stream40_euler":    (64, 200, 200, "stream40", "euler", True, True),
+    "config5_stream40_midpoint": (64, 200, 200, "stream40", "midpoint", True, True),
+}
+BIG_ORACLE_CASES = {
+    "config5_stream40_rk4":      (64, 200, 200, "stream40", "rk4", True, True),
+}
+
+
 # BEVerse-named secondary classes: tag -> (in_channels, latent_dim, h, w, n_future)
 BEVERSE_CASES = {
     "config1_c32": (32, 16, 50, 50, 4),     # BASELINE config 1: FuturePrediction(32, 16, 3, 3) at 50x50

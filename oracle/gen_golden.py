@@ -252,6 +252,39 @@ def gen_big(m, only_cases=False):
         json.dump(stats, f)
 
 
+def _stats_of(t):
+    flat = t.reshape(-1).double()
+    idx = torch.linspace(0, flat.numel() - 1, 256, dtype=torch.float64).long().clamp(max=flat.numel() - 1)
+    return {"shape": list(t.shape), "mean": flat.mean().item(), "absmax": flat.abs().max().item(), "std": flat.std().item(),
+            "sum": flat.sum().item(), "sample_idx": idx.tolist(), "samples": flat[idx].tolist()}
+
+
+def gen_big_stream(m):
+    """Round 3: BASELINE config 5 at full size.  Adds to big_stats.json (existing entries untouched): "cases" entries of
+    oracle.cases.BIG_STREAM_CASES from the real reference (euler, midpoint), "oracle_cases" entries of BIG_ORACLE_CASES from
+    oracle/ref_torch.py (rk4 is build-defined: the reference has no such solver)."""
+    from . import ref_torch as R
+    path = os.path.join(OUT, "big_stats.json")
+    stats = json.load(open(path))
+    for tag, cfg in cases.BIG_STREAM_CASES.items():
+        if tag not in stats["cases"]:
+            stats["cases"][tag] = _big_stats(m, *cfg)
+            json.dump(stats, open(path, "w"))
+    stats.setdefault("oracle_cases", {})
+    for tag, (C, H, W, ts, solver, impute, variable) in cases.BIG_ORACLE_CASES.items():
+        if tag in stats["oracle_cases"]:
+            continue
+        cts, lts, tts, dt = cases.timeset(ts)
+        _, sd = build_ref(m, C, "euler", impute, variable, dt)       # the reference class only provides the state_dict
+        cam, lid = cases.bev_inputs(C, H, W, cts.shape[1], lts.shape[1])
+        with torch.no_grad():
+            y, _ = R.future_prediction_ode_forward(sd, cases.present_input(cam, lid), cam, lid, cts, lts, tts, dt, 2, solver, impute, variable,
+                                                    hashfill.HashedNoise(cases.EPS_SEED))
+        stats["oracle_cases"][tag] = {"out": _stats_of(y)}
+        print(tag, stats["oracle_cases"][tag]["out"]["mean"], stats["oracle_cases"][tag]["out"]["absmax"])
+        json.dump(stats, open(path, "w"))
+
+
 def gen_lift():
     """N1: camera lift-splat.  The reference's own Python runs (bev_pool.py, streamingflow.bev_pool,
     projection_to_birds_eye_view, get_geometry, create_frustum, pose_vec2mat); only the CUDA kernel
@@ -519,6 +552,8 @@ def main():
         gen_big(m)
     if "big_cases" in todo:
         gen_big(m, only_cases=True)
+    if "big_stream" in todo:
+        gen_big_stream(m)
 
 
 if __name__ == "__main__":

@@ -91,6 +91,22 @@ def test_full_size_vs_reference_stats_and_oracle(tag):
     assert maxabs(y, yr) <= TOL_E2E
 
 
+_BIG5 = {**cases.BIG_STREAM_CASES, **cases.BIG_ORACLE_CASES}
+
+
+@pytest.mark.parametrize("tag", list(_BIG5))
+def test_config5_full_size_vs_reference_statistics(tag):
+    """BASELINE config 5 at the size it names: C=64, BEV 200x200, the 46-step streaming schedule, 43
+    decoded frames.  euler / midpoint against output statistics + 256 samples of the REAL reference run in the build
+    container (oracle/gen_golden.py --only big_stream), rk4 (build-defined) against the same statistics of the oracle."""
+    C, H, W, ts, solver, impute, variable = _BIG5[tag]
+    y, _, _ = _forward(C, H, W, ts, solver, impute, variable)
+    assert y.shape[1] == 43 and torch.isfinite(y).all()
+    st = json.load(open(os.path.join(GOLD, "big_stats.json")))
+    entry = st["cases"][tag] if tag in st["cases"] else st["oracle_cases"][tag]
+    _check_stats(y, entry["out"])
+
+
 def test_hipgraph_cache_follows_weight_updates():
     """A captured rollout graph holds raw pointers into the packed weights: after load_state_dict (new packs) the stale
     graph must be dropped and re-captured, not replayed (the cache key used id() of freed objects)."""
