@@ -276,7 +276,24 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       for (int i = 0; i < n; ++i) all3 = all3 && L.p[i].w3 != nullptr;
       for (int i = 0; i < n; ++i) L.p[i].use_w3 = all3 ? 1 : 0;
     }
+    if (!g_prof.on) {
+      SF_HIP(launch_conv_glds(L, epi, 5, 0, st));
+      return SF_OK;
+    }
+    ProfRec r;      // key 5 = "dmaLN128x64" (streamingflow_amd/_lib.py KERNEL_NAMES)
+    r.key = 5 * 8 + epi; r.flops = 0; r.bytes = 0;
+    for (int i = 0; i < n; ++i) {
+      const ConvProblem& q = ps[i];
+      const double Pi = (double)q.n_img * q.Hout * q.Wout;
+      const double K = (double)q.KH * q.KW * (q.c0 + q.c1);
+      r.flops += 2.0 * Pi * q.cout * K;
+      r.bytes += 4.0 * ((double)q.n_img * q.Hin * q.Win * (q.c0 + q.c1) + (double)q.cout * K + Pi * q.cout);
+    }
+    r.a = g_prof.get(); r.b = g_prof.get();
+    SF_HIP(hipEventRecord(r.a, st));
     SF_HIP(launch_conv_glds(L, epi, 5, 0, st));
+    SF_HIP(hipEventRecord(r.b, st));
+    g_prof.recs.push_back(r);
     return SF_OK;
   }
   if (sp_takes(ps, n, epi)) {

@@ -99,12 +99,12 @@ class IntersectionOverUnion(_Accumulator):
         if prediction.ndim == target.ndim + 1:      # class scores: the predicted label is the arg max over dim 1
             prediction = prediction.argmax(dim=1)
         n = self.n_classes
-        hist, flag = confusion(prediction, target, n + 1)      # one spare bin: label n is accepted and counted nowhere
+        hist, flag = confusion(prediction, target, n)          # any label outside [0, n) — n itself included — trips the flag (compute() raises)
         self._out_of_range = flag if self._out_of_range is None else torch.maximum(self._out_of_range, flag)
-        hist = hist[:n].to(torch.float32)                       # rows = target classes 0..n-1
-        hit = hist[:, :n].diagonal()
+        hist = hist.to(torch.float32)                           # rows = target classes 0..n-1
+        hit = hist.diagonal()
         self._accumulate("true_positive", hit)
-        self._accumulate("false_positive", hist[:, :n].sum(0) - hit)
+        self._accumulate("false_positive", hist.sum(0) - hit)
         self._accumulate("false_negative", hist.sum(1) - hit)
         self._accumulate("support", hist.sum(1))
 
@@ -114,7 +114,7 @@ class IntersectionOverUnion(_Accumulator):
 
     def compute(self):
         if self._out_of_range is not None and int(self._out_of_range.item()):
-            raise RuntimeError("IntersectionOverUnion: a label outside [0, n_classes] was seen")
+            raise RuntimeError("IntersectionOverUnion: a label outside [0, n_classes) was seen")
         tp, fp, fn = self.true_positive, self.false_positive, self.false_negative
         seen = (self.support + tp + fp) > 0
         scores = torch.where(seen, tp / (tp + fp + fn).clamp(min=1), torch.full_like(tp, float(self.absent_score)))
