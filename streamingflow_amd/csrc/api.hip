@@ -362,6 +362,11 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     }
     bool scaled = false;
     for (int i = 0; i < n; ++i) scaled = scaled || (ps[i].in_scale != nullptr) || (ps[i].se_sum != nullptr);
+    if (tune().b3) {      // opt-in math mode: every problem of the launch was packed with split-bf16 weights
+      bool all3 = true;
+      for (int i = 0; i < n; ++i) all3 = all3 && L.p[i].w3 != nullptr;
+      for (int i = 0; i < n; ++i) L.p[i].use_w3 = all3 ? 1 : 0;
+    }
     if (!g_prof.on) {
       SF_HIP(launch_conv_sp(L, epi, scaled, bn, st));
       return SF_OK;

@@ -267,10 +267,36 @@ __device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, cons
   }
 }
 
-template <int EPI, bool SCALE, int NT>
+// ---- opt-in math mode bf16x3 (see conv_igemm.hip): weights pre-split by sf_pack_conv, pixels split after the fragment read
+typedef __attribute__((ext_vector_type(8))) __bf16 sp_bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 sp_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float sp_f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned sp_u32x4;
+__device__ __forceinline__ unsigned sp_pk_bf16(float a, float b) {
+  const sp_bf16x2 t = __builtin_convertvector((sp_f32x2){a, b}, sp_bf16x2);
+  return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ void sp_split_bf16x8(const f32x4 x0, const f32x4 x1, sp_bf16x8& hi, sp_bf16x8& lo) {
+  sp_u32x4 h, l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = i < 2 ? x0[2 * i] : x1[2 * i - 4], b = i < 2 ? x0[2 * i + 1] : x1[2 * i - 3];
+    const unsigned pk = sp_pk_bf16(a, b);
+    h[i] = pk;
+    l[i] = sp_pk_bf16(a - __uint_as_float(pk << 16), b - __uint_as_float(pk & 0xffff0000u));
+  }
+  hi = __builtin_bit_cast(sp_bf16x8, h);
+  lo = __builtin_bit_cast(sp_bf16x8, l);
+}
+
+template <int EPI, bool SCALE, int NT, bool B3 = false>
 __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L) {
   typedef SpGeo<NT> G;
   constexpr int BN = G::BN;
+  // XOR mask of the 16-byte slot swizzle of the ring: 7 for the fp32 fragment reads (slots c + g), 5 for the bf16x3 loop
+  // (slots 2g / 2g + 1: conflict-free for the ds_read_b128 lane groups, see conv_igemm.hip)
+  constexpr int SWM = B3 ? 5 : 7;
+  constexpr int NKR = B3 ? 2 : 4;      // in-workgroup K split: halves (one 32-deep sub-chunk each) or quarters
   extern __shared__ __attribute__((aligned(16))) float smem[];   // ring | misc | SE scale rows
   // Workgroup -> (problem, K slice, cout tile, pixel tile).  Compact 1-D grid (L.wg_base): no idle workgroups.  Optionally
   // (L.xcd_shift, off by default) the dispatch id is first mapped so that each XCD gets a contiguous run of logical ids
@@ -458,7 +484,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = 8 * (lw + 4 * i) + (lane >> 3);
-      const int k4 = (lane & 7) ^ ((r >> 1) & 7);
+      const int k4 = (lane & 7) ^ ((r >> 1) & SWM);
       int grow = m_tile * SP_BM + r;
       grow = grow < P.cout_pad ? grow : P.cout_pad - 1;   // rows >= cout_pad are never stored
       a_voff[i] = (grow * P.ktot + k4 * 4) * (int)sizeof(float);
@@ -467,7 +493,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
 #pragma unroll
     for (int i = 0; i < G::NBI; ++i) {
       const int pr = 8 * (lw + 4 * i) + (lane >> 3);
-      b_c4[i] = 4 * ((lane & 7) ^ ((pr >> 1) & 7));
+      b_c4[i] = 4 * ((lane & 7) ^ ((pr >> 1) & SWM));
       const int gp = p_tile * BN + pr;
       const bool pvalid = gp < Ptot;
       const int img = pvalid ? gp / HWout : 0;
@@ -489,7 +515,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
       return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (int)nrec, 0x00020000);
     };
     const size_t imgs_left = (size_t)(P.n_img - img0);
-    const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(P.w, (size_t)P.cout_pad * P.ktot * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(B3 ? static_cast<const float*>(P.w3) : P.w, (size_t)P.cout_pad * P.ktot * sizeof(float));
     const __amdgpu_buffer_rsrc_t rsrc0 = make_rsrc(in0, imgs_left * P.Hin * P.Win * in0_cs * sizeof(float));
     const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(in1 ? in1 : in0, in1 ? imgs_left * P.Hin * P.Win * in1_cs * sizeof(float) : 0);
 #else
@@ -617,49 +643,83 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
 #endif
   } else {
     // ================================= consumer ===============================================================
-    const int mh = wave & 1, kq = wave >> 1;
     const int j = lane & 15, g = lane >> 4;
-    const int slot4 = ((((kq & 1) << 2) + g) ^ ((j >> 1) & 7)) * 4;
-    const int sub_off = (kq >> 1) * G::SUBF;
-    int a_off[2], b_off[NT];
+    // fp32: consumer (mh, kq) = cout half, K quarter of the chunk; all NT pixel tiles.
+    // bf16x3: consumer (mh, nh, kh) = cout half, pixel half, K half (= one 32-deep sub-chunk: one 16x16x32 MFMA per tile pair
+    // and product); lane (j, g) holds the 8 K values 8g .. 8g+7 of its row = slots 2g, 2g+1 (weights: hi / lo pieces)
+    constexpr int NTW = B3 ? NT / 2 : NT;      // pixel tiles per consumer wave
+    const int mh = wave & 1, kq = wave >> 1;
+    const int nh = B3 ? ((wave >> 1) & 1) : 0, kh = wave >> 2;
+    const int sxm = (j >> 1) & SWM;
+    const int slot4 = B3 ? ((2 * g) ^ sxm) * 4 : ((((kq & 1) << 2) + g) ^ sxm) * 4;
+    const int slot4b = B3 ? ((2 * g + 1) ^ sxm) * 4 : 0;
+    const int sub_off = (B3 ? kh : (kq >> 1)) * G::SUBF;
+    int a_off[2], b_off[NTW];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) a_off[m] = sub_off + (32 * mh + 16 * m + j) * 32 + slot4;
+    for (int m = 0; m < 2; ++m) a_off[m] = sub_off + (32 * mh + 16 * m + j) * 32;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) b_off[n] = sub_off + (SP_BM + 16 * n + j) * 32 + slot4;
-    // SE-scaled input: the lane's four K values of a chunk are channels kc*32 + (kq&1)*16 + 4g .. +3 of its sub-chunk
-    int s_kc = (2 * cb + (kq >> 1)) % kcpt;
+    for (int n = 0; n < NTW; ++n) b_off[n] = sub_off + (SP_BM + 16 * (nh * NTW + n) + j) * 32;
+    // SE-scaled input: the lane's K values of a chunk are channels kc*32 + (kq&1)*16 + 4g .. +3 (fp32) / kc*32 + 8g .. +7 (bf16x3) of its sub-chunk
+    int s_kc = (2 * cb + (B3 ? kh : (kq >> 1))) % kcpt;
     const int s_step = 2 % kcpt;
-    int simg[NT];
+    int simg[NTW];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int gp = p_tile * BN + 16 * n + j;
-      simg[n] = SCALE ? (gp < Ptot ? gp / HWout - img0 : 0) * cin_pad + ((kq & 1) << 4) + 4 * g : 0;
+    for (int n = 0; n < NTW; ++n) {
+      const int gp = p_tile * BN + 16 * (nh * NTW + n) + j;
+      simg[n] = SCALE ? (gp < Ptot ? gp / HWout - img0 : 0) * cin_pad + (B3 ? 8 * g : ((kq & 1) << 4) + 4 * g) : 0;
     }
-    f32x4 fa[2][2], fb[2][NT];
+    f32x4 fa[2][2][B3 ? 2 : 1], fb[2][NTW][B3 ? 2 : 1];
     auto read_frags = [&](const int buf, const int set) {
       const float* base = smem + buf * G::BUFF;
 #pragma unroll
-      for (int m = 0; m < 2; ++m) fa[set][m] = sp_lds_read128(base + a_off[m]);
+      for (int m = 0; m < 2; ++m) {
+        fa[set][m][0] = sp_lds_read128(base + a_off[m] + slot4);
+        if constexpr (B3) fa[set][m][1] = sp_lds_read128(base + a_off[m] + slot4b);
+      }
 #pragma unroll
-      for (int n = 0; n < NT; ++n) fb[set][n] = sp_lds_read128(base + b_off[n]);
+      for (int n = 0; n < NTW; ++n) {
+        fb[set][n][0] = sp_lds_read128(base + b_off[n] + slot4);
+        if constexpr (B3) fb[set][n][1] = sp_lds_read128(base + b_off[n] + slot4b);
+      }
       if (SCALE) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const f32x4 s4 = sp_lds_read128(sc_lds + simg[n] + s_kc * 32);
-          fb[set][n] = fb[set][n] * s4;
+        for (int n = 0; n < NTW; ++n) {
+          fb[set][n][0] = fb[set][n][0] * sp_lds_read128(sc_lds + simg[n] + s_kc * 32);
+          if constexpr (B3) fb[set][n][1] = fb[set][n][1] * sp_lds_read128(sc_lds + simg[n] + s_kc * 32 + 4);
         }
         s_kc += s_step;
         if (s_kc >= kcpt) s_kc -= kcpt;
       }
     };
     auto mfmas = [&](const int set) {
+      if constexpr (B3) {
+        sp_bf16x8 bh[NTW], bl[NTW];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int n = 0; n < NTW; ++n) sp_split_bf16x8(fb[set][n][0], fb[set][n][1], bh[n], bl[n]);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int n = 0; n < NT; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][m][e], fb[set][n][e], acc[m][n], 0, 0, 0);
+          for (int n = 0; n < NTW; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sp_bf16x8, fa[set][m][1]), bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NTW; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sp_bf16x8, fa[set][m][0]), bl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NTW; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sp_bf16x8, fa[set][m][0]), bh[n], acc[m][n], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][m][0][e], fb[set][n][0][e], acc[m][n], 0, 0, 0);
+      }
     };
     fill_scale_rows();
     SF_STAMP_AT(L, 1);
@@ -705,12 +765,14 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
   __syncthreads();                                        // every fragment read and every DMA of the ring is done
   float* const red = smem;                                // [4][BN][SP_RED_PITCH]
   if (wave < 8) {
-    const int mh = wave & 1, kq = wave >> 1, j = lane & 15, g = lane >> 4;
+    const int mh = wave & 1, j = lane & 15, g = lane >> 4;
+    constexpr int NTW = B3 ? NT / 2 : NT;
+    const int kr = B3 ? (wave >> 2) : (wave >> 1), n0 = B3 ? ((wave >> 1) & 1) * NTW : 0;      // K part / first pixel tile of this wave
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
-        spm_st4(red + ((kq * BN) + 16 * n + j) * SP_RED_PITCH + 32 * mh + 16 * m + 4 * g,
+      for (int n = 0; n < NTW; ++n)
+        spm_st4(red + ((kr * BN) + 16 * (n0 + n) + j) * SP_RED_PITCH + 32 * mh + 16 * m + 4 * g,
                 make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]));
   }
   __syncthreads();
@@ -720,7 +782,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
     v[i] = spm_zero4();
     if (wave < 8) {
 #pragma unroll
-      for (int kq = 0; kq < 4; ++kq) {
+      for (int kq = 0; kq < NKR; ++kq) {
         const float4 t = spm_ld4(red + (kq * BN + px[i]) * SP_RED_PITCH + 4 * quad);
         v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
       }
@@ -878,9 +940,17 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
 #endif
 }
 
+template <int EPI, bool SCALE, int NT, bool B3>
+static hipError_t launch_sp_tb(const ConvLaunch& L, hipStream_t stream);
 template <int EPI, bool SCALE, int NT>
-static hipError_t launch_sp_t(const ConvLaunch& L, hipStream_t stream) {
-  auto kern = conv_sp_kernel<EPI, SCALE, NT>;
+static hipError_t launch_sp_t(const ConvLaunch& L, hipStream_t stream) {      // bf16x3: every problem carries split weights (api.hip decides)
+  bool b3 = L.nprob > 0;
+  for (int i = 0; i < L.nprob; ++i) b3 = b3 && L.p[i].w3 != nullptr && L.p[i].use_w3;
+  return b3 ? launch_sp_tb<EPI, SCALE, NT, true>(L, stream) : launch_sp_tb<EPI, SCALE, NT, false>(L, stream);
+}
+template <int EPI, bool SCALE, int NT, bool B3>
+static hipError_t launch_sp_tb(const ConvLaunch& L, hipStream_t stream) {
+  auto kern = conv_sp_kernel<EPI, SCALE, NT, B3>;
   static bool attr_done[64] = {};      // the attribute is per device
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;

@@ -49,3 +49,33 @@ def test_full_size_forward_in_bf16x3(bf16x3):
     err = maxabs(y, yr)
     print("bf16x3 full-size forward max-abs vs oracle", err)
     assert err <= 2e-4      # north-star tolerance 1e-3; measured ~5e-5
+
+
+@pytest.mark.parametrize("solver", ["euler", "rk4"])
+def test_single_latent_stream40_rollout_in_bf16x3(solver):
+    """The 46-step streaming rollout (BASELINE config 5) on ONE 50x50x64 latent — the small-P kernel's split-bf16 loop, the
+    pipelined stages included — against the exact-fp32 rollout of the same inputs (itself checked against the oracle and the
+    reference in test_gpu_configs.py): chained over 46 steps (184 cell evaluations for rk4) the states stay within 2e-4."""
+    import streamingflow_amd as sfa
+    from streamingflow_amd import schedule as S
+    C, h, w = 64, 50, 50
+    cts, lts, tts, dt = cases.timeset("stream40")
+    net, _ = build_pair(C, solver, True, True, dt)
+    ode = net.gru_ode
+    times, _ = S.merge_observations(cts[0].tolist(), lts[0].tolist())
+    sc = S.build_schedule(times, tts[0].tolist(), dt, True, solver)
+    hx = (hashfill.normal("b3hx", (8, h, w, C), 61) * 0.5).cuda()
+    eps = hashfill.normal("b3eps", (sc.n_draws, h, w, C), 62).cuda()
+    a, fa = ode.rollout_nhwc(hx, sc, eps)
+    a, fa = a.clone(), fa.clone()
+    sfa.set_math_mode("bf16x3")
+    try:
+        b, fb = ode.rollout_nhwc(hx, sc, eps)
+        b2, _ = ode.rollout_nhwc(hx, sc, eps)
+        assert torch.equal(b, b2)
+    finally:
+        sfa.set_math_mode("fp32")
+    assert not torch.equal(a, b), "bf16x3 mode was not used"
+    err = max(maxabs(a, b), maxabs(fa, fb))
+    print(f"stream40 {solver}: bf16x3 vs fp32 max-abs over the 43 selected states", err, "scale", float(a.abs().max()))
+    assert err <= 2e-4

@@ -39,6 +39,8 @@ def time_chain(ode, n, solver, h, w, C, reps=20):
 
 
 def main():
+    import streamingflow_amd as sfa
+    sfa.set_math_mode(os.environ.get("SF_MATH_MODE", "fp32"))
     solver = sys.argv[1] if len(sys.argv) > 1 else "euler"
     n1, n2 = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (10, 30)
     h, w = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (50, 50)

@@ -12,6 +12,8 @@ from streamingflow_amd import schedule as S  # noqa: E402
 
 
 def main():
+    import streamingflow_amd as sfa
+    sfa.set_math_mode(os.environ.get("SF_MATH_MODE", "fp32"))
     name = sys.argv[1] if len(sys.argv) > 1 else "shipped"
     solver = sys.argv[2] if len(sys.argv) > 2 else "euler"
     C, h, w = 64, 50, 50
