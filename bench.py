@@ -567,6 +567,62 @@ def main():
         except Exception as ex:
             dec = {"error": repr(ex)}
 
+    # ---- opt-in math mode "bf16x3" (VERDICT r2 item 4): a SEPARATE object, never the headline -------------------------
+    # operands split into two bf16 pieces, three v_mfma_f32_16x16x32_bf16 products, fp32 accumulators; `value` above is exact fp32
+    b3 = None
+    if rank == 0 and world == 1 and not a.no_extras and not a.headline_only:
+        try:
+            torch.manual_seed(1234)
+            y32, _ = forward()
+            y32 = y32.clone()
+            sfa.set_math_mode("bf16x3")
+            torch.manual_seed(1234)
+            y3, _ = forward()                      # re-packs every module with split-bf16 weights
+            err = float((y3 - y32).abs().max())
+            for _ in range(2):
+                forward()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nb3 = max(3, a.steps // 4)
+            for _ in range(nb3):
+                forward()
+            torch.cuda.synchronize()
+            ms3 = 1e3 * (time.perf_counter() - t0) / nb3
+            forward1(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                forward1()
+            torch.cuda.synchronize()
+            ms3_1 = 1e3 * (time.perf_counter() - t0) / 3
+            step3 = roll3 = None
+            try:
+                med3, p953, _ = rollout_step_times(H // 4, W // 4)
+                step3 = {"us_per_step_median": med3, "us_per_step_p95": p953, "fp32_mfma_peak_equivalent_frac": 728.0 * C * C * (H // 4) * (W // 4) / (med3 * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+                ode.use_graph = True
+                for _ in range(2):
+                    ode.rollout_nhwc(hx, sc, eps)
+                torch.cuda.synchronize()
+                L.sf_event_record(e0, runtime.stream_ptr(dev))
+                for _ in range(10):
+                    ode.rollout_nhwc(hx, sc, eps)
+                L.sf_event_record(e1, runtime.stream_ptr(dev))
+                L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+                ode.use_graph = False
+                roll3 = ms.value / 10
+            except Exception as ex:
+                step3 = {"error": repr(ex)}
+            b3 = {"mode": "bf16x3", "opt_in": "streamingflow_amd.set_math_mode('bf16x3'); the default and every figure outside this object is exact fp32",
+                  "what": "operands split into two bf16 pieces (weights once by sf_pack_conv, activations in registers after the LDS read), "
+                          "hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16, fp32 accumulators; LDS-DMA kernel family and the small-P kernel",
+                  "max_abs_vs_fp32_same_forward": err, "absmax_of_output": float(y32.abs().max()), "tolerance_north_star": 1e-3,
+                  "max_abs_vs_oracle": "tests/test_gpu_bf16x3.py (4.4e-5 on the full-size forward), profiles/r03_bf16x3_accuracy_study.json (<= 1.1e-4 on configs 1, 2, 4, 5)",
+                  "ms_per_step": ms3, "ode_steps_per_s": n_ode * B / (ms3 * 1e-3), "speedup_vs_fp32_headline": ms_per_step / ms3,
+                  "batch1_forward_ms": ms3_1, "ode_step_in_rollout": step3, "rollout_18op_hipgraph_ms": roll3}
+        except Exception as ex:
+            b3 = {"error": repr(ex)}
+        finally:
+            sfa.set_math_mode("fp32")
+
     # ---- CPU baseline: the oracle (torch-CPU port of the reference path) on the host cores --------
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.headline_only:
@@ -602,7 +658,7 @@ def main():
                "single_sample_forward_ms": single_ms,
                "single_sample_ode_steps_per_s": None if single_ms is None else n_ode / (single_ms * 1e-3),
                "roofline_ode_step": roof_step, "multi_gpu": multi,
-               "ode_rollout_only": rollout, "ode_step_only": step_only, "lift_splat": lift, "lidar_voxelize": vox, "bev_decoder": dec, "roofline": roof, "cpu_baseline": cpu}
+               "ode_rollout_only": rollout, "ode_step_only": step_only, "lift_splat": lift, "lidar_voxelize": vox, "bev_decoder": dec, "bf16x3_mode": b3, "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -737,8 +737,18 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
 // fragments after the LDS read.  A reset-gate multiply is not: the GRU gates launch writes (1 - r) * s instead.
 // (tools/experiments/diag_loop.sh: without its staging the register-staged loop runs at 134 instead of 115 TFLOP/s on a
 // 7-frame 128->128 layer — global loads cost 10 %, the LDS writes 6 %; this kernel reaches 126, 134 at 224 frames.)
+// bf16x3 on the 128 x 128 tiles ("lean" loop, SF_B3_LEAN): no register double-buffering, two staging buffers, <= 128 VGPRs so that
+// TWO workgroups share a CU — one's barrier / DMA waits are the other's MFMA time
+#ifndef SF_B3_LEAN
+#define SF_B3_LEAN 1
+#endif
+#ifndef SF_B3_LEAN_MIN
+#define SF_B3_LEAN_MIN 0       // 16x16 tiles per workgroup from which the lean loop is used (measured, batch-32 forward in the mode: pipelined loop everywhere 162.4 ms, lean on the 128 x 128 tiles only 138.1, lean everywhere 135.8)
+#endif
+template <int MT, int NT, int WM, int WN, bool B3>
+constexpr bool glds_lean() { return B3 && SF_B3_LEAN && MT * NT * WM * WN >= SF_B3_LEAN_MIN; }
 template <int MT, int NT, int WM, int WN, int EPI, int NB, bool SCALE, bool B3 = false>
-__global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunch L) {
+__global__ __launch_bounds__(64 * WM * WN, (glds_lean<MT, NT, WM, WN, B3>() && WM * WN >= 8 ? 4 : 1)) void conv_glds_kernel(const ConvLaunch L) {
   constexpr int NWV = WM * WN;
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   constexpr int ROWS = BM + BN;
@@ -963,6 +973,48 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_glds_kernel(const ConvLaunc
         }
       }
     };
+    if constexpr (glds_lean<MT, NT, WM, WN, B3>()) {
+      static_assert(NB == 2, "lean bf16x3 loop: two staging buffers");
+      SF_STAMP_AT(L, 1);
+#pragma unroll
+      for (int q = 0; q < G; ++q) issue_one(cb, 0, q);
+      SF_STAMP_AT(L, 2);
+      for (int c = 0; c < nchunks; ++c) {
+        const int bufc = c & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk c landed (this wave's pieces) ...
+        __builtin_amdgcn_s_barrier();                          // ... everybody's; and every wave is done with the other buffer
+        if (c + 1 < nchunks) {
+#pragma unroll
+          for (int q = 0; q < G; ++q) issue_one(cb + c + 1, bufc ^ 1, q);
+        }
+        read3(bufc, std::integral_constant<int, 0>());
+        bf16x8 bh[NT], bl[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          f32x4 x0 = xb[0][n][0], x1 = xb[0][n][1];
+          if (SCALE && in_scale) { x0 = x0 * xs[0][n][0]; x1 = x1 * xs[0][n][1]; }
+          split_bf16x8(x0, x1, bh[n], bl[n]);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[0][m][1]), bh[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[0][m][0]), bl[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[0][m][0]), bh[n], acc[m][n], 0, 0, 0);
+          }
+        kc_cmp = kc_cmp + 1 == kcpt ? 0 : kc_cmp + 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      SF_STAMP_AT(L, 3);
+      if (nsplit > 1) {      // block-uniform
+        __syncthreads();
+        if (!splitk_handoff<MT, NT, NWV>(P, acc, nsplit, bid, wave, lane, tid, smem)) return;
+      }
+      SF_STAMP_AT(L, 4);
+      run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
+      return;
+    }
     SF_STAMP_AT(L, 1);
 #pragma unroll
     for (int c = 0; c < LA; ++c)
@@ -1167,7 +1219,7 @@ static hipError_t launch_glds_t(const ConvLaunch& L, hipStream_t stream) {
 }
 template <int MT, int NT, int WM, int WN, int EPI, bool SCALE, bool B3>
 static hipError_t launch_glds_tb(const ConvLaunch& L, hipStream_t stream) {
-  constexpr int NB = B3 ? SF_B3_NB : 2;
+  constexpr int NB = B3 ? (glds_lean<MT, NT, WM, WN, B3>() ? 2 : SF_B3_NB) : 2;
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   constexpr int lds = NB * (BM + BN) * 32 * 4 + (SCALE ? 4 * 256 * 4 : 0);   // staging buffers (+ the SE scale rows of up to 4 images x 256 channels)
   auto kern = conv_glds_kernel<MT, NT, WM, WN, EPI, NB, SCALE, B3>;
