@@ -611,13 +611,20 @@ def main():
                 roll3 = ms.value / 10
             except Exception as ex:
                 step3 = {"error": repr(ex)}
+            e2e3 = None
+            try:
+                import e2ebench
+                e2e3 = e2ebench.run(reps=2, dev=dev).get("ms_per_sample")      # the module-level mode is bf16x3 here
+            except Exception as ex:
+                e2e3 = repr(ex)
             b3 = {"mode": "bf16x3", "opt_in": "streamingflow_amd.set_math_mode('bf16x3'); the default and every figure outside this object is exact fp32",
                   "what": "operands split into two bf16 pieces (weights once by sf_pack_conv, activations in registers after the LDS read), "
                           "hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16, fp32 accumulators; LDS-DMA kernel family and the small-P kernel",
                   "max_abs_vs_fp32_same_forward": err, "absmax_of_output": float(y32.abs().max()), "tolerance_north_star": 1e-3,
                   "max_abs_vs_oracle": "tests/test_gpu_bf16x3.py (4.4e-5 on the full-size forward), profiles/r03_bf16x3_accuracy_study.json (<= 1.1e-4 on configs 1, 2, 4, 5)",
                   "ms_per_step": ms3, "ode_steps_per_s": n_ode * B / (ms3 * 1e-3), "speedup_vs_fp32_headline": ms_per_step / ms3,
-                  "batch1_forward_ms": ms3_1, "ode_step_in_rollout": step3, "rollout_18op_hipgraph_ms": roll3}
+                  "batch1_forward_ms": ms3_1, "ode_step_in_rollout": step3, "rollout_18op_hipgraph_ms": roll3,
+                  "end_to_end_after_image_backbone_ms_per_sample": e2e3}
         except Exception as ex:
             b3 = {"error": repr(ex)}
         finally:

@@ -20,6 +20,10 @@ def run(reps=3, dev=None):
     import liftbench
     import voxelbench
     dev = dev or torch.device("cuda", 0)
+    import streamingflow_amd as sfa
+    mode = os.environ.get("SF_MATH_MODE")
+    if mode:
+        sfa.set_math_mode(mode)
     cfg = default_cfg()
     net = streamingflow(cfg).eval()
     sd = hashfill.fill_state_dict(net.state_dict(), seed=91, gain=0.9)

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 out = {"commit": __import__("os").environ.get("SF_COMMIT"), "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/stepbench.py B h w %d; "
                  "sum over the sf:: kernels / steps; FETCH_SIZE x2 (gfx950), KiB.  These are L2 <-> fabric bytes (TCC_EA requests; Infinity-Cache hits are counted, MI355X_MICROARCH.md:297): an upper bound on HBM bytes, not HBM bytes" % N, "cases": {}}
-for tag in ("1_50_50", "8_50_50", "1_200_200"):
+for tag in ("8_50_50", "1_200_200"):
     tot = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         fs = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmcs_{c}_{tag}", "*", "*counter_collection.csv")))
@@ -36,6 +36,26 @@ for tag in ("1_50_50", "8_50_50", "1_200_200"):
                              "fetch_bytes": 2.0 * tot["FETCH_SIZE"] * 1024.0 / N, "write_bytes": tot["WRITE_SIZE"] * 1024.0 / N,
                              "kernel_us_per_step_under_pmc": ns / 1e3,
                              "fabric_gbs": by / ns if ns else None, "fabric_gbs_over_hbm_peak_8TBs": by / ns / 8000.0 if ns else None}
+# the single latent inside a rollout (pipelined stages: 9 launches per step): chains of 10 and 30 steps, 5 repetitions each
+# (tools/chainrun.py); per-step figure = difference of the two sums / (20 steps * 5 repetitions)
+def _chain(c, n):
+    fs = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmcc_{c}_{n}", "*", "*counter_collection.csv")))
+    if not fs:
+        return None, None
+    v = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(fs[-1])) if "sf::" in r["Kernel_Name"] and r["Counter_Name"] == c)
+    kt = fs[-1].replace("counter_collection", "kernel_trace")
+    ns = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt)) if "sf::" in r["Kernel_Name"]) if os.path.exists(kt) else 0
+    return v, ns
+ch = {c: (_chain(c, 10), _chain(c, 30)) for c in ("FETCH_SIZE", "WRITE_SIZE")}
+if all(ch[c][0][0] is not None and ch[c][1][0] is not None for c in ch):
+    REPS, DN = 5, 20
+    f = (ch["FETCH_SIZE"][1][0] - ch["FETCH_SIZE"][0][0]) * 2.0 * 1024.0 / (REPS * DN)
+    w = (ch["WRITE_SIZE"][1][0] - ch["WRITE_SIZE"][0][0]) * 1024.0 / (REPS * DN)
+    ns = (ch["WRITE_SIZE"][1][1] - ch["WRITE_SIZE"][0][1]) / (REPS * DN)
+    out["cases"]["1_50_50"] = {"batch": 1, "what": "steady-state Euler step of one 50x50x64 latent inside sf_nnfo_rollout_fwd (pipelined stages), (chain of 30 - chain of 10) / 20",
+                               "fabric_bytes_per_step_launch": f + w, "fabric_bytes_per_sample_step": f + w, "fetch_bytes": f, "write_bytes": w,
+                               "kernel_us_per_step_under_pmc": ns / 1e3, "fabric_gbs": (f + w) / ns if ns else None,
+                               "fabric_gbs_over_hbm_peak_8TBs": (f + w) / ns / 8000.0 if ns else None}
 for d in ("profiles", "gpurun_out"):
     json.dump(out, open(os.path.join(ROOT, d, "pmc_ode_step.json"), "w"), indent=1)
 print(json.dumps(out["cases"], indent=1))
