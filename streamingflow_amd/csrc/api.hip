@@ -15,6 +15,8 @@ hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant,
 hipError_t set_stamp_buffer(unsigned long long* p);
 hipError_t set_stamp_buffer_sp(unsigned long long* p);
 hipError_t launch_conv_sp(const ConvLaunch& L, int epi, bool scaled, int bn, hipStream_t stream);
+hipError_t launch_sp_segment(const SpSegment& S, bool b3, hipStream_t stream);
+bool sp_segment_has(int epi, bool scaled, int bn);
 hipError_t launch_transpose(const float* in, float* out, int n, int rows, int cols, hipStream_t s);
 hipError_t launch_transpose_strided(const float* in, float* out, int n, int rows, int cols, size_t in_stride, size_t out_stride,
                                     hipStream_t s);
@@ -144,11 +146,13 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
     Tune x;
+    x.persist = geti("SF_PERSIST", 0);             // 1: one latent: consecutive launches of a rollout run as phases of persistent segment launches (conv_sp.hip: sp_segment_kernel).  Built, bitwise equal to the launch-per-layer path (tests/test_gpu_persistent.py) and measured SLOWER: 228 us per steady-state step against 179 (one phase per segment launch: 201) — a grid-wide phase hand-off (write-through stores, drain, one atomic per workgroup, 256 pollers, acquire) costs more than the 3-4 us kernel boundary it replaces (MI355X_MICROARCH.md prices barrier-xcd at 4.1-4.8 us against 1.45-1.9 for a boundary).  Off by default
+    x.seg_maxph = geti("SF_SEG_MAXPH", SP_SEG_PHASES);   // phases per persistent segment (1: every phase its own launch of the segment kernel — diagnostic)
     x.fenced = geti("SF_HANDOFF_FENCED", 0);       // 1: split-K hand-offs also run the agent-scope release / acquire fences of round 1 (known-good reference for the fence-free sc1 form; gfx950 only either way)
     x.b3 = geti("SF_BF16X3", 1);                   // layers packed with split-bf16 weights (opt-in at pack time) run the bf16x3 K loop where a kernel has one (0: exact fp32 even then)
     x.pipe = geti("SF_PIPE", 2);                   // one latent: branch 2 of the NEXT dual cell (gates2 -> cand2, functions of the state only) rides in the launches of infer_state, its conv_decoder_2 in the candidate launch (0: every cell on its own, 5 launches)
@@ -239,6 +243,81 @@ int sp_bn(const ConvProblem* ps, int n) {
 // (the producer's whole launch group decides its tile)
 int chansum_tile_px(const ConvProblem* group, int n, int epi) { return sp_takes(group, n, epi) ? sp_bn(group, n) : 16; }
 
+// ---- persistent segments (one latent inside a rollout): run() records its small-P launches as phases instead of launching ----
+constexpr int DONE_COUNTERS = 4096;      // phase counters of one rollout
+struct SegBuilder {
+  SpSegment S;
+  hipStream_t st;
+  unsigned* done;
+  int next_done = 0;
+  bool b3 = false, failed = false;
+  int prev_idx = -1, prev_need = 0;      // the phase the next one waits for (inside the current segment only)
+  SegBuilder(unsigned* d, hipStream_t s) : st(s), done(d) { std::memset(&S, 0, sizeof(S)); S.done = d; }
+  int flush() {
+    if (S.nphase > 0) {
+      S.ph[S.nphase - 1].signal = 0;      // nobody inside this launch waits for its last phase; the kernel boundary orders what follows
+      if (launch_sp_segment(S, b3, st) != hipSuccess) return SF_ERR_LAUNCH;
+    }
+    std::memset(&S, 0, sizeof(S));
+    S.done = done;
+    prev_idx = -1; prev_need = 0;
+    return SF_OK;
+  }
+  SpPhase* open(int nprob, bool b3_phase) {
+    if (S.nphase > 0 && b3_phase != b3) { if (flush() != SF_OK) return nullptr; }
+    if (S.nphase >= tune().seg_maxph || S.nphase == SP_SEG_PHASES || S.nprob_total + nprob > SP_SEG_PROBS || next_done >= DONE_COUNTERS) { if (flush() != SF_OK) return nullptr; }
+    if (next_done >= DONE_COUNTERS) return nullptr;
+    b3 = b3_phase;
+    SpPhase& ph = S.ph[S.nphase];
+    std::memset(&ph, 0, sizeof(ph));
+    ph.nprob = nprob; ph.prob0 = S.nprob_total;
+    ph.wait_idx = prev_idx < 0 ? 0 : prev_idx;
+    ph.wait_need = prev_idx < 0 ? 0 : prev_need;
+    ph.done_idx = next_done++;
+    ph.signal = 1;
+    return &ph;
+  }
+  void close(SpPhase* ph, int finished_items) {
+    prev_idx = ph->done_idx; prev_need = finished_items;
+    S.nprob_total += ph->nprob;
+    S.nphase += 1;
+  }
+  int add(const ConvLaunch& L, int epi, bool scaled, int bn) {
+    bool all3 = L.nprob > 0;
+    for (int i = 0; i < L.nprob; ++i) all3 = all3 && L.p[i].w3 != nullptr && L.p[i].use_w3;
+    if (L.wg_base[L.nprob] < 1 || L.wg_base[L.nprob] > 256 || L.nprob > SP_SEG_PROBS || !sp_segment_has(epi, scaled, bn)) return SF_ERR_UNSUPPORTED;
+    SpPhase* ph = open(L.nprob, all3);
+    if (!ph) return SF_ERR_UNSUPPORTED;
+    ph->kind = SP_PHASE_CONV; ph->epi = epi; ph->scaled = scaled ? 1 : 0; ph->nt = bn / 16;
+    ph->n_wg = L.wg_base[L.nprob];
+    int tiles = 0;
+    for (int i = 0; i < L.nprob; ++i) {
+      S.p[ph->prob0 + i] = L.p[i];
+      const ConvProblem& q = L.p[i];
+      tiles += ((q.n_img * q.Hout * q.Wout + bn - 1) / bn) * ((q.cout_pad + 63) / 64);
+    }
+    for (int i = 0; i <= SF_MAX_GROUP; ++i) ph->wg_base[i] = L.wg_base[i];
+    close(ph, tiles);
+    return SF_OK;
+  }
+  int add_copy(const float* src, float* dst, size_t nfloats) {
+    if ((nfloats & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15) || nfloats / 4 > 0x7fffffff) return SF_ERR_UNSUPPORTED;
+    SpPhase* ph = open(1, b3);
+    if (!ph) return SF_ERR_UNSUPPORTED;
+    ConvProblem& q = S.p[ph->prob0];
+    std::memset(&q, 0, sizeof(q));
+    q.in0 = src; q.out = dst; q.ktot = (int)(nfloats / 4);
+    ph->kind = SP_PHASE_COPY;
+    int wgs = (int)((nfloats / 4 + 767) / 768);
+    ph->n_wg = wgs < 1 ? 1 : (wgs > 256 ? 256 : wgs);
+    close(ph, ph->n_wg);
+    return SF_OK;
+  }
+};
+thread_local SegBuilder* g_seg = nullptr;
+// anything that is not a small-P launch first sends the recorded phases on their way (stream order)
+int seg_flush() { return g_seg ? g_seg->flush() : SF_OK; }
+
 int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   ConvLaunch L;
   std::memset(&L, 0, sizeof(L));
@@ -263,6 +342,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   for (int i = 0; i < n; ++i) has_acc = has_acc || ps[i].acc_in != nullptr;
   if (has_acc && (wide_ln || !sp_takes(ps, n, epi))) return SF_ERR_UNSUPPORTED;      // K-partial inputs: small-P kernel only
   if (wide_ln) {
+    SF_TRY(seg_flush());
     // all channels of a pixel must sit in one wave: 128 cout x 64 px tiles of the LDS-DMA kernel, whatever the pixel count
     for (int i = 0; i < n; ++i) {
       const ConvProblem& q = ps[i];
@@ -367,6 +447,13 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       for (int i = 0; i < n; ++i) all3 = all3 && L.p[i].w3 != nullptr;
       for (int i = 0; i < n; ++i) L.p[i].use_w3 = all3 ? 1 : 0;
     }
+    if (g_seg && !g_prof.on && (tune().sp_xcd & 1) && !g_stamp_on) {      // inside a rollout: a phase of the current persistent segment
+      const int rc = g_seg->add(L, epi, scaled, bn);
+      if (rc == SF_OK) return SF_OK;
+      SF_TRY(g_seg->flush());                                               // does not fit the segment kernel: an ordinary launch
+    } else {
+      SF_TRY(seg_flush());
+    }
     if (!g_prof.on) {
       SF_HIP(launch_conv_sp(L, epi, scaled, bn, st));
       return SF_OK;
@@ -387,6 +474,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     g_prof.recs.push_back(r);
     return SF_OK;
   }
+  SF_TRY(seg_flush());
   int cfg = pick_cfg(P, epi);
   bool gathered = false;
   for (int i = 0; i < n; ++i) gathered = gathered || (ps[i].gather != nullptr);
@@ -784,6 +872,7 @@ int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p
   if (!A.ok()) return SF_ERR_WORKSPACE;
   if (!w.rb0.proj.w || w.rb1.proj.w) return SF_ERR_INVALID;
   auto gate = [&](const float* y, const float* rows, int nrows, const float* fc0, const float* fc2, float* scale) -> int {
+    SF_TRY(seg_flush());
     if (!tiles) {
       SF_HIP(launch_chan_partial(y, const_cast<float*>(rows), B, HW, C2, SE_SLABS, st));
       SF_HIP(launch_se_fc(rows, SE_SLABS, C2, C2 / 8, HW, fc0, fc2, scale, B, st));
@@ -1195,7 +1284,7 @@ struct Stage {
 
 size_t rollout_ws_floats(int C, int P) {
   const size_t cellw = dual_ws_floats(C, P), inf = infer_ws_floats(C, P);
-  return (cellw > inf ? cellw : inf) + 15 * al((size_t)P * C) + SPLIT_WS_FLOATS + 256;
+  return (cellw > inf ? cellw : inf) + 15 * al((size_t)P * C) + SPLIT_WS_FLOATS + DONE_COUNTERS + 256;
 }
 
 int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const float* eps, const unsigned long long* philox, int coef_stride,
@@ -1204,7 +1293,17 @@ int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const fl
   // buffers of the carried branch 2 (outside the per-stage arenas: written during one stage's infer_state, read by the next cell)
   Carry cb, cnow;
   cb.g2 = A.take(2 * PC); cb.rs2 = A.take(PC); cb.h2 = A.take(PC); cb.g1s = A.take(2 * PC);
+  unsigned* done = reinterpret_cast<unsigned*>(A.take(DONE_COUNTERS));
   if (!A.ok()) return SF_ERR_WORKSPACE;
+  // one latent: the launches of the stages become phases of persistent segment launches (conv_sp.hip: sp_segment_kernel)
+  const bool persist = tune().persist && B == 1 && (long)B * H * W < tune().sp_max_p && tune().sp && g_split != nullptr;
+  SegBuilder seg(done, st);
+  struct SegScope {      // g_seg is set for the duration of this function only
+    bool on;
+    SegScope(SegBuilder* b, bool enable) : on(enable) { if (on) g_seg = b; }
+    ~SegScope() { if (on) g_seg = nullptr; }
+  } seg_scope(&seg, persist);
+  if (persist) SF_HIP(zero_fill(done, DONE_COUNTERS * sizeof(unsigned), st));
   bool carried = false;
   for (size_t j = 0; j < stages.size(); ++j) {
     const Stage& g = stages[j];
@@ -1213,8 +1312,12 @@ int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const fl
     carried = false;
     if (g.op_end >= 0)
       for (int t = 0; t < n_targets; ++t)
-        if (sel_nops[t] == g.op_end + 1)
-          SF_HIP(copy_floats(g.out, out_states + (size_t)t * PC, PC, st));
+        if (sel_nops[t] == g.op_end + 1) {
+          if (!(g_seg && g_seg->add_copy(g.out, out_states + (size_t)t * PC, PC) == SF_OK)) {
+            SF_TRY(seg_flush());
+            SF_HIP(copy_floats(g.out, out_states + (size_t)t * PC, PC, st));
+          }
+        }
     if (g.infer_after) {
       Arena Ai = A;
       Side sd = {};
@@ -1229,6 +1332,7 @@ int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const fl
       carried = pipe;
     }
   }
+  SF_TRY(seg_flush());
   return SF_OK;
 }
 

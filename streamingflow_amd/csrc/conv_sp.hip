@@ -89,6 +89,49 @@ __device__ __forceinline__ float sp_wave_sum(float v) {
 }
 __device__ __forceinline__ float sp_reduce16(float v) { return spm_row16_sum(v); }   // sum over the 16 lanes (channel quads) of a pixel
 
+// Global stores of results.  PST (the persistent segment kernel, sp_segment_kernel): write-through (sc1) stores, so that a
+// workgroup of a LATER phase of the same launch — on any XCD — finds the bytes behind the phase counter + its acquire
+// (MI355X_MICROARCH.md, hand-off forms: every handed-off byte stored sc1, every storing wave drained before the signal).
+template <bool PST>
+__device__ __forceinline__ void sp_gst4(float* base, const size_t off, const float4 v) {      // base: block-uniform tensor pointer, off: this lane's element offset
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SF_PST_PLAIN)
+  if constexpr (PST) {
+    // a buffer store the compiler knows (its hazard recognizer and wait counters see it; an inline-asm global_store_dwordx4 sc1
+    // here gave wrong tiles — tests/test_gpu_persistent.py): 2-GB window on the tensor, aux 16 = sc1, as the split-K slabs
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4s;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128((u32x4s){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, rs, (int)(off * 4), 0, 16);
+  } else {
+    spm_st4(base + off, v);
+  }
+#else
+  spm_st4(base + off, v);
+#endif
+}
+template <bool PST>
+__device__ __forceinline__ void sp_gst2(float* p, const float2 v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SF_PST_PLAIN) && !defined(SF_PST_PLAIN2)
+  if constexpr (PST) {
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    const f32x2v t = {v.x, v.y};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+  } else {
+    *reinterpret_cast<float2*>(p) = v;
+  }
+#else
+  *reinterpret_cast<float2*>(p) = v;
+#endif
+}
+template <bool PST>
+__device__ __forceinline__ void sp_gst1(float* p, const float v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SF_PST_PLAIN) && !defined(SF_PST_PLAIN1)
+  if constexpr (PST) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else *p = v;
+#else
+  *p = v;
+#endif
+}
+
 // Epilogue operands of one (pixel, channel quad) item.  They are loaded by the consumer waves BEFORE the K loop (every one of
 // them was written by an earlier launch), so that the epilogue is arithmetic + stores only: measured 1.1-2.8 us per launch
 // when the loads sat behind the reduction (tools/r02/stamps.py).
@@ -156,7 +199,7 @@ __device__ __forceinline__ void sp_epi_load(const ConvProblem& P, const int gp, 
 // ---- epilogues in the (pixel, channel-quad) layout -------------------------------------------------------------------
 // v: the lane's four consecutive output channels c..c+3 of pixel gp (pre-activation accumulator sums).
 // y_out (AFFINE): the stored value, zero where not `on` (for the SE channel sums).
-template <int EPI>
+template <int EPI, bool PST = false>
 __device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, const int gp, const int c, const bool on,
                                             const SpOps& o, float4& y_out) {
   const size_t gpz = on ? (size_t)gp : 0;
@@ -183,14 +226,14 @@ __device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, cons
       } else if (P.add) { y.x += ad.x * as.x; y.y += ad.y * as.y; y.z += ad.z * as.z; y.w += ad.w * as.w; }
       if (act_last) y = spm_act4(y, P.act);
       if (on && gate_out)   // GRU gates, reset half: also emit (1 - r) * s, the candidate conv's input
-        spm_st4(P.out2 + gpz * P.out2_cs + cg, make_float4(sv.x * (1.f - y.x), sv.y * (1.f - y.y), sv.z * (1.f - y.z), sv.w * (1.f - y.w)));
+        sp_gst4<PST>(P.out2, gpz * P.out2_cs + cg, make_float4(sv.x * (1.f - y.x), sv.y * (1.f - y.y), sv.z * (1.f - y.z), sv.w * (1.f - y.w)));
     } else {
       const float4 u = o.a[2], s = o.a[3];
       v = spm_act4(v, P.act);
       if (P.mode & 1) y = make_float4(u.x * (v.x - s.x), u.y * (v.y - s.y), u.z * (v.z - s.z), u.w * (v.w - s.w));
       else y = make_float4((1.f - u.x) * s.x + u.x * v.x, (1.f - u.y) * s.y + u.y * v.y, (1.f - u.z) * s.z + u.z * v.z, (1.f - u.w) * s.w + u.w * v.w);
     }
-    if (on) spm_st4(P.out + gpz * P.out_cs + P.out_co + c, y);
+    if (on) sp_gst4<PST>(P.out, gpz * P.out_cs + P.out_co + c, y);
     y_out = on ? y : spm_zero4();
   }
 
@@ -213,7 +256,7 @@ __device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, cons
     if constexpr (EPI == EPI_LNG) {
       const float4 ad = o.a[2];      // Bottleblock residual (zero without one)
       const float4 y = make_float4(v.x + ad.x, v.y + ad.y, v.z + ad.z, v.w + ad.w);
-      if (on && P.out) spm_st4(P.out + gpz * P.out_cs + P.out_co + c, y);      // no `out`: the tile feeds the fused 1x1 layer only
+      if (on && P.out) sp_gst4<PST>(P.out, gpz * P.out_cs + P.out_co + c, y);      // no `out`: the tile feeds the fused 1x1 layer only
       y_out = on ? y : spm_zero4();
     } else {
       // trusting gate tail (temporal_ode_bayes.py:124-131 / :268-275, convolutions.py:375-380)
@@ -234,11 +277,11 @@ __device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, cons
           if (P.out2) {
             float4 a2 = (P.mode & 2) ? b2in : base;
             a2.x += c1f * d.x; a2.y += c1f * d.y; a2.z += c1f * d.z; a2.w += c1f * d.w;
-            spm_st4(P.out2 + po, a2);
+            sp_gst4<PST>(P.out2, po, a2);
           }
-          spm_st4(P.out + po, make_float4(base.x + c0f * d.x, base.y + c0f * d.y, base.z + c0f * d.z, base.w + c0f * d.w));
+          sp_gst4<PST>(P.out, po, make_float4(base.x + c0f * d.x, base.y + c0f * d.y, base.z + c0f * d.z, base.w + c0f * d.w));
         } else {
-          spm_st4(P.out + po, cur);
+          sp_gst4<PST>(P.out, po, cur);
         }
       }
     }
@@ -258,10 +301,10 @@ __device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, cons
       float2 r;
       r.x = q0 + e.x * (spm_softplus(q2) + 1e-8f);     // model_utils.py:84,107-108
       r.y = q1 + e.y * (spm_softplus(q3) + 1e-8f);
-      *reinterpret_cast<float2*>(P.out + gpz * Chalf + ch) = r;
+      sp_gst2<PST>(P.out + gpz * Chalf + ch, r);
       if (P.out2) {   // raw q parameters, reference channel order [loc | raw]
-        *reinterpret_cast<float2*>(P.out2 + gpz * P.cout + ch) = make_float2(q0, q1);
-        *reinterpret_cast<float2*>(P.out2 + gpz * P.cout + Chalf + ch) = make_float2(q2, q3);
+        sp_gst2<PST>(P.out2 + gpz * P.cout + ch, make_float2(q0, q1));
+        sp_gst2<PST>(P.out2 + gpz * P.cout + Chalf + ch, make_float2(q2, q3));
       }
     }
   }
@@ -289,51 +332,25 @@ __device__ __forceinline__ void sp_split_bf16x8(const f32x4 x0, const f32x4 x1, 
   lo = __builtin_bit_cast(sp_bf16x8, l);
 }
 
-template <int EPI, bool SCALE, int NT, bool B3 = false>
-__global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L) {
+struct SpStamp { int stamp_slot; };      // what the SF_STAMP macros read (diagnostic builds)
+
+// One (problem, tile, K slice) work item of a 768-thread workgroup: the whole body of the small-P kernel.  Called once by
+// conv_sp_kernel (one item per workgroup and launch) and once per phase by sp_segment_kernel (PST).  Returns true when this
+// workgroup ran the epilogue of its tile (false: the item is empty, or another slice's workgroup arrived last).  Every
+// branch that returns is block-uniform.
+template <int EPI, bool SCALE, int NT, bool B3, bool PST>
+__device__ __forceinline__ bool sp_body(const ConvProblem& P, const SpStamp L, int bx, int bz, const int m_tile, const int p_tile, float* const smem) {
   typedef SpGeo<NT> G;
   constexpr int BN = G::BN;
   // XOR mask of the 16-byte slot swizzle of the ring: 7 for the fp32 fragment reads (slots c + g), 5 for the bf16x3 loop
   // (slots 2g / 2g + 1: conflict-free for the ds_read_b128 lane groups, see conv_igemm.hip)
   constexpr int SWM = B3 ? 5 : 7;
   constexpr int NKR = B3 ? 2 : 4;      // in-workgroup K split: halves (one 32-deep sub-chunk each) or quarters
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // ring | misc | SE scale rows
-  // Workgroup -> (problem, K slice, cout tile, pixel tile).  Compact 1-D grid (L.wg_base): no idle workgroups.  Optionally
-  // (L.xcd_shift, off by default) the dispatch id is first mapped so that each XCD gets a contiguous run of logical ids
-  // (blocks are dealt round-robin to the 8 XCDs, each with its own L2; cdna_hip_programming.md T1): the ~30 workgroups of an
-  // XCD then stream the same weight columns.  Measured on the 50x50 step: 8 % less fabric traffic, 4 % MORE time — thirty
-  // workgroups fetching the same lines from one L2 at the same moment is slower than the same fetches spread over eight.
-  int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
-  const bool compact = L.wg_base[L.nprob] > 0;      // block-uniform
-  if (compact) {
-    const int total = (int)gridDim.x, id = bx;
-    const int q = total >> 3, r = total & 7, xcd = id & 7, slot = id >> 3;
-    const int lg = L.xcd_shift ? (xcd < r ? xcd * (q + 1) + slot : r * (q + 1) + (xcd - r) * q + slot) : id;
-    by = 0;
-#pragma unroll
-    for (int i = 1; i < SF_MAX_GROUP; ++i)
-      if (i < L.nprob && lg >= L.wg_base[i]) by = i;
-    bx = lg - L.wg_base[by];      // slice * tiles + tile, decoded below
-    bz = 0;
-  }
-  const ConvProblem& P = L.p[by];
   const int HWout = P.Hout * P.Wout;
   const int Ptot = P.n_img * HWout;
-  const int n_mt = (P.cout_pad + SP_BM - 1) / SP_BM;
-  int m_tile, p_tile;
-  if (compact) {
-    const int n_pt = (Ptot + BN - 1) / BN, tiles = n_pt * n_mt;
-    bz = bx / tiles;
-    bx -= bz * tiles;                                  // tile id (slab / ticket index): cout tile major
-    m_tile = bx / n_pt;
-    p_tile = bx - m_tile * n_pt;
-  } else {
-    m_tile = bx % n_mt;
-    p_tile = bx / n_mt;
-  }
-  if (p_tile * BN >= Ptot) return;                     // block-uniform
+  if (p_tile * BN >= Ptot) return false;               // block-uniform
   const int nsplit = P.nsplit > 1 ? P.nsplit : 1;
-  if (bz >= nsplit) return;                            // block-uniform
+  if (bz >= nsplit) return false;                      // block-uniform
   const int kcpt = P.cin_pad >> 5;                     // 32-deep sub-chunks per tap
   const int nsub_all = P.KH * P.KW * kcpt;
   const int nch_all = (nsub_all + 1) >> 1;
@@ -436,7 +453,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
 #pragma unroll
           for (int h = 0; h < 16; ++h) s += f2[h] * (h < Cr ? hid[h] : 0.f);
           sv = 1.f / (1.f + expf(-s));
-          if (P.se_out && bx == 0 && bz == 0) P.se_out[idx] = sv;
+          if (P.se_out && bx == 0 && bz == 0) sp_gst1<PST>(P.se_out + idx, sv);
         }
         sc_lds[idx] = sv;
       }
@@ -818,7 +835,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
       *flag = last;
     }
     __syncthreads();
-    if (*flag == 0) return;
+    if (*flag == 0) return false;
     if (wave < 8) {
 #pragma unroll
       for (int i = 0; i < G::NPX; ++i) v[i] = spm_zero4();
@@ -841,7 +858,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
 #pragma unroll
     for (int i = 0; i < G::NPX; ++i) {
       float4 y = spm_zero4();
-      sp_epilogue<EPI>(P, v[i], p_tile * BN + px[i], c, on_item[i], ops[i], y);
+      sp_epilogue<EPI, PST>(P, v[i], p_tile * BN + px[i], c, on_item[i], ops[i], y);
       ysum.x += y.x; ysum.y += y.y; ysum.z += y.z; ysum.w += y.w;
     }
   }
@@ -852,7 +869,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
 #pragma unroll
       for (int i = 0; i < G::NPX; ++i) {
         float4 y = spm_zero4();
-        sp_epilogue<EPI>(P, v[i], p_tile * BN + px[i], c, on_item[i], ops[i], y);
+        sp_epilogue<EPI, PST>(P, v[i], p_tile * BN + px[i], c, on_item[i], ops[i], y);
         if (wave < 8) {
           const int row = SP_BM + px[i];
           spm_st4(fz + (quad >> 3) * G::SUBF + row * 32 + (((quad & 7) ^ ((row >> 1) & 7)) << 2), y);
@@ -908,10 +925,10 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
           y.x = spm_gelu(fuse_lw.x * (dx * rstd) + fuse_lb.x); y.y = spm_gelu(fuse_lw.y * (dy * rstd) + fuse_lb.y);
           y.z = spm_gelu(fuse_lw.z * (dz * rstd) + fuse_lb.z); y.w = spm_gelu(fuse_lw.w * (dw * rstd) + fuse_lb.w);
           const int gp = p_tile * BN + px[i];
-          if (gp < Ptot && cv) spm_st4(P.fuse_out + (size_t)gp * P.fuse_cout + c, y);
+          if (gp < Ptot && cv) sp_gst4<PST>(P.fuse_out, (size_t)gp * P.fuse_cout + c, y);
         }
       }
-      return;
+      return true;
     }
   }
   if constexpr (EPI == EPI_AFFINE) {
@@ -929,7 +946,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
           const float4 b4 = spm_ld4(cs_lds + w8 * 64 + lane * 4);
           a4.x += b4.x; a4.y += b4.y; a4.z += b4.z; a4.w += b4.w;
         }
-        if (c < P.cout) spm_st4(P.chansum + (size_t)p_tile * P.cout + c, a4);
+        if (c < P.cout) sp_gst4<PST>(P.chansum, (size_t)p_tile * P.cout + c, a4);
       }
     }
   }
@@ -938,6 +955,120 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   SF_STAMP_AT(L, 6);
 #endif
+  return true;
+}
+
+// Logical workgroup id -> (problem, K slice, cout tile, pixel tile) on the compact 1-D grid: problem i owns the ids
+// [wg_base[i], wg_base[i + 1]), K slice major, then cout tile, then pixel tile.
+__device__ __forceinline__ void sp_decode(const ConvProblem* ps, const int* wg_base, const int nprob, const int lg, const int BN, int& by, int& bx, int& bz,
+                                          int& m_tile, int& p_tile) {
+  by = 0;
+#pragma unroll
+  for (int i = 1; i < SF_MAX_GROUP; ++i)
+    if (i < nprob && lg >= wg_base[i]) by = i;
+  bx = lg - wg_base[by];
+  const ConvProblem& P = ps[by];
+  const int Ptot = P.n_img * P.Hout * P.Wout;
+  const int n_mt = (P.cout_pad + SP_BM - 1) / SP_BM;
+  const int n_pt = (Ptot + BN - 1) / BN, tiles = n_pt * n_mt;
+  bz = bx / tiles;
+  bx -= bz * tiles;                                  // tile id (slab / ticket index): cout tile major
+  m_tile = bx / n_pt;
+  p_tile = bx - m_tile * n_pt;
+}
+
+template <int EPI, bool SCALE, int NT, bool B3 = false>
+__global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // ring | misc | SE scale rows
+  // Compact 1-D grid (L.wg_base): no idle workgroups.  Optionally (L.xcd_shift, off by default) the dispatch id is first mapped
+  // so that each XCD gets a contiguous run of logical ids (blocks are dealt round-robin to the 8 XCDs, each with its own L2;
+  // cdna_hip_programming.md T1).  Measured on the 50x50 step: 8 % less fabric traffic, 4 % MORE time — thirty workgroups
+  // fetching the same lines from one L2 at the same moment is slower than the same fetches spread over eight.
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z, m_tile, p_tile;
+  if (L.wg_base[L.nprob] > 0) {      // block-uniform
+    const int total = (int)gridDim.x, id = bx;
+    const int q = total >> 3, r = total & 7, xcd = id & 7, slot = id >> 3;
+    const int lg = L.xcd_shift ? (xcd < r ? xcd * (q + 1) + slot : r * (q + 1) + (xcd - r) * q + slot) : id;
+    sp_decode(L.p, L.wg_base, L.nprob, lg, SpGeo<NT>::BN, by, bx, bz, m_tile, p_tile);
+  } else {
+    const int n_mt = (L.p[by].cout_pad + SP_BM - 1) / SP_BM;
+    m_tile = bx % n_mt;
+    p_tile = bx / n_mt;
+  }
+  (void)sp_body<EPI, SCALE, NT, B3, false>(L.p[by], SpStamp{L.stamp_slot}, bx, bz, m_tile, p_tile, smem);
+}
+
+// ---- persistent segment kernel: several dependent launches of a rollout as phases of ONE launch ---------------------------------
+// (north star: "the ODE derivative cell ... and the stepping loop fused into one LDS-tiled kernel per step").  A segment is a list
+// of phases, each what a conv_sp_kernel launch was: a group of problems on the compact grid.  One workgroup per CU stays resident;
+// in phase k workgroup w runs item w of that phase (or idles), then signals, and waits for the phase to be complete before it
+// starts phase k + 1 — the kernel boundary replaced by a counter:
+//   producer (the workgroup that ran a tile's epilogue): results stored write-through (sc1), every wave s_waitcnt vmcnt(0),
+//     workgroup barrier, ONE agent-scope atomic add per workgroup;
+//   consumer: one lane polls the counter with sc1 loads until it equals the number of tiles of the phase, agent-scope acquire
+//     (buffer_inv sc1), s_waitcnt vmcnt(0), workgroup barrier, then plain loads / LDS-DMAs
+// (MI355X_MICROARCH.md "Valid forms").  Arithmetic, tile shapes, split-K slices and summation orders are those of the
+// launch-per-layer path: results are bitwise identical to it (tests/test_gpu_persistent.py).  Phase counters are per phase of the
+// whole rollout and zeroed once at its start; all workgroups of the grid are co-resident by construction (<= 256, one per CU).
+template <int EPI, bool SCALE, int NT, bool B3>
+__device__ __forceinline__ bool sp_phase_item(const SpSegment& S, const SpPhase& ph, const int wg, float* smem) {
+  int by, bx, bz, m_tile, p_tile;
+  sp_decode(S.p + ph.prob0, ph.wg_base, ph.nprob, wg, SpGeo<NT>::BN, by, bx, bz, m_tile, p_tile);
+  return sp_body<EPI, SCALE, NT, B3, true>(S.p[ph.prob0 + by], SpStamp{0}, bx, bz, m_tile, p_tile, smem);
+}
+
+template <bool B3>
+__global__ __launch_bounds__(SP_THREADS) void sp_segment_kernel(const SpSegment S_by_value) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // The 3.7-KB argument is indexed dynamically (phase k, problem prob0 + by): read it in place in the kernarg segment (scalar
+  // loads) — as a by-value object hipcc copies it to scratch first (4.2 KB per lane)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SF_SEG_BYVALUE)
+  typedef const __attribute__((address_space(4))) SpSegment* seg_cptr;
+  const SpSegment& S = *(const SpSegment*)(seg_cptr)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+  const SpSegment& S = S_by_value;
+#endif
+  (void)S_by_value;
+  const int wg = (int)blockIdx.x, tid = threadIdx.x;
+  for (int k = 0; k < S.nphase; ++k) {
+    const SpPhase& ph = S.ph[k];
+    if (ph.wait_need > 0) {      // block-uniform: the phase this one depends on must be complete
+      if (tid == 0) {
+        const unsigned* cnt = S.done + ph.wait_idx;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ph.wait_need) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+    }
+    bool fin = false;
+    if (wg < ph.n_wg) {          // block-uniform
+      if (ph.kind == SP_PHASE_COPY) {      // state copy-out: src -> dst, n4 float4s, every workgroup a slice (only later launches read dst)
+        const float4* src = reinterpret_cast<const float4*>(S.p[ph.prob0].in0);
+        float4* dst = reinterpret_cast<float4*>(S.p[ph.prob0].out);
+        const size_t n4 = (size_t)S.p[ph.prob0].ktot;
+        for (size_t i = (size_t)wg * SP_THREADS + tid; i < n4; i += (size_t)ph.n_wg * SP_THREADS) dst[i] = src[i];
+        fin = true;
+      } else {
+        const int key = ph.epi * 4 + (ph.scaled ? 2 : 0) + (ph.nt == 4 ? 1 : 0);
+        switch (key) {
+          case EPI_AFFINE * 4 + 0: fin = sp_phase_item<EPI_AFFINE, false, 2, B3>(S, ph, wg, smem); break;
+          case EPI_AFFINE * 4 + 1: fin = sp_phase_item<EPI_AFFINE, false, 4, B3>(S, ph, wg, smem); break;
+          case EPI_AFFINE * 4 + 3: fin = sp_phase_item<EPI_AFFINE, true, 4, B3>(S, ph, wg, smem); break;
+          case EPI_BLEND * 4 + 1:  fin = sp_phase_item<EPI_BLEND, false, 4, B3>(S, ph, wg, smem); break;
+          case EPI_LNG * 4 + 1:    fin = sp_phase_item<EPI_LNG, false, 4, B3>(S, ph, wg, smem); break;
+          case EPI_TRUST * 4 + 0:  fin = sp_phase_item<EPI_TRUST, false, 2, B3>(S, ph, wg, smem); break;
+          case EPI_SAMPLE * 4 + 3: fin = sp_phase_item<EPI_SAMPLE, true, 4, B3>(S, ph, wg, smem); break;
+          default: break;
+        }
+      }
+    }
+    // signal: every wave's stores are out, then one add per workgroup that finished a tile (the others only fed a slab);
+    // the barrier also keeps the next phase's first LDS-DMAs behind this phase's last LDS reads
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (fin && tid == 0 && ph.signal) __hip_atomic_fetch_add(S.done + ph.done_idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 template <int EPI, bool SCALE, int NT, bool B3>
@@ -994,6 +1125,37 @@ static hipError_t launch_sp_n(const ConvLaunch& L, int epi, bool scaled, hipStre
     case EPI_SAMPLE: return launch_sp_t<EPI_SAMPLE, false, NT>(L, stream);
   }
   return hipErrorInvalidValue;
+}
+
+// the (epilogue, SE-scaled, tile) variants sp_segment_kernel carries: the ones a 50x50x64 rollout uses; a phase that needs
+// another one runs as an ordinary launch between two segments
+bool sp_segment_has(int epi, bool scaled, int bn) {
+  const int key = epi * 4 + (scaled ? 2 : 0) + (bn == 64 ? 1 : 0);
+  return key == EPI_AFFINE * 4 + 0 || key == EPI_AFFINE * 4 + 1 || key == EPI_AFFINE * 4 + 3 || key == EPI_BLEND * 4 + 1 || key == EPI_LNG * 4 + 1 ||
+         key == EPI_TRUST * 4 + 0 || key == EPI_SAMPLE * 4 + 3;
+}
+// one persistent launch for a segment of dependent phases (sp_segment_kernel); b3: every phase runs the split-bf16 loop
+hipError_t launch_sp_segment(const SpSegment& S, bool b3, hipStream_t stream) {
+  if (S.nphase < 1) return hipSuccess;
+  const void* kern = b3 ? reinterpret_cast<const void*>(sp_segment_kernel<true>) : reinterpret_cast<const void*>(sp_segment_kernel<false>);
+  constexpr int lds = sp_lds_bytes<4>(true) + SpGeo<4>::BUFF * 4;      // the largest variant: 64-px tiles, SE rows, fused 1x1 buffer
+  static bool attr_done[64][2] = {};
+  static int n_cu[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!attr_done[dev][b3 ? 1 : 0]) {
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    if (hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return hipErrorInvalidDevice;
+    attr_done[dev][b3 ? 1 : 0] = true;
+  }
+  int grid = 0;
+  for (int k = 0; k < S.nphase; ++k) grid = S.ph[k].n_wg > grid ? S.ph[k].n_wg : grid;
+  if (grid < 1) return hipSuccess;
+  if (grid > n_cu[dev]) return hipErrorInvalidConfiguration;      // every workgroup must be resident (one per CU): phases wait for each other
+  if (b3) hipLaunchKernelGGL(sp_segment_kernel<true>, dim3(grid), dim3(SP_THREADS), lds, stream, S);
+  else hipLaunchKernelGGL(sp_segment_kernel<false>, dim3(grid), dim3(SP_THREADS), lds, stream, S);
+  return hipGetLastError();
 }
 
 // bn: pixels per tile (32 or 64); scaled: every problem carries an SE input scale (single input, cin_pad <= 256)

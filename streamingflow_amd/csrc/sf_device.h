@@ -109,6 +109,28 @@ struct ConvLaunch {
   int wg_base[SF_MAX_GROUP + 1];
 };
 
+// Persistent segment of the small-P kernel (conv_sp.hip: sp_segment_kernel): up to SP_SEG_PHASES dependent phases — each what
+// one conv_sp_kernel launch was — with up to SP_SEG_PROBS problems in all, passed by value (kernarg limit 4 KB).
+#define SP_SEG_PHASES 7
+#define SP_SEG_PROBS 7
+#define SP_PHASE_CONV 0
+#define SP_PHASE_COPY 1
+struct SpPhase {
+  int kind;                      // SP_PHASE_CONV | SP_PHASE_COPY (p[prob0]: in0 = src, out = dst, ktot = number of float4s)
+  int nprob, prob0;              // problems p[prob0 .. prob0 + nprob) of the segment
+  int epi, scaled, nt;           // kernel variant of the phase (epilogue family, SE-scaled inputs, 16-pixel tiles per wave: 2 | 4)
+  int n_wg;                      // workgroups that have an item in this phase (the others idle)
+  int wait_idx, wait_need;       // before starting: done[wait_idx] must have reached wait_need (0: nothing to wait for)
+  int done_idx, signal;          // after a finished tile: done[done_idx] += 1 (signal == 0: nobody waits for this phase in this launch or later)
+  int wg_base[SF_MAX_GROUP + 1];
+};
+struct SpSegment {
+  int nphase, nprob_total;
+  unsigned int* done;            // phase counters of the rollout (zero at its start)
+  SpPhase ph[SP_SEG_PHASES];
+  ConvProblem p[SP_SEG_PROBS];
+};
+
 // Diagnostic builds only (-DSF_STAMP, tools/r02/stamps.py): wave 0 of every workgroup records s_memrealtime (100 MHz)
 // at fixed points of the kernel into a debug buffer no other code reads.  The product build compiles none of it.
 #ifdef SF_STAMP
