@@ -29,7 +29,7 @@ cp $R/profiles/pmc_ode_step.json $R/gpurun_out/pmc_ode_step.json
 rm -rf $R/gpurun_out/final_trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_trace -- python3 $R/bench.py --steps 5 --warmup 2 --headline-only > $R/gpurun_out/final_trace_bench.json 2> $R/gpurun_out/final_trace.err
 cp $(ls $R/gpurun_out/final_trace/*/*kernel_stats.csv | tail -1) $R/gpurun_out/r03_z_kernel_stats_bench.csv
-bash $R/tools/r03_trace_chain.sh chain 9 > /dev/null 2>&1
+bash $R/tools/r03/trace_chain.sh chain 9 > /dev/null 2>&1
 for cfg in "8 50 50" "1 200 200"; do
   tag=$(echo $cfg | tr ' ' '_')
   rm -rf $R/gpurun_out/st_$tag
