@@ -146,12 +146,13 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int wide64, seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
     Tune x;
     x.persist = geti("SF_PERSIST", 0);             // 1: one latent: consecutive launches of a rollout run as phases of persistent segment launches (conv_sp.hip: sp_segment_kernel).  Built, bitwise equal to the launch-per-layer path (tests/test_gpu_persistent.py) and measured SLOWER: 228 us per steady-state step against 179 (one phase per segment launch: 201) — a grid-wide phase hand-off (write-through stores, drain, one atomic per workgroup, 256 pollers, acquire) costs more than the 3-4 us kernel boundary it replaces (MI355X_MICROARCH.md prices barrier-xcd at 4.1-4.8 us against 1.45-1.9 for a boundary).  Off by default
+    x.wide64 = geti("SF_WIDE64", 0);               // 1: 64-cout layers at >= 131072 pixels on 64 x 256 tiles (variant 10) instead of 64 x 128
     x.seg_maxph = geti("SF_SEG_MAXPH", SP_SEG_PHASES);   // phases per persistent segment (1: every phase its own launch of the segment kernel — diagnostic)
     x.fenced = geti("SF_HANDOFF_FENCED", 0);       // 1: split-K hand-offs also run the agent-scope release / acquire fences of round 1 (known-good reference for the fence-free sc1 form; gfx950 only either way)
     x.b3 = geti("SF_BF16X3", 1);                   // layers packed with split-bf16 weights (opt-in at pack time) run the bf16x3 K loop where a kernel has one (0: exact fp32 even then)
@@ -582,7 +583,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     }
     if (ok && cfg == 9 && (tune().glds & 1)) glds_tile = 0;
     if (ok && cfg == 1 && (tune().glds & 2)) {
-      glds_tile = 1; glds_var = pmin >= 131072 ? 6 : 4;
+      glds_tile = 1; glds_var = pmin >= 131072 ? (tune().wide64 ? 10 : 6) : 4;
       bool narrow = true;      // every problem has at most 32 output channels: half of a 64-row tile would multiply zeros
       for (int i = 0; i < n; ++i) narrow = narrow && L.p[i].cout_pad <= 32;
       if (narrow && tune().narrow >= 0) glds_var = tune().narrow;
@@ -634,7 +635,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     return SF_OK;
   }
   ProfRec r;
-  r.key = (glds_tile < 0 ? cfg : glds_tile == 4 ? 15 : glds_tile == 0 ? 10 : glds_tile == 2 ? 13 : glds_var == 6 ? 12 : 11) * 8 + epi; r.flops = 0; r.bytes = 0;
+  r.key = (glds_tile < 0 ? cfg : glds_tile == 4 ? 15 : glds_tile == 0 ? 10 : glds_tile == 2 ? 13 : (glds_var == 6 || glds_var == 10) ? 12 : 11) * 8 + epi; r.flops = 0; r.bytes = 0;
   for (int i = 0; i < n; ++i) {
     const ConvProblem& q = ps[i];
     const double Pi = (double)q.n_img * q.Hout * q.Wout;

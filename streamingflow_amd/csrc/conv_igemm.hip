@@ -1306,6 +1306,7 @@ hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant,
     case 6: return launch_glds_e<2, 2, 2, 4>(L, epi, stream);   // 64 cout x 128 px, 8 waves of 32x32
     case 7: return launch_glds_e<4, 2, 1, 4>(L, epi, stream);   // 64 cout x 128 px, 4 waves of 64x32
     case 9: return launch_glds_e<1, 4, 2, 2>(L, epi, stream);   // 32 cout x 128 px, 4 waves of 16x64 (narrow layers: 16- / 32-channel sparse stages)
+    case 10: return launch_glds_e<2, 4, 2, 4>(L, epi, stream);  // 64 cout x 256 px, 8 waves of 32x64 (64-channel layers at large P: the staged bytes per FLOP of the 128 x 128 tile)
   }
   return hipErrorInvalidValue;
 }

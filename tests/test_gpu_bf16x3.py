@@ -79,3 +79,47 @@ def test_single_latent_stream40_rollout_in_bf16x3(solver):
     err = max(maxabs(a, b), maxabs(fa, fb))
     print(f"stream40 {solver}: bf16x3 vs fp32 max-abs over the 43 selected states", err, "scale", float(a.abs().max()))
     assert err <= 2e-4
+
+
+def test_bn_fold_is_the_librarys_own():
+    """packing.bn_fold is a caller of sf_bn_fold (the device code sf_pack_conv folds with): compare with the textbook formula."""
+    import torch.nn as nn
+    from streamingflow_amd import packing
+    bn = nn.BatchNorm2d(20, eps=1e-3).cuda().eval()
+    with torch.no_grad():
+        bn.weight.copy_(hashfill.uniform("bnw", (20,), 0.5, 1.5, 7)); bn.bias.copy_(hashfill.uniform("bnb", (20,), -1, 1, 8))
+        bn.running_mean.copy_(hashfill.uniform("bnm", (20,), -1, 1, 9)); bn.running_var.copy_(hashfill.uniform("bnv", (20,), 0.2, 2.0, 10))
+    cb = hashfill.uniform("bncb", (20,), -1, 1, 11).cuda()
+    sc, bi = packing.bn_fold(bn, cb)
+    want_sc = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    want_bi = bn.bias - bn.running_mean * want_sc + cb * want_sc
+    assert maxabs(sc, want_sc) <= 1e-6 and maxabs(bi, want_bi) <= 2e-6
+    sc2, bi2 = packing.bn_fold(bn)
+    assert maxabs(bi2, bn.bias - bn.running_mean * want_sc) <= 2e-6
+
+
+def test_math_mode_switch_repacks_and_drops_graphs():
+    """set_math_mode changes the pack signature: modules re-pack on their next call and captured rollout graphs (raw pointers
+    into the old packs) are dropped; switching back restores the exact results bit for bit."""
+    import streamingflow_amd as sfa
+    from streamingflow_amd import schedule as S
+    C, h, w = 16, 12, 12
+    cts, lts, tts, dt = cases.timeset("shipped")
+    net, _ = build_pair(C, "euler", True, True, dt)
+    ode = net.gru_ode
+    times, _ = S.merge_observations(cts[0].tolist(), lts[0].tolist())
+    sc = S.build_schedule(times, tts[0].tolist(), dt, True, "euler")
+    hx = (hashfill.normal("mmhx", (len(times), h, w, C), 61) * 0.5).cuda()
+    eps = hashfill.normal("mmeps", (sc.n_draws, h, w, C), 62).cuda()
+    ode.use_graph = True
+    a, _ = ode.rollout_nhwc(hx, sc, eps); a = a.clone()
+    g0 = ode.gru_c.pack_generation()
+    sfa.set_math_mode("bf16x3")
+    try:
+        b, _ = ode.rollout_nhwc(hx, sc, eps); b = b.clone()
+        assert ode.gru_c.pack_generation() != g0 and len(ode._graphs) == 1
+    finally:
+        sfa.set_math_mode("fp32")
+    c, _ = ode.rollout_nhwc(hx, sc, eps)
+    assert torch.equal(a, c) and maxabs(a, b) <= 2e-4
+    ode.use_graph = False
