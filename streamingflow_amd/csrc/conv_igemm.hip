@@ -103,9 +103,6 @@ __device__ __forceinline__ void split_bf16x8(const f32x4 x0, const f32x4 x1, bf1
   lo = __builtin_bit_cast(bf16x8, l);
 }
 
-#ifndef SF_B3_NB
-#define SF_B3_NB 3      // staging buffers of the bf16x3 loop (measured, batch-32 forward: 2 -> 166.5 ms, 3 -> 162.4, 4 -> 182.6: the 64x128 tiles lose their second and third workgroup per CU)
-#endif
 #ifndef SF_SETPRIO
 #define SF_SETPRIO 1
 #endif
@@ -737,18 +734,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
 // fragments after the LDS read.  A reset-gate multiply is not: the GRU gates launch writes (1 - r) * s instead.
 // (tools/experiments/diag_loop.sh: without its staging the register-staged loop runs at 134 instead of 115 TFLOP/s on a
 // 7-frame 128->128 layer — global loads cost 10 %, the LDS writes 6 %; this kernel reaches 126, 134 at 224 frames.)
-// bf16x3 on the 128 x 128 tiles ("lean" loop, SF_B3_LEAN): no register double-buffering, two staging buffers, <= 128 VGPRs so that
-// TWO workgroups share a CU — one's barrier / DMA waits are the other's MFMA time
-#ifndef SF_B3_LEAN
-#define SF_B3_LEAN 1
-#endif
-#ifndef SF_B3_LEAN_MIN
-#define SF_B3_LEAN_MIN 0       // 16x16 tiles per workgroup from which the lean loop is used (measured, batch-32 forward in the mode: pipelined loop everywhere 162.4 ms, lean on the 128 x 128 tiles only 138.1, lean everywhere 135.8)
-#endif
-template <int MT, int NT, int WM, int WN, bool B3>
-constexpr bool glds_lean() { return B3 && SF_B3_LEAN && MT * NT * WM * WN >= SF_B3_LEAN_MIN; }
+// bf16x3 instantiations of the 8-wave tiles ask for two workgroups per CU (their loop needs <= 100 VGPRs)
 template <int MT, int NT, int WM, int WN, int EPI, int NB, bool SCALE, bool B3 = false>
-__global__ __launch_bounds__(64 * WM * WN, (glds_lean<MT, NT, WM, WN, B3>() && WM * WN >= 8 ? 4 : 1)) void conv_glds_kernel(const ConvLaunch L) {
+__global__ __launch_bounds__(64 * WM * WN, (B3 && WM * WN >= 8 ? 4 : 1)) void conv_glds_kernel(const ConvLaunch L) {
   constexpr int NWV = WM * WN;
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   constexpr int ROWS = BM + BN;
@@ -950,12 +938,10 @@ __global__ __launch_bounds__(64 * WM * WN, (glds_lean<MT, NT, WM, WN, B3>() && W
   if constexpr (B3) {
     // ---- split-bf16 K loop: one v_mfma_f32_16x16x32_bf16 per (tile pair, product) and 32-deep chunk.  Lane (j, g) holds the
     // 8 K values 8g .. 8g+7 of its row: the 16-byte slots 2g and 2g+1 (weights: hi and lo pieces; pixels: two float4).
-    // Software pipeline over the two staging buffers: after the barrier that publishes chunk c+1 its fragments are read into
-    // the other register set while the third product (lo x hi) of chunk c is still being multiplied.
-    // NB staging buffers, NB - 1 chunks in flight: a chunk's arithmetic is ~4x shorter than in fp32, so one chunk of
-    // look-ahead no longer covers the latency of the DMAs (measured with NB = 2: 1.48x over fp32; profiles/r03_*)
+    // No register double-buffering and <= 100 VGPRs: TWO workgroups share a CU and one's barrier / DMA wait is the other's MFMA
+    // time (measured against a software-pipelined loop with 2 / 3 / 4 staging buffers: profiles/README.md round-3 log).
     const int o0 = 4 * ((2 * g) ^ sx), o1 = 4 * ((2 * g + 1) ^ sx);
-    f32x4 wa[2][MT][2], xb[2][NT][2], xs[2][NT][2];
+    f32x4 wa[1][MT][2], xb[1][NT][2], xs[1][NT][2];
     int kc_cmp = cb % kcpt;
     auto read3 = [&](int buf, auto SET) {
       constexpr int st = decltype(SET)::value;
@@ -973,8 +959,8 @@ __global__ __launch_bounds__(64 * WM * WN, (glds_lean<MT, NT, WM, WN, B3>() && W
         }
       }
     };
-    if constexpr (glds_lean<MT, NT, WM, WN, B3>()) {
-      static_assert(NB == 2, "lean bf16x3 loop: two staging buffers");
+    {
+      static_assert(NB == 2, "bf16x3 loop: two staging buffers");
       SF_STAMP_AT(L, 1);
 #pragma unroll
       for (int q = 0; q < G; ++q) issue_one(cb, 0, q);
@@ -1015,75 +1001,6 @@ __global__ __launch_bounds__(64 * WM * WN, (glds_lean<MT, NT, WM, WN, B3>() && W
       run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
       return;
     }
-    SF_STAMP_AT(L, 1);
-#pragma unroll
-    for (int c = 0; c < LA; ++c)
-      if (c < nchunks) {      // block-uniform
-#pragma unroll
-        for (int q = 0; q < G; ++q) issue_one(cb + c, c, q);
-      }
-    if (LA > 1 && nchunks >= LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    SF_STAMP_AT(L, 2);
-    read3(0, std::integral_constant<int, 0>());
-    int buf = 0, ibuf = LA;      // buffer of the chunk being multiplied / of the next chunk to fetch
-    auto step = [&](const int c, auto SET) {
-      constexpr int st = decltype(SET)::value;
-      const bool more = c + LA < nchunks;
-      if (more) {              // into the buffer of chunk c - 1: every wave read it before the barrier of step c - 1
-#pragma unroll
-        for (int q = 0; q < G; ++q) issue_one(cb + c + LA, ibuf, q);
-      }
-      bf16x8 bh[NT], bl[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        f32x4 x0 = xb[st][n][0], x1 = xb[st][n][1];
-        if (SCALE && in_scale) { x0 = x0 * xs[st][n][0]; x1 = x1 * xs[st][n][1]; }
-        split_bf16x8(x0, x1, bh[n], bl[n]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (SETPRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[st][m][0]), bl[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[st][m][0]), bh[n], acc[m][n], 0, 0, 0);
-      if (SETPRIO) __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      kc_cmp = kc_cmp + 1 == kcpt ? 0 : kc_cmp + 1;
-      buf = buf == NB - 1 ? 0 : buf + 1;
-      ibuf = ibuf == NB - 1 ? 0 : ibuf + 1;
-      if (c + 1 < nchunks) {   // chunk c + 1 landed (the LA - 1 younger ones stay in flight), published, its fragments requested
-        if (LA > 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        read3(buf, std::integral_constant<int, st ^ 1>());
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[st][m][1]), bh[n], acc[m][n], 0, 0, 0);
-    };
-    for (int c = 0; c < nchunks; c += 2) {
-      step(c, std::integral_constant<int, 0>());
-      if (c + 1 < nchunks) step(c + 1, std::integral_constant<int, 1>());
-    }
-    SF_STAMP_AT(L, 3);
-    if (nsplit > 1) {      // block-uniform
-      __syncthreads();
-      if (!splitk_handoff<MT, NT, NWV>(P, acc, nsplit, bid, wave, lane, tid, smem)) return;
-    }
-    SF_STAMP_AT(L, 4);
-    run_epilogue<MT, NT, EPI>(P, acc, m_tile * BM + wm * MT * 16, p_tile * BN + wn * NT * 16, lane, Ptot, HWout);
-    return;
   }
   auto koff = [&](int t4) { return 4 * ((2 * t4 + (g >> 1)) ^ sx) + ((2 * g) & 3); };
   // Barrier in the middle of the MFMA stream (two buffers): the last k-group of chunk c is multiplied AFTER the
@@ -1219,7 +1136,7 @@ static hipError_t launch_glds_t(const ConvLaunch& L, hipStream_t stream) {
 }
 template <int MT, int NT, int WM, int WN, int EPI, bool SCALE, bool B3>
 static hipError_t launch_glds_tb(const ConvLaunch& L, hipStream_t stream) {
-  constexpr int NB = B3 ? (glds_lean<MT, NT, WM, WN, B3>() ? 2 : SF_B3_NB) : 2;
+  constexpr int NB = 2;
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   constexpr int lds = NB * (BM + BN) * 32 * 4 + (SCALE ? 4 * 256 * 4 : 0);   // staging buffers (+ the SE scale rows of up to 4 images x 256 channels)
   auto kern = conv_glds_kernel<MT, NT, WM, WN, EPI, NB, SCALE, B3>;
