@@ -339,9 +339,9 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     const double e0 = 2.0 * ps[i].Hin * ps[i].Win * ps[i].in0_cs, e1 = 2.0 * ps[i].Hin * ps[i].Win * ps[i].in1_cs;
     if (!ps[i].gather && (e0 >= 2147483648.0 || e1 >= 2147483648.0)) return SF_ERR_UNSUPPORTED;
   }
-  bool has_acc = false;
-  for (int i = 0; i < n; ++i) has_acc = has_acc || ps[i].acc_in != nullptr;
-  if (has_acc && (wide_ln || !sp_takes(ps, n, epi))) return SF_ERR_UNSUPPORTED;      // K-partial inputs: small-P kernel only
+  bool has_acc = false;      // K-partial inputs and the blend mode of the AFFINE epilogue: small-P kernel only (never silently ignored)
+  for (int i = 0; i < n; ++i) has_acc = has_acc || ps[i].acc_in != nullptr || (epi == EPI_AFFINE && (ps[i].mode & 4));
+  if (has_acc && (wide_ln || !sp_takes(ps, n, epi))) return SF_ERR_UNSUPPORTED;
   if (wide_ln) {
     SF_TRY(seg_flush());
     // all channels of a pixel must sit in one wave: 128 cout x 64 px tiles of the LDS-DMA kernel, whatever the pixel count
@@ -779,7 +779,14 @@ struct Side {                // extra problems for infer_state's launches (AFFIN
 };
 bool carry_ok(const sf_dual_w& w, int B, int H, int W) {
   const long P = (long)B * H * W;
-  return tune().pipe && B == 1 && P < tune().sp_max_p && tune().sp && pregate(P, w.cand1) && pregate(P, w.cand2);
+  if (!(tune().pipe && B == 1 && P < tune().sp_max_p && tune().sp && pregate(P, w.cand1) && pregate(P, w.cand2))) return false;
+  // every layer that changes its launch must be one the small-P kernel takes (its AFFINE epilogue alone has the blend mode and acc_in)
+  const sf_conv_w* ws[5] = {&w.gates2, &w.cand2, &w.dec2, &w.cand1, &w.gates1};
+  for (const sf_conv_w* c : ws) {
+    const ConvProblem q = problem(*c, nullptr, nullptr, nullptr, B, H, W);
+    if (!sp_takes(&q, 1, EPI_AFFINE)) return false;
+  }
+  return true;
 }
 // the two side problems of cell `w` on state `s` (= the output of the cell before it)
 void side_problems(const sf_dual_w& w, const float* s, const Carry& c, int B, int H, int W, Side& sd) {
