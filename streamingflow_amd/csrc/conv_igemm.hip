@@ -862,8 +862,12 @@ __global__ __launch_bounds__(64 * WM * WN, (B3 && WM * WN >= 8 ? 4 : 1)) void co
     for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   int cur_kc = cb % kcpt, cur_ty = (cb / kcpt) / KW, cur_tx = (cb / kcpt) % KW;     // cursor of the next chunk to ISSUE
+  // per tap and pixel slot: byte offset of the gathered pixel in either source, this lane's 16-byte channel slot included, or
+  // 0x80000000 outside the image / the table (beyond any buffer: the range check zero-fills).  Per chunk a DMA then needs no
+  // vector arithmetic at all — the channel chunk goes into the scalar offset (fp32 MFMAs share the vector ALU)
   int tap_off0[GB], tap_off1[GB];
   bool tap_fresh = true;
+  const bool whole_chunks = (c01 % BK) == 0;      // block-uniform: no channel padding inside a chunk
 
   typedef __attribute__((address_space(3))) void lds_void;
   // one LDS-DMA of the chunk at the cursor: slot q of G (weights first); the last slot advances the cursor
@@ -895,8 +899,8 @@ __global__ __launch_bounds__(64 * WM * WN, (B3 && WM * WN >= 8 ? 4 : 1)) void co
           for (int i = 0; i < GB; ++i) {
             const int gp = p_tile * BN + (wave * GB + i) * 8 + (lane >> 3);
             const int px = gp < Ptot ? gather[(size_t)gp * KHg + cur_ty] : -1;
-            tap_off0[i] = px >= 0 ? px * in0_cs : -1;
-            tap_off1[i] = (px >= 0 ? px : 0) * in1_cs - c0;
+            tap_off0[i] = px >= 0 ? (px * in0_cs + b_c4[i]) * 4 : (int)0x80000000;
+            tap_off1[i] = px >= 0 ? (px * in1_cs + b_c4[i]) * 4 : (int)0x80000000;
           }
         } else {
 #pragma unroll
@@ -904,21 +908,20 @@ __global__ __launch_bounds__(64 * WM * WN, (B3 && WM * WN >= 8 ? 4 : 1)) void co
             const int iy = b_iy0[i] + cur_ty * dil, ix = b_ix0[i] + cur_tx * dil;
             const bool in = (iy >= 0) & (iy < Hlog) & (ix >= 0) & (ix < Wlog);
             const int px = in ? b_base[i] + (iy >> in_up) * Win + (ix >> in_up) : 0;
-            tap_off0[i] = in ? px * in0_cs : -1;
-            tap_off1[i] = px * in1_cs - c0;
+            tap_off0[i] = in ? (px * in0_cs + b_c4[i]) * 4 : (int)0x80000000;
+            tap_off1[i] = in ? (px * in1_cs + b_c4[i]) * 4 : (int)0x80000000;
           }
         }
       }
-      const int c = cur_kc * BK + b_c4[qb];
       float* dst = smem + buf * BUF + (BM + (wave * GB + qb) * 8) * 32;
 #if defined(__HIP_DEVICE_COMPILE__)
       const bool from1 = cur_kc * BK >= c0;                               // wave-uniform: the whole chunk reads in1
-      const bool ok = (tap_off0[qb] >= 0) & (c < c01);
-      const int voff = ok ? (c + (from1 ? tap_off1[qb] : tap_off0[qb])) * 4 : -1;
-      if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (lds_void*)dst, 16, voff, 0, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (lds_void*)dst, 16, voff, 0, 0, 0);
+      int voff = from1 ? tap_off1[qb] : tap_off0[qb];
+      if (!whole_chunks) voff = (cur_kc * BK + b_c4[qb] < c01) ? voff : (int)0x80000000;      // channels past cin inside the chunk: zero
+      if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (lds_void*)dst, 16, voff, (cur_kc * BK - c0) * 4, 0, 0);      // the vector offset alone is range-checked: it must not go negative
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (lds_void*)dst, 16, voff, cur_kc * (BK * 4), 0, 0);
 #else
-      (void)dst; (void)c;
+      (void)dst;
 #endif
     }
 #if SF_GDIAG != 3
@@ -1059,12 +1062,16 @@ __global__ __launch_bounds__(64 * WM * WN, (B3 && WM * WN >= 8 ? 4 : 1)) void co
   // the barrier just freed (chunk c-1's), then k-groups 0..NG-2 of chunk c, then retire chunk c+1 (a counted vmcnt:
   // the LA-1 younger chunks stay in flight).  No LDS read is in flight across the back edge, so the compiler's
   // lgkmcnt bookkeeping stays exact.
-  int buf = 0, ibuf = LA;
+  // The two staging buffers are compile-time constants of the two halves of an unrolled pair of chunks: the fragment
+  // addresses are then loop-invariant registers + an immediate ds_read offset (buffer, tile row) instead of 8 v_add per chunk
+  // — fp32 MFMAs share the vector ALU, every VALU instruction in this loop is matrix time.
+  static_assert(NB == 2 && LA == 1, "two staging buffers");
 #ifdef SF_STAMP
   unsigned long long cyc_issue = 0, cyc_wait = 0, cyc_bar = 0;
   const unsigned long long cyc_loop0 = __builtin_amdgcn_s_memtime();
 #endif
-  for (int c = 0; c < nchunks; ++c) {
+  auto chunk_step = [&](const int c, auto BUFC) {
+    constexpr int buf = decltype(BUFC)::value, ibuf = buf ^ 1;
     const bool more = c + LA < nchunks;
     read_frags(buf, 0, 0);
     if (c > 0) mfmas((NG - 1) & 1);
@@ -1099,9 +1106,11 @@ __global__ __launch_bounds__(64 * WM * WN, (B3 && WM * WN >= 8 ? 4 : 1)) void co
       cyc_bar += __builtin_amdgcn_s_memtime() - tw1;
 #endif
     }
-    buf = buf == NB - 1 ? 0 : buf + 1;
-    ibuf = ibuf == NB - 1 ? 0 : ibuf + 1;
     kc_cmp = kc_cmp + 1 == kcpt ? 0 : kc_cmp + 1;
+  };
+  for (int c = 0; c < nchunks; c += 2) {
+    chunk_step(c, std::integral_constant<int, 0>());
+    if (c + 1 < nchunks) chunk_step(c + 1, std::integral_constant<int, 1>());
   }
   mfmas((NG - 1) & 1);
   SF_STAMP_AT(L, 3);

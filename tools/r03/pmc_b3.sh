@@ -21,7 +21,7 @@ for d in sorted(glob.glob(os.path.join(R, "gpurun_out", "pmcb3_*"))):
     fs = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
     if not fs: continue
     for r in csv.DictReader(open(fs[-1])):
-        for key in ("conv_glds_kernel<4, 2, 2, 4, 0", "conv_glds_kernel<2, 2, 2, 4, 0"):
+        for key in ("conv_glds_kernel<4, 2, 2, 4, 0", "conv_glds_kernel<2, 2, 2, 4, 0", "conv_glds_kernel<4, 2, 1, 4, 2", "conv_glds_kernel<2, 2, 2, 2, 0, 2, false"):
             if key in r["Kernel_Name"]:
                 agg[key + " (all launches of the batch-8 forward)"][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = os.path.join(R, "gpurun_out", f"r03_pmc_diag_{sys.argv[1]}.txt")
