@@ -458,6 +458,9 @@ int sf_bn_fold(const float* conv_bias, const float* bn_weight, const float* bn_b
  * and wave 0 of each workgroup records s_memrealtime (100 MHz) at entry / prologue done / first chunk landed / K loop
  * done / split-K hand-off done / epilogue stores issued / stores drained.  NULL switches it off. */
 int sf_debug_stamps(void* buf);
+/* diagnostic: workgroups per CU the runtime grants the large LDS-DMA tiles with their dynamic LDS
+ * (0: 128x128 fp32, 1: 128x128 bf16x3, 2: 64x128 fp32, 3: 64x128 bf16x3); -1 on error */
+int sf_debug_occupancy(int which);
 
 #ifdef __cplusplus
 }

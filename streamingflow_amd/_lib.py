@@ -161,6 +161,7 @@ SIGNATURES = {
     "sf_prof_collect": (_i, [i32p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sf_debug_stamps": (_i, [_vp]),
     "sf_pack_conv_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "sf_debug_occupancy": (_i, [_i]),
     "sf_bn_fold": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i, _vp, _vp, _vp]),
     "sf_pack_conv": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, C.POINTER(ConvW), _vp]),
 }

@@ -13,6 +13,7 @@ hipError_t launch_conv(const ConvLaunch& L, int epi, int cfg, hipStream_t stream
 hipError_t launch_conv_direct(const ConvLaunch& L, int epi, int mt, int ks, hipStream_t stream);
 hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant, hipStream_t stream);
 hipError_t set_stamp_buffer(unsigned long long* p);
+int glds_occupancy(int which);
 hipError_t set_stamp_buffer_sp(unsigned long long* p);
 hipError_t launch_conv_sp(const ConvLaunch& L, int epi, bool scaled, int bn, hipStream_t stream);
 hipError_t launch_sp_segment(const SpSegment& S, bool b3, hipStream_t stream);
@@ -1659,6 +1660,9 @@ int sf_debug_stamps(void* buf) {
   g_stamp_slot = 0;
   return SF_OK;
 }
+
+/* diagnostic: workgroups per CU of the large LDS-DMA tiles (0: 128x128 fp32, 1: 128x128 bf16x3, 2: 64x128 fp32, 3: 64x128 bf16x3) */
+int sf_debug_occupancy(int which) { return glds_occupancy(which); }
 
 int sf_prof_enable(int on) {
   g_prof.on = on != 0;

@@ -1194,6 +1194,17 @@ static hipError_t launch_glds_s(const ConvLaunch& L, int epi, hipStream_t stream
   return hipErrorInvalidValue;
 }
 
+// diagnostic: workgroups per CU the runtime grants the 128 x 128 and 64 x 128 (8-wave) AFFINE tiles with their LDS (tools/r03/occupancy.py)
+int glds_occupancy(int which) {
+  int n = -1;
+  hipError_t e = hipErrorInvalidValue;
+  if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_glds_kernel<4, 2, 2, 4, EPI_AFFINE, 2, false, false>, 512, 2 * 256 * 32 * 4);
+  if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_glds_kernel<4, 2, 2, 4, EPI_AFFINE, 2, false, true>, 512, 2 * 256 * 32 * 4);
+  if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_glds_kernel<2, 2, 2, 4, EPI_AFFINE, 2, false, false>, 512, 2 * 192 * 32 * 4);
+  if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_glds_kernel<2, 2, 2, 4, EPI_AFFINE, 2, false, true>, 512, 2 * 192 * 32 * 4);
+  return e == hipSuccess ? n : -1;
+}
+
 // tile: 0 = 128 cout x 128 px (2x4 waves of 64x32), 1 = 64 x 64 (2x2 waves of 32x32);  variant: buffers / issue placement
 hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant, hipStream_t stream) {
   bool scaled = false;
