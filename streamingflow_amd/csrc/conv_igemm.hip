@@ -734,9 +734,21 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const Con
 // fragments after the LDS read.  A reset-gate multiply is not: the GRU gates launch writes (1 - r) * s instead.
 // (tools/experiments/diag_loop.sh: without its staging the register-staged loop runs at 134 instead of 115 TFLOP/s on a
 // 7-frame 128->128 layer — global loads cost 10 %, the LDS writes 6 %; this kernel reaches 126, 134 at 224 frames.)
-// bf16x3 instantiations of the 8-wave tiles ask for two workgroups per CU (their loop needs <= 100 VGPRs)
+// bf16x3 staging depth.  SF_B3_DEEP=0 (shipped): two buffers and as many workgroups per CU as fit (2 for the 128 x 128 tiles, 3 for
+// 64 x 128).  -DSF_B3_DEEP=1 (experiment): as many 32-deep buffers as ~150 KB of LDS hold, one workgroup per CU, NB - 1 chunks in
+// flight — measured 186.5 ms per batch-32 forward against 137.3: the loop is not short of bytes in flight, it is short of other
+// workgroups to run while one waits at its per-chunk barrier.
+#ifndef SF_B3_DEEP
+#define SF_B3_DEEP 0
+#endif
+template <int MT, int NT, int WM, int WN>
+constexpr int b3_nb() {
+  if (!SF_B3_DEEP || WM * WN < 8) return 2;      // the 4-wave tiles keep two buffers and several workgroups per CU
+  const int per = 16 * (MT * WM + NT * WN) * 128, n = (150 * 1024) / per;
+  return n < 2 ? 2 : (n > 6 ? 6 : n);
+}
 template <int MT, int NT, int WM, int WN, int EPI, int NB, bool SCALE, bool B3 = false>
-__global__ __launch_bounds__(64 * WM * WN, (B3 && WM * WN >= 8 ? 4 : 1)) void conv_glds_kernel(const ConvLaunch L) {
+__global__ __launch_bounds__(64 * WM * WN, (B3 && !SF_B3_DEEP && WM * WN >= 8 ? 4 : 1)) void conv_glds_kernel(const ConvLaunch L) {
   constexpr int NWV = WM * WN;
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   constexpr int ROWS = BM + BN;
@@ -963,18 +975,23 @@ __global__ __launch_bounds__(64 * WM * WN, (B3 && WM * WN >= 8 ? 4 : 1)) void co
       }
     };
     {
-      static_assert(NB == 2, "bf16x3 loop: two staging buffers");
       SF_STAMP_AT(L, 1);
 #pragma unroll
-      for (int q = 0; q < G; ++q) issue_one(cb, 0, q);
-      SF_STAMP_AT(L, 2);
-      for (int c = 0; c < nchunks; ++c) {
-        const int bufc = c & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk c landed (this wave's pieces) ...
-        __builtin_amdgcn_s_barrier();                          // ... everybody's; and every wave is done with the other buffer
-        if (c + 1 < nchunks) {
+      for (int c = 0; c < LA; ++c)
+        if (c < nchunks) {      // block-uniform
 #pragma unroll
-          for (int q = 0; q < G; ++q) issue_one(cb + c + 1, bufc ^ 1, q);
+          for (int q = 0; q < G; ++q) issue_one(cb + c, c, q);
+        }
+      SF_STAMP_AT(L, 2);
+      int bufc = 0, ibuf = LA % NB;
+      for (int c = 0; c < nchunks; ++c) {
+        // chunk c landed (this wave's pieces; the LA - 1 younger chunks stay in flight) ...
+        if (LA > 1 && c + LA - 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (LA - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // ... everybody's; and every wave is done with the buffer of chunk c - 1
+        if (c + LA < nchunks) {
+#pragma unroll
+          for (int q = 0; q < G; ++q) issue_one(cb + c + LA, ibuf, q);
         }
         read3(bufc, std::integral_constant<int, 0>());
         bf16x8 bh[NT], bl[NT];
@@ -993,6 +1010,8 @@ __global__ __launch_bounds__(64 * WM * WN, (B3 && WM * WN >= 8 ? 4 : 1)) void co
             acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[0][m][0]), bh[n], acc[m][n], 0, 0, 0);
           }
         kc_cmp = kc_cmp + 1 == kcpt ? 0 : kc_cmp + 1;
+        bufc = bufc == NB - 1 ? 0 : bufc + 1;
+        ibuf = ibuf == NB - 1 ? 0 : ibuf + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       SF_STAMP_AT(L, 3);
@@ -1065,7 +1084,7 @@ __global__ __launch_bounds__(64 * WM * WN, (B3 && WM * WN >= 8 ? 4 : 1)) void co
   // The two staging buffers are compile-time constants of the two halves of an unrolled pair of chunks: the fragment
   // addresses are then loop-invariant registers + an immediate ds_read offset (buffer, tile row) instead of 8 v_add per chunk
   // — fp32 MFMAs share the vector ALU, every VALU instruction in this loop is matrix time.
-  static_assert(NB == 2 && LA == 1, "two staging buffers");
+  static_assert(B3 || (NB == 2 && LA == 1), "two staging buffers");
 #ifdef SF_STAMP
   unsigned long long cyc_issue = 0, cyc_wait = 0, cyc_bar = 0;
   const unsigned long long cyc_loop0 = __builtin_amdgcn_s_memtime();
@@ -1145,8 +1164,8 @@ static hipError_t launch_glds_t(const ConvLaunch& L, hipStream_t stream) {
 }
 template <int MT, int NT, int WM, int WN, int EPI, bool SCALE, bool B3>
 static hipError_t launch_glds_tb(const ConvLaunch& L, hipStream_t stream) {
-  constexpr int NB = 2;
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
+  constexpr int NB = B3 ? b3_nb<MT, NT, WM, WN>() : 2;
   constexpr int lds = NB * (BM + BN) * 32 * 4 + (SCALE ? 4 * 256 * 4 : 0);   // staging buffers (+ the SE scale rows of up to 4 images x 256 channels)
   auto kern = conv_glds_kernel<MT, NT, WM, WN, EPI, NB, SCALE, B3>;
   // the attribute is per device (a process may touch more than one GPU); one process per GPU and one launching
@@ -1199,9 +1218,9 @@ int glds_occupancy(int which) {
   int n = -1;
   hipError_t e = hipErrorInvalidValue;
   if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_glds_kernel<4, 2, 2, 4, EPI_AFFINE, 2, false, false>, 512, 2 * 256 * 32 * 4);
-  if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_glds_kernel<4, 2, 2, 4, EPI_AFFINE, 2, false, true>, 512, 2 * 256 * 32 * 4);
+  if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_glds_kernel<4, 2, 2, 4, EPI_AFFINE, b3_nb<4, 2, 2, 4>(), false, true>, 512, b3_nb<4, 2, 2, 4>() * 256 * 32 * 4);
   if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_glds_kernel<2, 2, 2, 4, EPI_AFFINE, 2, false, false>, 512, 2 * 192 * 32 * 4);
-  if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_glds_kernel<2, 2, 2, 4, EPI_AFFINE, 2, false, true>, 512, 2 * 192 * 32 * 4);
+  if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_glds_kernel<2, 2, 2, 4, EPI_AFFINE, b3_nb<2, 2, 2, 4>(), false, true>, 512, b3_nb<2, 2, 2, 4>() * 192 * 32 * 4);
   return e == hipSuccess ? n : -1;
 }
 
