@@ -426,17 +426,17 @@ def main():
             L.sf_graph_destroy(ex)
             ts.sort()
             return ts[len(ts) // 2], ts[min(len(ts) - 1, int(round(0.95 * (len(ts) - 1))))], n
-        def rollout_step_times(h, w, n1=10, n2=30, n=25):
+        def rollout_step_times(h, w, n1=10, n2=30, n=25, Bs=1):
             """the same step inside a rollout (what FuturePredictionODE.forward runs): hipGraph replays of rollouts with one jump +
             N Euler steps for N = n1 and n2; per-step time = (t(n2) - median t(n1)) / (n2 - n1).  Inside a rollout branch 2 of the
             next cell and the state half of its gates ride in infer_state's launches (csrc/api.hip: Carry): 9 launches per step."""
             per = S.DRAWS_PER_STEP[a.solver]
-            hx1 = torch.randn((1, h, w, C), device=dev) * 0.5
+            hx1 = torch.randn((1, Bs, h, w, C), device=dev) * 0.5
             out = {}
             for nn_ in (n1, n2):
                 scn = S.Schedule(ops=[(_lib.OP_JUMP, 0)] + [(_lib.OP_STEP, i) for i in range(nn_)], dts=[float(dt)] * nn_, sel_nops=[nn_ + 1],
                                  n_draws=1 + per * nn_)
-                en = torch.randn((scn.n_draws, h, w, C), device=dev)
+                en = torch.randn((scn.n_draws, Bs, h, w, C), device=dev)
                 ode.use_graph = True
                 for _ in range(3):
                     ode.rollout_nhwc(hx1, scn, en)
@@ -482,6 +482,15 @@ def main():
                          "steps_per_s": 1e6 / med_us}
         except Exception as ex:      # secondary object: never lose the headline line over it
             roof_step = {"error": repr(ex)}
+        try:      # the same two cases inside a rollout (pipelined stages where they pay: DESIGN 4.1)
+            mult = {"euler": 1, "midpoint": 2, "rk4": 4}[a.solver]
+            for key, (Bs, hh_, ww_, n1_, n2_) in {"batch8": (8, H // 4, W // 4, 6, 16), "stress_latent_200x200": (1, H, W, 3, 8)}.items():
+                med_, p95_, _ = rollout_step_times(hh_, ww_, n1_, n2_, 9, Bs)
+                fl_ = mult * 728.0 * C * C * hh_ * ww_ * Bs
+                step_only[key]["in_rollout"] = {"us_per_step_median": med_, "us_per_step_p95": p95_, "tflops": fl_ / (med_ * 1e-6) / 1e12,
+                                                "mfma_frac": fl_ / (med_ * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        except Exception as ex:
+            step_only["in_rollout_error"] = repr(ex)
 
     # ---- roofline of the dominant kernel: per-launch hipEvents in a dedicated pass ---------------
     roof = None

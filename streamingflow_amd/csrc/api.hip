@@ -780,6 +780,9 @@ struct Side {                // extra problems for infer_state's launches (AFFIN
 };
 bool carry_ok(const sf_dual_w& w, int B, int H, int W) {
   const long P = (long)B * H * W;
+  // One latent only.  (Measured with the blend mode / acc_in also in the large-tile AFFINE epilogues: per steady-state step 8 samples
+  // 684 -> 669 us, one 200x200 latent 1200 -> 1200, 32 samples 2178 -> 2197 — and the two extra branches cost every AFFINE launch
+  // of the batched forward 0.9 % (255.5 -> 257.8 ms): not worth the headline, reverted; profiles/README.md round-3 log.)
   if (!(tune().pipe && B == 1 && P < tune().sp_max_p && tune().sp && pregate(P, w.cand1) && pregate(P, w.cand2))) return false;
   // every layer that changes its launch must be one the small-P kernel takes (its AFFINE epilogue alone has the blend mode and acc_in)
   const sf_conv_w* ws[5] = {&w.gates2, &w.cand2, &w.dec2, &w.cand1, &w.gates1};
