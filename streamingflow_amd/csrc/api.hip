@@ -147,12 +147,13 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int wide64, seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int b3_small_tiles, wide64, seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
     Tune x;
     x.persist = geti("SF_PERSIST", 0);             // 1: one latent: consecutive launches of a rollout run as phases of persistent segment launches (conv_sp.hip: sp_segment_kernel).  Built, bitwise equal to the launch-per-layer path (tests/test_gpu_persistent.py) and measured SLOWER: 228 us per steady-state step against 179 (one phase per segment launch: 201) — a grid-wide phase hand-off (write-through stores, drain, one atomic per workgroup, 256 pollers, acquire) costs more than the 3-4 us kernel boundary it replaces (MI355X_MICROARCH.md prices barrier-xcd at 4.1-4.8 us against 1.45-1.9 for a boundary).  Off by default
+    x.b3_small_tiles = geti("SF_B3_SMALL_TILES", 0);   // experiment: bf16x3 layers with 128-multiple cout on 64 x 128 tiles (3 workgroups per CU) instead of 128 x 128 (2)
     x.wide64 = geti("SF_WIDE64", 0);               // 1: 64-cout layers at >= 131072 pixels on 64 x 256 tiles (variant 10) instead of 64 x 128
     x.seg_maxph = geti("SF_SEG_MAXPH", SP_SEG_PHASES);   // phases per persistent segment (1: every phase its own launch of the segment kernel — diagnostic)
     x.fenced = geti("SF_HANDOFF_FENCED", 0);       // 1: split-K hand-offs also run the agent-scope release / acquire fences of round 1 (known-good reference for the fence-free sc1 form; gfx950 only either way)
@@ -490,7 +491,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     bool big = true;
     for (int i = 0; i < n; ++i)
       big = big && (ps[i].cout_pad % 128 == 0) && ((long)ps[i].n_img * ps[i].Hout * ps[i].Wout >= 131072);
-    if (big) cfg = 9;
+    if (big && !(tune().b3_small_tiles && ps[0].w3 != nullptr)) cfg = 9;
   }
   // small pixel counts: direct-fragment kernel (no LDS staging), see conv_igemm.hip
   int mt = 0, ks = 1;
