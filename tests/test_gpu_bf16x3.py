@@ -123,3 +123,21 @@ def test_math_mode_switch_repacks_and_drops_graphs():
     c, _ = ode.rollout_nhwc(hx, sc, eps)
     assert torch.equal(a, c) and maxabs(a, b) <= 2e-4
     ode.use_graph = False
+
+
+@pytest.mark.parametrize("tag", ["config4_future16", "config1_c32", "config5_stream40_euler", "config5_stream40_midpoint"])
+def test_full_size_configs_in_bf16x3_vs_reference_statistics(tag, bf16x3):
+    """The mode at full size on the other BASELINE configurations (1: C=32, 4 fixed Euler steps; 4: 19 frames, 8 s horizon; 5: the
+    46-step streaming schedule, 43 frames, euler and midpoint) against the statistics + 256 samples of the REAL reference
+    (tests/golden/big_stats.json): within the north-star tolerance, with the measured margin printed."""
+    import json
+    import os
+    import test_gpu_configs as TC
+    cfgs = {**cases.BIG_CASES, **cases.BIG_STREAM_CASES}
+    C, H, W, ts, solver, impute, variable = cfgs[tag]
+    y, _, _ = TC._forward(C, H, W, ts, solver, impute, variable)
+    st = json.load(open(os.path.join(TC.GOLD, "big_stats.json")))["cases"][tag]["out"]
+    flat = y.reshape(-1).double().cpu()
+    err = float((flat[torch.tensor(st["sample_idx"])] - torch.tensor(st["samples"])).abs().max())
+    print(f"bf16x3 {tag}: max-abs over the reference's 256 samples {err:.2e}, |mean - ref| {abs(flat.mean().item() - st['mean']):.1e}")
+    assert list(y.shape) == st["shape"] and err <= 1e-3 and abs(flat.mean().item() - st["mean"]) <= 1e-4
