@@ -139,6 +139,16 @@ def dry_run(a, world):
         dist.destroy_process_group()
 
 
+def _all_ranks(value, world, device):
+    """every rank's integer `value` (all-gather of one int64 each)"""
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    return [int(g.item()) for g in got]
+
+
 def main():
     a = parse()
     if a.gpus < 1:
@@ -196,7 +206,7 @@ def main():
         torch.cuda.synchronize()
 
     from streamingflow_amd import dist as sfd
-    do_gather = world > 1 and not a.no_gather and backend == "nccl"
+    do_gather = world > 1 and not a.no_gather      # nccl: RCCL all-gather on the device; gloo: the same call, staged through the host
     side = torch.cuda.Stream(device=dev) if do_gather else None
     gathered = [None]
 
@@ -249,20 +259,31 @@ def main():
         multi = {"rccl_world": dist.get_world_size(), "backend": dist.get_backend(), "gather_in_timed_region": do_gather,
                  "gather_bytes_per_rank": gbytes, "gather_bytes_total": gbytes * world, "gather_ms_standalone": gms,
                  "gather_estimate_ms": gbytes / 153e9 * 1e3,      # one xGMI hop at ~153 GB/s per link
-                 "what": "all_gather_into_tensor of one sample's [T, C, H, W] fp32 BEV grid per rank (streamingflow_amd.dist.gather_predictions), side stream, overlapped with the next forward; metric counters: all_reduce(SUM)"}
+                 "devices": sorted({int(v) for v in _all_ranks(local, world, dev if backend == "nccl" else "cpu")}),
+                 "what": "all_gather_into_tensor of one sample's [T, C, H, W] fp32 BEV grid per rank (streamingflow_amd.dist.gather_predictions), side stream, overlapped with the next forward"
+                         + ("" if backend == "nccl" else " [gloo: staged through the host, the host blocks on it]") + "; metric counters: all_reduce(SUM)"}
 
     # ---- single-sample latency of the same forward (batch 1) -----------------------------------------
     def forward1():
         return net(x_in[:1], cam_d[:1], lid_d[:1], cts, lts, tts)
-    single_ms = None
+    single_ms = single_eager_ms = None
     if not a.headline_only:
-        forward1()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            forward1()
-        torch.cuda.synchronize()
-        single_ms = 1e3 * (time.perf_counter() - t0) / 3
+        def time_forward1(n=5):
+            for _ in range(2):
+                forward1()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                forward1()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t0) / n
+        # the module's defaults (what a caller of evaluate.py gets): rollout replayed from a hipGraph, noise drawn in the
+        # sampling epilogue (Philox) ...
+        single_ms = time_forward1()
+        # ... and the round-1..3 form of the same call: rollout enqueued launch by launch, eps from one torch.randn
+        net.gru_ode.use_graph, net.gru_ode.in_kernel_noise = False, False
+        single_eager_ms = time_forward1()
+        net.gru_ode.use_graph, net.gru_ode.in_kernel_noise = None, None
 
     L = _lib.lib()
     rollout = step_only = roof_step = None
@@ -271,6 +292,7 @@ def main():
         ode = net.gru_ode
         hx = torch.randn((len(times), H // 4, W // 4, C), device=dev) * 0.5
         eps = torch.randn((sc.n_draws, H // 4, W // 4, C), device=dev)
+        ode.use_graph = False                   # eager first (the module default replays single-latent rollouts from a graph)
         for _ in range(2):
             ode.rollout_nhwc(hx, sc, eps)
         torch.cuda.synchronize()
@@ -296,7 +318,7 @@ def main():
         L.sf_event_record(e1, runtime.stream_ptr(dev))
         L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
         rollout_graph_ms = ms.value / reps
-        ode.use_graph = False
+        ode.use_graph = None
         # BASELINE config 5: streaming 0.05 s x 40 targets -> 46 ODE steps + 8 jumps, the whole rollout one hipGraph
         stream40 = None
         try:
@@ -313,7 +335,7 @@ def main():
                 ode.rollout_nhwc(hx, sc5, eps5)
             L.sf_event_record(e1, runtime.stream_ptr(dev))
             L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
-            ode.use_graph = False
+            ode.use_graph = None
             m5 = ms.value / reps
             stream40 = {"hipgraph_replay_ms": m5, "ode_steps": sc5.n_steps, "jumps": sc5.n_jumps, "solver": a.solver,
                         "us_per_op": 1e3 * m5 / len(sc5.ops), "ode_steps_per_s": sc5.n_steps / (m5 * 1e-3)}
@@ -449,7 +471,7 @@ def main():
                     L.sf_event_record(e1, sp)
                     L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
                     ts.append(ms.value * 1e3)
-                ode.use_graph = False
+                ode.use_graph = None
                 ts.sort()
                 out[nn_] = ts
             base = out[n1][len(out[n1]) // 2]
@@ -616,7 +638,7 @@ def main():
                     ode.rollout_nhwc(hx, sc, eps)
                 L.sf_event_record(e1, runtime.stream_ptr(dev))
                 L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
-                ode.use_graph = False
+                ode.use_graph = None
                 roll3 = ms.value / 10
             except Exception as ex:
                 step3 = {"error": repr(ex)}
@@ -668,9 +690,14 @@ def main():
                           "batch_per_gpu": B,
                           "parallelism": f"replicas x{world} (sample sharding; " + ("RCCL all-gather of one BEV grid per rank per forward on a side stream)" if do_gather else "no data-path collective)")},
                "samples_per_s": B * a.steps * world / el, "batch_per_gpu": B, "ms_per_sample": ms_per_step / B,
+               "rollout_mode": ("eager launches (the batched rollout is not launch-bound; auto-graph applies to single-latent rollouts only), "
+                                "eps drawn in the sampling epilogue (Philox4x32-10, module default when no noise source is injected)"),
                "batch1_forward": None if single_ms is None else {
                    "what": "the same FuturePredictionODE.forward at the reference's own batch size (evaluate.py:46: one sample per call)",
-                   "ms_per_forward": single_ms, "ode_steps_per_s": n_ode / (single_ms * 1e-3), "samples_per_s": 1e3 / single_ms},
+                   "ms_per_forward": single_ms, "ode_steps_per_s": n_ode / (single_ms * 1e-3), "samples_per_s": 1e3 / single_ms,
+                   "mode": "module defaults: rollout replayed from a captured hipGraph, eps drawn in the sampling epilogue (Philox4x32-10)",
+                   "ms_per_forward_eager_randn": single_eager_ms,
+                   "mode_eager_randn": "use_graph=False, in_kernel_noise=False: rollout enqueued launch by launch, eps from one torch.randn (the form rounds 1-3 timed)"},
                "single_sample_forward_ms": single_ms,
                "single_sample_ode_steps_per_s": None if single_ms is None else n_ode / (single_ms * 1e-3),
                "roofline_ode_step": roof_step, "multi_gpu": multi,

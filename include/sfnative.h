@@ -141,8 +141,38 @@ typedef struct sf_bottleneck_w {
   int32_t downsample;
 } sf_bottleneck_w;
 
+/* Bottleblock (streamingflow/layers/convolutions.py:348-380), see sf_bottleblock_fwd */
+typedef struct sf_bottle_w {
+  sf_conv_w c7, c1, c3; /* layers.0 / .3 / .6 with the LayerNorm weight / bias in scale / bias */
+  sf_conv_w proj;       /* projection.0; proj.w == NULL when in == out */
+} sf_bottle_w;
+
 int sf_version(void);
 const char* sf_status_string(int status);
+
+/* ---- ABI guard ---------------------------------------------------------------------------------------------------------
+ * The structs above are passed by pointer and sf_conv_w is embedded by value in every composite, so a host compiled
+ * against an older header would hand the library mis-sized structs (round 3 grew sf_conv_w from 72 to 80 bytes and
+ * sf_dual_w by two members).  SF_ABI_VERSION changes whenever a public struct changes layout.  A host calls
+ * sf_abi_check_header() once after loading the library — it passes the sizes ITS compiler saw — and must not call
+ * anything else unless it returns SF_OK; bindings without a C compiler (ctypes, cgo, JNI) compare their own struct sizes
+ * with sf_abi_sizeof() the same way (streamingflow_amd/_lib.py does, INTEGRATION.md shows it).  Hosts must zero-initialise
+ * the structs (optional members are "NULL = absent") and recompile when SF_ABI_VERSION changes. */
+#define SF_ABI_VERSION 4
+enum {
+  SF_STRUCT_CONV_W = 0, SF_STRUCT_GRU_W, SF_STRUCT_DUAL_W, SF_STRUCT_RES_W, SF_STRUCT_PMODEL_W, SF_STRUCT_ENCODER_W,
+  SF_STRUCT_DECODER_W, SF_STRUCT_CONVNEXT_W, SF_STRUCT_DEEPLAB_W, SF_STRUCT_BOTTLENECK_W, SF_STRUCT_BOTTLE_W, SF_STRUCT_COUNT
+};
+int sf_abi_version(void);                 /* the library's SF_ABI_VERSION */
+size_t sf_abi_sizeof(int which);          /* sizeof(struct SF_STRUCT_<which>) as the library was compiled; 0 for an unknown id */
+/* SF_OK when abi_version and all n = SF_STRUCT_COUNT sizes equal the library's, SF_ERR_INVALID otherwise */
+int sf_abi_check(int abi_version, const size_t* struct_sizes, int n);
+static inline int sf_abi_check_header(void) {
+  const size_t sizes[SF_STRUCT_COUNT] = {sizeof(sf_conv_w),     sizeof(sf_gru_w),      sizeof(sf_dual_w),     sizeof(sf_res_w),
+                                         sizeof(sf_pmodel_w),   sizeof(sf_encoder_w),  sizeof(sf_decoder_w),  sizeof(sf_convnext_w),
+                                         sizeof(sf_deeplab_w),  sizeof(sf_bottleneck_w), sizeof(sf_bottle_w)};
+  return sf_abi_check(SF_ABI_VERSION, sizes, SF_STRUCT_COUNT);
+}
 
 /* layout: [n][C][HW] <-> [n][HW][C] */
 int sf_nchw_to_nhwc(const float* src, float* dst, int n, int C, int HW, void* stream);
@@ -200,11 +230,7 @@ int sf_trust_mix_fwd(const sf_dual_w* w, const float* r1, const float* r2, const
 
 /* Bottleblock.forward — convolutions.py:348-380 on cat[x0, x1] (x1 may be NULL): 7x7 + LN + GELU -> 1x1 + LN + GELU ->
  * 3x3 + LN + GELU, plus projection(x) (1x1 + GELU) or x itself when in == out (then x1 must be NULL).
- * Channel counts of the LayerNorm layers <= 64. */
-typedef struct sf_bottle_w {
-  sf_conv_w c7, c1, c3; /* layers.0 / .3 / .6 with the LayerNorm weight / bias in scale / bias */
-  sf_conv_w proj;       /* projection.0; proj.w == NULL when in == out */
-} sf_bottle_w;
+ * Channel counts of the LayerNorm layers <= 64.  Weights: struct sf_bottle_w, above. */
 int sf_bottleblock_fwd(const sf_bottle_w* w, const float* x0, const float* x1, float* out, int n_img, int H, int W,
                        float* ws, size_t ws_bytes, void* stream);
 size_t sf_bottleblock_ws_bytes(int cin, int cout, int n_img, int H, int W);

@@ -13,6 +13,7 @@ f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
 
 SF_COEF_STRIDE = 12
+SF_ABI_VERSION = 4       # include/sfnative.h: changes whenever a public struct changes layout
 SF_PROF_KEYS = 128
 PACK_TRANSPOSED, PACK_FOLD_DUP, PACK_INTERLEAVE, PACK_BF16X3 = 1, 2, 4, 8      # SF_PACK_* of sfnative.h
 ACT = {"none": 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4, "gelu": 5}
@@ -74,6 +75,9 @@ class BottleneckW(C.Structure):
     _fields_ = [("down", ConvW), ("conv", ConvW), ("up", ConvW), ("proj", ConvW), ("downsample", C.c_int32)]
 
 
+# SF_STRUCT_* order of sfnative.h: what lib() hands to sf_abi_check
+ABI_STRUCTS = (ConvW, GruW, DualW, ResW, PModelW, EncoderW, DecoderW, ConvNextW, DeepLabW, BottleneckW, BottleW)
+
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 # name -> (restype, argtypes); every symbol declared in include/sfnative.h
 _f3 = C.POINTER(C.c_float * 3)
@@ -81,6 +85,9 @@ _i3 = C.POINTER(C.c_int32 * 3)
 _f6 = C.POINTER(C.c_float * 6)
 SIGNATURES = {
     "sf_version": (_i, []),
+    "sf_abi_version": (_i, []),
+    "sf_abi_sizeof": (_sz, [_i]),
+    "sf_abi_check": (_i, [_i, C.POINTER(_sz), _i]),
     "sf_status_string": (C.c_char_p, [_i]),
     "sf_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sf_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -187,6 +194,12 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)     # AttributeError => missing export
             fn.restype, fn.argtypes = res, args
+        # ABI guard: this binding's struct layouts against the ones the library was compiled with
+        sizes = (_sz * len(ABI_STRUCTS))(*[C.sizeof(t) for t in ABI_STRUCTS])
+        if h.sf_abi_check(SF_ABI_VERSION, sizes, len(ABI_STRUCTS)) != 0:
+            theirs = [h.sf_abi_sizeof(i) for i in range(len(ABI_STRUCTS))]
+            raise RuntimeError(f"{LIB_PATH}: ABI mismatch (library ABI {h.sf_abi_version()}, sizes {theirs}; binding ABI "
+                               f"{SF_ABI_VERSION}, sizes {list(sizes)}): rebuild with `python -m streamingflow_amd.build`")
         _LIB = h
     return _LIB
 

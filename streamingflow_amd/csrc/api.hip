@@ -1014,7 +1014,32 @@ int res_block(const sf_res_w& w, const float* x, float* out, float* t, float* pr
 // =================================================================================================
 extern "C" {
 
-int sf_version(void) { return 100; }
+int sf_version(void) { return 110; }
+
+// ABI guard (include/sfnative.h): the sizes this translation unit was compiled with
+int sf_abi_version(void) { return SF_ABI_VERSION; }
+size_t sf_abi_sizeof(int which) {
+  switch (which) {
+    case SF_STRUCT_CONV_W: return sizeof(sf_conv_w);
+    case SF_STRUCT_GRU_W: return sizeof(sf_gru_w);
+    case SF_STRUCT_DUAL_W: return sizeof(sf_dual_w);
+    case SF_STRUCT_RES_W: return sizeof(sf_res_w);
+    case SF_STRUCT_PMODEL_W: return sizeof(sf_pmodel_w);
+    case SF_STRUCT_ENCODER_W: return sizeof(sf_encoder_w);
+    case SF_STRUCT_DECODER_W: return sizeof(sf_decoder_w);
+    case SF_STRUCT_CONVNEXT_W: return sizeof(sf_convnext_w);
+    case SF_STRUCT_DEEPLAB_W: return sizeof(sf_deeplab_w);
+    case SF_STRUCT_BOTTLENECK_W: return sizeof(sf_bottleneck_w);
+    case SF_STRUCT_BOTTLE_W: return sizeof(sf_bottle_w);
+  }
+  return 0;
+}
+int sf_abi_check(int abi_version, const size_t* struct_sizes, int n) {
+  if (abi_version != SF_ABI_VERSION || !struct_sizes || n != SF_STRUCT_COUNT) return SF_ERR_INVALID;
+  for (int i = 0; i < n; ++i)
+    if (struct_sizes[i] != sf_abi_sizeof(i)) return SF_ERR_INVALID;
+  return SF_OK;
+}
 
 const char* sf_status_string(int s) {
   switch (s) {

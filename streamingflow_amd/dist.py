@@ -47,7 +47,14 @@ def gather_predictions(local, n_samples, like=None):
     for slot, i in enumerate(mine):
         buf[slot] = local[i]
     out = ref.new_empty((w * per,) + tuple(ref.shape))
-    dist.all_gather_into_tensor(out, buf)
+    if ref.is_cuda and dist.get_backend() == "gloo":
+        # gloo has no device all-gather: stage the shard through the host (the multi-rank path on a box without RCCL
+        # peers, e.g. two ranks sharing one GPU — bench.py SF_BENCH_BACKEND=gloo)
+        host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+        dist.all_gather_into_tensor(host, buf.cpu())
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, buf)
     out = out.view((w, per) + tuple(ref.shape))
     return [out[i % w, i // w] for i in range(n_samples)]
 

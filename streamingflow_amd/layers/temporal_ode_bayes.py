@@ -247,10 +247,15 @@ class NNFOwithBayesianJumps(nn.Module):
         self.noise = None    # None: torch.randn on the device; else callable(shape, dtype, device) -> NCHW eps per draw
         # throughput mode: the noise of infer_state is generated inside the sampling epilogue (Philox4x32-10 keyed by
         # (noise_seed, call counter)); no eps tensor exists.  Same distribution, its own stream; ignored when eps is given
-        self.in_kernel_noise = False
+        # None = auto: on whenever no `noise` source was injected (nothing to replay), True / False force it
+        self.in_kernel_noise = None
         self.noise_seed = 0x5EED5F10
         self._noise_calls = 0
-        self.use_graph = False   # capture the rollout of each schedule structure into a hipGraph and replay it
+        # capture the rollout of each schedule structure into a hipGraph and replay it.  None = auto: on for rollouts that
+        # run on the launch-bound single-latent kernels (B*h*w < 4096), where ~9 short launches per step are replayed from one
+        # graph; the results are cloned out of the graph's static buffers.  True: always, and the returned tensors ARE the
+        # static buffers (valid until the next replay); False: never
+        self.use_graph = None
         self._graphs = {}
         self._graph_gens = None
         self.apply(init_weights)
@@ -359,7 +364,9 @@ class NNFOwithBayesianJumps(nn.Module):
         # would make them read past the end of eps)
         need = s0.n_jumps + sched.DRAWS_PER_STEP[self.solver] * s0.n_steps
         philox = None
-        if eps is None and self.in_kernel_noise and self.noise is None:
+        in_kernel = self.noise is None if self.in_kernel_noise is None else bool(self.in_kernel_noise)
+        auto_graph = self.use_graph is None and B * h * w < 4096
+        if eps is None and in_kernel and self.noise is None:
             self._noise_calls += 1
             philox = torch.tensor([self.noise_seed, self._noise_calls], dtype=torch.int64, device=dev)
             eps = torch.empty((0, B, h, w, C), dtype=torch.float32, device=dev)      # placeholder (shape key of the graph cache)
@@ -373,7 +380,7 @@ class NNFOwithBayesianJumps(nn.Module):
         coef = torch.from_numpy(np.ascontiguousarray(coef_np)).to(dev)
         L = _lib.lib()
         nbytes = L.sf_nnfo_rollout_ws_bytes(C, B, h, w)
-        if not self.use_graph:
+        if not (self.use_graph or auto_graph):
             out = torch.empty((len(s0.sel_nops), B, h, w, C), dtype=torch.float32, device=dev)
             final = torch.empty((B, h, w, C), dtype=torch.float32, device=dev)
             ws = runtime.workspace(nbytes, dev)
@@ -415,6 +422,8 @@ class NNFOwithBayesianJumps(nn.Module):
                 g["philox"].copy_(philox)
             _lib.check(L.sf_graph_launch(g["exec"], runtime.stream_ptr(dev)), "graph_launch")
             out, final = g["out"], g["final"]      # valid until the next replay of this graph
+            if auto_graph:                          # nobody asked for the zero-copy form: hand out fresh tensors
+                out, final = out.clone(), final.clone()
         return (out[:, 0], final[0]) if one else (out, final)
 
     def make_schedule(self, times, delta_t, T):

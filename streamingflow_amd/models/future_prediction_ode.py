@@ -112,6 +112,7 @@ class FuturePredictionODE(nn.Module):
         per sample.  Samples with a different structure are processed in their own group."""
         some = camera_states if camera_states is not None else lidar_states
         runtime.require_cuda(some)
+        runtime.require_no_grad(future_prediction_input, camera_states, lidar_states)
         b = some.shape[0]
         groups, meta = {}, []
         states = (camera_states, lidar_states)

@@ -34,6 +34,18 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def require_no_grad(*tensors):
+    """Inference only (the reference evaluates under torch.no_grad(), evaluate.py:117): the HIP path records no autograd
+    history, so an input that asks for gradients while grad mode is on would silently get none — refuse it instead.
+    Parameters with requires_grad=True are fine: calling a module outside no_grad() works and returns detached tensors
+    (INTEGRATION.md, "Observable differences")."""
+    if torch.is_grad_enabled():
+        for t in tensors:
+            if t is not None and t.requires_grad:
+                raise RuntimeError("streamingflow_amd is inference-only: an input has requires_grad=True under enabled grad mode, "
+                                   "but the HIP path records no autograd history (detach the input or use torch.no_grad())")
+
+
 def f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
@@ -41,6 +53,7 @@ def f32c(t):
 def to_nhwc(x):
     """(n, C, H, W) fp32 cuda -> (n, H, W, C) contiguous (libsfnative transpose kernel)."""
     require_cuda(x)
+    require_no_grad(x)      # every module entry point converts its NCHW inputs here
     x = f32c(x)
     n, c, h, w = x.shape
     out = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)

@@ -37,7 +37,13 @@ int main(void) {
     const double v = (acc + cb[o] - mu[o]) / sqrt((double)var[o] + eps) * g[o] + b[o];
     ref[n][i][j][o] = (float)(v > 0.0 ? v : 0.0);
   }
-  if (sf_version() < 100) { printf("unexpected library version\n"); return 1; }
+  if (sf_version() < 110) { printf("unexpected library version\n"); return 1; }
+  /* ABI guard: the struct sizes THIS compiler saw against the library's; a stale size must be refused */
+  if (sf_abi_check_header() != SF_OK) { printf("ABI mismatch: header %d, library %d\n", SF_ABI_VERSION, sf_abi_version()); return 1; }
+  { size_t stale[SF_STRUCT_COUNT];
+    for (int i = 0; i < SF_STRUCT_COUNT; ++i) stale[i] = sf_abi_sizeof(i);
+    stale[SF_STRUCT_CONV_W] = 72;   /* the round-2 sf_conv_w */
+    if (sf_abi_check(SF_ABI_VERSION, stale, SF_STRUCT_COUNT) != SF_ERR_INVALID || sf_abi_check(SF_ABI_VERSION - 1, NULL, 0) != SF_ERR_INVALID) return 1; }
   float *dw, *dcb, *dg, *db, *dmu, *dvar, *dx, *dy;
   void* blob;
   CK(hipMalloc((void**)&dw, sizeof(w))); CK(hipMalloc((void**)&dcb, sizeof(cb))); CK(hipMalloc((void**)&dg, sizeof(g)));
