@@ -688,7 +688,7 @@ def main():
                                       f"({len(times)} observations, {tts.shape[1]} targets), variable-step {a.solver}: "
                                       f"{n_ode} ODE steps + {sc.n_jumps} jumps per sample, {B} sample(s) per forward per GPU",
                           "batch_per_gpu": B,
-                          "parallelism": f"replicas x{world} (sample sharding; " + ("RCCL all-gather of one BEV grid per rank per forward on a side stream)" if do_gather else "no data-path collective)")},
+                          "parallelism": f"replicas x{world} (sample sharding; " + ((("RCCL" if backend == "nccl" else "gloo, host-staged") + " all-gather of one BEV grid per rank per forward on a side stream)") if do_gather else "no data-path collective)")},
                "samples_per_s": B * a.steps * world / el, "batch_per_gpu": B, "ms_per_sample": ms_per_step / B,
                "rollout_mode": ("eager launches (the batched rollout is not launch-bound; auto-graph applies to single-latent rollouts only), "
                                 "eps drawn in the sampling epilogue (Philox4x32-10, module default when no noise source is injected)"),
