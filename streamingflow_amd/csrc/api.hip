@@ -16,8 +16,10 @@ hipError_t set_stamp_buffer(unsigned long long* p);
 int glds_occupancy(int which);
 hipError_t set_stamp_buffer_sp(unsigned long long* p);
 hipError_t launch_conv_sp(const ConvLaunch& L, int epi, bool scaled, int bn, hipStream_t stream);
-hipError_t launch_sp_segment(const SpSegment& S, bool b3, hipStream_t stream);
-bool sp_segment_has(int epi, bool scaled, int bn);
+hipError_t launch_sp_flow(const SpFlow& F, int grid, bool b3, hipStream_t stream);
+hipError_t launch_flow_write(const void* host_src, void* dev_dst, size_t bytes, hipStream_t stream);
+bool sp_flow_has(int epi, bool scaled, int bn);
+int sp_flow_capacity(bool b3);
 hipError_t launch_transpose(const float* in, float* out, int n, int rows, int cols, hipStream_t s);
 hipError_t launch_transpose_strided(const float* in, float* out, int n, int rows, int cols, size_t in_stride, size_t out_stride,
                                     hipStream_t s);
@@ -147,7 +149,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int b3_small_tiles, wide64, seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int flow_timeout, flow_sc1, b3_small_tiles, wide64, seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -155,7 +157,9 @@ const Tune& tune() {
     x.persist = geti("SF_PERSIST", 0);             // 1: one latent: consecutive launches of a rollout run as phases of persistent segment launches (conv_sp.hip: sp_segment_kernel).  Built, bitwise equal to the launch-per-layer path (tests/test_gpu_persistent.py) and measured SLOWER: 228 us per steady-state step against 179 (one phase per segment launch: 201) — a grid-wide phase hand-off (write-through stores, drain, one atomic per workgroup, 256 pollers, acquire) costs more than the 3-4 us kernel boundary it replaces (MI355X_MICROARCH.md prices barrier-xcd at 4.1-4.8 us against 1.45-1.9 for a boundary).  Off by default
     x.b3_small_tiles = geti("SF_B3_SMALL_TILES", 0);   // experiment: bf16x3 layers with 128-multiple cout on 64 x 128 tiles (3 workgroups per CU) instead of 128 x 128 (2)
     x.wide64 = geti("SF_WIDE64", 0);               // 1: 64-cout layers at >= 131072 pixels on 64 x 256 tiles (variant 10) instead of 64 x 128
-    x.seg_maxph = geti("SF_SEG_MAXPH", SP_SEG_PHASES);   // phases per persistent segment (1: every phase its own launch of the segment kernel — diagnostic)
+    x.seg_maxph = geti("SF_SEG_MAXPH", 1 << 30);   // diagnostic: at most this many phases per persistent flow launch (1: every phase its own launch of the flow kernel)
+    x.flow_timeout = geti("SF_FLOW_TIMEOUT", 1 << 22);   // polls before a dependency wait of the flow kernel gives up (~1 us each: seconds); bring-up runs use a small value
+    x.flow_sc1 = geti("SF_FLOW_SC1", 0);           // experiment: flow kernel without the acquire fence (every load of handed-off bytes an sc1 load)
     x.fenced = geti("SF_HANDOFF_FENCED", 0);       // 1: split-K hand-offs also run the agent-scope release / acquire fences of round 1 (known-good reference for the fence-free sc1 form; gfx950 only either way)
     x.b3 = geti("SF_BF16X3", 1);                   // layers packed with split-bf16 weights (opt-in at pack time) run the bf16x3 K loop where a kernel has one (0: exact fp32 even then)
     x.pipe = geti("SF_PIPE", 2);                   // one latent: branch 2 of the NEXT dual cell (gates2 -> cand2, functions of the state only) rides in the launches of infer_state, its conv_decoder_2 in the candidate launch (0: every cell on its own, 5 launches)
@@ -246,78 +250,134 @@ int sp_bn(const ConvProblem* ps, int n) {
 // (the producer's whole launch group decides its tile)
 int chansum_tile_px(const ConvProblem* group, int n, int epi) { return sp_takes(group, n, epi) ? sp_bn(group, n) : 16; }
 
-// ---- persistent segments (one latent inside a rollout): run() records its small-P launches as phases instead of launching ----
-constexpr int DONE_COUNTERS = 4096;      // phase counters of one rollout
-struct SegBuilder {
-  SpSegment S;
+// ---- persistent flow (one latent inside a rollout, SF_PERSIST=1): run() records its small-P launch groups as phases of ONE
+// persistent launch (conv_sp.hip: sp_flow_kernel) instead of launching them.  The phase / problem tables are built on the host,
+// written into the caller's workspace by small writer kernels (table pieces travel as kernel arguments: stateless and
+// graph-capturable) and the flow kernel is launched when the rollout ends or something that is not a small-P launch intervenes.
+constexpr size_t FLOW_TABLE_BYTES = size_t(1) << 20;       // phases + problems of one flow
+constexpr int FLOW_DONE_COUNTERS = 1 << 18;                // tile counters of one flow (81 per phase)
+constexpr size_t FLOW_WS_FLOATS = FLOW_TABLE_BYTES / 4 + FLOW_DONE_COUNTERS + 256;
+struct FlowBuilder {
+  std::vector<FlowPhase> phases;
+  std::vector<ConvProblem> probs;
   hipStream_t st;
-  unsigned* done;
+  unsigned char* table;          // device: [phases | problems]
+  unsigned* done;                // device: tile counters (zeroed at the start of the rollout), done[-64 .. -1] = error words
+  unsigned* err;
   int next_done = 0;
-  bool b3 = false, failed = false;
-  int prev_idx = -1, prev_need = 0;      // the phase the next one waits for (inside the current segment only)
-  SegBuilder(unsigned* d, hipStream_t s) : st(s), done(d) { std::memset(&S, 0, sizeof(S)); S.done = d; }
+  bool b3 = false;
+  int grid = 0;
+  int launches = 0;
+  // a pending state copy-out (src = an output of the last recorded phase): rides in the next phase
+  const float* copy_src = nullptr; float* copy_dst = nullptr; int copy_n4 = 0;
+  FlowBuilder(unsigned char* t, unsigned* d, unsigned* e, hipStream_t s) : st(s), table(t), done(d), err(e) {}
+  int problem_index(const ConvProblem& q) {      // identical problems (steady-state steps ping-pong between two sets) are stored once
+    for (size_t i = probs.size(); i-- > 0 && probs.size() - i <= 64;)
+      if (std::memcmp(&probs[i], &q, sizeof(q)) == 0) return (int)i;
+    probs.push_back(q);
+    return (int)probs.size() - 1;
+  }
   int flush() {
-    if (S.nphase > 0) {
-      S.ph[S.nphase - 1].signal = 0;      // nobody inside this launch waits for its last phase; the kernel boundary orders what follows
-      if (launch_sp_segment(S, b3, st) != hipSuccess) return SF_ERR_LAUNCH;
+    if (copy_n4 > 0 && !phases.empty()) {      // no later phase to ride in: a copy kernel behind the flow (kernel boundary = visibility)
+      const int rc = launch();
+      if (rc != SF_OK) return rc;
+      if (copy_floats(copy_src, copy_dst, (size_t)copy_n4 * 4, st) != hipSuccess) return SF_ERR_LAUNCH;
+      copy_n4 = 0;
+      return SF_OK;
     }
-    std::memset(&S, 0, sizeof(S));
-    S.done = done;
-    prev_idx = -1; prev_need = 0;
+    return launch();
+  }
+  int launch() {
+    if (phases.empty()) return SF_OK;
+    const size_t pb = phases.size() * sizeof(FlowPhase), qb = ((probs.size() * sizeof(ConvProblem)) + 15) & ~size_t(15);
+    if (pb + qb > FLOW_TABLE_BYTES) return SF_ERR_WORKSPACE;
+    // tables of the PREVIOUS flow launch of this call are dead once that launch has run: stream order
+    if (launch_flow_write(phases.data(), table, pb, st) != hipSuccess) return SF_ERR_LAUNCH;
+    std::vector<unsigned char> tmp(qb, 0);
+    std::memcpy(tmp.data(), probs.data(), probs.size() * sizeof(ConvProblem));
+    if (launch_flow_write(tmp.data(), table + pb, qb, st) != hipSuccess) return SF_ERR_LAUNCH;
+    SpFlow F;
+    std::memset(&F, 0, sizeof(F));
+    F.nphase = (int)phases.size();
+    F.timeout_polls = tune().flow_timeout;      // ~1 us per poll round: seconds, then the wait gives up instead of hanging the GPU
+    F.ph = reinterpret_cast<const FlowPhase*>(table);
+    F.p = reinterpret_cast<const ConvProblem*>(table + pb);
+    F.done = done;
+    F.err = err;
+    F.sc1_loads = tune().flow_sc1;
+    if (launch_sp_flow(F, grid, b3, st) != hipSuccess) return SF_ERR_LAUNCH;
+    ++launches;
+    phases.clear(); probs.clear();
     return SF_OK;
   }
-  SpPhase* open(int nprob, bool b3_phase) {
-    if (S.nphase > 0 && b3_phase != b3) { if (flush() != SF_OK) return nullptr; }
-    if (S.nphase >= tune().seg_maxph || S.nphase == SP_SEG_PHASES || S.nprob_total + nprob > SP_SEG_PROBS || next_done >= DONE_COUNTERS) { if (flush() != SF_OK) return nullptr; }
-    if (next_done >= DONE_COUNTERS) return nullptr;
-    b3 = b3_phase;
-    SpPhase& ph = S.ph[S.nphase];
-    std::memset(&ph, 0, sizeof(ph));
-    ph.nprob = nprob; ph.prob0 = S.nprob_total;
-    ph.wait_idx = prev_idx < 0 ? 0 : prev_idx;
-    ph.wait_need = prev_idx < 0 ? 0 : prev_need;
-    ph.done_idx = next_done++;
-    ph.signal = 1;
-    return &ph;
-  }
-  void close(SpPhase* ph, int finished_items) {
-    prev_idx = ph->done_idx; prev_need = finished_items;
-    S.nprob_total += ph->nprob;
-    S.nphase += 1;
-  }
+  // record one launch group as a phase.  SF_ERR_UNSUPPORTED: the caller launches it the ordinary way (after flush()).
   int add(const ConvLaunch& L, int epi, bool scaled, int bn) {
     bool all3 = L.nprob > 0;
     for (int i = 0; i < L.nprob; ++i) all3 = all3 && L.p[i].w3 != nullptr && L.p[i].use_w3;
-    if (L.wg_base[L.nprob] < 1 || L.wg_base[L.nprob] > 256 || L.nprob > SP_SEG_PROBS || !sp_segment_has(epi, scaled, bn)) return SF_ERR_UNSUPPORTED;
-    SpPhase* ph = open(L.nprob, all3);
-    if (!ph) return SF_ERR_UNSUPPORTED;
-    ph->kind = SP_PHASE_CONV; ph->epi = epi; ph->scaled = scaled ? 1 : 0; ph->nt = bn / 16;
-    ph->n_wg = L.wg_base[L.nprob];
-    int tiles = 0;
-    for (int i = 0; i < L.nprob; ++i) {
-      S.p[ph->prob0 + i] = L.p[i];
-      const ConvProblem& q = L.p[i];
-      tiles += ((q.n_img * q.Hout * q.Wout + bn - 1) / bn) * ((q.cout_pad + 63) / 64);
+    const int cap = sp_flow_capacity(all3);
+    if (L.wg_base[L.nprob] < 1 || L.wg_base[L.nprob] > cap || !sp_flow_has(epi, scaled, bn)) return SF_ERR_UNSUPPORTED;
+    if (!phases.empty() && (all3 != b3 || (int)phases.size() >= tune().seg_maxph)) SF_TRY(flush());
+    if ((phases.size() + 1) * sizeof(FlowPhase) + (probs.size() + L.nprob) * sizeof(ConvProblem) + 64 > FLOW_TABLE_BYTES ||
+        next_done + SP_FLOW_MAX_TILES + 1 > FLOW_DONE_COUNTERS)
+      SF_TRY(flush());
+    if (next_done + SP_FLOW_MAX_TILES + 1 > FLOW_DONE_COUNTERS) return SF_ERR_UNSUPPORTED;
+    b3 = all3;
+    grid = cap;
+    FlowPhase ph;
+    std::memset(&ph, 0, sizeof(ph));
+    // the problems of a phase sit next to each other in the table
+    const int first = (int)probs.size();
+    bool contiguous = true;
+    int idx[SF_MAX_GROUP];
+    for (int i = 0; i < L.nprob; ++i) { idx[i] = problem_index(L.p[i]); contiguous = contiguous && idx[i] == idx[0] + i; }
+    if (!contiguous) {      // some were found earlier, some not: store the group again, in order
+      probs.resize(first);
+      for (int i = 0; i < L.nprob; ++i) probs.push_back(L.p[i]);
+      idx[0] = first;
     }
-    for (int i = 0; i <= SF_MAX_GROUP; ++i) ph->wg_base[i] = L.wg_base[i];
-    close(ph, tiles);
+    ph.nprob = L.nprob; ph.prob0 = idx[0];
+    ph.epi = epi; ph.scaled = scaled ? 1 : 0; ph.nt = bn / 16;
+    ph.n_wg = L.wg_base[L.nprob];
+    for (int i = 0; i <= SF_MAX_GROUP; ++i) ph.wg_base[i] = L.wg_base[i];
+    // every problem of a phase covers the same pixels (one latent): its tiles are counted per pixel tile
+    const int Ptot = L.p[0].n_img * L.p[0].Hout * L.p[0].Wout;
+    int expect = 0, halo = 0, full = 0;
+    for (int i = 0; i < L.nprob; ++i) {
+      const ConvProblem& q = L.p[i];
+      if (q.n_img * q.Hout * q.Wout != Ptot || q.n_img != 1 || q.stride != 1 || q.in_up || q.Hin != q.Hout || q.Win != q.Wout) return SF_ERR_UNSUPPORTED;
+      expect += (q.cout_pad + 63) / 64;
+      const int ry = (q.KH - 1) / 2 * q.dil, rx = (q.KW - 1) / 2 * q.dil;
+      const int h = ry * q.Win + rx;
+      halo = h > halo ? h : halo;
+      full = full || q.se_sum != nullptr;      // the SE gate of the prologue is a reduction over the whole producer
+    }
+    ph.bn = bn; ph.n_ptiles = (Ptot + bn - 1) / bn; ph.expect = expect;
+    if (ph.n_ptiles > SP_FLOW_MAX_TILES) return SF_ERR_UNSUPPORTED;
+    ph.done_base = next_done;
+    next_done += SP_FLOW_MAX_TILES + 1;
+    ph.halo_px = halo; ph.dep_full = full;
+    const size_t n = phases.size();
+    if (n >= 1) {
+      const FlowPhase& a = phases[n - 1];
+      ph.prev_bn = a.bn; ph.prev_ntiles = a.n_ptiles; ph.prev_expect = a.expect; ph.prev_base = a.done_base;
+    }
+    if (n >= 2) {
+      const FlowPhase& a = phases[n - 2];
+      // ... its tiles and, where it carried a state copy, the copying workgroups (slot n_ptiles of its counters)
+      ph.lag_ntiles = a.n_ptiles; ph.lag_expect = a.expect; ph.lag_base = a.done_base;
+      ph.lag_copy_expect = a.copy_n4 > 0 ? (grid - a.n_wg > 0 ? grid - a.n_wg : grid) : 0;
+    }
+    if (copy_n4 > 0) { ph.copy_n4 = copy_n4; ph.copy_src = copy_src; ph.copy_dst = copy_dst; copy_n4 = 0; }
+    phases.push_back(ph);
     return SF_OK;
   }
   int add_copy(const float* src, float* dst, size_t nfloats) {
-    if ((nfloats & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15) || nfloats / 4 > 0x7fffffff) return SF_ERR_UNSUPPORTED;
-    SpPhase* ph = open(1, b3);
-    if (!ph) return SF_ERR_UNSUPPORTED;
-    ConvProblem& q = S.p[ph->prob0];
-    std::memset(&q, 0, sizeof(q));
-    q.in0 = src; q.out = dst; q.ktot = (int)(nfloats / 4);
-    ph->kind = SP_PHASE_COPY;
-    int wgs = (int)((nfloats / 4 + 767) / 768);
-    ph->n_wg = wgs < 1 ? 1 : (wgs > 256 ? 256 : wgs);
-    close(ph, ph->n_wg);
+    if ((nfloats & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15) || nfloats / 4 > 0x7fffffff || phases.empty() || copy_n4 > 0) return SF_ERR_UNSUPPORTED;
+    copy_src = src; copy_dst = dst; copy_n4 = (int)(nfloats / 4);
     return SF_OK;
   }
 };
-thread_local SegBuilder* g_seg = nullptr;
+thread_local FlowBuilder* g_seg = nullptr;
 // anything that is not a small-P launch first sends the recorded phases on their way (stream order)
 int seg_flush() { return g_seg ? g_seg->flush() : SF_OK; }
 
@@ -413,8 +473,14 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       wgs -= tiles_of[k];
       --ns_of[k];
     }
-    size_t slab_off = 0;
-    int cnt_off = 0;
+    // inside a persistent flow consecutive phases overlap in time (a slice of phase q+1 may start while a last arriver of phase q
+    // still reads its slabs): slabs and tickets alternate between the two halves of the scratch by phase parity (phase q+2 starts
+    // only when phase q is complete)
+    const int parity = g_seg ? (int)(g_seg->phases.size() & 1) : 0;
+    const size_t slab_lim = g_split ? (g_seg ? (parity + 1) * (g_split->slab_floats / 2) : g_split->slab_floats) : 0;
+    const int cnt_lim = g_split ? (g_seg ? (parity + 1) * (g_split->ncounters / 2) : g_split->ncounters) : 0;
+    size_t slab_off = (g_seg && g_split) ? parity * (g_split->slab_floats / 2) : 0;
+    int cnt_off = (g_seg && g_split) ? parity * (g_split->ncounters / 2) : 0;
     for (int i = 0; i < n && may_split; ++i) {
       ConvProblem& q = L.p[i];
       int ns = ns_of[i];
@@ -423,7 +489,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       ns = (nch_of[i] + cps - 1) / cps;      // every slice non-empty
       if (ns < 2) continue;
       const size_t per = (size_t)64 * bn;
-      if (slab_off + (size_t)tiles_of[i] * ns * per > g_split->slab_floats || cnt_off + tiles_of[i] > g_split->ncounters) continue;
+      if (slab_off + (size_t)tiles_of[i] * ns * per > slab_lim || cnt_off + tiles_of[i] > cnt_lim) continue;
       q.nsplit = ns;
       q.slab = g_split->slab + slab_off;
       q.counters = g_split->counters + cnt_off;
@@ -450,10 +516,11 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       for (int i = 0; i < n; ++i) all3 = all3 && L.p[i].w3 != nullptr;
       for (int i = 0; i < n; ++i) L.p[i].use_w3 = all3 ? 1 : 0;
     }
-    if (g_seg && !g_prof.on && (tune().sp_xcd & 1) && !g_stamp_on) {      // inside a rollout: a phase of the current persistent segment
+    if (g_seg && !g_prof.on && (tune().sp_xcd & 1) && !g_stamp_on) {      // inside a rollout: a phase of the persistent flow
       const int rc = g_seg->add(L, epi, scaled, bn);
       if (rc == SF_OK) return SF_OK;
-      SF_TRY(g_seg->flush());                                               // does not fit the segment kernel: an ordinary launch
+      if (rc != SF_ERR_UNSUPPORTED) return rc;
+      SF_TRY(g_seg->flush());                                               // does not fit the flow kernel: an ordinary launch
     } else {
       SF_TRY(seg_flush());
     }
@@ -1322,7 +1389,7 @@ struct Stage {
 
 size_t rollout_ws_floats(int C, int P) {
   const size_t cellw = dual_ws_floats(C, P), inf = infer_ws_floats(C, P);
-  return (cellw > inf ? cellw : inf) + 15 * al((size_t)P * C) + SPLIT_WS_FLOATS + DONE_COUNTERS + 256;
+  return (cellw > inf ? cellw : inf) + 15 * al((size_t)P * C) + SPLIT_WS_FLOATS + FLOW_WS_FLOATS + 256;
 }
 
 int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const float* eps, const unsigned long long* philox, int coef_stride,
@@ -1331,17 +1398,18 @@ int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const fl
   // buffers of the carried branch 2 (outside the per-stage arenas: written during one stage's infer_state, read by the next cell)
   Carry cb, cnow;
   cb.g2 = A.take(2 * PC); cb.rs2 = A.take(PC); cb.h2 = A.take(PC); cb.g1s = A.take(2 * PC);
-  unsigned* done = reinterpret_cast<unsigned*>(A.take(DONE_COUNTERS));
-  if (!A.ok()) return SF_ERR_WORKSPACE;
-  // one latent: the launches of the stages become phases of persistent segment launches (conv_sp.hip: sp_segment_kernel)
+  // one latent: the launch groups of the stages become phases of ONE persistent flow launch (conv_sp.hip: sp_flow_kernel)
   const bool persist = tune().persist && B == 1 && (long)B * H * W < tune().sp_max_p && tune().sp && g_split != nullptr;
-  SegBuilder seg(done, st);
+  unsigned char* table = persist ? reinterpret_cast<unsigned char*>(A.take(FLOW_TABLE_BYTES / 4)) : nullptr;
+  unsigned* done = persist ? reinterpret_cast<unsigned*>(A.take(FLOW_DONE_COUNTERS + 64)) : nullptr;
+  if (!A.ok()) return SF_ERR_WORKSPACE;
+  FlowBuilder seg(table, done, done ? done + FLOW_DONE_COUNTERS : nullptr, st);
   struct SegScope {      // g_seg is set for the duration of this function only
     bool on;
-    SegScope(SegBuilder* b, bool enable) : on(enable) { if (on) g_seg = b; }
+    SegScope(FlowBuilder* b, bool enable) : on(enable) { if (on) g_seg = b; }
     ~SegScope() { if (on) g_seg = nullptr; }
   } seg_scope(&seg, persist);
-  if (persist) SF_HIP(zero_fill(done, DONE_COUNTERS * sizeof(unsigned), st));
+  if (persist) SF_HIP(zero_fill(done, (FLOW_DONE_COUNTERS + 64) * sizeof(unsigned), st));
   bool carried = false;
   for (size_t j = 0; j < stages.size(); ++j) {
     const Stage& g = stages[j];

@@ -28,6 +28,7 @@
 // time, every VALU instruction 4-8; the shipped loop runs at ~70 % of the MFMA rate on 64x64 tiles.
 #include "sf_math.h"
 
+#include <cstring>
 #include <type_traits>
 
 namespace sf {
@@ -143,8 +144,8 @@ struct SpOps {
 };
 // `on`: the lane owns a real element (consumer wave, pixel < P, channel < cout); lanes that are not `on` load from safe
 // addresses and store nothing.
-template <int EPI>
-__device__ __forceinline__ void sp_epi_load(const ConvProblem& P, const int gp, const int c, const bool on, const int HWout, SpOps& o) {
+template <int EPI, class PT>
+__device__ __forceinline__ void sp_epi_load(const PT& P, const int gp, const int c, const bool on, const int HWout, SpOps& o) {
   const int img = on ? gp / HWout : 0;
   const size_t gpz = on ? (size_t)gp : 0;
   const int cz = on ? c : 0;
@@ -199,8 +200,8 @@ __device__ __forceinline__ void sp_epi_load(const ConvProblem& P, const int gp, 
 // ---- epilogues in the (pixel, channel-quad) layout -------------------------------------------------------------------
 // v: the lane's four consecutive output channels c..c+3 of pixel gp (pre-activation accumulator sums).
 // y_out (AFFINE): the stored value, zero where not `on` (for the SE channel sums).
-template <int EPI, bool PST = false>
-__device__ __forceinline__ void sp_epilogue(const ConvProblem& P, float4 v, const int gp, const int c, const bool on,
+template <int EPI, bool PST = false, class PT = ConvProblem>
+__device__ __forceinline__ void sp_epilogue(const PT& P, float4 v, const int gp, const int c, const bool on,
                                             const SpOps& o, float4& y_out) {
   const size_t gpz = on ? (size_t)gp : 0;
   const int cz = on ? c : 0;
@@ -334,12 +335,46 @@ __device__ __forceinline__ void sp_split_bf16x8(const f32x4 x0, const f32x4 x1, 
 
 struct SpStamp { int stamp_slot; };      // what the SF_STAMP macros read (diagnostic builds)
 
-// One (problem, tile, K slice) work item of a 768-thread workgroup: the whole body of the small-P kernel.  Called once by
-// conv_sp_kernel (one item per workgroup and launch) and once per phase by sp_segment_kernel (PST).  Returns true when this
-// workgroup ran the epilogue of its tile (false: the item is empty, or another slice's workgroup arrived last).  Every
-// branch that returns is block-uniform.
-template <int EPI, bool SCALE, int NT, bool B3, bool PST>
-__device__ __forceinline__ bool sp_body(const ConvProblem& P, const SpStamp L, int bx, int bz, const int m_tile, const int p_tile, float* const smem) {
+// Flow mode (sp_flow_kernel): what an item waits for before it loads activations — tile counters of the two phases before it
+// (sf_device.h, FlowPhase).  All members are workgroup-uniform.
+struct SpDep {
+  const unsigned* done;
+  unsigned* err;
+  int lag_base, lag_n, lag_expect;        // every counter done[lag_base .. +lag_n) must have reached lag_expect (phase q-2 complete)
+  int lag_copy_expect;                    // ... and done[lag_base + lag_n] this (the workgroups that copied a state out in phase q-2; 0: none)
+  int prev_base, prev_n, prev_expect;     // and done[prev_base .. +prev_n) prev_expect: the tiles of phase q-1 under this item's halo
+  int timeout;                            // polls before the wait gives up (err[0] += 1): a lost signal must not hang the GPU
+  int sc1_loads;
+};
+// One wave waits for the counters, lane-parallel: lane l polls entries l, l + 64, ... with sc1 (L1-bypassing) loads until every
+// entry has reached its count.  Returns with the counters seen; the caller runs the acquire and the workgroup barrier.
+__device__ __forceinline__ void sp_dep_wait(const SpDep& d, const int lane) {
+  const int n_lag = d.lag_n + (d.lag_copy_expect > 0 ? 1 : 0);
+  const int total = n_lag + d.prev_n;
+  if (total <= 0) return;
+  int spins = 0;
+  for (int base = 0; base < total; base += 64) {      // wave-uniform trip count
+    const int e = base + lane;
+    const bool mine = e < total;
+    const bool lag = e < n_lag;
+    const int idx = lag ? d.lag_base + e : d.prev_base + (e - n_lag);
+    const unsigned* const addr = d.done + (mine ? idx : (n_lag ? d.lag_base : d.prev_base));
+    const unsigned need = !mine ? 0u : (unsigned)(e < d.lag_n ? d.lag_expect : (lag ? d.lag_copy_expect : d.prev_expect));
+    for (;;) {
+      const unsigned v = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all(v >= need)) break;
+      if (++spins >= d.timeout) {                     // wave-uniform (spins is)
+        if (lane == 0) __hip_atomic_fetch_add(d.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+}
+
+template <int EPI, bool SCALE, int NT, bool B3, bool PST, class PT>
+__device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, int bz, const int m_tile, const int p_tile, float* const smem, const int tid,
+                                        const SpDep dep = SpDep()) {
   typedef SpGeo<NT> G;
   constexpr int BN = G::BN;
   // XOR mask of the 16-byte slot swizzle of the ring: 7 for the fp32 fragment reads (slots c + g), 5 for the bf16x3 loop
@@ -358,7 +393,6 @@ __device__ __forceinline__ bool sp_body(const ConvProblem& P, const SpStamp L, i
   const int cb = bz * cps;
   const int nchunks = (nch_all - cb) < cps ? (nch_all - cb) : cps;
 
-  const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   float* const misc = smem + G::RING;
@@ -471,6 +505,11 @@ __device__ __forceinline__ bool sp_body(const ConvProblem& P, const SpStamp L, i
   // and their operands, fetched now (consumer waves) and used after the K loop
   const int quad = lane & 15;
   const int c_out = m_tile * SP_BM + 4 * quad;
+  // Their operands are loaded by the consumers BEFORE the K loop on 32-pixel tiles (one item per lane; those launches have no
+  // hand-off that would hide the round trip), and right BEHIND it on 64-pixel tiles (two items per lane: 48-92 registers that the
+  // K loop would carry beside its accumulators and fragment sets — the 64-pixel kernels sat at the 168-register cap of a
+  // 768-thread workgroup and the TRUST one spilled; the two barriers of the K-quarter reduction and the split-K hand-off cover the loads).
+  constexpr bool OPS_EARLY = (NT != 4);
   int px[G::NPX];
   bool on_item[G::NPX];
   SpOps ops[G::NPX];
@@ -478,12 +517,83 @@ __device__ __forceinline__ bool sp_body(const ConvProblem& P, const SpStamp L, i
   for (int i = 0; i < G::NPX; ++i) {
     px[i] = (wave < 8 ? 4 * wave : 0) + (lane >> 4) + 32 * i;
     on_item[i] = (wave < 8) && (p_tile * BN + px[i]) < Ptot && c_out < P.cout;
-    if (wave < 8) sp_epi_load<EPI>(P, p_tile * BN + px[i], c_out, on_item[i], HWout, ops[i]);
   }
   // fused 1x1 layer (LNG launches, block-uniform): its weights and this tile's output meet in a chunk-shaped buffer behind
   // the ring — [2 sub-chunks][64 weight rows | BN pixel rows][32] — and run through the consumers' fragment / MFMA code once more
   const bool fuse = (EPI == EPI_LNG) && P.fuse_w != nullptr;
   float* const fz = misc + SP_MISC + (SCALE ? SP_SC_FLOATS : 0);
+  // ---- loader constants that do not depend on activations (flow mode issues the weight DMAs before the dependency wait) ----
+  const int lw = wave - 8;      // loader index (waves 8-11)
+  // a sub-chunk is 8 + BN/8 DMA instructions of 8 rows x 128 B: loader lw takes the weight row blocks lw and lw + 4
+  // and the pixel row blocks lw + 4 i
+  int a_voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = 8 * ((lw & 3) + 4 * i) + (lane >> 3);
+    const int k4 = (lane & 7) ^ ((r >> 1) & SWM);
+    int grow = m_tile * SP_BM + r;
+    grow = grow < P.cout_pad ? grow : P.cout_pad - 1;   // rows >= cout_pad are never stored
+    a_voff[i] = (grow * P.ktot + k4 * 4) * (int)sizeof(float);
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  auto make_rsrc = [](const float* base, size_t bytes) {
+    const unsigned nrec = bytes < 0x7fffffffull ? (unsigned)bytes : 0x7fffffffu;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (int)nrec, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(B3 ? static_cast<const float*>(P.w3) : P.w, (size_t)P.cout_pad * P.ktot * sizeof(float));
+  // the weight half of chunk `cidx` of this K slice (two 32-deep sub-chunks) into ring buffer `buf`: 4 DMAs per loader
+  auto issue_weights = [&](const int buf, const int cidx) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int scw = 2 * (cb + cidx) + s2;
+      float* const blk = smem + buf * G::BUFF + s2 * G::SUBF;
+      const bool live = scw < nsub_all;                    // wave-uniform (odd sub-chunk count: the last half is zero)
+      const int minus1 = -1;                               // offset -1 fails the buffer range check: the DMA writes zeros
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * lw) * 32), 16, live ? a_voff[0] : minus1, live ? scw * 128 : 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * (lw + 4)) * 32), 16, live ? a_voff[1] : minus1, live ? scw * 128 : 0, 0, 0);
+    }
+  };
+  auto issue_fuse_weights = [&]() {      // the fused layer's weights: 2 sub-chunks x 64 rows, this loader's row blocks lw and lw + 4 (zeros past its K)
+    const __amdgpu_buffer_rsrc_t rsrc_f = make_rsrc(P.fuse_w, (size_t)P.fuse_cout_pad * P.fuse_kpad * sizeof(float));
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = 8 * (lw + 4 * i) + (lane >> 3);
+        const int k4 = (lane & 7) ^ ((r >> 1) & 7);
+        const int grow = r < P.fuse_cout_pad ? r : P.fuse_cout_pad - 1;
+        const int vo = (s2 * 32 < P.fuse_kpad) ? (grow * P.fuse_kpad + s2 * 32 + k4 * 4) * (int)sizeof(float) : -1;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_f, (sp_lds_void*)(fz + s2 * G::SUBF + (8 * (lw + 4 * i)) * 32), 16, vo, 0, 0, 0);
+      }
+  };
+#endif
+  // Flow mode: activations (and the epilogue operands, the SE sums) may be outputs of the phase before this one.  The loaders
+  // send the weights of the first chunks on their way — weights depend on nothing — then wave 0 waits for the tile counters,
+  // runs the agent-scope acquire (this CU's L1 may hold lines another CU has rewritten) and the workgroup barrier releases
+  // every wave's loads.
+  constexpr int W_EARLY = PST ? SP_LA : 0;      // chunks whose weight halves are issued before the wait
+  if constexpr (PST) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (wave >= 8) {
+      if (fuse) issue_fuse_weights();
+#pragma unroll
+      for (int c = 0; c < SP_LA; ++c)
+        if (c < nchunks) issue_weights(c, c);             // block-uniform
+    }
+    if (wave == 0) {
+      sp_dep_wait(dep, lane);
+      if (!dep.sc1_loads) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+#endif
+    sp_barrier();
+  }
+  if (OPS_EARLY && wave < 8) {
+#pragma unroll
+    for (int i = 0; i < G::NPX; ++i) sp_epi_load<EPI>(P, p_tile * BN + px[i], c_out, on_item[i], HWout, ops[i]);
+  }
   float4 fuse_lw = spm_zero4(), fuse_lb = spm_zero4();
   if (fuse && wave < 8) {
     const int cz = c_out < P.fuse_cout ? c_out : 0;
@@ -494,18 +604,6 @@ __device__ __forceinline__ bool sp_body(const ConvProblem& P, const SpStamp L, i
 
   if (wave >= 8) {
     // ================================= loader =================================================================
-    const int lw = wave - 8;
-    // a sub-chunk is 8 + BN/8 DMA instructions of 8 rows x 128 B: loader lw takes the weight row blocks lw and lw + 4
-    // and the pixel row blocks lw + 4 i
-    int a_voff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = 8 * (lw + 4 * i) + (lane >> 3);
-      const int k4 = (lane & 7) ^ ((r >> 1) & SWM);
-      int grow = m_tile * SP_BM + r;
-      grow = grow < P.cout_pad ? grow : P.cout_pad - 1;   // rows >= cout_pad are never stored
-      a_voff[i] = (grow * P.ktot + k4 * 4) * (int)sizeof(float);
-    }
     int b_c4[G::NBI], iy0[G::NBI], ix0[G::NBI], pbase[G::NBI];
 #pragma unroll
     for (int i = 0; i < G::NBI; ++i) {
@@ -527,31 +625,14 @@ __device__ __forceinline__ bool sp_body(const ConvProblem& P, const SpStamp L, i
     const int Win = P.Win, in_up = P.in_up, dil = P.dil, KW = P.KW;
     const int Hlog = P.Hin << P.in_up, Wlog = P.Win << P.in_up;
 #if defined(__HIP_DEVICE_COMPILE__)
-    auto make_rsrc = [](const float* base, size_t bytes) {
-      const unsigned nrec = bytes < 0x7fffffffull ? (unsigned)bytes : 0x7fffffffu;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (int)nrec, 0x00020000);
-    };
     const size_t imgs_left = (size_t)(P.n_img - img0);
-    const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(B3 ? static_cast<const float*>(P.w3) : P.w, (size_t)P.cout_pad * P.ktot * sizeof(float));
     const __amdgpu_buffer_rsrc_t rsrc0 = make_rsrc(in0, imgs_left * P.Hin * P.Win * in0_cs * sizeof(float));
     const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(in1 ? in1 : in0, in1 ? imgs_left * P.Hin * P.Win * in1_cs * sizeof(float) : 0);
 #else
     (void)in0; (void)in1;
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (fuse) {      // the fused layer's weights: 2 sub-chunks x 64 rows, this loader's row blocks lw and lw + 4 (zeros past its K)
-      const __amdgpu_buffer_rsrc_t rsrc_f = make_rsrc(P.fuse_w, (size_t)P.fuse_cout_pad * P.fuse_kpad * sizeof(float));
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int r = 8 * (lw + 4 * i) + (lane >> 3);
-          const int k4 = (lane & 7) ^ ((r >> 1) & 7);
-          const int grow = r < P.fuse_cout_pad ? r : P.fuse_cout_pad - 1;
-          const int vo = (s2 * 32 < P.fuse_kpad) ? (grow * P.fuse_kpad + s2 * 32 + k4 * 4) * (int)sizeof(float) : -1;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_f, (sp_lds_void*)(fz + s2 * G::SUBF + (8 * (lw + 4 * i)) * 32), 16, vo, 0, 0, 0);
-        }
-    }
+    if (!PST && fuse) issue_fuse_weights();
 #endif
     // cursor of the next sub-chunk to fetch
     int sc = 2 * cb;
@@ -566,7 +647,7 @@ __device__ __forceinline__ bool sp_body(const ConvProblem& P, const SpStamp L, i
     for (int i = 0; i < G::NBI; ++i) { vb0[i] = (int)0x80000000; vb1[i] = (int)0x80000000; }
     const bool whole_chunks = (c0 % 32 == 0) && (c01 % 32 == 0) && c01 == cin_pad;      // block-uniform: no channel padding inside a sub-chunk
     const int minus1 = -1;
-    auto issue_chunk = [&](const int buf) {
+    auto issue_chunk = [&](const int buf, const bool with_w = true) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bool live = sc < nsub_all;                       // wave-uniform (odd sub-chunk count: the last half is zero)
@@ -585,8 +666,10 @@ __device__ __forceinline__ bool sp_body(const ConvProblem& P, const SpStamp L, i
         float* const blk = smem + buf * G::BUFF + s2 * G::SUBF;
 #if defined(__HIP_DEVICE_COMPILE__)
         if (live) {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * lw) * 32), 16, a_voff[0], sc * 128, 0, 0);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * (lw + 4)) * 32), 16, a_voff[1], sc * 128, 0, 0);
+          if (with_w) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * lw) * 32), 16, a_voff[0], sc * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * (lw + 4)) * 32), 16, a_voff[1], sc * 128, 0, 0);
+          }
 #pragma unroll
           for (int i = 0; i < G::NBI; ++i) {
             float* const dB = blk + (SP_BM + 8 * (lw + 4 * i)) * 32;
@@ -599,8 +682,10 @@ __device__ __forceinline__ bool sp_body(const ConvProblem& P, const SpStamp L, i
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (sp_lds_void*)dB, 16, vob, 0, 0, 0);
           }
         } else {      // offset -1 fails the buffer range check: the DMA writes zeros
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * lw) * 32), 16, minus1, 0, 0, 0);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * (lw + 4)) * 32), 16, minus1, 0, 0, 0);
+          if (with_w) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * lw) * 32), 16, minus1, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * (lw + 4)) * 32), 16, minus1, 0, 0, 0);
+          }
 #pragma unroll
           for (int i = 0; i < G::NBI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (sp_lds_void*)(blk + (SP_BM + 8 * (lw + 4 * i)) * 32), 16, minus1, 0, 0, 0);
@@ -623,9 +708,11 @@ __device__ __forceinline__ bool sp_body(const ConvProblem& P, const SpStamp L, i
 #endif
 #pragma unroll
     for (int c = 0; c < SP_LA; ++c)
-      if (c < nchunks) issue_chunk(c);                    // block-uniform
+      if (c < nchunks) issue_chunk(c, c >= W_EARLY);      // block-uniform; flow mode: the weight halves are already on their way
     fill_scale_rows();
-    if (nchunks >= SP_LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::DPC * (SP_LA - 1)) : "memory");
+    // chunk 0 has landed once everything but the youngest chunk's DMAs is done: a whole chunk in launch mode, its pixel half in
+    // flow mode (issue order there: weights 0, weights 1, pixels 0, pixels 1)
+    if (nchunks >= SP_LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PST ? 2 * G::NBI : G::DPC) * (SP_LA - 1)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     sp_barrier();                                         // chunk 0 published
     int ibuf = SP_LA % SP_NB;
@@ -779,6 +866,10 @@ __device__ __forceinline__ bool sp_body(const ConvProblem& P, const SpStamp L, i
   }
   // ================================= reduction over the K quarters + epilogue ===================================
   SF_STAMP_AT(L, 3);
+  if (!OPS_EARLY && wave < 8) {
+#pragma unroll
+    for (int i = 0; i < G::NPX; ++i) sp_epi_load<EPI>(P, p_tile * BN + px[i], c_out, on_item[i], HWout, ops[i]);
+  }
   __syncthreads();                                        // every fragment read and every DMA of the ring is done
   float* const red = smem;                                // [4][BN][SP_RED_PITCH]
   if (wave < 8) {
@@ -960,14 +1051,15 @@ __device__ __forceinline__ bool sp_body(const ConvProblem& P, const SpStamp L, i
 
 // Logical workgroup id -> (problem, K slice, cout tile, pixel tile) on the compact 1-D grid: problem i owns the ids
 // [wg_base[i], wg_base[i + 1]), K slice major, then cout tile, then pixel tile.
-__device__ __forceinline__ void sp_decode(const ConvProblem* ps, const int* wg_base, const int nprob, const int lg, const int BN, int& by, int& bx, int& bz,
+template <class PT, class IT>
+__device__ __forceinline__ void sp_decode(const PT* ps, const IT* wg_base, const int nprob, const int lg, const int BN, int& by, int& bx, int& bz,
                                           int& m_tile, int& p_tile) {
   by = 0;
 #pragma unroll
   for (int i = 1; i < SF_MAX_GROUP; ++i)
     if (i < nprob && lg >= wg_base[i]) by = i;
   bx = lg - wg_base[by];
-  const ConvProblem& P = ps[by];
+  const PT& P = ps[by];
   const int Ptot = P.n_img * P.Hout * P.Wout;
   const int n_mt = (P.cout_pad + SP_BM - 1) / SP_BM;
   const int n_pt = (Ptot + BN - 1) / BN, tiles = n_pt * n_mt;
@@ -995,80 +1087,148 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
     m_tile = bx % n_mt;
     p_tile = bx / n_mt;
   }
-  (void)sp_body<EPI, SCALE, NT, B3, false>(L.p[by], SpStamp{L.stamp_slot}, bx, bz, m_tile, p_tile, smem);
+  (void)sp_body<EPI, SCALE, NT, B3, false>(L.p[by], SpStamp{L.stamp_slot}, bx, bz, m_tile, p_tile, smem, (int)threadIdx.x);
 }
 
-// ---- persistent segment kernel: several dependent launches of a rollout as phases of ONE launch ---------------------------------
-// (north star: "the ODE derivative cell ... and the stepping loop fused into one LDS-tiled kernel per step").  A segment is a list
-// of phases, each what a conv_sp_kernel launch was: a group of problems on the compact grid.  One workgroup per CU stays resident;
-// in phase k workgroup w runs item w of that phase (or idles), then signals, and waits for the phase to be complete before it
-// starts phase k + 1 — the kernel boundary replaced by a counter:
-//   producer (the workgroup that ran a tile's epilogue): results stored write-through (sc1), every wave s_waitcnt vmcnt(0),
-//     workgroup barrier, ONE agent-scope atomic add per workgroup;
-//   consumer: one lane polls the counter with sc1 loads until it equals the number of tiles of the phase, agent-scope acquire
-//     (buffer_inv sc1), s_waitcnt vmcnt(0), workgroup barrier, then plain loads / LDS-DMAs
-// (MI355X_MICROARCH.md "Valid forms").  Arithmetic, tile shapes, split-K slices and summation orders are those of the
-// launch-per-layer path: results are bitwise identical to it (tests/test_gpu_persistent.py).  Phase counters are per phase of the
-// whole rollout and zeroed once at its start; all workgroups of the grid are co-resident by construction (<= 256, one per CU).
-template <int EPI, bool SCALE, int NT, bool B3>
-__device__ __forceinline__ bool sp_phase_item(const SpSegment& S, const SpPhase& ph, const int wg, float* smem) {
+// ---- persistent flow kernel: every launch group of a rollout as a phase of ONE launch, ordered by tile-level dataflow --------------
+// (north star: "the ODE derivative cell ... and the stepping loop fused into one LDS-tiled kernel per step"; sf_device.h, FlowPhase.)
+// One workgroup per CU stays resident and runs item `wg` of every phase, in phase order:
+//   item start   the loaders send the weight halves of the first chunks (they depend on nothing); wave 0 polls the tile counters
+//                of phase q-2 (all) and of phase q-1 (the tiles under the item's halo), then agent-scope acquire + workgroup barrier;
+//   item end     results leave with write-through (sc1) stores, every wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE
+//                agent-scope atomic add on the (phase, pixel tile) counter by the workgroup that ran the tile's epilogue
+// (MI355X_MICROARCH.md "Valid forms"; hand-off table, row 3).  Arithmetic, tiles, split-K slices and summation orders are those of
+// the launch-per-layer path: results are bitwise identical to it (tests/test_gpu_persistent.py).  Split-K slabs / tickets alternate
+// between two halves of the scratch by phase parity (a slice of phase q+1 may start while a last arriver of phase q still reads).
+// Every workgroup of the grid must be resident at once (launch_sp_flow checks the occupancy; the device must be otherwise idle);
+// every spin is bounded (SpFlow::timeout_polls) so that a lost signal cannot hang the GPU.
+typedef const __attribute__((address_space(4))) FlowPhase FlowPhaseK;      // tables are read with scalar loads
+typedef const __attribute__((address_space(4))) ConvProblem ConvProblemK;
+
+template <int EPI, bool SCALE, int NT, bool B3, class FT>
+__device__ __forceinline__ bool sp_flow_item(const FT& F, FlowPhaseK& ph, const int wg, float* smem, const int tid) {
+  ConvProblemK* const ps = (ConvProblemK*)F.p + ph.prob0;
   int by, bx, bz, m_tile, p_tile;
-  sp_decode(S.p + ph.prob0, ph.wg_base, ph.nprob, wg, SpGeo<NT>::BN, by, bx, bz, m_tile, p_tile);
-  return sp_body<EPI, SCALE, NT, B3, true>(S.p[ph.prob0 + by], SpStamp{0}, bx, bz, m_tile, p_tile, smem);
+  sp_decode(ps, ph.wg_base, ph.nprob, wg, SpGeo<NT>::BN, by, bx, bz, m_tile, p_tile);
+  // tiles of phase q-1 under this item's pixels + halo, in phase q-1's own tiling
+  SpDep d;
+  d.done = F.done; d.err = F.err; d.timeout = F.timeout_polls; d.sc1_loads = F.sc1_loads;
+  d.lag_base = ph.lag_base; d.lag_n = ph.lag_ntiles; d.lag_expect = ph.lag_expect; d.lag_copy_expect = ph.lag_copy_expect;
+  d.prev_base = ph.prev_base; d.prev_n = 0; d.prev_expect = ph.prev_expect;
+  if (ph.prev_ntiles > 0) {
+    int lo = 0, hi = ph.prev_ntiles - 1;
+    if (!ph.dep_full) {
+      const int p0 = p_tile * SpGeo<NT>::BN - ph.halo_px, p1 = p_tile * SpGeo<NT>::BN + SpGeo<NT>::BN - 1 + ph.halo_px;
+      lo = (p0 < 0 ? 0 : p0) / ph.prev_bn;
+      const int h = p1 / ph.prev_bn;
+      hi = h < hi ? h : hi;
+    }
+    d.prev_base += lo;
+    d.prev_n = hi - lo + 1;
+  }
+  return sp_body<EPI, SCALE, NT, B3, true>(ps[by], SpStamp{0}, bx, bz, m_tile, p_tile, smem, tid, d);
 }
 
 template <bool B3>
-__global__ __launch_bounds__(SP_THREADS) void sp_segment_kernel(const SpSegment S_by_value) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  // The 3.7-KB argument is indexed dynamically (phase k, problem prob0 + by): read it in place in the kernarg segment (scalar
-  // loads) — as a by-value object hipcc copies it to scratch first (4.2 KB per lane)
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SF_SEG_BYVALUE)
-  typedef const __attribute__((address_space(4))) SpSegment* seg_cptr;
-  const SpSegment& S = *(const SpSegment*)(seg_cptr)__builtin_amdgcn_kernarg_segment_ptr();
+__global__ __launch_bounds__(SP_THREADS) void sp_flow_kernel(const SpFlow F_by_value) {
+  extern __shared__ __attribute__((aligned(16))) float smem_base[];
+  const int wg = (int)blockIdx.x, n_grid = (int)gridDim.x;
+  // Nothing may be carried across the phase loop: hipcc otherwise hoists everything that is invariant in it — the argument's
+  // fields, thread-index arithmetic, LDS addresses and float constants of all seven inlined bodies — and keeps it in registers
+  // for the whole kernel (168 VGPRs, 41-94 SGPR spills, 244-383 VGPR spills in round 3's kernel).  So once per phase the
+  // argument pointer (read in place in the kernarg segment), the thread index and the LDS base offset pass through an empty asm:
+  // every body computes what it needs from them and it dies with the body.
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) SpFlow* flow_cptr;
+  flow_cptr Fk = (flow_cptr)__builtin_amdgcn_kernarg_segment_ptr();      // F is the only argument (offset 0)
 #else
-  const SpSegment& S = S_by_value;
+  const SpFlow* Fk = &F_by_value;
 #endif
-  (void)S_by_value;
-  const int wg = (int)blockIdx.x, tid = threadIdx.x;
-  for (int k = 0; k < S.nphase; ++k) {
-    const SpPhase& ph = S.ph[k];
-    if (ph.wait_need > 0) {      // block-uniform: the phase this one depends on must be complete
-      if (tid == 0) {
-        const unsigned* cnt = S.done + ph.wait_idx;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ph.wait_need) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __syncthreads();
-    }
+  (void)F_by_value;
+  const int nphase = Fk->nphase;
+  for (int k = 0; k < nphase; ++k) {
+    int tid = (int)threadIdx.x;
+    unsigned lds_off = 0;
+    asm volatile("" : "+s"(Fk), "+v"(tid), "+s"(lds_off));
+    float* const smem = smem_base + (lds_off >> 2);
+    const auto& F = *Fk;
+    FlowPhaseK& ph = ((FlowPhaseK*)F.ph)[k];
     bool fin = false;
+    int p_tile_done = 0;
     if (wg < ph.n_wg) {          // block-uniform
-      if (ph.kind == SP_PHASE_COPY) {      // state copy-out: src -> dst, n4 float4s, every workgroup a slice (only later launches read dst)
-        const float4* src = reinterpret_cast<const float4*>(S.p[ph.prob0].in0);
-        float4* dst = reinterpret_cast<float4*>(S.p[ph.prob0].out);
-        const size_t n4 = (size_t)S.p[ph.prob0].ktot;
-        for (size_t i = (size_t)wg * SP_THREADS + tid; i < n4; i += (size_t)ph.n_wg * SP_THREADS) dst[i] = src[i];
-        fin = true;
-      } else {
-        const int key = ph.epi * 4 + (ph.scaled ? 2 : 0) + (ph.nt == 4 ? 1 : 0);
-        switch (key) {
-          case EPI_AFFINE * 4 + 0: fin = sp_phase_item<EPI_AFFINE, false, 2, B3>(S, ph, wg, smem); break;
-          case EPI_AFFINE * 4 + 1: fin = sp_phase_item<EPI_AFFINE, false, 4, B3>(S, ph, wg, smem); break;
-          case EPI_AFFINE * 4 + 3: fin = sp_phase_item<EPI_AFFINE, true, 4, B3>(S, ph, wg, smem); break;
-          case EPI_BLEND * 4 + 1:  fin = sp_phase_item<EPI_BLEND, false, 4, B3>(S, ph, wg, smem); break;
-          case EPI_LNG * 4 + 1:    fin = sp_phase_item<EPI_LNG, false, 4, B3>(S, ph, wg, smem); break;
-          case EPI_TRUST * 4 + 0:  fin = sp_phase_item<EPI_TRUST, false, 2, B3>(S, ph, wg, smem); break;
-          case EPI_SAMPLE * 4 + 3: fin = sp_phase_item<EPI_SAMPLE, true, 4, B3>(S, ph, wg, smem); break;
-          default: break;
+      const int key = ph.epi * 4 + (ph.scaled ? 2 : 0) + (ph.nt == 4 ? 1 : 0);
+      switch (key) {
+        case EPI_AFFINE * 4 + 0: fin = sp_flow_item<EPI_AFFINE, false, 2, B3>(F, ph, wg, smem, tid); break;
+        case EPI_AFFINE * 4 + 1: fin = sp_flow_item<EPI_AFFINE, false, 4, B3>(F, ph, wg, smem, tid); break;
+        case EPI_AFFINE * 4 + 3: fin = sp_flow_item<EPI_AFFINE, true, 4, B3>(F, ph, wg, smem, tid); break;
+        case EPI_BLEND * 4 + 1:  fin = sp_flow_item<EPI_BLEND, false, 4, B3>(F, ph, wg, smem, tid); break;
+        case EPI_LNG * 4 + 1:    fin = sp_flow_item<EPI_LNG, false, 4, B3>(F, ph, wg, smem, tid); break;
+        case EPI_TRUST * 4 + 0:  fin = sp_flow_item<EPI_TRUST, false, 2, B3>(F, ph, wg, smem, tid); break;
+        case EPI_SAMPLE * 4 + 3: fin = sp_flow_item<EPI_SAMPLE, true, 4, B3>(F, ph, wg, smem, tid); break;
+        default: break;
+      }
+      if (fin) {                 // which pixel tile this workgroup finished (the counter it signals)
+        ConvProblemK* const ps = (ConvProblemK*)F.p + ph.prob0;
+        int by, bx, bz, m_tile;
+        sp_decode(ps, ph.wg_base, ph.nprob, wg, ph.bn, by, bx, bz, m_tile, p_tile_done);
+      }
+    }
+    // state copy-out riding in this phase: src is an output of phase q-1 (all of it), nobody inside the flow reads dst.  The
+    // workgroups without an item copy (all of them when every workgroup has one), after their own wait for phase q-1
+    if (ph.copy_n4 > 0) {        // block-uniform
+      const int n_idle = n_grid - ph.n_wg;
+      const int part = n_idle > 0 ? wg - ph.n_wg : wg, parts = n_idle > 0 ? n_idle : n_grid;
+      if (part >= 0) {
+        if (tid < 64) {
+          SpDep d;
+          d.done = F.done; d.err = F.err; d.timeout = F.timeout_polls; d.sc1_loads = 0;
+          d.lag_base = 0; d.lag_n = 0; d.lag_expect = 0; d.lag_copy_expect = 0;
+          d.prev_base = ph.prev_base; d.prev_n = ph.prev_ntiles; d.prev_expect = ph.prev_expect;
+          sp_dep_wait(d, tid);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        __syncthreads();
+        const float4* src = reinterpret_cast<const float4*>(ph.copy_src);
+        float4* dst = reinterpret_cast<float4*>(ph.copy_dst);
+        for (size_t i = (size_t)part * SP_THREADS + tid; i < (size_t)ph.copy_n4; i += (size_t)parts * SP_THREADS) dst[i] = src[i];
       }
     }
     // signal: every wave's stores are out, then one add per workgroup that finished a tile (the others only fed a slab);
-    // the barrier also keeps the next phase's first LDS-DMAs behind this phase's last LDS reads
+    // the barrier also keeps the next item's first LDS-DMAs behind this item's last LDS reads
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (fin && tid == 0 && ph.signal) __hip_atomic_fetch_add(S.done + ph.done_idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      if (fin) __hip_atomic_fetch_add(F.done + ph.done_base + p_tile_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the copies count too (slot n_ptiles of the phase): phase q+2 may overwrite src only when they are done
+      if (ph.copy_n4 > 0 && ((n_grid - ph.n_wg > 0) ? wg >= ph.n_wg : true))
+        __hip_atomic_fetch_add(F.done + ph.done_base + ph.n_ptiles, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
+}
+
+// one table piece per launch, passed by value: FlowBlob -> dst (n bytes, a multiple of 16)
+__global__ void flow_write_kernel(const FlowBlob blob, unsigned char* dst, int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) uint4* src_cptr;
+  src_cptr src = (src_cptr)__builtin_amdgcn_kernarg_segment_ptr();      // blob is the first argument (offset 0)
+  for (int i = threadIdx.x; i * 16 < n; i += blockDim.x) reinterpret_cast<uint4*>(dst)[i] = src[i];
+#endif
+  (void)blob;
+}
+hipError_t launch_flow_write(const void* host_src, void* dev_dst, size_t bytes, hipStream_t stream) {
+  const unsigned char* s = static_cast<const unsigned char*>(host_src);
+  unsigned char* d = static_cast<unsigned char*>(dev_dst);
+  if (bytes & 15) return hipErrorInvalidValue;
+  for (size_t off = 0; off < bytes; off += SP_WRITER_BYTES) {
+    FlowBlob b;
+    const size_t n = bytes - off < SP_WRITER_BYTES ? bytes - off : SP_WRITER_BYTES;
+    std::memcpy(b.b, s + off, n);
+    hipLaunchKernelGGL(flow_write_kernel, dim3(1), dim3(256), 0, stream, b, d + off, (int)n);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 template <int EPI, bool SCALE, int NT, bool B3>
@@ -1127,34 +1287,42 @@ static hipError_t launch_sp_n(const ConvLaunch& L, int epi, bool scaled, hipStre
   return hipErrorInvalidValue;
 }
 
-// the (epilogue, SE-scaled, tile) variants sp_segment_kernel carries: the ones a 50x50x64 rollout uses; a phase that needs
-// another one runs as an ordinary launch between two segments
-bool sp_segment_has(int epi, bool scaled, int bn) {
+// the (epilogue, SE-scaled, tile) variants sp_flow_kernel carries: the ones a 50x50x64 rollout uses; a launch group that needs
+// another one ends the flow and runs as an ordinary launch
+bool sp_flow_has(int epi, bool scaled, int bn) {
   const int key = epi * 4 + (scaled ? 2 : 0) + (bn == 64 ? 1 : 0);
   return key == EPI_AFFINE * 4 + 0 || key == EPI_AFFINE * 4 + 1 || key == EPI_AFFINE * 4 + 3 || key == EPI_BLEND * 4 + 1 || key == EPI_LNG * 4 + 1 ||
          key == EPI_TRUST * 4 + 0 || key == EPI_SAMPLE * 4 + 3;
 }
-// one persistent launch for a segment of dependent phases (sp_segment_kernel); b3: every phase runs the split-bf16 loop
-hipError_t launch_sp_segment(const SpSegment& S, bool b3, hipStream_t stream) {
-  if (S.nphase < 1) return hipSuccess;
-  const void* kern = b3 ? reinterpret_cast<const void*>(sp_segment_kernel<true>) : reinterpret_cast<const void*>(sp_segment_kernel<false>);
+// Workgroups of the flow kernel that can be resident at once on this device (0: none / error).  The phases wait for each other
+// inside the launch, so the grid must not exceed this — and the device must be otherwise idle (another stream's kernel, a CU
+// mask or reserved CUs are invisible to the occupancy query; the bounded spins then end the launch with err[0] != 0 instead of
+// hanging it).
+int sp_flow_capacity(bool b3) {
+  const void* kern = b3 ? reinterpret_cast<const void*>(sp_flow_kernel<true>) : reinterpret_cast<const void*>(sp_flow_kernel<false>);
   constexpr int lds = sp_lds_bytes<4>(true) + SpGeo<4>::BUFF * 4;      // the largest variant: 64-px tiles, SE rows, fused 1x1 buffer
-  static bool attr_done[64][2] = {};
-  static int n_cu[64] = {};
+  static int cap[64][2] = {};
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-  if (!attr_done[dev][b3 ? 1 : 0]) {
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    if (hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return hipErrorInvalidDevice;
-    attr_done[dev][b3 ? 1 : 0] = true;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  int& c = cap[dev][b3 ? 1 : 0];
+  if (c == 0) {
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 0;
+    int n_cu = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    hipError_t e = b3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sp_flow_kernel<true>, SP_THREADS, lds)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sp_flow_kernel<false>, SP_THREADS, lds);
+    if (e != hipSuccess || per_cu < 1) { c = -1; return 0; }
+    c = n_cu;      // ONE workgroup per CU (the LDS footprint admits no second one; one per CU is also what the items are sized for)
   }
-  int grid = 0;
-  for (int k = 0; k < S.nphase; ++k) grid = S.ph[k].n_wg > grid ? S.ph[k].n_wg : grid;
-  if (grid < 1) return hipSuccess;
-  if (grid > n_cu[dev]) return hipErrorInvalidConfiguration;      // every workgroup must be resident (one per CU): phases wait for each other
-  if (b3) hipLaunchKernelGGL(sp_segment_kernel<true>, dim3(grid), dim3(SP_THREADS), lds, stream, S);
-  else hipLaunchKernelGGL(sp_segment_kernel<false>, dim3(grid), dim3(SP_THREADS), lds, stream, S);
+  return c > 0 ? c : 0;
+}
+// one persistent launch for a flow of dependent phases (sp_flow_kernel); b3: every phase runs the split-bf16 loop
+hipError_t launch_sp_flow(const SpFlow& F, int grid, bool b3, hipStream_t stream) {
+  if (F.nphase < 1 || grid < 1) return hipSuccess;
+  constexpr int lds = sp_lds_bytes<4>(true) + SpGeo<4>::BUFF * 4;
+  if (grid > sp_flow_capacity(b3)) return hipErrorInvalidConfiguration;      // every workgroup must be resident: phases wait for each other
+  if (b3) hipLaunchKernelGGL(sp_flow_kernel<true>, dim3(grid), dim3(SP_THREADS), lds, stream, F);
+  else hipLaunchKernelGGL(sp_flow_kernel<false>, dim3(grid), dim3(SP_THREADS), lds, stream, F);
   return hipGetLastError();
 }
 

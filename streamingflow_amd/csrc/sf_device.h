@@ -109,27 +109,47 @@ struct ConvLaunch {
   int wg_base[SF_MAX_GROUP + 1];
 };
 
-// Persistent segment of the small-P kernel (conv_sp.hip: sp_segment_kernel): up to SP_SEG_PHASES dependent phases — each what
-// one conv_sp_kernel launch was — with up to SP_SEG_PROBS problems in all, passed by value (kernarg limit 4 KB).
-#define SP_SEG_PHASES 7
-#define SP_SEG_PROBS 7
+// Persistent "flow" form of the small-P kernel (conv_sp.hip: sp_flow_kernel, SF_PERSIST=1): every launch group of a rollout —
+// what one conv_sp_kernel launch was — is a PHASE of one persistent launch.  The phase and problem tables live in device memory
+// (the caller's workspace, written by small writer kernels at the start of the call) and are read through the constant address
+// space (scalar loads).  One 768-thread workgroup per CU stays resident and runs item `wg` of every phase in order.  Ordering
+// is by dataflow, not by a grid barrier: finished tiles are counted per (phase, pixel tile) in `done`, and an item starts when
+//   (1) every tile of phase q-2 is done (covers every input older than the previous phase and every buffer-reuse hazard:
+//       api.hip's scratch aliasing has a reuse distance of >= 2 phases), and
+//   (2) the tiles of phase q-1 under its halo are done (all of them for an SE gate, which is a global reduction).
+#define SP_FLOW_MAX_TILES 80         // pixel tiles of one phase (one 50x50 latent on 32-pixel tiles: 79)
 #define SP_PHASE_CONV 0
-#define SP_PHASE_COPY 1
-struct SpPhase {
-  int kind;                      // SP_PHASE_CONV | SP_PHASE_COPY (p[prob0]: in0 = src, out = dst, ktot = number of float4s)
-  int nprob, prob0;              // problems p[prob0 .. prob0 + nprob) of the segment
+struct FlowPhase {
+  int nprob, prob0;              // problems p[prob0 .. prob0 + nprob) of the flow
   int epi, scaled, nt;           // kernel variant of the phase (epilogue family, SE-scaled inputs, 16-pixel tiles per wave: 2 | 4)
-  int n_wg;                      // workgroups that have an item in this phase (the others idle)
-  int wait_idx, wait_need;       // before starting: done[wait_idx] must have reached wait_need (0: nothing to wait for)
-  int done_idx, signal;          // after a finished tile: done[done_idx] += 1 (signal == 0: nobody waits for this phase in this launch or later)
+  int n_wg;                      // workgroups that have an item in this phase (the others idle or copy)
   int wg_base[SF_MAX_GROUP + 1];
+  int bn, n_ptiles, expect;      // pixels per tile, pixel tiles, finished (problem, cout tile) items per pixel tile
+  int done_base;                 // this phase's counters: done[done_base .. done_base + n_ptiles)
+  int halo_px;                   // reach of the phase's convolutions in linear pixels (pad * W + pad, the largest of its problems)
+  int dep_full;                  // 1: wait for ALL tiles of phase q-1 (an SE gate in the prologue; a state copy)
+  int prev_bn, prev_ntiles, prev_expect, prev_base;      // tiling / counters of phase q-1 (prev_ntiles == 0: no such phase)
+  int lag_ntiles, lag_expect, lag_base;                  // phase q-2: complete before this one starts (0 tiles: none)
+  int copy_n4;                   // optional state copy-out riding in this phase (float4 count; 0: none): workgroups without an
+  const float* copy_src;         //   item copy src -> dst after the phase's dependency wait (src is an output of phase q-1)
+  float* copy_dst;
+  int lag_copy_expect;           // workgroups that copied in phase q-2 (they count in slot lag_ntiles of its counters; 0: no copy there)
+  int pad_[4];
 };
-struct SpSegment {
-  int nphase, nprob_total;
-  unsigned int* done;            // phase counters of the rollout (zero at its start)
-  SpPhase ph[SP_SEG_PHASES];
-  ConvProblem p[SP_SEG_PROBS];
+static_assert(sizeof(FlowPhase) % 16 == 0, "table pieces are written 16 bytes at a time");
+struct SpFlow {
+  int nphase;
+  int timeout_polls;             // every spin is bounded: after this many polls the workgroup gives up, sets err[0] and runs on
+  const FlowPhase* ph;           // device tables
+  const ConvProblem* p;
+  unsigned int* done;            // tile counters of the flow (zero at its start)
+  unsigned int* err;             // [0]: number of timed-out waits (0 after a healthy run)
+  int sc1_loads;                 // experiment: 1 = no acquire fence; every load of handed-off bytes is an sc1 load / sc1 LDS-DMA
 };
+static_assert(sizeof(ConvProblem) % 8 == 0, "problems are stored back to back in the table");
+// table writer: up to SP_WRITER_BYTES of a table per launch, passed by value
+#define SP_WRITER_BYTES 3840
+struct FlowBlob { unsigned char b[SP_WRITER_BYTES]; };
 
 // Diagnostic builds only (-DSF_STAMP, tools/r02/stamps.py): wave 0 of every workgroup records s_memrealtime (100 MHz)
 // at fixed points of the kernel into a debug buffer no other code reads.  The product build compiles none of it.

@@ -189,3 +189,38 @@ def test_shipped_sizes_full_cloud_is_reproducible():
     occ = float((lid.abs().amax(1) > 0).float().mean())
     print("LiDAR BEV occupancy", occ)
     assert tuple(lid.shape) == (5, 256, 200, 200) and 0.05 < occ <= 1.0
+
+
+def test_sparse_encoder_full_clouds_vs_oracle_statistics():
+    """the SparseEncoder at the SHIPPED size — 5 frames x 350 000 points -> 800 000 voxels, shipped grid and
+    channel widths — against statistics of the numpy / torch oracle on the same clouds (tests/golden/sparse_full_cloud_stats.json,
+    generated once by oracle/gen_sparse_full_stats.py: ~10 CPU-minutes).  Per frame: 512 strided samples, mean, mean-abs,
+    abs-max, BEV occupancy and the float64 sum of the [256, 200, 200] output."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import voxelbench
+    from oracle.gen_sparse_full_stats import sample_index
+    want = json.load(open(os.path.join(root, "tests", "golden", "sparse_full_cloud_stats.json")))
+    cfg, net, sd = _shipped_model()
+    pts = [voxelbench.cloud(seed=10 + t).cuda() for t in range(5)]
+    lid = net.extract_lidar_features(pts)
+    assert list(lid.shape) == want["shape"]
+    lid = lid.cpu()
+    for t, w in enumerate(want["frames"]):
+        f = lid[t].double().flatten()
+        idx = torch.from_numpy(sample_index(f.numel(), want["n_samples"]))
+        got = lid[t].flatten()[idx].double()
+        ref = torch.tensor(w["samples"], dtype=torch.float64)
+        scale = max(1.0, w["abs_max"])
+        e = float((got - ref).abs().max())
+        print(f"frame {t}: samples max-abs {e:.3e} (abs-max of the frame {w['abs_max']:.3f}), mean {float(f.mean()):.6e} vs {w['mean']:.6e}")
+        assert e <= 1e-4 * scale, (t, e)
+        assert float((ref != 0).double().mean()) > 0.05          # the samples do hit occupied cells
+        assert abs(float(f.mean()) - w["mean"]) <= 1e-5 * scale
+        assert abs(float(f.abs().mean()) - w["mean_abs"]) <= 1e-5 * scale
+        assert abs(float(f.abs().max()) - w["abs_max"]) <= 1e-4 * scale
+        assert abs(float((lid[t].abs().amax(0) > 0).double().mean()) - w["occupancy"]) <= 1e-4
+        assert abs(float(f.sum()) - w["sum"]) <= 1e-5 * scale * f.numel() ** 0.5 * 10
