@@ -61,6 +61,11 @@ typedef struct sf_conv_w {
    * whose struct carries it run the split-bf16 K loop where a kernel has one; results then differ from the exact-fp32
    * path by ~1e-5 (profiles/r03_bf16x3_*).  The default build of every module leaves it NULL: exact fp32. */
   const void* w_bf16x3;
+  /* optional, NULL unless packed with SF_PACK_WINOGRAD and the layer qualifies (3x3, stride 1, pad 1, no dilation, cin a multiple of
+   * 32, cout_pad a multiple of 64): the packed weights in Winograd F(2x2, 3x3) form, U = G g G^T as [cin/16][16][cout_pad][16].
+   * Launches with enough pixels then run csrc/conv_wino.hip: exact fp32 arithmetic, 2.25x fewer multiplies, different rounding
+   * (<= 7e-6 on the BEV outputs, profiles/r04_winograd_accuracy_study.json). */
+  const float* w_wino;
 } sf_conv_w;
 
 /* ---- weight packing on the device (load time) ---------------------------------------------------------------------
@@ -77,7 +82,7 @@ typedef struct sf_conv_w {
  *   c0 + c1 = cin: channels read from the first / second input tensor; pad < 0 = "same" ((kh-1)*dil/2).
  * The composite structs below (sf_gru_w ... sf_deeplab_w) are assembled from packed convolutions by plain struct
  * assignment; [update ; reset] gate pairs are packed from the two weights stored one after the other (cout = 2*hidden). */
-enum { SF_PACK_TRANSPOSED = 1, SF_PACK_FOLD_DUP = 2, SF_PACK_INTERLEAVE = 4, SF_PACK_BF16X3 = 8 };
+enum { SF_PACK_TRANSPOSED = 1, SF_PACK_FOLD_DUP = 2, SF_PACK_INTERLEAVE = 4, SF_PACK_BF16X3 = 8, SF_PACK_WINOGRAD = 16 };
 
 /* conv-GRU cell: SpatialGRU.gru_cell (streamingflow/layers/temporal.py:44-57) */
 typedef struct sf_gru_w {
@@ -149,6 +154,12 @@ typedef struct sf_bottle_w {
 
 int sf_version(void);
 const char* sf_status_string(int status);
+/* Persistent "flow" form of the single-latent rollout (csrc/conv_sp.hip: sp_flow_kernel): every launch group of sf_nnfo_rollout_* runs
+ * as a phase of ONE resident launch ordered by tile-level dataflow — bitwise the results of the launch-per-layer form, ~5 % less time
+ * per ODE step.  It needs every CU of an otherwise IDLE device (one workgroup per CU must be resident at once; waits are bounded, so a
+ * device shared with another process or stream ends the launch with wrong results instead of hanging): opt-in.  on: 1 / 0, -1 = the
+ * SF_PERSIST environment variable (default 0).  Returns the previous setting.  Process-wide; set it before capturing a graph. */
+int sf_set_flow_mode(int on);
 
 /* ---- ABI guard ---------------------------------------------------------------------------------------------------------
  * The structs above are passed by pointer and sf_conv_w is embedded by value in every composite, so a host compiled
@@ -158,7 +169,7 @@ const char* sf_status_string(int status);
  * anything else unless it returns SF_OK; bindings without a C compiler (ctypes, cgo, JNI) compare their own struct sizes
  * with sf_abi_sizeof() the same way (streamingflow_amd/_lib.py does, INTEGRATION.md shows it).  Hosts must zero-initialise
  * the structs (optional members are "NULL = absent") and recompile when SF_ABI_VERSION changes. */
-#define SF_ABI_VERSION 4
+#define SF_ABI_VERSION 5
 enum {
   SF_STRUCT_CONV_W = 0, SF_STRUCT_GRU_W, SF_STRUCT_DUAL_W, SF_STRUCT_RES_W, SF_STRUCT_PMODEL_W, SF_STRUCT_ENCODER_W,
   SF_STRUCT_DECODER_W, SF_STRUCT_CONVNEXT_W, SF_STRUCT_DEEPLAB_W, SF_STRUCT_BOTTLENECK_W, SF_STRUCT_BOTTLE_W, SF_STRUCT_COUNT
@@ -463,7 +474,7 @@ int sf_event_destroy(void* ev);
 /* Per-launch profiler for bench.py (off by default): when enabled every implicit-GEMM launch is
  * bracketed by hipEvents on its own stream.  sf_prof_collect fills SF_PROF_KEYS-entry arrays indexed by
  * kernel key = tile_config*8 + epilogue (calls, total ms, algorithmic flops, algorithmic bytes). */
-#define SF_PROF_KEYS 128
+#define SF_PROF_KEYS 160
 int sf_prof_enable(int on);
 int sf_prof_collect(int32_t* calls, double* ms, double* flops, double* bytes);
 

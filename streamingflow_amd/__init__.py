@@ -11,4 +11,4 @@ from .models.lift_splat import LiftSplat  # noqa: F401
 from .bev_pool import bev_pool  # noqa: F401
 
 __version__ = "0.1.0"
-from .packing import set_math_mode, math_mode  # noqa: F401,E402  (opt-in "bf16x3"; the default "fp32" is exact)
+from .packing import set_math_mode, math_mode, set_winograd, winograd, set_persistent_flow  # noqa: F401,E402  (opt-in "bf16x3"; the default "fp32" is exact)

@@ -13,9 +13,9 @@ f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
 
 SF_COEF_STRIDE = 12
-SF_ABI_VERSION = 4       # include/sfnative.h: changes whenever a public struct changes layout
-SF_PROF_KEYS = 128
-PACK_TRANSPOSED, PACK_FOLD_DUP, PACK_INTERLEAVE, PACK_BF16X3 = 1, 2, 4, 8      # SF_PACK_* of sfnative.h
+SF_ABI_VERSION = 5       # include/sfnative.h: changes whenever a public struct changes layout
+SF_PROF_KEYS = 160
+PACK_TRANSPOSED, PACK_FOLD_DUP, PACK_INTERLEAVE, PACK_BF16X3, PACK_WINOGRAD = 1, 2, 4, 8, 16      # SF_PACK_* of sfnative.h
 ACT = {"none": 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4, "gelu": 5}
 SOLVER = {"euler": 0, "midpoint": 1, "rk4": 2}
 OP_JUMP, OP_STEP = 0, 1
@@ -25,7 +25,7 @@ class ConvW(C.Structure):
     _fields_ = [("w", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p),
                 ("cout", C.c_int32), ("cout_pad", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
                 ("cin_pad", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("dil", C.c_int32),
-                ("stride", C.c_int32), ("pad", C.c_int32), ("act", C.c_int32), ("reserved", C.c_int32), ("w_bf16x3", C.c_void_p)]
+                ("stride", C.c_int32), ("pad", C.c_int32), ("act", C.c_int32), ("reserved", C.c_int32), ("w_bf16x3", C.c_void_p), ("w_wino", C.c_void_p)]
 
 
 class GruW(C.Structure):
@@ -85,6 +85,7 @@ _i3 = C.POINTER(C.c_int32 * 3)
 _f6 = C.POINTER(C.c_float * 6)
 SIGNATURES = {
     "sf_version": (_i, []),
+    "sf_set_flow_mode": (_i, [_i]),
     "sf_abi_version": (_i, []),
     "sf_abi_sizeof": (_sz, [_i]),
     "sf_abi_check": (_i, [_i, C.POINTER(_sz), _i]),
@@ -174,9 +175,9 @@ SIGNATURES = {
 }
 
 # kernel key = tile_config*8 + epilogue  (csrc/conv_igemm.hip launch_conv; configs 10..13: the LDS-DMA kernel conv_glds_kernel)
-KERNEL_NAMES = {c * 8 + e: (f"conv_glds<{cn[3:]},{en}>" if cn.startswith("dma") else f"conv_sp<{cn[2:]},{en}>" if cn.startswith("sp") else f"conv_igemm<{cn},{en}>")
+KERNEL_NAMES = {c * 8 + e: (f"conv_wino<{cn[4:]},{en}>" if cn.startswith("wino") else f"conv_glds<{cn[3:]},{en}>" if cn.startswith("dma") else f"conv_sp<{cn[2:]},{en}>" if cn.startswith("sp") else f"conv_igemm<{cn},{en}>")
                 for c, cn in enumerate(("S16x64k4", "L64x64", "LN64x128", "direct16px", "T64x64splitK", "dmaLN128x64", "L64x128", "L128x128w4", "L64x128w8", "L128x128w8",
-                                        "dma128x128w8", "dma64x64", "dma64x128w8", "dmaLN64x128", "sp64x32", "dmaT64x64splitK"))
+                                        "dma128x128w8", "dma64x64", "dma64x128w8", "dmaLN64x128", "sp64x32", "dmaT64x64splitK", "wino128x32t"))
                 for e, en in enumerate(("affine", "blend", "ln_gelu", "trust", "sample"))}
 
 _LIB = None

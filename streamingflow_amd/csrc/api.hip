@@ -16,6 +16,8 @@ hipError_t set_stamp_buffer(unsigned long long* p);
 int glds_occupancy(int which);
 hipError_t set_stamp_buffer_sp(unsigned long long* p);
 hipError_t launch_conv_sp(const ConvLaunch& L, int epi, bool scaled, int bn, hipStream_t stream);
+hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream);
+bool wino_takes(const ConvProblem& q, int epi);
 hipError_t launch_sp_flow(const SpFlow& F, int grid, bool b3, hipStream_t stream);
 hipError_t launch_flow_write(const void* host_src, void* dev_dst, size_t bytes, hipStream_t stream);
 bool sp_flow_has(int epi, bool scaled, int bn);
@@ -111,7 +113,7 @@ ConvProblem problem(const sf_conv_w& w, const float* in0, const float* in1, floa
                     int Win, int in_up = 0) {
   ConvProblem p;
   std::memset(&p, 0, sizeof(p));
-  p.in0 = in0; p.in1 = in1; p.w = w.w; p.w3 = w.w_bf16x3; p.scale = w.scale; p.bias = w.bias; p.out = out;
+  p.in0 = in0; p.in1 = in1; p.w = w.w; p.w3 = w.w_bf16x3; p.w_wino = w.w_wino; p.scale = w.scale; p.bias = w.bias; p.out = out;
   p.c0 = w.c0; p.c1 = w.c1; p.in0_cs = w.c0; p.in1_cs = w.c1;
   p.n_img = n_img; p.Hin = Hin; p.Win = Win; p.in_up = in_up;
   const int Hl = Hin << in_up, Wl = Win << in_up;
@@ -149,7 +151,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int flow_timeout, flow_sc1, b3_small_tiles, wide64, seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int wino, wino_min_p, flow_timeout, flow_sc1, b3_small_tiles, wide64, seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -158,6 +160,8 @@ const Tune& tune() {
     x.b3_small_tiles = geti("SF_B3_SMALL_TILES", 0);   // experiment: bf16x3 layers with 128-multiple cout on 64 x 128 tiles (3 workgroups per CU) instead of 128 x 128 (2)
     x.wide64 = geti("SF_WIDE64", 0);               // 1: 64-cout layers at >= 131072 pixels on 64 x 256 tiles (variant 10) instead of 64 x 128
     x.seg_maxph = geti("SF_SEG_MAXPH", 1 << 30);   // diagnostic: at most this many phases per persistent flow launch (1: every phase its own launch of the flow kernel)
+    x.wino = geti("SF_WINO", 1);                   // layers packed with Winograd weights run conv_wino.hip from wino_min_p pixels (0: direct form everywhere)
+    x.wino_min_p = geti("SF_WINO_MIN_P", 131072);
     x.flow_timeout = geti("SF_FLOW_TIMEOUT", 1 << 22);   // polls before a dependency wait of the flow kernel gives up (~1 us each: seconds); bring-up runs use a small value
     x.flow_sc1 = geti("SF_FLOW_SC1", 0);           // experiment: flow kernel without the acquire fence (every load of handed-off bytes an sc1 load)
     x.fenced = geti("SF_HANDOFF_FENCED", 0);       // 1: split-K hand-offs also run the agent-scope release / acquire fences of round 1 (known-good reference for the fence-free sc1 form; gfx950 only either way)
@@ -255,7 +259,7 @@ int chansum_tile_px(const ConvProblem* group, int n, int epi) { return sp_takes(
 // written into the caller's workspace by small writer kernels (table pieces travel as kernel arguments: stateless and
 // graph-capturable) and the flow kernel is launched when the rollout ends or something that is not a small-P launch intervenes.
 constexpr size_t FLOW_TABLE_BYTES = size_t(1) << 20;       // phases + problems of one flow
-constexpr int FLOW_DONE_COUNTERS = 1 << 18;                // tile counters of one flow (81 per phase)
+constexpr int FLOW_DONE_COUNTERS = 1 << 20;                // counter dwords of one flow (SP_FLOW_PHASE_DWORDS = 1536 per phase: every polled counter on its own line)
 constexpr size_t FLOW_WS_FLOATS = FLOW_TABLE_BYTES / 4 + FLOW_DONE_COUNTERS + 256;
 struct FlowBuilder {
   std::vector<FlowPhase> phases;
@@ -292,10 +296,10 @@ struct FlowBuilder {
     const size_t pb = phases.size() * sizeof(FlowPhase), qb = ((probs.size() * sizeof(ConvProblem)) + 15) & ~size_t(15);
     if (pb + qb > FLOW_TABLE_BYTES) return SF_ERR_WORKSPACE;
     // tables of the PREVIOUS flow launch of this call are dead once that launch has run: stream order
-    if (launch_flow_write(phases.data(), table, pb, st) != hipSuccess) return SF_ERR_LAUNCH;
-    std::vector<unsigned char> tmp(qb, 0);
-    std::memcpy(tmp.data(), probs.data(), probs.size() * sizeof(ConvProblem));
-    if (launch_flow_write(tmp.data(), table + pb, qb, st) != hipSuccess) return SF_ERR_LAUNCH;
+    std::vector<unsigned char> tmp(pb + qb, 0);
+    std::memcpy(tmp.data(), phases.data(), pb);
+    std::memcpy(tmp.data() + pb, probs.data(), probs.size() * sizeof(ConvProblem));
+    if (launch_flow_write(tmp.data(), table, pb + qb, st) != hipSuccess) return SF_ERR_LAUNCH;
     SpFlow F;
     std::memset(&F, 0, sizeof(F));
     F.nphase = (int)phases.size();
@@ -318,9 +322,13 @@ struct FlowBuilder {
     if (L.wg_base[L.nprob] < 1 || L.wg_base[L.nprob] > cap || !sp_flow_has(epi, scaled, bn)) return SF_ERR_UNSUPPORTED;
     if (!phases.empty() && (all3 != b3 || (int)phases.size() >= tune().seg_maxph)) SF_TRY(flush());
     if ((phases.size() + 1) * sizeof(FlowPhase) + (probs.size() + L.nprob) * sizeof(ConvProblem) + 64 > FLOW_TABLE_BYTES ||
-        next_done + SP_FLOW_MAX_TILES + 1 > FLOW_DONE_COUNTERS)
+        next_done + SP_FLOW_PHASE_DWORDS > FLOW_DONE_COUNTERS) {
       SF_TRY(flush());
-    if (next_done + SP_FLOW_MAX_TILES + 1 > FLOW_DONE_COUNTERS) return SF_ERR_UNSUPPORTED;
+      if (next_done + SP_FLOW_PHASE_DWORDS > FLOW_DONE_COUNTERS) {      // counters used up: start over (stream order: the flow that used them is done)
+        if (zero_fill(done, (size_t)FLOW_DONE_COUNTERS * sizeof(unsigned), st) != hipSuccess) return SF_ERR_LAUNCH;
+        next_done = 0;
+      }
+    }
     b3 = all3;
     grid = cap;
     FlowPhase ph;
@@ -351,23 +359,25 @@ struct FlowBuilder {
       halo = h > halo ? h : halo;
       full = full || q.se_sum != nullptr;      // the SE gate of the prologue is a reduction over the whole producer
     }
-    ph.bn = bn; ph.n_ptiles = (Ptot + bn - 1) / bn; ph.expect = expect;
+    ph.bn = bn; ph.n_ptiles = (Ptot + bn - 1) / bn;
     if (ph.n_ptiles > SP_FLOW_MAX_TILES) return SF_ERR_UNSUPPORTED;
-    ph.done_base = next_done;
-    next_done += SP_FLOW_MAX_TILES + 1;
+    ph.tile_base = next_done; ph.tile_expect = expect;
+    ph.tot_base = next_done + SP_FLOW_MAX_TILES * SP_FLOW_TILE_STRIDE;
+    next_done += SP_FLOW_PHASE_DWORDS;
+    if (copy_n4 > 0) { ph.copy_n4 = copy_n4; ph.copy_src = copy_src; ph.copy_dst = copy_dst; copy_n4 = 0; }
+    // finished items (every (problem, cout tile, pixel tile) once) + the workgroups that copy
+    ph.tot_expect = expect * ph.n_ptiles + (ph.copy_n4 > 0 ? (grid - ph.n_wg > 0 ? grid - ph.n_wg : grid) : 0);
     ph.halo_px = halo; ph.dep_full = full;
     const size_t n = phases.size();
     if (n >= 1) {
       const FlowPhase& a = phases[n - 1];
-      ph.prev_bn = a.bn; ph.prev_ntiles = a.n_ptiles; ph.prev_expect = a.expect; ph.prev_base = a.done_base;
+      ph.prev_bn = a.bn; ph.prev_ntiles = a.n_ptiles; ph.prev_tile_base = a.tile_base; ph.prev_tile_expect = a.tile_expect;
+      ph.prev_tot_base = a.tot_base; ph.prev_tot_expect = a.tot_expect;
     }
     if (n >= 2) {
       const FlowPhase& a = phases[n - 2];
-      // ... its tiles and, where it carried a state copy, the copying workgroups (slot n_ptiles of its counters)
-      ph.lag_ntiles = a.n_ptiles; ph.lag_expect = a.expect; ph.lag_base = a.done_base;
-      ph.lag_copy_expect = a.copy_n4 > 0 ? (grid - a.n_wg > 0 ? grid - a.n_wg : grid) : 0;
+      ph.lag_tot_base = a.tot_base; ph.lag_tot_expect = a.tot_expect;
     }
-    if (copy_n4 > 0) { ph.copy_n4 = copy_n4; ph.copy_src = copy_src; ph.copy_dst = copy_dst; copy_n4 = 0; }
     phases.push_back(ph);
     return SF_OK;
   }
@@ -378,6 +388,7 @@ struct FlowBuilder {
   }
 };
 thread_local FlowBuilder* g_seg = nullptr;
+int g_flow_mode = -1;      // -1: SF_PERSIST from the environment (default 0); 0 / 1: set by sf_set_flow_mode
 // anything that is not a small-P launch first sends the recorded phases on their way (stream order)
 int seg_flush() { return g_seg ? g_seg->flush() : SF_OK; }
 
@@ -438,6 +449,37 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     SF_HIP(hipEventRecord(r.b, st));
     g_prof.recs.push_back(r);
     return SF_OK;
+  }
+  // Winograd F(2x2, 3x3) for the 3x3 / stride-1 layers of large launches (conv_wino.hip): 2.25x fewer MACs, exact fp32 arithmetic.
+  // Groups are launched problem by problem (the kernel takes one); the profiler prices the launch at its EXECUTED FLOPs (key 16).
+  if (tune().wino && P >= tune().wino_min_p && (epi == EPI_AFFINE || epi == EPI_BLEND)) {
+    bool all = true;
+    for (int i = 0; i < n; ++i) all = all && wino_takes(ps[i], epi) && (ps[i].cout_pad % 128) == 0 && !(tune().b3 && ps[i].w3);
+    if (all) {
+      SF_TRY(seg_flush());
+      for (int i = 0; i < n; ++i) {
+        ConvLaunch W1;
+        std::memset(&W1, 0, sizeof(W1));
+        W1.p[0] = ps[i];
+        W1.nprob = 1;
+        if (!g_prof.on) {
+          SF_HIP(launch_conv_wino(W1, epi, st));
+          continue;
+        }
+        const ConvProblem& q = ps[i];
+        ProfRec r;
+        r.key = 16 * 8 + epi;
+        const double tiles = (double)q.n_img * ((q.Hout + 1) / 2) * ((q.Wout + 1) / 2);
+        r.flops = 2.0 * 16.0 * tiles * q.cout * (q.c0 + q.c1);      // executed: 16 products per 2x2 outputs and (cin, cout) pair
+        r.bytes = 4.0 * ((double)q.n_img * q.Hin * q.Win * (q.c0 + q.c1) + 16.0 * q.cout * (q.c0 + q.c1) + (double)q.n_img * q.Hout * q.Wout * q.cout);
+        r.a = g_prof.get(); r.b = g_prof.get();
+        SF_HIP(hipEventRecord(r.a, st));
+        SF_HIP(launch_conv_wino(W1, epi, st));
+        SF_HIP(hipEventRecord(r.b, st));
+        g_prof.recs.push_back(r);
+      }
+      return SF_OK;
+    }
   }
   if (sp_takes(ps, n, epi)) {
     // K ranges are split across workgroups (sc1 slab hand-off) so that the launch has about sp_split_wgs workgroups of
@@ -516,7 +558,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       for (int i = 0; i < n; ++i) all3 = all3 && L.p[i].w3 != nullptr;
       for (int i = 0; i < n; ++i) L.p[i].use_w3 = all3 ? 1 : 0;
     }
-    if (g_seg && !g_prof.on && (tune().sp_xcd & 1) && !g_stamp_on) {      // inside a rollout: a phase of the persistent flow
+    if (g_seg && !g_prof.on && (tune().sp_xcd & 1)) {      // inside a rollout: a phase of the persistent flow (diagnostic stamps: slot = phase index mod 64)
       const int rc = g_seg->add(L, epi, scaled, bn);
       if (rc == SF_OK) return SF_OK;
       if (rc != SF_ERR_UNSUPPORTED) return rc;
@@ -1399,7 +1441,7 @@ int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const fl
   Carry cb, cnow;
   cb.g2 = A.take(2 * PC); cb.rs2 = A.take(PC); cb.h2 = A.take(PC); cb.g1s = A.take(2 * PC);
   // one latent: the launch groups of the stages become phases of ONE persistent flow launch (conv_sp.hip: sp_flow_kernel)
-  const bool persist = tune().persist && B == 1 && (long)B * H * W < tune().sp_max_p && tune().sp && g_split != nullptr;
+  const bool persist = (g_flow_mode < 0 ? tune().persist : g_flow_mode) && B == 1 && (long)B * H * W < tune().sp_max_p && tune().sp && g_split != nullptr;
   unsigned char* table = persist ? reinterpret_cast<unsigned char*>(A.take(FLOW_TABLE_BYTES / 4)) : nullptr;
   unsigned* done = persist ? reinterpret_cast<unsigned*>(A.take(FLOW_DONE_COUNTERS + 64)) : nullptr;
   if (!A.ok()) return SF_ERR_WORKSPACE;
@@ -1751,6 +1793,12 @@ int sf_graph_destroy(void* exec) {
 /* Diagnostic builds (-DSF_STAMP) only: `buf` = 64 slots x 4096 workgroups x 8 uint64 device buffer (NULL switches the
  * stamps off); conv launches then record in-kernel s_memrealtime stamps into consecutive slots.  SF_ERR_UNSUPPORTED
  * in the product build. */
+int sf_set_flow_mode(int on) {
+  const int was = g_flow_mode < 0 ? tune().persist : g_flow_mode;
+  g_flow_mode = on < 0 ? -1 : (on ? 1 : 0);
+  return was;
+}
+
 int sf_debug_stamps(void* buf) {
   if (set_stamp_buffer((unsigned long long*)buf) != hipSuccess || set_stamp_buffer_sp((unsigned long long*)buf) != hipSuccess) return SF_ERR_UNSUPPORTED;
   g_stamp_on = buf != nullptr;

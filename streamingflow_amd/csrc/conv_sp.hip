@@ -76,17 +76,17 @@ __device__ __forceinline__ void sp_barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
-// Sum over the 64 lanes of a wave, the same value in every lane.  DPP within the 16-lane rows (quad swaps, half mirror, row
-// mirror: VALU, no LDS round trips — six ds_bpermute steps cost ~1500 cycles in the SE prologue), v_readlane across the rows.
-__device__ __forceinline__ float sp_wave_sum(float v) {
+// Sum over the 64 lanes of a wave, valid in LANE 63 only: DPP within the 16-lane rows (quad swaps, half mirror, row mirror), then
+// row_bcast15 / row_bcast31 across the rows — (r0 + r1) + (r2 + r3), the order of the v_readlane form this replaces (bitwise the
+// same sum), all VALU, no LDS round trips (six ds_bpermute steps cost ~1500 cycles in the SE prologue) and no scalar registers
+// (four v_readlane results per sum were what spilled SGPRs in the flow kernel's SE prologue).
+__device__ __forceinline__ float sp_wave_sum_lane63(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   v = spm_row16_sum(v);
-  const int b = __float_as_int(v);
-  return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
-         (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
-#else
-  return v;
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));      // row_bcast15 into rows 1, 3
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));      // row_bcast31 into rows 2, 3
 #endif
+  return v;
 }
 __device__ __forceinline__ float sp_reduce16(float v) { return spm_row16_sum(v); }   // sum over the 16 lanes (channel quads) of a pixel
 
@@ -97,11 +97,14 @@ template <bool PST>
 __device__ __forceinline__ void sp_gst4(float* base, const size_t off, const float4 v) {      // base: block-uniform tensor pointer, off: this lane's element offset
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SF_PST_PLAIN)
   if constexpr (PST) {
-    // a buffer store the compiler knows (its hazard recognizer and wait counters see it; an inline-asm global_store_dwordx4 sc1
-    // here gave wrong tiles — tests/test_gpu_persistent.py): 2-GB window on the tensor, aux 16 = sc1, as the split-K slabs
-    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4s;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, 0x7fffffff, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128((u32x4s){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, rs, (int)(off * 4), 0, 16);
+    // a store the compiler knows (its hazard recognizer and wait counters see it; an inline-asm global_store_dwordx4 sc1 here
+    // gave wrong tiles — tests/test_gpu_persistent.py): a volatile store to the GLOBAL address space is emitted as
+    // global_store_dwordx4 ... sc0 sc1 (write-through at system scope: the line leaves this XCD's L2, as with sc1 alone).  Round 3
+    // used raw buffer stores with aux = sc1: four more scalar registers per store for the resource, which the flow kernel's epilogues
+    // do not have (81 SGPR spills with them, none without).
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) volatile f32x4v* gptr;
+    *(gptr)(base + off) = (f32x4v){v.x, v.y, v.z, v.w};
   } else {
     spm_st4(base + off, v);
   }
@@ -133,6 +136,35 @@ __device__ __forceinline__ void sp_gst1(float* p, const float v) {
 #endif
 }
 
+// Flow mode, build flag SF_FLOW_SC1 (default 1): every load of bytes another workgroup of the same launch may have written — pixel
+// DMAs, epilogue operands, SE sums — bypasses this CU's L1 (sc0 sc1 / sc1: served by L2, which the hardware keeps coherent with the
+// write-through stores of the producers), so an item needs NO agent-scope acquire behind its dependency wait (the buffer_inv sc1
+// took 0.8-1.3 us of every item: profiles/r04_c_flow_stamps.txt).  MI355X_MICROARCH.md lists this form for global_/buffer_ loads to
+// registers (hand-off table, row 3); for LDS-DMA it is OBSERVED here — tests/test_gpu_persistent.py compares every rollout bit for
+// bit with the launch-per-layer path, with cache sweeps in between.  SF_FLOW_SC1=0 builds the acquire form (plain loads).
+#ifndef SF_FLOW_SC1
+#define SF_FLOW_SC1 1
+#endif
+template <bool VOL>
+__device__ __forceinline__ float4 sp_gld4(const float* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (VOL) {
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) volatile f32x4v* gptr;      // global_load_dwordx4 ... sc0 sc1
+    const f32x4v t = *(gptr)p;
+    return make_float4(t.x, t.y, t.z, t.w);
+  }
+#endif
+  return spm_ld4(p);
+}
+template <bool VOL>
+__device__ __forceinline__ float sp_gld1(const float* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (VOL) return *(const __attribute__((address_space(1))) volatile float*)p;
+#endif
+  return *p;
+}
+
 // Epilogue operands of one (pixel, channel quad) item.  They are loaded by the consumer waves BEFORE the K loop (every one of
 // them was written by an earlier launch), so that the epilogue is arithmetic + stores only: measured 1.1-2.8 us per launch
 // when the loads sat behind the reduction (tools/r02/stamps.py).
@@ -144,45 +176,45 @@ struct SpOps {
 };
 // `on`: the lane owns a real element (consumer wave, pixel < P, channel < cout); lanes that are not `on` load from safe
 // addresses and store nothing.
-template <int EPI, class PT>
+template <int EPI, bool VOL = false, class PT = ConvProblem>
 __device__ __forceinline__ void sp_epi_load(const PT& P, const int gp, const int c, const bool on, const int HWout, SpOps& o) {
   const int img = on ? gp / HWout : 0;
   const size_t gpz = on ? (size_t)gp : 0;
   const int cz = on ? c : 0;
-  o.pre = P.acc_in ? spm_ld4(P.acc_in + gpz * P.acc_cs + cz) : spm_zero4();
+  o.pre = P.acc_in ? sp_gld4<VOL>(P.acc_in + gpz * P.acc_cs + cz) : spm_zero4();
   if constexpr (EPI == EPI_AFFINE || EPI == EPI_BLEND) {
-    o.a[0] = P.scale ? spm_ld4(P.scale + cz) : make_float4(1.f, 1.f, 1.f, 1.f);
-    o.a[1] = P.bias ? spm_ld4(P.bias + (P.bias_per_img ? (size_t)img * P.cout : 0) + cz) : spm_zero4();
+    o.a[0] = P.scale ? sp_gld4<VOL>(P.scale + cz) : make_float4(1.f, 1.f, 1.f, 1.f);
+    o.a[1] = P.bias ? sp_gld4<VOL>(P.bias + (P.bias_per_img ? (size_t)img * P.cout : 0) + cz) : spm_zero4();
     if constexpr (EPI == EPI_AFFINE) {
       if (P.mode & 4) {      // block-uniform: conv-GRU blend inside an AFFINE launch (a candidate grouped with plain layers)
-        o.a[2] = spm_ld4(P.e0 + gpz * P.e0_cs + cz);
-        o.a[3] = spm_ld4(P.e1 + gpz * P.e1_cs + cz);
+        o.a[2] = sp_gld4<VOL>(P.e0 + gpz * P.e0_cs + cz);
+        o.a[3] = sp_gld4<VOL>(P.e1 + gpz * P.e1_cs + cz);
       } else {
-        o.a[2] = P.add ? spm_ld4(P.add + gpz * P.add_cs + cz) : spm_zero4();
-        o.a[3] = (P.add && P.add_scale) ? spm_ld4(P.add_scale + (size_t)img * P.cout + cz) : make_float4(1.f, 1.f, 1.f, 1.f);
+        o.a[2] = P.add ? sp_gld4<VOL>(P.add + gpz * P.add_cs + cz) : spm_zero4();
+        o.a[3] = (P.add && P.add_scale) ? sp_gld4<VOL>(P.add_scale + (size_t)img * P.cout + cz) : make_float4(1.f, 1.f, 1.f, 1.f);
       }
       const int cg = (P.out2 && cz >= P.gate_from) ? cz - P.gate_from : 0;
-      o.a[4] = P.out2 ? spm_ld4(P.e1 + gpz * P.e1_cs + cg) : spm_zero4();
+      o.a[4] = P.out2 ? sp_gld4<VOL>(P.e1 + gpz * P.e1_cs + cg) : spm_zero4();
     } else {
-      o.a[2] = spm_ld4(P.e0 + gpz * P.e0_cs + cz);
-      o.a[3] = spm_ld4(P.e1 + gpz * P.e1_cs + cz);
+      o.a[2] = sp_gld4<VOL>(P.e0 + gpz * P.e0_cs + cz);
+      o.a[3] = sp_gld4<VOL>(P.e1 + gpz * P.e1_cs + cz);
     }
   }
   if constexpr (EPI == EPI_LNG || EPI == EPI_TRUST) {
     const size_t po = gpz * P.cout + cz;
     const bool do_ln = (EPI == EPI_TRUST) || (P.mode & 1);      // a plain GELU layer (the gate's 1x1 projection) has no LayerNorm parameters
-    o.a[0] = do_ln ? spm_ld4(P.scale + cz) : spm_zero4();
-    o.a[1] = do_ln ? spm_ld4(P.bias + cz) : spm_zero4();
+    o.a[0] = do_ln ? sp_gld4<VOL>(P.scale + cz) : spm_zero4();
+    o.a[1] = do_ln ? sp_gld4<VOL>(P.bias + cz) : spm_zero4();
     o.c0f = 0.f; o.c1f = 0.f;
-    if constexpr (EPI == EPI_LNG) o.a[2] = P.add ? spm_ld4(P.add + gpz * P.add_cs + cz) : spm_zero4();
+    if constexpr (EPI == EPI_LNG) o.a[2] = P.add ? sp_gld4<VOL>(P.add + gpz * P.add_cs + cz) : spm_zero4();
     if constexpr (EPI == EPI_TRUST) {
-      o.a[2] = spm_ld4(P.e0 + po);
-      o.a[3] = spm_ld4(P.e1 + cz); o.a[4] = spm_ld4(P.e1 + P.cout + cz);
-      o.a[5] = spm_ld4(P.e2 + po); o.a[6] = spm_ld4(P.e3 + po);
+      o.a[2] = sp_gld4<VOL>(P.e0 + po);
+      o.a[3] = sp_gld4<VOL>(P.e1 + cz); o.a[4] = sp_gld4<VOL>(P.e1 + P.cout + cz);
+      o.a[5] = sp_gld4<VOL>(P.e2 + po); o.a[6] = sp_gld4<VOL>(P.e3 + po);
       const bool deriv = (P.mode & 1) != 0;
-      o.a[7] = deriv ? spm_ld4(P.e4 + po) : spm_zero4();
-      o.a[8] = deriv ? spm_ld4(P.e5 + po) : spm_zero4();
-      o.a[9] = (P.out2 && (P.mode & 2)) ? spm_ld4(P.out2 + po) : spm_zero4();
+      o.a[7] = deriv ? sp_gld4<VOL>(P.e4 + po) : spm_zero4();
+      o.a[8] = deriv ? sp_gld4<VOL>(P.e5 + po) : spm_zero4();
+      o.a[9] = (P.out2 && (P.mode & 2)) ? sp_gld4<VOL>(P.out2 + po) : spm_zero4();
       const float* cf = P.coef ? P.coef + (size_t)img * P.coef_stride : nullptr;
       o.c0f = cf ? cf[0] : 0.f;
       o.c1f = (cf && P.out2) ? cf[1] : 0.f;
@@ -192,8 +224,8 @@ __device__ __forceinline__ void sp_epi_load(const PT& P, const int gp, const int
     const int Chalf = P.cout >> 1;
     const int ch = ((c >> 4) << 3) + 2 * ((c >> 2) & 3);
     const bool ok = on && ch < Chalf;
-    o.a[0] = P.bias ? spm_ld4(P.bias + cz) : spm_zero4();
-    o.e = P.e0 ? *reinterpret_cast<const float2*>(P.e0 + (ok ? gpz : 0) * Chalf + (ok ? ch : 0)) : make_float2(0.f, 0.f);
+    o.a[0] = P.bias ? sp_gld4<VOL>(P.bias + cz) : spm_zero4();
+    o.e = P.e0 ? *reinterpret_cast<const float2*>(P.e0 + (ok ? gpz : 0) * Chalf + (ok ? ch : 0)) : make_float2(0.f, 0.f);      // eps: an input of the call
   }
 }
 
@@ -340,35 +372,30 @@ struct SpStamp { int stamp_slot; };      // what the SF_STAMP macros read (diagn
 struct SpDep {
   const unsigned* done;
   unsigned* err;
-  int lag_base, lag_n, lag_expect;        // every counter done[lag_base .. +lag_n) must have reached lag_expect (phase q-2 complete)
-  int lag_copy_expect;                    // ... and done[lag_base + lag_n] this (the workgroups that copied a state out in phase q-2; 0: none)
-  int prev_base, prev_n, prev_expect;     // and done[prev_base .. +prev_n) prev_expect: the tiles of phase q-1 under this item's halo
+  int lag_idx, lag_expect;                // done[lag_idx] (this workgroup's replica of phase q-2's total) must reach lag_expect (0: none)
+  int full_idx, full_expect;              // done[full_idx] (replica of phase q-1's total) must reach full_expect (0: none)
+  int tile_idx, tile_n, tile_expect;      // done[tile_idx + i * SP_FLOW_TILE_STRIDE], i < tile_n (<= 62): tiles of phase q-1 under the halo
   int timeout;                            // polls before the wait gives up (err[0] += 1): a lost signal must not hang the GPU
-  int sc1_loads;
 };
-// One wave waits for the counters, lane-parallel: lane l polls entries l, l + 64, ... with sc1 (L1-bypassing) loads until every
-// entry has reached its count.  Returns with the counters seen; the caller runs the acquire and the workgroup barrier.
+// One wave waits for the counters, lane-parallel: lane 0 the phase-(q-2) total, lane 1 the phase-(q-1) total, lanes 2.. one tile
+// counter each — every counter on a line of its own, read with sc1 (L1-bypassing) loads until all have reached their counts.
+// The caller runs the workgroup barrier (and the acquire, in builds that need one).
 __device__ __forceinline__ void sp_dep_wait(const SpDep& d, const int lane) {
-  const int n_lag = d.lag_n + (d.lag_copy_expect > 0 ? 1 : 0);
-  const int total = n_lag + d.prev_n;
-  if (total <= 0) return;
+  const bool l0 = lane == 0 && d.lag_expect > 0, l1 = lane == 1 && d.full_expect > 0, lt = lane >= 2 && lane - 2 < d.tile_n;
+  const bool mine = l0 || l1 || lt;
+  if (!__any(mine)) return;
+  const int idx = l0 ? d.lag_idx : (l1 ? d.full_idx : (lt ? d.tile_idx + (lane - 2) * SP_FLOW_TILE_STRIDE : 0));
+  const unsigned need = l0 ? (unsigned)d.lag_expect : (l1 ? (unsigned)d.full_expect : (lt ? (unsigned)d.tile_expect : 0u));
+  const unsigned* const addr = d.done + (mine ? idx : 0);
   int spins = 0;
-  for (int base = 0; base < total; base += 64) {      // wave-uniform trip count
-    const int e = base + lane;
-    const bool mine = e < total;
-    const bool lag = e < n_lag;
-    const int idx = lag ? d.lag_base + e : d.prev_base + (e - n_lag);
-    const unsigned* const addr = d.done + (mine ? idx : (n_lag ? d.lag_base : d.prev_base));
-    const unsigned need = !mine ? 0u : (unsigned)(e < d.lag_n ? d.lag_expect : (lag ? d.lag_copy_expect : d.prev_expect));
-    for (;;) {
-      const unsigned v = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__all(v >= need)) break;
-      if (++spins >= d.timeout) {                     // wave-uniform (spins is)
-        if (lane == 0) __hip_atomic_fetch_add(d.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-      }
-      __builtin_amdgcn_s_sleep(2);
+  for (;;) {
+    const unsigned v = mine ? __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    if (__all(!mine || v >= need)) break;
+    if (++spins >= d.timeout) {                       // wave-uniform (spins is)
+      if (lane == 0) __hip_atomic_fetch_add(d.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
     }
+    __builtin_amdgcn_s_sleep(2);
   }
 }
 
@@ -377,6 +404,8 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
                                         const SpDep dep = SpDep()) {
   typedef SpGeo<NT> G;
   constexpr int BN = G::BN;
+  constexpr bool VOL = PST && (SF_FLOW_SC1 != 0);      // flow mode: L1-bypassing loads of activations instead of an acquire
+  constexpr int PX_AUX = VOL ? 16 : 0;                 // aux bits of the pixel DMAs (16 = sc1)
   // XOR mask of the 16-byte slot swizzle of the ring: 7 for the fp32 fragment reads (slots c + g), 5 for the bf16x3 loop
   // (slots 2g / 2g + 1: conflict-free for the ds_read_b128 lane groups, see conv_igemm.hip)
   constexpr int SWM = B3 ? 5 : 7;
@@ -436,7 +465,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
 #pragma unroll
         for (int q = 0; q < SE_Q; ++q) {                // rows grp, grp + G, ...: unconditional loads, selected afterwards
           const int t = grp + q * G;
-          r[q] = P.se_sum[(size_t)min(t, nt - 1) * C + ch];
+          r[q] = sp_gld1<VOL>(P.se_sum + (size_t)min(t, nt - 1) * C + ch);
         }
         // hipcc sinks a load whose value is only needed under a lane mask into that region and drains vmcnt(0) behind it:
         // every value is "used" here, unconditionally, after ALL the loads were issued -> one wait for the lot
@@ -475,9 +504,9 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
           m_hi += (q < G && lane + 64 < C) ? ph[q] : 0.f;
         }
         m_lo *= P.se_inv_hw; m_hi *= P.se_inv_hw;
-        const float s = sp_wave_sum(f0a * m_lo + f0b * m_hi), u = sp_wave_sum(f0c * m_lo + f0d * m_hi);
-        if (lane == 0 && wave < Cr) hid[wave] = s > 0.f ? s : 0.f;
-        if (lane == 0 && wave + 8 < Cr) hid[wave + 8] = u > 0.f ? u : 0.f;
+        const float s = sp_wave_sum_lane63(f0a * m_lo + f0b * m_hi), u = sp_wave_sum_lane63(f0c * m_lo + f0d * m_hi);      // in lane 63
+        if (lane == 63 && wave < Cr) hid[wave] = s > 0.f ? s : 0.f;
+        if (lane == 63 && wave + 8 < Cr) hid[wave + 8] = u > 0.f ? u : 0.f;
       }
       __syncthreads();
       for (int idx = tid; idx < SP_SC_IMGS * cin_pad; idx += SP_THREADS) {
@@ -496,7 +525,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
       const float* const in_scale = P.in_scale;
       for (int idx = tid; idx < SP_SC_IMGS * cin_pad; idx += SP_THREADS) {
         const int si = idx / cin_pad, ch = idx - si * cin_pad;
-        sc_lds[idx] = (in_scale && img0 + si < P.n_img && ch < P.c0) ? in_scale[(size_t)(img0 + si) * P.c0 + ch] : (in_scale ? 0.f : 1.f);
+        sc_lds[idx] = (in_scale && img0 + si < P.n_img && ch < P.c0) ? sp_gld1<VOL>(in_scale + (size_t)(img0 + si) * P.c0 + ch) : (in_scale ? 0.f : 1.f);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -567,43 +596,40 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
       }
   };
 #endif
-  // Flow mode: activations (and the epilogue operands, the SE sums) may be outputs of the phase before this one.  The loaders
-  // send the weights of the first chunks on their way — weights depend on nothing — then wave 0 waits for the tile counters,
-  // runs the agent-scope acquire (this CU's L1 may hold lines another CU has rewritten) and the workgroup barrier releases
-  // every wave's loads.
+  // Flow mode: activations (and the epilogue operands, the SE sums) may be outputs of the phase before this one.  Each role first
+  // does everything that depends on nothing — the loaders send the weight halves of the first chunks on their way and compute
+  // their pixel addresses, the consumers their fragment addresses — then wave 0 waits for the tile counters (+ the agent-scope
+  // acquire in SF_FLOW_SC1=0 builds: this CU's L1 may hold lines another CU has rewritten) and ONE workgroup barrier releases
+  // every wave's loads of activations.
   constexpr int W_EARLY = PST ? SP_LA : 0;      // chunks whose weight halves are issued before the wait
-  if constexpr (PST) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (wave >= 8) {
-      if (fuse) issue_fuse_weights();
-#pragma unroll
-      for (int c = 0; c < SP_LA; ++c)
-        if (c < nchunks) issue_weights(c, c);             // block-uniform
-    }
-    if (wave == 0) {
-      sp_dep_wait(dep, lane);
-      if (!dep.sc1_loads) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    }
-#endif
-    sp_barrier();
-  }
-  if (OPS_EARLY && wave < 8) {
-#pragma unroll
-    for (int i = 0; i < G::NPX; ++i) sp_epi_load<EPI>(P, p_tile * BN + px[i], c_out, on_item[i], HWout, ops[i]);
-  }
+  if constexpr (PST) SF_STAMP_AT(L, 7);
   float4 fuse_lw = spm_zero4(), fuse_lb = spm_zero4();
   if (fuse && wave < 8) {
     const int cz = c_out < P.fuse_cout ? c_out : 0;
     fuse_lw = spm_ld4(P.fuse_scale + cz);
     fuse_lb = spm_ld4(P.fuse_bias + cz);
   }
-  SF_STAMP_AT(L, 0);
+  auto consumer_operands = [&]() {              // consumer waves, behind the flow wait
+    if (OPS_EARLY) {
+#pragma unroll
+      for (int i = 0; i < G::NPX; ++i) sp_epi_load<EPI, VOL>(P, p_tile * BN + px[i], c_out, on_item[i], HWout, ops[i]);
+    }
+  };
+  if constexpr (!PST) {
+    if (wave < 8) consumer_operands();
+    SF_STAMP_AT(L, 0);
+  }
 
   if (wave >= 8) {
     // ================================= loader =================================================================
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (PST) {
+      if (fuse) issue_fuse_weights();
+#pragma unroll
+      for (int c = 0; c < SP_LA; ++c)
+        if (c < nchunks) issue_weights(c, c);             // block-uniform
+    }
+#endif
     int b_c4[G::NBI], iy0[G::NBI], ix0[G::NBI], pbase[G::NBI];
 #pragma unroll
     for (int i = 0; i < G::NBI; ++i) {
@@ -634,6 +660,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
 #if defined(__HIP_DEVICE_COMPILE__)
     if (!PST && fuse) issue_fuse_weights();
 #endif
+    if constexpr (PST) sp_barrier();                      // flow: the dependency wait of wave 0 is over (weights were issued above)
     // cursor of the next sub-chunk to fetch
     int sc = 2 * cb;
     int cur_kc = sc % kcpt, cur_ty = (sc / kcpt) / KW, cur_tx = (sc / kcpt) % KW;
@@ -678,8 +705,8 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
               const int c = cur_kc * 32 + b_c4[i];
               vob = (c < c01) ? vob : -1;
             }
-            if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (sp_lds_void*)dB, 16, vob, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (sp_lds_void*)dB, 16, vob, 0, 0, 0);
+            if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (sp_lds_void*)dB, 16, vob, 0, 0, PX_AUX);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (sp_lds_void*)dB, 16, vob, 0, 0, PX_AUX);
           }
         } else {      // offset -1 fails the buffer range check: the DMA writes zeros
           if (with_w) {
@@ -825,6 +852,20 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
               acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][m][0][e], fb[set][n][0][e], acc[m][n], 0, 0, 0);
       }
     };
+    if constexpr (PST) {
+      if (wave == 0) {
+        sp_dep_wait(dep, lane);
+        SF_STAMP_AT(L, 9);
+        if constexpr (!VOL) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      sp_barrier();
+      SF_STAMP_AT(L, 10);
+      consumer_operands();
+      SF_STAMP_AT(L, 0);
+    }
     fill_scale_rows();
     SF_STAMP_AT(L, 1);
     sp_barrier();                         // chunk 0 published (and the SE scale rows)
@@ -868,7 +909,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
   SF_STAMP_AT(L, 3);
   if (!OPS_EARLY && wave < 8) {
 #pragma unroll
-    for (int i = 0; i < G::NPX; ++i) sp_epi_load<EPI>(P, p_tile * BN + px[i], c_out, on_item[i], HWout, ops[i]);
+    for (int i = 0; i < G::NPX; ++i) sp_epi_load<EPI, VOL>(P, p_tile * BN + px[i], c_out, on_item[i], HWout, ops[i]);
   }
   __syncthreads();                                        // every fragment read and every DMA of the ring is done
   float* const red = smem;                                // [4][BN][SP_RED_PITCH]
@@ -1019,6 +1060,11 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
           if (gp < Ptot && cv) sp_gst4<PST>(P.fuse_out, (size_t)gp * P.fuse_cout + c, y);
         }
       }
+#ifdef SF_STAMP
+      SF_STAMP_AT(L, 5);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SF_STAMP_AT(L, 6);
+#endif
       return true;
     }
   }
@@ -1106,27 +1152,30 @@ typedef const __attribute__((address_space(4))) FlowPhase FlowPhaseK;      // ta
 typedef const __attribute__((address_space(4))) ConvProblem ConvProblemK;
 
 template <int EPI, bool SCALE, int NT, bool B3, class FT>
-__device__ __forceinline__ bool sp_flow_item(const FT& F, FlowPhaseK& ph, const int wg, float* smem, const int tid) {
+__device__ __forceinline__ bool sp_flow_item(const FT& F, FlowPhaseK& ph, const int wg, float* smem, const int tid, const int stamp_slot) {
   ConvProblemK* const ps = (ConvProblemK*)F.p + ph.prob0;
   int by, bx, bz, m_tile, p_tile;
   sp_decode(ps, ph.wg_base, ph.nprob, wg, SpGeo<NT>::BN, by, bx, bz, m_tile, p_tile);
   // tiles of phase q-1 under this item's pixels + halo, in phase q-1's own tiling
   SpDep d;
-  d.done = F.done; d.err = F.err; d.timeout = F.timeout_polls; d.sc1_loads = F.sc1_loads;
-  d.lag_base = ph.lag_base; d.lag_n = ph.lag_ntiles; d.lag_expect = ph.lag_expect; d.lag_copy_expect = ph.lag_copy_expect;
-  d.prev_base = ph.prev_base; d.prev_n = 0; d.prev_expect = ph.prev_expect;
+  d.done = F.done; d.err = F.err; d.timeout = F.timeout_polls;
+  const int rep = (wg & 7) * SP_FLOW_TOT_STRIDE;      // blocks are dealt round-robin over the XCDs: wg & 7 spreads the pollers (speed only)
+  d.lag_idx = ph.lag_tot_base + rep; d.lag_expect = ph.lag_tot_expect;
+  d.full_idx = ph.prev_tot_base + rep; d.full_expect = 0;
+  d.tile_idx = ph.prev_tile_base; d.tile_n = 0; d.tile_expect = ph.prev_tile_expect;
   if (ph.prev_ntiles > 0) {
-    int lo = 0, hi = ph.prev_ntiles - 1;
-    if (!ph.dep_full) {
-      const int p0 = p_tile * SpGeo<NT>::BN - ph.halo_px, p1 = p_tile * SpGeo<NT>::BN + SpGeo<NT>::BN - 1 + ph.halo_px;
-      lo = (p0 < 0 ? 0 : p0) / ph.prev_bn;
-      const int h = p1 / ph.prev_bn;
-      hi = h < hi ? h : hi;
+    const int p0 = p_tile * SpGeo<NT>::BN - ph.halo_px, p1 = p_tile * SpGeo<NT>::BN + SpGeo<NT>::BN - 1 + ph.halo_px;
+    const int lo = (p0 < 0 ? 0 : p0) / ph.prev_bn;
+    int hi = p1 / ph.prev_bn;
+    hi = hi < ph.prev_ntiles - 1 ? hi : ph.prev_ntiles - 1;
+    if (ph.dep_full || hi - lo + 1 > 62) {
+      d.full_expect = ph.prev_tot_expect;
+    } else {
+      d.tile_idx += lo * SP_FLOW_TILE_STRIDE;
+      d.tile_n = hi - lo + 1;
     }
-    d.prev_base += lo;
-    d.prev_n = hi - lo + 1;
   }
-  return sp_body<EPI, SCALE, NT, B3, true>(ps[by], SpStamp{0}, bx, bz, m_tile, p_tile, smem, tid, d);
+  return sp_body<EPI, SCALE, NT, B3, true>(ps[by], SpStamp{stamp_slot}, bx, bz, m_tile, p_tile, smem, tid, d);
 }
 
 template <bool B3>
@@ -1151,58 +1200,63 @@ __global__ __launch_bounds__(SP_THREADS) void sp_flow_kernel(const SpFlow F_by_v
     unsigned lds_off = 0;
     asm volatile("" : "+s"(Fk), "+v"(tid), "+s"(lds_off));
     float* const smem = smem_base + (lds_off >> 2);
+    bool fin = false;
+    {
+      const auto& F = *Fk;
+      FlowPhaseK& ph = ((FlowPhaseK*)F.ph)[k];
+      if (wg < ph.n_wg) {          // block-uniform
+        const int key = ph.epi * 4 + (ph.scaled ? 2 : 0) + (ph.nt == 4 ? 1 : 0);
+        switch (key) {
+          case EPI_AFFINE * 4 + 0: fin = sp_flow_item<EPI_AFFINE, false, 2, B3>(F, ph, wg, smem, tid, k & 63); break;
+          case EPI_AFFINE * 4 + 1: fin = sp_flow_item<EPI_AFFINE, false, 4, B3>(F, ph, wg, smem, tid, k & 63); break;
+          case EPI_AFFINE * 4 + 3: fin = sp_flow_item<EPI_AFFINE, true, 4, B3>(F, ph, wg, smem, tid, k & 63); break;
+          case EPI_BLEND * 4 + 1:  fin = sp_flow_item<EPI_BLEND, false, 4, B3>(F, ph, wg, smem, tid, k & 63); break;
+          case EPI_LNG * 4 + 1:    fin = sp_flow_item<EPI_LNG, false, 4, B3>(F, ph, wg, smem, tid, k & 63); break;
+          case EPI_TRUST * 4 + 0:  fin = sp_flow_item<EPI_TRUST, false, 2, B3>(F, ph, wg, smem, tid, k & 63); break;
+          case EPI_SAMPLE * 4 + 3: fin = sp_flow_item<EPI_SAMPLE, true, 4, B3>(F, ph, wg, smem, tid, k & 63); break;
+          default: break;
+        }
+      }
+    }
+    // second cut: what follows re-derives the phase record from the laundered pointer, so nothing of it is carried through the body
+    asm volatile("" : "+s"(Fk), "+v"(tid));
     const auto& F = *Fk;
     FlowPhaseK& ph = ((FlowPhaseK*)F.ph)[k];
-    bool fin = false;
     int p_tile_done = 0;
-    if (wg < ph.n_wg) {          // block-uniform
-      const int key = ph.epi * 4 + (ph.scaled ? 2 : 0) + (ph.nt == 4 ? 1 : 0);
-      switch (key) {
-        case EPI_AFFINE * 4 + 0: fin = sp_flow_item<EPI_AFFINE, false, 2, B3>(F, ph, wg, smem, tid); break;
-        case EPI_AFFINE * 4 + 1: fin = sp_flow_item<EPI_AFFINE, false, 4, B3>(F, ph, wg, smem, tid); break;
-        case EPI_AFFINE * 4 + 3: fin = sp_flow_item<EPI_AFFINE, true, 4, B3>(F, ph, wg, smem, tid); break;
-        case EPI_BLEND * 4 + 1:  fin = sp_flow_item<EPI_BLEND, false, 4, B3>(F, ph, wg, smem, tid); break;
-        case EPI_LNG * 4 + 1:    fin = sp_flow_item<EPI_LNG, false, 4, B3>(F, ph, wg, smem, tid); break;
-        case EPI_TRUST * 4 + 0:  fin = sp_flow_item<EPI_TRUST, false, 2, B3>(F, ph, wg, smem, tid); break;
-        case EPI_SAMPLE * 4 + 3: fin = sp_flow_item<EPI_SAMPLE, true, 4, B3>(F, ph, wg, smem, tid); break;
-        default: break;
-      }
-      if (fin) {                 // which pixel tile this workgroup finished (the counter it signals)
-        ConvProblemK* const ps = (ConvProblemK*)F.p + ph.prob0;
-        int by, bx, bz, m_tile;
-        sp_decode(ps, ph.wg_base, ph.nprob, wg, ph.bn, by, bx, bz, m_tile, p_tile_done);
-      }
+    if (fin) {                   // block-uniform: which pixel tile this workgroup finished (the counter it signals)
+      ConvProblemK* const ps = (ConvProblemK*)F.p + ph.prob0;
+      int by, bx, bz, m_tile;
+      sp_decode(ps, ph.wg_base, ph.nprob, wg, ph.bn, by, bx, bz, m_tile, p_tile_done);
     }
     // state copy-out riding in this phase: src is an output of phase q-1 (all of it), nobody inside the flow reads dst.  The
     // workgroups without an item copy (all of them when every workgroup has one), after their own wait for phase q-1
-    if (ph.copy_n4 > 0) {        // block-uniform
-      const int n_idle = n_grid - ph.n_wg;
+    const int n_idle = n_grid - ph.n_wg;
+    const bool copier = ph.copy_n4 > 0 && (n_idle > 0 ? wg >= ph.n_wg : true);      // block-uniform
+    if (copier) {
       const int part = n_idle > 0 ? wg - ph.n_wg : wg, parts = n_idle > 0 ? n_idle : n_grid;
-      if (part >= 0) {
-        if (tid < 64) {
-          SpDep d;
-          d.done = F.done; d.err = F.err; d.timeout = F.timeout_polls; d.sc1_loads = 0;
-          d.lag_base = 0; d.lag_n = 0; d.lag_expect = 0; d.lag_copy_expect = 0;
-          d.prev_base = ph.prev_base; d.prev_n = ph.prev_ntiles; d.prev_expect = ph.prev_expect;
-          sp_dep_wait(d, tid);
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        const float4* src = reinterpret_cast<const float4*>(ph.copy_src);
-        float4* dst = reinterpret_cast<float4*>(ph.copy_dst);
-        for (size_t i = (size_t)part * SP_THREADS + tid; i < (size_t)ph.copy_n4; i += (size_t)parts * SP_THREADS) dst[i] = src[i];
+      if (tid < 64) {
+        SpDep d;
+        d.done = F.done; d.err = F.err; d.timeout = F.timeout_polls;
+        d.lag_idx = 0; d.lag_expect = 0; d.tile_idx = 0; d.tile_n = 0; d.tile_expect = 0;
+        d.full_idx = ph.prev_tot_base + (wg & 7) * SP_FLOW_TOT_STRIDE; d.full_expect = ph.prev_ntiles > 0 ? ph.prev_tot_expect : 0;
+        sp_dep_wait(d, tid);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the copy reads with plain loads
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      __syncthreads();
+      const float4* src = reinterpret_cast<const float4*>(ph.copy_src);
+      float4* dst = reinterpret_cast<float4*>(ph.copy_dst);
+      for (size_t i = (size_t)part * SP_THREADS + tid; i < (size_t)ph.copy_n4; i += (size_t)parts * SP_THREADS) dst[i] = src[i];
     }
     // signal: every wave's stores are out, then one add per workgroup that finished a tile (the others only fed a slab);
     // the barrier also keeps the next item's first LDS-DMAs behind this item's last LDS reads
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-      if (fin) __hip_atomic_fetch_add(F.done + ph.done_base + p_tile_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // the copies count too (slot n_ptiles of the phase): phase q+2 may overwrite src only when they are done
-      if (ph.copy_n4 > 0 && ((n_grid - ph.n_wg > 0) ? wg >= ph.n_wg : true))
-        __hip_atomic_fetch_add(F.done + ph.done_base + ph.n_ptiles, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // lanes 0-7: the eight replicas of the phase total (a finished item and a copy each count once); lane 8: the tile counter
+    if (tid < 9 && (fin || copier)) {
+      const int n_add = (fin ? 1 : 0) + (copier ? 1 : 0);
+      if (tid < 8) __hip_atomic_fetch_add(F.done + ph.tot_base + tid * SP_FLOW_TOT_STRIDE, (unsigned)n_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (fin) __hip_atomic_fetch_add(F.done + ph.tile_base + p_tile_done * SP_FLOW_TILE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -1212,7 +1266,8 @@ __global__ void flow_write_kernel(const FlowBlob blob, unsigned char* dst, int n
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef const __attribute__((address_space(4))) uint4* src_cptr;
   src_cptr src = (src_cptr)__builtin_amdgcn_kernarg_segment_ptr();      // blob is the first argument (offset 0)
-  for (int i = threadIdx.x; i * 16 < n; i += blockDim.x) reinterpret_cast<uint4*>(dst)[i] = src[i];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i * 16 < n) reinterpret_cast<uint4*>(dst)[i] = src[i];
 #endif
   (void)blob;
 }
@@ -1224,7 +1279,7 @@ hipError_t launch_flow_write(const void* host_src, void* dev_dst, size_t bytes, 
     FlowBlob b;
     const size_t n = bytes - off < SP_WRITER_BYTES ? bytes - off : SP_WRITER_BYTES;
     std::memcpy(b.b, s + off, n);
-    hipLaunchKernelGGL(flow_write_kernel, dim3(1), dim3(256), 0, stream, b, d + off, (int)n);
+    hipLaunchKernelGGL(flow_write_kernel, dim3((unsigned)((n / 16 + 255) / 256)), dim3(256), 0, stream, b, d + off, (int)n);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

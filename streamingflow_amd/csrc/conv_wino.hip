@@ -1,0 +1,397 @@
+// Winograd F(2x2, 3x3) convolution for the 3x3 / stride-1 layers of the batched forward (gfx950 only).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 4x4 input tile d (stride 2), 3x3 filter g, 2x2 outputs Y
+// in exact fp32 arithmetic on v_mfma_f32_16x16x4_f32: 16 multiplies per 2x2 outputs and (cin, cout) pair instead of 36 — 2.25x fewer
+// MACs than the direct form the implicit-GEMM kernels compute; different rounding (the transforms add / subtract before the products):
+// tools/r04/winograd_study.py measured <= 7e-6 max-abs on the BEV output of every BASELINE config with all eligible layers switched
+// (north-star tolerance 1e-3).  FLOP accounting: bench.py prices these launches at their EXECUTED FLOPs for the roofline and keeps the
+// algorithmic (direct-form) count for ODE-steps/s (savings are not credited as achieved FLOPs).
+//
+// Structure — one 512-thread workgroup per CU, tile = COUT_T output channels x (TH x 8) Winograd tiles (= 2TH x 16 output pixels):
+//   * weights are transformed once at pack time (pack.hip: U[cin/16][16 positions][cout_pad][16], sf_conv_w::w_wino);
+//   * per 16-channel chunk the (2TH+2) x 18 pixel patch of the input is DMA'd to LDS (buffer_load ... lds, zero fill = the range
+//     check), every thread transforms its share (B^T d B: 8 float4 LDS reads, 8 float4 add/sub, 4 float4 LDS writes) into
+//     V[16 positions][tile][16 channels];
+//   * 8 stages per chunk, two positions each: U[2 positions][COUT_T][16] streams through a ring of 3 LDS buffers (2 stages in flight,
+//     counted vmcnt), one barrier per stage between a stage's fragment reads and its MFMAs (as conv_sp.hip / conv_glds_kernel);
+//   * wave (wm, wn) owns 32 cout x 16 tiles x ALL 16 positions: 32 accumulator tiles (128 VGPRs), so the output transform A^T M A is
+//     register-local: lane (tile j, channel quad g) ends with its four channels of the tile's 2x2 output pixels;
+//   * fused epilogues as in the other kernels: AFFINE (scale / bias = conv bias or BN fold, activation, residual add, GRU reset-gate
+//     second output) and BLEND (conv-GRU state update).
+// LDS rows are 16 floats (64 B); the 16-byte slot s of row r lives at slot s ^ ((r >> 2) & 2): conflict-free for the ds_read_b128
+// lane groups of a 16-row fragment (MI355X_MICROARCH.md, LDS table).
+#include "sf_math.h"
+
+namespace sf {
+
+constexpr int WN_THREADS = 512;
+typedef __attribute__((address_space(3))) void wn_lds_void;
+
+template <int COUT_T, int TH>
+struct WinoGeo {
+  static constexpr int TW = 8, WT = TH * TW;                   // Winograd tiles of a workgroup: TH rows x 8 columns
+  static constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;       // input patch (pixels)
+  static constexpr int NPX = PH * PW;
+  static constexpr int WMW = COUT_T / 32, WNW = WT / 16;       // waves along cout / tiles
+  static_assert(WMW * WNW == 8, "eight waves: 32 cout x 16 tiles each");
+  static constexpr int NU = COUT_T / 64;                       // U DMAs per wave and stage (a stage = 2 positions x COUT_T rows of 64 B)
+  static constexpr int NP = (NPX * 4 + 511) / 512;             // patch DMAs per wave and chunk
+  static constexpr int NVB = (WT == 32) ? 2 : 1;               // V buffers
+  static constexpr int U_FLOATS = 2 * COUT_T * 16;             // one stage
+  static constexpr int V_FLOATS = 16 * WT * 16;                // one chunk
+  static constexpr int P_FLOATS = 8 * NP * 64 * 4;             // one patch, padded to whole DMAs
+  static constexpr int LDS_FLOATS = 3 * U_FLOATS + NVB * V_FLOATS + 2 * P_FLOATS;
+};
+
+__device__ __forceinline__ f32x4 wn_lds_read128(const float* p) {
+  typedef const __attribute__((address_space(3))) f32x4 lds_f4;
+  return *(lds_f4*)p;
+}
+__device__ __forceinline__ void wn_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// s_waitcnt vmcnt(n) for a wave-uniform n (the instruction needs an immediate): all but the n youngest vector-memory operations
+// of this wave are done.  n <= the true number of younger operations is always safe (it only waits for more).
+__device__ __forceinline__ void wn_wait(const int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+  }
+}
+
+// per-element epilogue: v = the lane's four consecutive output channels c .. c+3 of pixel gp (semantics of conv_igemm.hip run_epilogue)
+template <int EPI>
+__device__ __forceinline__ void wn_epilogue(const ConvProblem& P, float4 v, const size_t gp, const int c, const int img) {
+  const float4 sc = P.scale ? spm_ld4(P.scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 bi = P.bias ? spm_ld4(P.bias + (P.bias_per_img ? (size_t)img * P.cout : 0) + c) : spm_zero4();
+  v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
+  float4 y;
+  if constexpr (EPI == EPI_AFFINE) {
+    const bool act_last = (P.mode & 2) != 0;
+    y = act_last ? v : spm_act4(v, P.act);
+    if (P.clamp_from >= 0) {
+      if (c + 0 >= P.clamp_from) y.x = fminf(fmaxf(y.x, P.clamp_lo), P.clamp_hi);
+      if (c + 1 >= P.clamp_from) y.y = fminf(fmaxf(y.y, P.clamp_lo), P.clamp_hi);
+      if (c + 2 >= P.clamp_from) y.z = fminf(fmaxf(y.z, P.clamp_lo), P.clamp_hi);
+      if (c + 3 >= P.clamp_from) y.w = fminf(fmaxf(y.w, P.clamp_lo), P.clamp_hi);
+    }
+    if (P.add) {
+      float4 ad = spm_ld4(P.add + gp * P.add_cs + c);
+      if (P.add_scale) {
+        const float4 as = spm_ld4(P.add_scale + (size_t)img * P.cout + c);
+        ad.x *= as.x; ad.y *= as.y; ad.z *= as.z; ad.w *= as.w;
+      }
+      y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w;
+    }
+    if (act_last) y = spm_act4(y, P.act);
+    if (P.out2 && c >= P.gate_from) {   // GRU gates, reset half: also emit (1 - r) * s, the candidate conv's input
+      const int cg = c - P.gate_from;
+      const float4 sv = spm_ld4(P.e1 + gp * P.e1_cs + cg);
+      spm_st4(P.out2 + gp * P.out2_cs + cg, make_float4(sv.x * (1.f - y.x), sv.y * (1.f - y.y), sv.z * (1.f - y.z), sv.w * (1.f - y.w)));
+    }
+  } else {      // EPI_BLEND (temporal.py:56)
+    v = spm_act4(v, P.act);
+    const float4 u = spm_ld4(P.e0 + gp * P.e0_cs + c), s = spm_ld4(P.e1 + gp * P.e1_cs + c);
+    if (P.mode & 1) y = make_float4(u.x * (v.x - s.x), u.y * (v.y - s.y), u.z * (v.z - s.z), u.w * (v.w - s.w));
+    else y = make_float4((1.f - u.x) * s.x + u.x * v.x, (1.f - u.y) * s.y + u.y * v.y, (1.f - u.z) * s.z + u.z * v.z, (1.f - u.w) * s.w + u.w * v.w);
+  }
+  spm_st4(P.out + gp * P.out_cs + P.out_co + c, y);
+}
+
+template <int COUT_T, int TH, int EPI>
+__global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(const ConvLaunch L) {
+  typedef WinoGeo<COUT_T, TH> G;
+  constexpr int TW = G::TW, WT = G::WT, PW = G::PW, NU = G::NU, NP = G::NP, NVB = G::NVB;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const Ubuf = smem;
+  float* const Vbuf = Ubuf + 3 * G::U_FLOATS;
+  float* const Pbuf = Vbuf + NVB * G::V_FLOATS;
+  const ConvProblem& P = L.p[0];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = P.Hout, W = P.Wout;                            // stride 1, pad 1: input size = output size
+  const int tiles_x = (W + 1) >> 1, tiles_y = (H + 1) >> 1;
+  const int nbx = (tiles_x + TW - 1) / TW, nby = (tiles_y + TH - 1) / TH;
+  int b = (int)blockIdx.x;
+  const int bx = b % nbx; b /= nbx;
+  const int by = b % nby;
+  const int img = b / nby;
+  const int ty0 = by * TH, tx0 = bx * TW;
+  const int cout0 = (int)blockIdx.y * COUT_T;
+  const int nkc = P.cin_pad >> 4;                              // 16-channel chunks
+  const int NS = nkc * 8;                                      // stages
+  const int c0 = P.c0;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+  auto make_rsrc = [](const float* base, size_t bytes) {
+    const unsigned nrec = bytes < 0x7fffffffull ? (unsigned)bytes : 0x7fffffffu;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (int)nrec, 0x00020000);
+  };
+  const size_t img_px = (size_t)H * W;
+  const __amdgpu_buffer_rsrc_t rsrc0 = make_rsrc(P.in0 + (size_t)img * img_px * P.in0_cs, img_px * P.in0_cs * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(P.in1 ? P.in1 + (size_t)img * img_px * P.in1_cs : P.in0, P.in1 ? img_px * P.in1_cs * sizeof(float) : 0);
+  const __amdgpu_buffer_rsrc_t rsrc_u = make_rsrc(P.w_wino, (size_t)nkc * 16 * P.cout_pad * 16 * sizeof(float));
+#endif
+  // ---- patch DMA: element e = (pixel, channel quad) of the (2TH+2) x 18 patch, 16 bytes each, LDS linear in e -----------------
+  int pv0[NP], pv1[NP];
+#pragma unroll
+  for (int d = 0; d < NP; ++d) {
+    const int e = (wave * NP + d) * 64 + lane;
+    const int pix = e >> 2, quad = e & 3;
+    const int py = pix / PW, px = pix - py * PW;
+    const int iy = 2 * ty0 - 1 + py, ix = 2 * tx0 - 1 + px;
+    const bool ok = pix < G::NPX && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const int pofs = iy * W + ix;
+    pv0[d] = ok ? (pofs * P.in0_cs + quad * 4) * 4 : (int)0x80000000;      // + the chunk's channel offset stays out of range: zero fill
+    pv1[d] = ok ? (pofs * P.in1_cs - c0 + quad * 4) * 4 : (int)0x80000000;
+  }
+  auto issue_patch = [&](const int kc) {
+    float* const dst = Pbuf + (kc & 1) * G::P_FLOATS;
+    const bool from1 = kc * 16 >= c0;                           // wave-uniform: the whole chunk reads in1 (c0 % 16 == 0)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int d = 0; d < NP; ++d) {
+      float* const dB = dst + (wave * NP + d) * 256;
+      if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (wn_lds_void*)dB, 16, pv1[d] + kc * 64, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, pv0[d] + kc * 64, 0, 0, 0);
+    }
+#else
+    (void)dst; (void)from1;
+#endif
+  };
+  // ---- U DMA: stage S = (chunk kc, position pair st): rows r of [2 positions][COUT_T], 64 B each; piece q = 16 rows ------------
+  int uv[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int r = (wave * NU + u) * 16 + (lane >> 2);          // row of the stage
+    const int p = r / COUT_T, row = r - p * COUT_T;
+    const int slot = (lane & 3) ^ ((row >> 2) & 2);            // LDS slot (lane & 3) holds source slot `slot`
+    int grow = cout0 + row;
+    grow = grow < P.cout_pad ? grow : P.cout_pad - 1;
+    uv[u] = ((p * P.cout_pad + grow) * 16 + slot * 4) * 4;
+  }
+  const int u_stage_bytes = 2 * P.cout_pad * 16 * 4;            // two positions
+  auto issue_u = [&](const int S) {
+    float* const dst = Ubuf + (S % 3) * G::U_FLOATS;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_u, (wn_lds_void*)(dst + (wave * NU + u) * 256), 16, uv[u], S * u_stage_bytes, 0, 0);
+#else
+    (void)dst;
+#endif
+  };
+  // ---- input transform: task (tile wt, channel quad, row i of B^T d B): 8 reads, 8 add/sub, 4 writes (float4) ------------------
+  constexpr int NTASK = WT * 16 / WN_THREADS;                  // 1 (32 tiles) or 2 (64 tiles)
+  auto transform = [&](const int kc) {
+    const float* const src = Pbuf + (kc & 1) * G::P_FLOATS;
+    float* const dst = Vbuf + (NVB == 2 ? (kc & 1) : 0) * G::V_FLOATS;
+#pragma unroll
+    for (int t = 0; t < NTASK; ++t) {
+      const int task = tid + t * WN_THREADS;
+      const int i = task & 3, quad = (task >> 2) & 3, wt = task >> 4;
+      const int tyl = wt / TW, txl = wt - tyl * TW;
+      // B^T rows: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+      const int r1 = (i == 0) ? 0 : (i == 2 ? 2 : 1), r2 = (i == 3) ? 3 : (i == 2 ? 1 : 2);
+      const float sg = (i == 1) ? 1.f : -1.f;
+      const float* const a = src + (((2 * tyl + r1) * PW + 2 * txl) * 4 + quad) * 4;
+      const float* const bb = src + (((2 * tyl + r2) * PW + 2 * txl) * 4 + quad) * 4;
+      f32x4 w[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) w[c] = wn_lds_read128(a + c * 16) + sg * wn_lds_read128(bb + c * 16);
+      const f32x4 v0 = w[0] - w[2], v1 = w[1] + w[2], v2 = w[2] - w[1], v3 = w[1] - w[3];
+      float* const o = dst + ((i * 4) * WT + wt) * 16 + ((quad ^ ((wt >> 2) & 2)) << 2);
+      typedef __attribute__((address_space(3))) f32x4 lds_f4w;
+      *(lds_f4w*)(o) = v0;
+      *(lds_f4w*)(o + WT * 16) = v1;
+      *(lds_f4w*)(o + 2 * WT * 16) = v2;
+      *(lds_f4w*)(o + 3 * WT * 16) = v3;
+    }
+  };
+  // ---- fragments: wave (wm, wn) = 32 cout x 16 tiles; lane (j, g): row j of a 16-row fragment, K slot g --------------------------
+  const int wm = wave % G::WMW, wn = wave / G::WMW;
+  const int j = lane & 15, g = lane >> 4;
+  int a_off[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int row = wm * 32 + m * 16 + j;
+    a_off[m] = row * 16 + ((g ^ ((row >> 2) & 2)) << 2);
+  }
+  const int wtl = wn * 16 + j;
+  const int b_off = wtl * 16 + ((g ^ ((wtl >> 2) & 2)) << 2);
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[p][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 fa[2][2][2], fb[2][2];                                 // [set][position of the pair][m]
+  auto read_frags = [&](const int S, const int set) {
+    const float* const ub = Ubuf + (S % 3) * G::U_FLOATS;
+    const int kc = S >> 3, st = S & 7;
+    const float* const vb = Vbuf + (NVB == 2 ? (kc & 1) : 0) * G::V_FLOATS + (2 * st) * WT * 16;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) fa[set][p][m] = wn_lds_read128(ub + p * COUT_T * 16 + a_off[m]);
+      fb[set][p] = wn_lds_read128(vb + p * WT * 16 + b_off);
+    }
+  };
+
+  // ---- prologue: patch 0, three U stages (the ring), transform 0, patch 1 ------------------------------------------------------------
+  const int n_u0 = NS < 3 ? NS : 3;
+  issue_patch(0);
+  for (int S = 0; S < n_u0; ++S) issue_u(S);
+  wn_wait(NU * n_u0);                                           // the patch is the oldest: everything but the U stages
+  wn_barrier();
+  transform(0);
+  if (nkc > 1) issue_patch(1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  wn_wait(NU * (n_u0 - 1) + (nkc > 1 ? NP : 0));                // U(0) landed (younger: U(1), U(2), patch(1))
+  wn_barrier();
+  read_frags(0, 0);
+
+  for (int kc = 0; kc < nkc; ++kc) {
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int S = kc * 8 + st;
+      const int set = st & 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // fragments of stage S are in registers (and this wave's V writes are out)
+      if (S + 1 < NS) {
+        // U(S+1) landed: younger DMAs of this wave are U(S+2) and — for two stages behind its issue point — the next patch
+        const bool patch_young = (st == 4 || st == 5) && (kc + 2 < nkc);
+        wn_wait((S + 2 < NS ? NU : 0) + (patch_young ? NP : 0));
+        wn_barrier();                                             // stage S+1 (and, at st == 7, the next chunk's V) published; buffer S % 3 free
+        if (S + 3 < NS) issue_u(S + 3);
+        read_frags(S + 1, set ^ 1);
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            acc[2 * st + p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][p][m][e], fb[set][p][e], acc[2 * st + p][m], 0, 0, 0);
+      if constexpr (NVB == 2) {
+        if (st == 3 && kc + 1 < nkc) {                            // next chunk's transform beside this chunk's stages (its patch landed a chunk ago)
+          transform(kc + 1);
+          if (kc + 2 < nkc) issue_patch(kc + 2);                  // into the buffer transform(kc) read: every wave passed >= 4 barriers since
+        }
+      }
+    }
+  }
+
+  // ---- output transform A^T M A (register-local) + epilogue ---------------------------------------------------------------------------
+  const int ty = ty0 + wtl / TW, tx = tx0 + wtl % TW;
+  const size_t img_base = (size_t)img * H * W;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int c = cout0 + wm * 32 + m * 16 + 4 * g;
+    f32x4 t0[4], t1[4];                                           // rows of M A: t0[i] = M[i][0] + M[i][1] + M[i][2], t1[i] = M[i][1] - M[i][2] - M[i][3]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      t0[i] = acc[4 * i + 0][m] + acc[4 * i + 1][m] + acc[4 * i + 2][m];
+      t1[i] = acc[4 * i + 1][m] - acc[4 * i + 2][m] - acc[4 * i + 3][m];
+    }
+    f32x4 y[2][2];
+    y[0][0] = t0[0] + t0[1] + t0[2]; y[0][1] = t1[0] + t1[1] + t1[2];
+    y[1][0] = t0[1] - t0[2] - t0[3]; y[1][1] = t1[1] - t1[2] - t1[3];
+    if (c < P.cout) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bq = 0; bq < 2; ++bq) {
+          const int oy = 2 * ty + a, ox = 2 * tx + bq;
+          if (oy < H && ox < W)
+            wn_epilogue<EPI>(P, make_float4(y[a][bq][0], y[a][bq][1], y[a][bq][2], y[a][bq][3]), img_base + (size_t)oy * W + ox, c, img);
+        }
+    }
+  }
+}
+
+// weights: packed direct form w[cout_pad][9 * cin_pad] (tap-major, channel-minor) -> U[cin_pad/16][16][cout_pad][16] = G g G^T
+__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int cout_pad, int cin_pad) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (co, ci)
+  if (idx >= (long)cout_pad * cin_pad) return;
+  const int co = (int)(idx / cin_pad), ci = (int)(idx - (long)co * cin_pad);
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) g[a][b] = w[(size_t)co * 9 * cin_pad + (a * 3 + b) * cin_pad + ci];
+  // G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]]
+  float t[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    t[0][b] = g[0][b];
+    t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+    t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+    t[3][b] = g[2][b];
+  }
+  const int kc = ci >> 4, cl = ci & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]), u3 = t[i][2];
+    const float uu[4] = {u0, u1, u2, u3};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) U[(((size_t)kc * 16 + i * 4 + jj) * cout_pad + co) * 16 + cl] = uu[jj];
+  }
+}
+hipError_t launch_wino_weights(const float* w, float* U, int cout_pad, int cin_pad, hipStream_t stream) {
+  const long n = (long)cout_pad * cin_pad;
+  hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, U, cout_pad, cin_pad);
+  return hipGetLastError();
+}
+
+// what the kernel takes: 3x3, stride 1, pad 1, no dilation / upsampling / gather / gate / SE scale / split-K / channel sums; inputs
+// in whole 16-channel chunks; transformed weights present; images of at least one workgroup tile
+bool wino_takes(const ConvProblem& q, int epi) {
+  if (epi != EPI_AFFINE && epi != EPI_BLEND) return false;
+  if (!q.w_wino || q.KH != 3 || q.KW != 3 || q.stride != 1 || q.dil != 1 || q.pad != 1 || q.in_up || q.gather || q.gate || q.in_scale || q.se_sum ||
+      q.nsplit > 1 || q.chansum || q.acc_in || q.fuse_w || (epi == EPI_AFFINE && (q.mode & 4)))
+    return false;
+  if ((q.c0 % 16) || (q.c1 % 16) || q.c0 + q.c1 != q.cin_pad || (q.cout_pad % 64) || (q.cout % 4)) return false;
+  if (q.Hout != q.Hin || q.Wout != q.Win || q.Hout < 16 || q.Wout < 32) return false;
+  const double img_bytes = 4.0 * q.Hin * q.Win;
+  if (img_bytes * q.in0_cs >= 2147483648.0 || img_bytes * q.in1_cs >= 2147483648.0 || 4.0 * 16 * q.cout_pad * q.cin_pad >= 2147483648.0) return false;
+  return true;
+}
+
+template <int COUT_T, int TH, int EPI>
+static hipError_t launch_wino_t(const ConvLaunch& L, hipStream_t stream) {
+  typedef WinoGeo<COUT_T, TH> G;
+  auto kern = conv_wino_kernel<COUT_T, TH, EPI>;
+  constexpr int lds = G::LDS_FLOATS * 4;
+  static bool attr_done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_done[dev] = true;
+  }
+  const ConvProblem& P = L.p[0];
+  const int tiles_x = (P.Wout + 1) / 2, tiles_y = (P.Hout + 1) / 2;
+  const long blocks = (long)P.n_img * ((tiles_y + TH - 1) / TH) * ((tiles_x + G::TW - 1) / G::TW);
+  if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(P.cout_pad / COUT_T), 1), dim3(WN_THREADS), lds, stream, L);
+  return hipGetLastError();
+}
+// one problem per launch
+hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream) {
+  if (L.nprob != 1 || !wino_takes(L.p[0], epi)) return hipErrorInvalidValue;
+  if (L.p[0].cout_pad % 128 == 0)
+    return epi == EPI_AFFINE ? launch_wino_t<128, 4, EPI_AFFINE>(L, stream) : launch_wino_t<128, 4, EPI_BLEND>(L, stream);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace sf

@@ -193,37 +193,38 @@ __global__ void bev_pool_intervals_kernel(int d, int h, int w, int c, int n_inte
   out[((((size_t)g[3] * d + g[2]) * h + g[0]) * w + g[1]) * c + cc] = acc;
 }
 
-// softmax over the depth axis of [rows][D][fHW] (streamingflow.py:304): one thread per (row, hw); the
-// D <= 64 logits of a ray are read once (all loads in flight together) and kept in registers.
+// softmax over the depth axis of [rows][D][fHW] (streamingflow.py:304): one thread per (row, hw).  DT > 0: D == DT (a multiple of 16,
+// the shipped 48 bins among them): the logits of a ray are read once, all loads in flight together, and kept in registers — no
+// per-bin bounds test (64 of them as scalar conditions cost 34 SGPR spills).  DT == 0: any D, three passes over the ray.
+template <int DT>
 __global__ void depth_softmax_kernel(const float* __restrict__ logits, float* __restrict__ prob, int rows, int D, int fHW) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * fHW) return;
   const int r = i / fHW, hw = i - r * fHW;
   const float* in = logits + (size_t)r * D * fHW + hw;
   float* o = prob + (size_t)r * D * fHW + hw;
-  if (D <= 64) {
-    float v[64];
+  if constexpr (DT > 0) {
+    float v[DT];
 #pragma unroll
-    for (int d = 0; d < 64; ++d) v[d] = d < D ? in[(size_t)d * fHW] : -INFINITY;
+    for (int d = 0; d < DT; ++d) v[d] = in[(size_t)d * fHW];
     float m = -INFINITY;
 #pragma unroll
-    for (int d = 0; d < 64; ++d) m = fmaxf(m, v[d]);
+    for (int d = 0; d < DT; ++d) m = fmaxf(m, v[d]);
     float sum = 0.f;
 #pragma unroll
-    for (int d = 0; d < 64; ++d) {
-      v[d] = d < D ? expf(v[d] - m) : 0.f;
+    for (int d = 0; d < DT; ++d) {
+      v[d] = expf(v[d] - m);
       sum += v[d];
     }
 #pragma unroll
-    for (int d = 0; d < 64; ++d)
-      if (d < D) o[(size_t)d * fHW] = v[d] / sum;
-    return;
+    for (int d = 0; d < DT; ++d) o[(size_t)d * fHW] = v[d] / sum;
+  } else {
+    float m = -INFINITY;
+    for (int d = 0; d < D; ++d) m = fmaxf(m, in[(size_t)d * fHW]);
+    float sum = 0.f;
+    for (int d = 0; d < D; ++d) sum += expf(in[(size_t)d * fHW] - m);
+    for (int d = 0; d < D; ++d) o[(size_t)d * fHW] = expf(in[(size_t)d * fHW] - m) / sum;
   }
-  float m = -INFINITY;
-  for (int d = 0; d < D; ++d) m = fmaxf(m, in[(size_t)d * fHW]);
-  float sum = 0.f;
-  for (int d = 0; d < D; ++d) sum += expf(in[(size_t)d * fHW] - m);
-  for (int d = 0; d < D; ++d) o[(size_t)d * fHW] = expf(in[(size_t)d * fHW] - m) / sum;
 }
 
 inline int key_bits(unsigned sentinel) {
@@ -373,8 +374,15 @@ int sf_lift_pool_fused_fwd(const float* feat, const float* depth_prob, int D, in
 int sf_depth_softmax_fwd(const float* logits, float* prob, int rows, int D, int fHW, void* stream) {
   if (!logits || !prob || rows < 1 || D < 1 || fHW < 1) return SF_ERR_INVALID;
   const long total = (long)rows * fHW;
-  hipLaunchKernelGGL(depth_softmax_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), logits,
-                     prob, rows, D, fHW);
+  const dim3 grid((unsigned)((total + 63) / 64));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (D) {      // same arithmetic and summation order in every instantiation
+    case 16: hipLaunchKernelGGL(depth_softmax_kernel<16>, grid, dim3(64), 0, st, logits, prob, rows, D, fHW); break;
+    case 32: hipLaunchKernelGGL(depth_softmax_kernel<32>, grid, dim3(64), 0, st, logits, prob, rows, D, fHW); break;
+    case 48: hipLaunchKernelGGL(depth_softmax_kernel<48>, grid, dim3(64), 0, st, logits, prob, rows, D, fHW); break;
+    case 64: hipLaunchKernelGGL(depth_softmax_kernel<64>, grid, dim3(64), 0, st, logits, prob, rows, D, fHW); break;
+    default: hipLaunchKernelGGL(depth_softmax_kernel<0>, grid, dim3(64), 0, st, logits, prob, rows, D, fHW); break;
+  }
   return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
 }
 

@@ -99,6 +99,9 @@ __global__ void pack_affine_kernel(const float* __restrict__ conv_bias, const fl
 
 }  // namespace sf
 
+namespace sf {
+hipError_t launch_wino_weights(const float* w, float* U, int cout_pad, int cin_pad, hipStream_t stream);
+}
 using namespace sf;
 
 extern "C" {
@@ -113,10 +116,16 @@ static int packed_dims(int cout, int cin, int flags, int* cout_pad, int* cin_pad
   return SF_OK;
 }
 
+// the Winograd copy exists for 3x3 layers whose input is whole 16-channel chunks and whose outputs fill 64-row tiles (conv_wino.hip)
+static bool wino_packable(int cp, int ip, int cin, int kh, int kw, int flags) {
+  return (flags & SF_PACK_WINOGRAD) && !(flags & SF_PACK_INTERLEAVE) && kh == 3 && kw == 3 && cin == ip && (cp % 64) == 0;
+}
+
 size_t sf_pack_conv_bytes(int cout, int cin, int kh, int kw, int flags) {
   int cp = 0, ip = 0;
   if (packed_dims(cout, cin, flags, &cp, &ip) != SF_OK || kh < 1 || kw < 1) return 0;
-  return (a64((size_t)cp * kh * kw * ip) * ((flags & SF_PACK_BF16X3) ? 2 : 1) + 2 * a64((size_t)cp)) * sizeof(float);
+  return (a64((size_t)cp * kh * kw * ip) * ((flags & SF_PACK_BF16X3) ? 2 : 1) + 2 * a64((size_t)cp) +
+          (wino_packable(cp, ip, cin, kh, kw, flags) ? a64((size_t)16 * cp * ip) : 0)) * sizeof(float);
 }
 
 int sf_pack_conv(const float* weight, const float* conv_bias, const float* scale, const float* bn_weight, const float* bn_bias,
@@ -146,10 +155,16 @@ int sf_pack_conv(const float* weight, const float* conv_bias, const float* scale
     const long groups = total / 8;
     hipLaunchKernelGGL(pack_split_bf16_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, wp, groups, reinterpret_cast<unsigned*>(w3));
   }
+  float* wu = nullptr;
+  if (wino_packable(cp, ip, cin, kh, kw, flags) && stride == 1 && dil == 1 && (pad < 0 || pad == 1) && (c0 % 16) == 0 && (c1 % 16) == 0) {
+    wu = bp + a64((size_t)cp) + ((flags & SF_PACK_BF16X3) ? a64((size_t)total) : 0);
+    if (launch_wino_weights(wp, wu, cp, ip, st) != hipSuccess) return SF_ERR_LAUNCH;
+  }
   if (hipGetLastError() != hipSuccess) return SF_ERR_LAUNCH;
   std::memset(out, 0, sizeof(*out));
   out->w = wp;
   out->w_bf16x3 = w3;
+  out->w_wino = wu;
   out->scale = has_scale ? sp : nullptr;
   out->bias = has_bias ? bp : nullptr;
   out->cout = cout; out->cout_pad = cp; out->c0 = c0; out->c1 = c1; out->cin_pad = ip;

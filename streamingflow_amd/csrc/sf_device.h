@@ -93,6 +93,9 @@ struct ConvProblem {
   // bytes and row pitch as `w`); use_w3 is set by the host when the launch runs on a kernel that has the split-bf16 K loop
   int use_w3;
   const void* w3;
+  // Winograd F(2x2, 3x3): the packed weights transformed at pack time, U[cin_pad / 16][16 positions][cout_pad][16] (conv_wino.hip);
+  // null: the layer runs in the direct form
+  const float* w_wino;
   // split-K hand-off: 1 = the round-1 form as a known-good reference (SF_HANDOFF_FENCED=1): an agent-scope release fence
   // before the arrival ticket and an acquire fence behind it, on top of the sc1 stores / loads (tests/test_gpu_splitk_stress.py)
   int fenced;
@@ -124,19 +127,27 @@ struct FlowPhase {
   int epi, scaled, nt;           // kernel variant of the phase (epilogue family, SE-scaled inputs, 16-pixel tiles per wave: 2 | 4)
   int n_wg;                      // workgroups that have an item in this phase (the others idle or copy)
   int wg_base[SF_MAX_GROUP + 1];
-  int bn, n_ptiles, expect;      // pixels per tile, pixel tiles, finished (problem, cout tile) items per pixel tile
-  int done_base;                 // this phase's counters: done[done_base .. done_base + n_ptiles)
+  int bn, n_ptiles;              // pixels per tile, pixel tiles
+  // Counters (dwords of `done`, zero at the start of the flow).  Every counter that many workgroups poll sits on a line of its
+  // own — 240 pollers on the three lines that held a phase's 80 tile counters serialised behind each other and behind the
+  // finishers' atomics (MI355X_MICROARCH.md: one word saturates at ~88 accesses / us; replicas: hand-off table row 2):
+  //   tile t:   done[tile_base + t * SP_FLOW_TILE_STRIDE] += 1 per finished (problem, cout tile) of pixel tile t  -> tile_expect
+  //   total:    done[tot_base + r * SP_FLOW_TOT_STRIDE], r = 0..7, EVERY replica += 1 per finished item and per copying
+  //             workgroup -> tot_expect; a waiter polls replica (wg & 7)
+  int tile_base, tile_expect, tot_base, tot_expect;
   int halo_px;                   // reach of the phase's convolutions in linear pixels (pad * W + pad, the largest of its problems)
-  int dep_full;                  // 1: wait for ALL tiles of phase q-1 (an SE gate in the prologue; a state copy)
-  int prev_bn, prev_ntiles, prev_expect, prev_base;      // tiling / counters of phase q-1 (prev_ntiles == 0: no such phase)
-  int lag_ntiles, lag_expect, lag_base;                  // phase q-2: complete before this one starts (0 tiles: none)
+  int dep_full;                  // 1: wait for ALL of phase q-1 (an SE gate in the prologue is a global reduction)
+  int prev_bn, prev_ntiles, prev_tile_base, prev_tile_expect, prev_tot_base, prev_tot_expect;      // phase q-1 (prev_ntiles == 0: none)
+  int lag_tot_base, lag_tot_expect;                                                                 // phase q-2 (lag_tot_expect == 0: none)
   int copy_n4;                   // optional state copy-out riding in this phase (float4 count; 0: none): workgroups without an
   const float* copy_src;         //   item copy src -> dst after the phase's dependency wait (src is an output of phase q-1)
   float* copy_dst;
-  int lag_copy_expect;           // workgroups that copied in phase q-2 (they count in slot lag_ntiles of its counters; 0: no copy there)
   int pad_[4];
 };
 static_assert(sizeof(FlowPhase) % 16 == 0, "table pieces are written 16 bytes at a time");
+#define SP_FLOW_TILE_STRIDE 16       // dwords between tile counters (64 B)
+#define SP_FLOW_TOT_STRIDE 32        // dwords between the replicas of a phase total (128 B)
+#define SP_FLOW_PHASE_DWORDS (SP_FLOW_MAX_TILES * SP_FLOW_TILE_STRIDE + 8 * SP_FLOW_TOT_STRIDE)
 struct SpFlow {
   int nphase;
   int timeout_polls;             // every spin is bounded: after this many polls the workgroup gives up, sets err[0] and runs on
@@ -147,8 +158,8 @@ struct SpFlow {
   int sc1_loads;                 // experiment: 1 = no acquire fence; every load of handed-off bytes is an sc1 load / sc1 LDS-DMA
 };
 static_assert(sizeof(ConvProblem) % 8 == 0, "problems are stored back to back in the table");
-// table writer: up to SP_WRITER_BYTES of a table per launch, passed by value
-#define SP_WRITER_BYTES 3840
+// table writer: up to SP_WRITER_BYTES of a table per launch, passed by value (one or two launches per rollout)
+#define SP_WRITER_BYTES 61440     /* measured on this runtime (tools/r04/kernarg_probe.hip): kernel arguments of 64 KB launch and capture fine */
 struct FlowBlob { unsigned char b[SP_WRITER_BYTES]; };
 
 // Diagnostic builds only (-DSF_STAMP, tools/r02/stamps.py): wave 0 of every workgroup records s_memrealtime (100 MHz)

@@ -392,7 +392,9 @@ class NNFOwithBayesianJumps(nn.Module):
             if self._graph_gens != gens:
                 self.drop_graphs()
                 self._graph_gens = gens
-            key = (s0.key(), per_image, tuple(hx_obs.shape), tuple(eps.shape), str(dev), self.solver, bool(self.impute), philox is not None)
+            from .. import packing
+            key = (s0.key(), per_image, tuple(hx_obs.shape), tuple(eps.shape), str(dev), self.solver, bool(self.impute), philox is not None,
+                   packing._FLOW[0])      # a graph keeps the form (launch per layer / persistent flow) it was captured in
             g = self._graphs.get(key)
             if g is None:
                 g = {"hx": torch.empty_like(hx_obs), "eps": torch.empty_like(eps), "coef": torch.empty_like(coef),

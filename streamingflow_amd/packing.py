@@ -25,6 +25,22 @@ def math_mode():
     return _MATH_MODE[0]
 
 
+# Winograd F(2x2, 3x3) for the 3x3 / stride-1 layers of large launches (csrc/conv_wino.hip): exact fp32 arithmetic, 2.25x fewer
+# multiplies, different rounding (<= 7e-6 on the BEV outputs of every BASELINE config: profiles/r04_winograd_accuracy_study.json).
+# Decided when a module packs its weights (the transformed weights are a second copy); SF_WINO=0 or set_winograd(False) keeps
+# every layer in the direct form.
+import os as _os
+_WINOGRAD = [_os.environ.get("SF_WINO", "1") != "0"]
+
+
+def set_winograd(on):
+    _WINOGRAD[0] = bool(on)
+
+
+def winograd():
+    return _WINOGRAD[0]
+
+
 def _round_up(v, m):
     return (v + m - 1) // m * m
 
@@ -84,6 +100,8 @@ def conv_w(holder, weight, c0, c1=0, scale=None, bias=None, act="none", dil=1, s
     flags = (_lib.PACK_TRANSPOSED if transposed else 0) | (_lib.PACK_FOLD_DUP if fold_dup else 0) | (_lib.PACK_INTERLEAVE if interleave else 0)
     if _MATH_MODE[0] == "bf16x3":
         flags |= _lib.PACK_BF16X3
+    elif _WINOGRAD[0]:
+        flags |= _lib.PACK_WINOGRAD      # the library adds the transformed copy where the layer qualifies (3x3, stride 1, ...)
     L = _lib.lib()
     nbytes = L.sf_pack_conv_bytes(cout, cin, kh, kw, flags)
     if nbytes == 0:
@@ -108,3 +126,14 @@ def conv_w(holder, weight, c0, c1=0, scale=None, bias=None, act="none", dil=1, s
 
 def null_conv():
     return _lib.ConvW()
+
+
+_FLOW = [None]
+
+
+def set_persistent_flow(on):
+    """Opt in to (True) / out of (False) the persistent flow kernel for single-latent rollouts, or back to the SF_PERSIST
+    environment default (None).  It needs an otherwise idle device: include/sfnative.h, sf_set_flow_mode.  Graphs captured
+    before the switch keep the form they were captured in (NNFOwithBayesianJumps.drop_graphs() re-captures)."""
+    _FLOW[0] = None if on is None else bool(on)
+    return bool(_lib.lib().sf_set_flow_mode(-1 if on is None else int(bool(on))))

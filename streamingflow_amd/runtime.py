@@ -83,7 +83,7 @@ class PackedModule(torch.nn.Module):
 
     def _param_signature(self):
         from . import packing
-        sig = [packing.math_mode()]
+        sig = [packing.math_mode(), packing.winograd()]
         for t in list(self.parameters()) + list(self.buffers()):
             sig.append((t.data_ptr(), t._version, t.device))
         return tuple(sig)

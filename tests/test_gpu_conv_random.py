@@ -79,7 +79,17 @@ def test_dma_conv(i):
     assert used and all(u.startswith("conv_glds") for u in used), used   # the case really ran on the LDS-DMA kernel
 
 
-def _run(c, i, tol=2e-4):
+def _run(c, i, tol=2e-4, wino=False):
+    from streamingflow_amd import _lib, packing, runtime
+    was = packing.winograd()
+    packing.set_winograd(wino)      # the direct-form tests pack without Winograd weights (several of their layers would qualify)
+    try:
+        return _run_packed(c, i, tol)
+    finally:
+        packing.set_winograd(was)
+
+
+def _run_packed(c, i, tol):
     from streamingflow_amd import _lib, packing, runtime
     k, n, H, W, c0, c1, cout = c["k"], c["n"], c["H"], c["W"], c["c0"], c["c1"], c["cout"]
     up = c.get("in_up", 0)
@@ -153,3 +163,41 @@ def test_dma_conv_is_bitwise_reproducible(i):
     torch.cuda.synchronize()
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+# Layers that qualify for the Winograd F(2x2, 3x3) kernel (csrc/conv_wino.hip: 3x3, stride 1, pad 1, inputs in whole 16-channel
+# chunks, cout a multiple of 128, >= 131072 pixels): one and two sources, odd sizes (ragged tile blocks at the right / bottom
+# edge, odd H / W: a half-used last Winograd tile), two cout tiles, many small images, channel-sliced inputs / outputs, every
+# activation, the residual before and after it.  Same oracle and tolerance as the direct form.
+_WINO = [
+    dict(c0=128, c1=0, cout=128, n=4, H=200, W=200),
+    dict(c0=64, c1=64, cout=128, n=5, H=181, W=187),
+    dict(c0=64, c1=0, cout=128, n=9, H=100, W=151),
+    dict(c0=32, c1=96, cout=256, n=4, H=150, W=231),
+    dict(c0=16, c1=48, cout=128, n=100, H=40, W=41),
+    dict(c0=256, c1=0, cout=128, n=60, H=50, W=50),
+]
+
+
+@pytest.mark.parametrize("i", range(len(_WINO)))
+def test_winograd_conv(i):
+    c = dict(k=3, stride=1, dil=1, pad=1, act=["relu", "none", "lrelu", "tanh"][i % 4], add=i % 3 != 1, after=i % 2 == 0, in_slack=8 * (i % 2),
+             out_slack=[0, 4, 16][i % 3])
+    c.update(_WINO[i])
+    from streamingflow_amd import _lib
+    L = _lib.lib()
+    NK = _lib.SF_PROF_KEYS
+    calls, ms = (ctypes.c_int32 * NK)(), (ctypes.c_double * NK)()
+    fl, by = (ctypes.c_double * NK)(), (ctypes.c_double * NK)()
+    L.sf_prof_enable(1)
+    try:
+        got = _run(c, 300 + i, wino=True)
+        torch.cuda.synchronize()
+        L.sf_prof_collect(calls, ms, fl, by)
+    finally:
+        L.sf_prof_enable(0)
+    used = [_lib.KERNEL_NAMES[k] for k in range(NK) if calls[k]]
+    assert used and all(u.startswith("conv_wino") for u in used), used      # the case really ran on the Winograd kernel
+    # ... and agrees with the direct form of the same layer far inside the tolerance both have against torch
+    direct = _run(c, 300 + i, wino=False)
+    assert maxabs(got, direct) <= 5e-5, maxabs(got, direct)
