@@ -454,7 +454,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   // Groups are launched problem by problem (the kernel takes one); the profiler prices the launch at its EXECUTED FLOPs (key 16).
   if (tune().wino && P >= tune().wino_min_p && (epi == EPI_AFFINE || epi == EPI_BLEND)) {
     bool all = true;
-    for (int i = 0; i < n; ++i) all = all && wino_takes(ps[i], epi) && (ps[i].cout_pad % 128) == 0 && !(tune().b3 && ps[i].w3);
+    for (int i = 0; i < n; ++i) all = all && wino_takes(ps[i], epi) && !(tune().b3 && ps[i].w3);
     if (all) {
       SF_TRY(seg_flush());
       for (int i = 0; i < n; ++i) {

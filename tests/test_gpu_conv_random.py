@@ -176,6 +176,11 @@ _WINO = [
     dict(c0=32, c1=96, cout=256, n=4, H=150, W=231),
     dict(c0=16, c1=48, cout=128, n=100, H=40, W=41),
     dict(c0=256, c1=0, cout=128, n=60, H=50, W=50),
+    # cout not a multiple of 128: 64 cout x 64 Winograd tiles per workgroup (one V buffer, transform between the chunks)
+    dict(c0=64, c1=0, cout=64, n=4, H=200, W=200),
+    dict(c0=64, c1=64, cout=64, n=5, H=181, W=187),
+    dict(c0=128, c1=0, cout=192, n=4, H=150, W=231),
+    dict(c0=32, c1=0, cout=64, n=30, H=67, W=70),
 ]
 
 

@@ -26,7 +26,10 @@ def main():
              ("GRU gates cat[64|64]->128, 224 x 200x200", 224, 200, 200, 64, 64, 128),
              ("encoder 64->128, 256 x 100x100", 256, 100, 100, 64, 0, 128),
              ("128->128, 256 x 100x100", 256, 100, 100, 128, 0, 128),
-             ("128->128, 8 x 200x200", 8, 200, 200, 128, 0, 128)]
+             ("128->128, 8 x 200x200", 8, 200, 200, 128, 0, 128),
+             ("decoder / encoder 64->64, 224 x 200x200", 224, 200, 200, 64, 0, 64),
+             ("GRU candidate cat[64|64]->64, 224 x 200x200", 224, 200, 200, 64, 64, 64),
+             ("128->64, 256 x 100x100", 256, 100, 100, 128, 0, 64)]
     for name, n, H, W, c0, c1, cout in cases:
         g = torch.Generator(device="cuda").manual_seed(1)
         a0 = torch.randn((n, H, W, c0), device=dev, generator=g)
