@@ -502,6 +502,40 @@ def main():
                          "flops_per_step": fl, "algorithmic_bytes_per_step": by,
                          "hbm_frac_if_bytes_bound": by / (med_us * 1e-6) / 1e9 / PEAK_HBM_GBS,
                          "steps_per_s": 1e6 / med_us}
+            # the opt-in persistent flow kernel (sf_set_flow_mode / SF_PERSIST=1): the same rollouts as ONE resident launch ordered by
+            # tile-level dataflow (north star: "one LDS-tiled kernel per step"; bitwise the same results; needs an otherwise idle device)
+            try:
+                sfa.set_persistent_flow(True)
+                fmed, fp95, _ = rollout_step_times(hh, ww)
+                c5f = None
+                try:
+                    c5, l5, t5, dt5 = cases.timeset("stream40")
+                    tm5, _ = S.merge_observations(c5[0].tolist(), l5[0].tolist())
+                    sc5 = S.build_schedule(tm5, t5[0].tolist(), dt5, True, a.solver)
+                    hx5 = torch.randn((len(tm5), hh, ww, C), device=dev) * 0.5
+                    eps5 = torch.randn((sc5.n_draws, hh, ww, C), device=dev)
+                    ode.use_graph = True
+                    for _ in range(2):
+                        ode.rollout_nhwc(hx5, sc5, eps5)
+                    torch.cuda.synchronize()
+                    L.sf_event_record(e0, runtime.stream_ptr(dev))
+                    for _ in range(10):
+                        ode.rollout_nhwc(hx5, sc5, eps5)
+                    L.sf_event_record(e1, runtime.stream_ptr(dev))
+                    L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+                    c5f = ms.value / 10
+                finally:
+                    ode.use_graph = None
+                roof_step["persistent_flow_kernel"] = {
+                    "what": "opt-in (sf_set_flow_mode(1) / SF_PERSIST=1): every launch group of the rollout a phase of one resident launch, tile-level "
+                            "dependencies instead of kernel boundaries; same measurement as us_per_step_median",
+                    "us_per_step_median": fmed, "us_per_step_p95": fp95, "frac": fl / (fmed * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                    "vs_launch_per_layer": med_us / fmed, "stream40_rollout_hipgraph_ms": c5f, "launches_per_rollout": 3}
+            except Exception as ex:
+                roof_step["persistent_flow_kernel"] = {"error": repr(ex)}
+            finally:
+                sfa.set_persistent_flow(None)
+                ode.drop_graphs()
         except Exception as ex:      # secondary object: never lose the headline line over it
             roof_step = {"error": repr(ex)}
         try:      # the same two cases inside a rollout (pipelined stages where they pay: DESIGN 4.1)
@@ -560,6 +594,9 @@ def main():
         roof["ode_step_frac"] = roof_step["frac"]
         roof["ode_step_launches"] = roof_step.get("launches_per_step")
         roof["ode_step_traffic_ratio"] = (roof_step["traffic"] / roof_step["algorithmic_bytes_per_step"]) if roof_step.get("traffic") else None
+        pf = roof_step.get("persistent_flow_kernel") or {}
+        roof["ode_step_flow_kernel_us_median"] = pf.get("us_per_step_median")      # opt-in persistent flow kernel, same measurement
+        roof["ode_step_flow_kernel_frac"] = pf.get("frac")
     if roof is not None:
         roof["batch1_forward_ms"] = single_ms
 

@@ -880,24 +880,40 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
 #else
 #define SP_BAR_T(stmt) stmt
 #endif
+    // The steady-state body is ONE basic block: with a run-time branch between a chunk's fragment reads and the previous chunk's
+    // MFMAs (the round-2/3 form: `if (c + 1 < nchunks) read ...; mfmas`) hipcc's wait-count pass merges the two paths at the
+    // join and puts s_waitcnt lgkmcnt(0) in front of the MFMAs — every second chunk's MFMAs then waited for the NEXT chunk's six
+    // fragment reads (found in the ISA, round 4).  sched_barrier keeps the reads in front of the MFMAs.
     read_frags(0, 0);
-    for (int c = 0; c < nchunks; c += 2) {
+    int c = 0;
+    for (; c + 2 < nchunks; c += 2) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (c + 1 < nchunks) {
-        SP_BAR_T(sp_barrier());
-        buf = buf == SP_NB - 1 ? 0 : buf + 1;
-        read_frags(buf, 1);
-      }
+      SP_BAR_T(sp_barrier());
+      buf = buf == SP_NB - 1 ? 0 : buf + 1;
+      read_frags(buf, 1);
+      __builtin_amdgcn_sched_barrier(0);
       mfmas(0);
-      if (c + 1 < nchunks) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (c + 2 < nchunks) {
-          SP_BAR_T(sp_barrier());
-          buf = buf == SP_NB - 1 ? 0 : buf + 1;
-          read_frags(buf, 0);
-        }
-        mfmas(1);
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      SP_BAR_T(sp_barrier());
+      buf = buf == SP_NB - 1 ? 0 : buf + 1;
+      read_frags(buf, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (c + 1 < nchunks) {            // two chunks left
+      SP_BAR_T(sp_barrier());
+      buf = buf == SP_NB - 1 ? 0 : buf + 1;
+      read_frags(buf, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      mfmas(1);
+    } else {                          // one
+      mfmas(0);
     }
 #ifdef SF_STAMP
     SF_STAMP_VAL(L, 8, __builtin_amdgcn_s_memtime() - c_loop0);

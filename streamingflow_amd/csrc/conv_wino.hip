@@ -29,20 +29,25 @@ namespace sf {
 constexpr int WN_THREADS = 512;
 typedef __attribute__((address_space(3))) void wn_lds_void;
 
-template <int COUT_T, int TH>
+// MW: 16-row cout tiles per wave (2: wave = 32 cout x 16 tiles, 128 accumulator registers, one workgroup per CU;
+//     1: wave = 16 cout x 16 tiles, 64 accumulator registers, <= 128 registers and <= 80 KB LDS: TWO workgroups per CU, each
+//     one's barriers, transform, prologue and epilogue under the other's MFMAs)
+template <int COUT_T, int TH, int MW>
 struct WinoGeo {
   static constexpr int TW = 8, WT = TH * TW;                   // Winograd tiles of a workgroup: TH rows x 8 columns
   static constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;       // input patch (pixels)
   static constexpr int NPX = PH * PW;
-  static constexpr int WMW = COUT_T / 32, WNW = WT / 16;       // waves along cout / tiles
-  static_assert(WMW * WNW == 8, "eight waves: 32 cout x 16 tiles each");
+  static constexpr int WMW = COUT_T / (16 * MW), WNW = WT / 16; // waves along cout / tiles
+  static_assert(WMW * WNW == 8, "eight waves");
   static constexpr int NU = COUT_T / 64;                       // U DMAs per wave and stage (a stage = 2 positions x COUT_T rows of 64 B)
   static constexpr int NP = (NPX * 4 + 511) / 512;             // patch DMAs per wave and chunk
-  static constexpr int NVB = (WT == 32) ? 2 : 1;               // V buffers
+  static constexpr int NVB = (WT == 32 && MW == 2) ? 2 : 1;    // V buffers
+  static constexpr int NPB = MW == 2 ? 2 : 1;                  // patch buffers (1: the next patch is issued behind the chunk-boundary barrier)
   static constexpr int U_FLOATS = 2 * COUT_T * 16;             // one stage
   static constexpr int V_FLOATS = 16 * WT * 16;                // one chunk
   static constexpr int P_FLOATS = 8 * NP * 64 * 4;             // one patch, padded to whole DMAs
-  static constexpr int LDS_FLOATS = 3 * U_FLOATS + NVB * V_FLOATS + 2 * P_FLOATS;
+  static constexpr int LDS_FLOATS = 3 * U_FLOATS + NVB * V_FLOATS + NPB * P_FLOATS;
+  static constexpr int WG_PER_CU = MW == 2 ? 1 : 2;
 };
 
 __device__ __forceinline__ f32x4 wn_lds_read128(const float* p) {
@@ -72,8 +77,8 @@ __device__ __forceinline__ void wn_wait(const int n) {
 }
 
 // per-element epilogue: v = the lane's four consecutive output channels c .. c+3 of pixel gp (semantics of conv_igemm.hip run_epilogue)
-template <int EPI, class PT>
-__device__ __forceinline__ void wn_epilogue(const PT& P, float4 v, const size_t gp, const int c, const int img) {
+template <int EPI>
+__device__ __forceinline__ void wn_epilogue(const ConvProblem& P, float4 v, const size_t gp, const int c, const int img) {
   const float4 sc = P.scale ? spm_ld4(P.scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
   const float4 bi = P.bias ? spm_ld4(P.bias + (P.bias_per_img ? (size_t)img * P.cout : 0) + c) : spm_zero4();
   v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
@@ -110,73 +115,55 @@ __device__ __forceinline__ void wn_epilogue(const PT& P, float4 v, const size_t 
   spm_st4(P.out + gp * P.out_cs + P.out_co + c, y);
 }
 
-template <int COUT_T, int TH, int EPI>
-__global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(const ConvLaunch L_by_value) {
-  typedef WinoGeo<COUT_T, TH> G;
-  constexpr int TW = G::TW, WT = G::WT, PW = G::PW, NU = G::NU, NP = G::NP, NVB = G::NVB;
+template <int COUT_T, int TH, int MW, int EPI>
+__global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kernel(const ConvLaunch L) {
+  typedef WinoGeo<COUT_T, TH, MW> G;
+  constexpr int TW = G::TW, WT = G::WT, PW = G::PW, NU = G::NU, NP = G::NP, NVB = G::NVB, NPB = G::NPB;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const Ubuf = smem;
   float* const Vbuf = Ubuf + 3 * G::U_FLOATS;
   float* const Pbuf = Vbuf + NVB * G::V_FLOATS;
-  // The argument is read in place in the kernarg segment through a pointer that is laundered once per tile: every field of the
-  // problem is loaded (scalar loads) where it is used.  As a by-value object hipcc hoists all of them out of the persistent tile loop
-  // and keeps them in scalar registers across it (82 SGPR spills).
-#if defined(__HIP_DEVICE_COMPILE__)
-  typedef const __attribute__((address_space(4))) ConvLaunch* launch_cptr;
-  launch_cptr Lk = (launch_cptr)__builtin_amdgcn_kernarg_segment_ptr();      // the only argument (offset 0)
-#else
-  const ConvLaunch* Lk = &L_by_value;
-#endif
-  (void)L_by_value;
-#define P (Lk->p[0])
+  const ConvProblem& P = L.p[0];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = P.Hout, W = P.Wout;                            // stride 1, pad 1: input size = output size
   const int tiles_x = (W + 1) >> 1, tiles_y = (H + 1) >> 1;
   const int nbx = (tiles_x + TW - 1) / TW, nby = (tiles_y + TH - 1) / TH;
-  const int n_tiles = P.n_img * nby * nbx;                     // workgroup tiles of this cout tile
+  int b = (int)blockIdx.x;
+  const int bx = b % nbx; b /= nbx;
+  const int by = b % nby;
+  const int img = b / nby;
+  const int ty0 = by * TH, tx0 = bx * TW;
   const int cout0 = (int)blockIdx.y * COUT_T;
   const int nkc = P.cin_pad >> 4;                              // 16-channel chunks
   const int NS = nkc * 8;                                      // stages
   const int c0 = P.c0;
-  // The workgroup is persistent over tiles t = blockIdx.x, + gridDim.x, ...: the next tile's first DMAs (patch 0, the first three
-  // U stages) are issued BEFORE the finished tile's output transform + epilogue, which cover their flight.
-  int img = 0, ty0 = 0, tx0 = 0;
+
 #if defined(__HIP_DEVICE_COMPILE__)
   auto make_rsrc = [](const float* base, size_t bytes) {
     const unsigned nrec = bytes < 0x7fffffffull ? (unsigned)bytes : 0x7fffffffu;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (int)nrec, 0x00020000);
   };
   const size_t img_px = (size_t)H * W;
-  __amdgpu_buffer_rsrc_t rsrc0 = make_rsrc(P.in0, 0), rsrc1 = make_rsrc(P.in0, 0);
+  const __amdgpu_buffer_rsrc_t rsrc0 = make_rsrc(P.in0 + (size_t)img * img_px * P.in0_cs, img_px * P.in0_cs * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(P.in1 ? P.in1 + (size_t)img * img_px * P.in1_cs : P.in0, P.in1 ? img_px * P.in1_cs * sizeof(float) : 0);
   const __amdgpu_buffer_rsrc_t rsrc_u = make_rsrc(P.w_wino, (size_t)nkc * 16 * P.cout_pad * 16 * sizeof(float));
 #endif
   // ---- patch DMA: element e = (pixel, channel quad) of the (2TH+2) x 18 patch, 16 bytes each, LDS linear in e -----------------
   int pv0[NP], pv1[NP];
-  auto setup_tile = [&](const int t) {
-    int b = t;
-    const int bx = b % nbx; b /= nbx;
-    const int by = b % nby;
-    img = b / nby;
-    ty0 = by * TH; tx0 = bx * TW;
-#if defined(__HIP_DEVICE_COMPILE__)
-    rsrc0 = make_rsrc(P.in0 + (size_t)img * img_px * P.in0_cs, img_px * P.in0_cs * sizeof(float));
-    rsrc1 = make_rsrc(P.in1 ? P.in1 + (size_t)img * img_px * P.in1_cs : P.in0, P.in1 ? img_px * P.in1_cs * sizeof(float) : 0);
-#endif
 #pragma unroll
-    for (int d = 0; d < NP; ++d) {
-      const int e = (wave * NP + d) * 64 + lane;
-      const int pix = e >> 2, quad = e & 3;
-      const int py = pix / PW, px = pix - py * PW;
-      const int iy = 2 * ty0 - 1 + py, ix = 2 * tx0 - 1 + px;
-      const bool ok = pix < G::NPX && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      const int pofs = iy * W + ix;
-      pv0[d] = ok ? (pofs * P.in0_cs + quad * 4) * 4 : (int)0x80000000;      // + the chunk's channel offset stays out of range: zero fill
-      pv1[d] = ok ? (pofs * P.in1_cs - c0 + quad * 4) * 4 : (int)0x80000000;
-    }
-  };
+  for (int d = 0; d < NP; ++d) {
+    const int e = (wave * NP + d) * 64 + lane;
+    const int pix = e >> 2, quad = e & 3;
+    const int py = pix / PW, px = pix - py * PW;
+    const int iy = 2 * ty0 - 1 + py, ix = 2 * tx0 - 1 + px;
+    const bool ok = pix < G::NPX && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const int pofs = iy * W + ix;
+    pv0[d] = ok ? (pofs * P.in0_cs + quad * 4) * 4 : (int)0x80000000;      // + the chunk's channel offset stays out of range: zero fill
+    pv1[d] = ok ? (pofs * P.in1_cs - c0 + quad * 4) * 4 : (int)0x80000000;
+  }
   auto issue_patch = [&](const int kc) {
-    float* const dst = Pbuf + (kc & 1) * G::P_FLOATS;
+    float* const dst = Pbuf + (NPB == 2 ? (kc & 1) : 0) * G::P_FLOATS;
     const bool from1 = kc * 16 >= c0;                           // wave-uniform: the whole chunk reads in1 (c0 % 16 == 0)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -191,17 +178,15 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(const ConvLaunch 
   };
   // ---- U DMA: stage S = (chunk kc, position pair st): rows r of [2 positions][COUT_T], 64 B each; piece q = 16 rows ------------
   int uv[NU];
-  auto setup_u = [&](const int ln) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const int r = (wave * NU + u) * 16 + (ln >> 2);          // row of the stage
-      const int p = r / COUT_T, row = r - p * COUT_T;
-      const int slot = (ln & 3) ^ ((row >> 2) & 2);            // LDS slot (lane & 3) holds source slot `slot`
-      int grow = cout0 + row;
-      grow = grow < P.cout_pad ? grow : P.cout_pad - 1;
-      uv[u] = ((p * P.cout_pad + grow) * 16 + slot * 4) * 4;
-    }
-  };
+  for (int u = 0; u < NU; ++u) {
+    const int r = (wave * NU + u) * 16 + (lane >> 2);          // row of the stage
+    const int p = r / COUT_T, row = r - p * COUT_T;
+    const int slot = (lane & 3) ^ ((row >> 2) & 2);            // LDS slot (lane & 3) holds source slot `slot`
+    int grow = cout0 + row;
+    grow = grow < P.cout_pad ? grow : P.cout_pad - 1;
+    uv[u] = ((p * P.cout_pad + grow) * 16 + slot * 4) * 4;
+  }
   const int u_stage_bytes = 2 * P.cout_pad * 16 * 4;            // two positions
   auto issue_u = [&](const int S) {
     float* const dst = Ubuf + (S % 3) * G::U_FLOATS;
@@ -216,7 +201,7 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(const ConvLaunch 
   // ---- input transform: task (tile wt, channel quad, row i of B^T d B): 8 reads, 8 add/sub, 4 writes (float4) ------------------
   constexpr int NTASK = WT * 16 / WN_THREADS;                  // 1 (32 tiles) or 2 (64 tiles)
   auto transform = [&](const int kc) {
-    const float* const src = Pbuf + (kc & 1) * G::P_FLOATS;
+    const float* const src = Pbuf + (NPB == 2 ? (kc & 1) : 0) * G::P_FLOATS;
     float* const dst = Vbuf + (NVB == 2 ? (kc & 1) : 0) * G::V_FLOATS;
 #pragma unroll
     for (int t = 0; t < NTASK; ++t) {
@@ -242,20 +227,21 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(const ConvLaunch 
   };
   // ---- fragments: wave (wm, wn) = 32 cout x 16 tiles; lane (j, g): row j of a 16-row fragment, K slot g --------------------------
   const int wm = wave % G::WMW, wn = wave / G::WMW;
-  int j = 0, g = 0, wtl = 0, b_off = 0;
-  int a_off[2];
-  auto setup_frag = [&](const int ln) {
-    j = ln & 15; g = ln >> 4;
+  const int j = lane & 15, g = lane >> 4;
+  int a_off[MW];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int row = wm * 32 + m * 16 + j;
-      a_off[m] = row * 16 + ((g ^ ((row >> 2) & 2)) << 2);
-    }
-    wtl = wn * 16 + j;
-    b_off = wtl * 16 + ((g ^ ((wtl >> 2) & 2)) << 2);
-  };
-  f32x4 acc[16][2];
-  f32x4 fa[2][2][2], fb[2][2];                                 // [set][position of the pair][m]
+  for (int m = 0; m < MW; ++m) {
+    const int row = wm * 16 * MW + m * 16 + j;
+    a_off[m] = row * 16 + ((g ^ ((row >> 2) & 2)) << 2);
+  }
+  const int wtl = wn * 16 + j;
+  const int b_off = wtl * 16 + ((g ^ ((wtl >> 2) & 2)) << 2);
+  f32x4 acc[16][MW];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int m = 0; m < MW; ++m) acc[p][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 fa[2][2][MW], fb[2][2];                                 // [set][position of the pair][m]
   auto read_frags = [&](const int S, const int set) {
     const float* const ub = Ubuf + (S % 3) * G::U_FLOATS;
     const int kc = S >> 3, st = S & 7;
@@ -263,137 +249,135 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(const ConvLaunch 
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m) fa[set][p][m] = wn_lds_read128(ub + p * COUT_T * 16 + a_off[m]);
+      for (int m = 0; m < MW; ++m) fa[set][p][m] = wn_lds_read128(ub + p * COUT_T * 16 + a_off[m]);
       fb[set][p] = wn_lds_read128(vb + p * WT * 16 + b_off);
     }
   };
 
-  // ---- first tile: patch 0 and the first three U stages (the ring) on their way ---------------------------------------------------------
+  // ---- prologue: patch 0, three U stages (the ring), transform 0, patch 1 ------------------------------------------------------------
   const int n_u0 = NS < 3 ? NS : 3;
-  const bool late = (Lk->xcd_shift & 1) && wave >= 4;           // the staggered half (host option, on by default)
-  int tile = (int)blockIdx.x;
-  if (tile >= n_tiles) return;                                  // block-uniform
-  setup_tile(tile);
-  setup_u(lane);
   issue_patch(0);
   for (int S = 0; S < n_u0; ++S) issue_u(S);
-  for (;;) {
-  // the lane-derived address tables are rebuilt per tile from a laundered lane index, so that they are not carried through the
-  // epilogue (128 accumulator registers + its operands are what is live there)
-  int ln = lane;
-  asm volatile("" : "+v"(ln), "+s"(Lk));
-  setup_frag(ln);
-  setup_u(ln);
-#pragma unroll
-  for (int p = 0; p < 16; ++p)
-#pragma unroll
-    for (int m = 0; m < 2; ++m) acc[p][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // everything this wave has in flight — patch 0, three U stages and, from the second tile on, the previous tile's epilogue stores
-  // (younger than the DMAs: a counted wait cannot tell them apart) — is done
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wn_wait(NU * n_u0);                                           // the patch is the oldest: everything but the U stages
   wn_barrier();
   transform(0);
-  if (nkc > 1) issue_patch(1);
+  if (NPB == 2 && nkc > 1) issue_patch(1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  wn_wait(NU * (n_u0 - 1) + ((NPB == 2 && nkc > 1) ? NP : 0));  // U(0) landed (younger: U(1), U(2), patch(1))
   wn_barrier();
+  if (NPB == 1 && nkc > 1) issue_patch(1);                      // one patch buffer: every wave has finished transform(0)
   read_frags(0, 0);
 
-  for (int kc = 0; kc < nkc; ++kc) {
+  // (Measured and not kept, profiles/r04_[hij]_winobench_*: a persistent tile loop with the next tile's DMAs issued before the
+  // epilogue; the SIMD-partner stagger of MI355X_MICROARCH.md item 9 as a second code path and as a deferred DMA issue.  Each cost
+  // more in the compiler's schedule of this loop — 227 -> 239-254 registers, scalar spills in the stage code — than it bought: 14.6 ms
+  // for the 128 -> 128 layer on 224 frames with the loop below, 15.3-16.9 ms with them.)
+  if constexpr (NVB == 2) {
+    // Conditions are written in (kc, st) so that they fold for st < 5 / 6 / 7 after unrolling: with a run-time branch between a
+    // stage's fragment reads and its MFMAs hipcc's wait-count pass loses track of which LDS reads are pending at the merge and
+    // puts s_waitcnt lgkmcnt(0) in front of the MFMAs — they then wait for the NEXT stage's reads (seen in the ISA of the first
+    // version: 51 % of the MFMA peak).
+    for (int kc = 0; kc < nkc; ++kc) {
+      const bool more = kc + 1 < nkc;                               // wave-uniform
 #pragma unroll
-    for (int st = 0; st < 8; ++st) {
-      const int S = kc * 8 + st;
-      const int set = st & 1;
-      auto mfmas = [&]() {
+      for (int st = 0; st < 8; ++st) {
+        const int S = kc * 8 + st;
+        const int set = st & 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // fragments of stage S are in registers (and this wave's V writes are out)
+        if (st < 7 || more) {
+          // U(S+1) landed: younger DMAs of this wave are U(S+2) and — for two stages behind its issue point — the next patch
+          const bool patch_young = (st == 4 || st == 5) && (kc + 2 < nkc);
+          wn_wait(((st < 6 || more) ? NU : 0) + (patch_young ? NP : 0));
+          wn_barrier();                                             // stage S+1 (and, at st == 7, the next chunk's V) published; buffer S % 3 free
+          if (st < 5 || more) issue_u(S + 3);
+          read_frags(S + 1, set ^ 1);
+        }
+        // the next stage's fragment reads stay IN FRONT of this stage's MFMAs (the machine scheduler otherwise sinks them behind the
+        // MFMAs to save registers and every MFMA group then waits for an LDS round trip)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MW; ++m)
               acc[2 * st + p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][p][m][e], fb[set][p][e], acc[2 * st + p][m], 0, 0, 0);
-      };
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // fragments of stage S are in registers (and this wave's V writes are out)
-      if (S + 1 < NS) {
-        // U(S+1) landed: younger DMAs of this wave are U(S+2) and — for two stages behind its issue point — the next patch
-        const bool patch_young = NVB == 2 ? ((st == 4 || st == 5) && (kc + 2 < nkc)) : (st <= 1 && (kc + 1 < nkc));
-        wn_wait((S + 2 < NS ? NU : 0) + (patch_young ? NP : 0));
-        wn_barrier();                                             // stage S+1 published; every wave holds stage S in registers: buffer S % 3 (and, at st == 7, V) free
-        if (NVB == 1 && st == 7) {
-          if (S + 3 < NS) issue_u(S + 3);
-          // one V buffer: the next chunk's transform sits between the last read of this chunk's V (behind the barrier above) and the
-          // first read of the next one; this stage's MFMAs cover its LDS writes
+        __builtin_amdgcn_sched_barrier(0);
+        if (st == 3 && more) {                                      // next chunk's transform beside this chunk's stages (its patch landed a chunk ago)
           transform(kc + 1);
-          if (kc + 2 < nkc) issue_patch(kc + 2);
-          mfmas();
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          wn_barrier();
-          read_frags(S + 1, set ^ 1);
-          continue;
+          if (kc + 2 < nkc) issue_patch(kc + 2);                    // into the buffer transform(kc) read: every wave passed >= 4 barriers since
         }
-        // Stagger (MI355X_MICROARCH.md, "Two waves per SIMD", item 9): waves w and w + 4 share a SIMD and would otherwise issue their
-        // DMAs / fragment reads together and then fight over the matrix pipe together.  Waves 4-7 run their MFMAs first and issue the
-        // stage's DMAs behind them: each half's DMA issue sits under the other half's MFMAs.
-        if (late) {
-          read_frags(S + 1, set ^ 1);
-          mfmas();
-          if (S + 3 < NS) issue_u(S + 3);
-          if constexpr (NVB == 2) {
-            if (st == 3 && kc + 1 < nkc) { transform(kc + 1); if (kc + 2 < nkc) issue_patch(kc + 2); }
-          }
-          continue;
-        }
-        if (S + 3 < NS) issue_u(S + 3);
-        read_frags(S + 1, set ^ 1);
       }
-      mfmas();
-      if constexpr (NVB == 2) {
-        if (st == 3 && kc + 1 < nkc) {                            // next chunk's transform beside this chunk's stages (its patch landed a chunk ago)
+    }
+  } else {
+    // one V buffer (64 tiles x 16 positions x 16 channels = 64 KB): the next chunk's transform sits between the last read of this
+    // chunk's V (behind the barrier of stage 7) and the first read of the next one; stage 7's MFMAs cover its LDS writes
+    for (int kc = 0; kc < nkc; ++kc) {
+      const bool more = kc + 1 < nkc;                               // wave-uniform
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const int S = kc * 8 + st;
+        const int set = st & 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (st < 7) {                                               // inside a chunk: as the two-buffer kernel
+          const bool patch_young = st <= 1 && more;                 // the patch is issued at the chunk boundary: young for two stages
+          wn_wait(((st < 6 || more) ? NU : 0) + (patch_young ? NP : 0));
+          wn_barrier();
+          if (st < 5 || more) issue_u(S + 3);
+          read_frags(S + 1, set ^ 1);
+        } else if (more) {                                          // chunk boundary
+          wn_wait(NU);
+          wn_barrier();                                             // every wave holds this chunk's last fragments: V is free
+          issue_u(S + 3);
           transform(kc + 1);
-          if (kc + 2 < nkc) issue_patch(kc + 2);                  // into the buffer transform(kc) read: every wave passed >= 4 barriers since
+          if (NPB == 2 && kc + 2 < nkc) issue_patch(kc + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+              acc[2 * st + p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][p][m][e], fb[set][p][e], acc[2 * st + p][m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st == 7 && more) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          wn_barrier();                                             // the next chunk's V is visible (and every wave is done with the patch)
+          if (NPB == 1 && kc + 2 < nkc) issue_patch(kc + 2);
+          read_frags(S + 1, set ^ 1);
         }
       }
     }
   }
 
-  // ---- next tile's first DMAs, then this tile's output transform A^T M A (register-local) + epilogue ---------------------------------------
-  const int cur_img = img, cur_ty0 = ty0, cur_tx0 = tx0;
-  tile += (int)gridDim.x;
-  const bool more_tiles = tile < n_tiles;                         // block-uniform
-  wn_barrier();                                                   // every wave has read its last fragments: ring, V and patch buffers are free
-  if (more_tiles) {
-    setup_tile(tile);
-    issue_patch(0);
-    for (int S = 0; S < n_u0; ++S) issue_u(S);
-  }
-  const int ty = cur_ty0 + wtl / TW, tx = cur_tx0 + wtl % TW;
-  const size_t img_base = (size_t)cur_img * H * W;
+  // ---- output transform A^T M A (register-local) + epilogue ---------------------------------------------------------------------------
+  const int ty = ty0 + wtl / TW, tx = tx0 + wtl % TW;
+  const size_t img_base = (size_t)img * H * W;
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int c = cout0 + wm * 32 + m * 16 + 4 * g;
-    f32x4 t0[4], t1[4];                                           // rows of M A: t0[i] = M[i][0] + M[i][1] + M[i][2], t1[i] = M[i][1] - M[i][2] - M[i][3]
+  for (int m = 0; m < MW; ++m) {
+    const int c = cout0 + wm * 16 * MW + m * 16 + 4 * g;
+    // one output column bq at a time (16 + 8 live registers beside the accumulators instead of 48):
+    //   t[i] = (M A)[i][bq]:  bq = 0: M[i][0] + M[i][1] + M[i][2],   bq = 1: M[i][1] - M[i][2] - M[i][3]
+    //   Y[0][bq] = t[0] + t[1] + t[2],   Y[1][bq] = t[1] - t[2] - t[3]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      t0[i] = acc[4 * i + 0][m] + acc[4 * i + 1][m] + acc[4 * i + 2][m];
-      t1[i] = acc[4 * i + 1][m] - acc[4 * i + 2][m] - acc[4 * i + 3][m];
-    }
-    f32x4 y[2][2];
-    y[0][0] = t0[0] + t0[1] + t0[2]; y[0][1] = t1[0] + t1[1] + t1[2];
-    y[1][0] = t0[1] - t0[2] - t0[3]; y[1][1] = t1[1] - t1[2] - t1[3];
-    if (c < P.cout) {
+    for (int bq = 0; bq < 2; ++bq) {
+      f32x4 t[4];
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int bq = 0; bq < 2; ++bq) {
-          const int oy = 2 * ty + a, ox = 2 * tx + bq;
-          if (oy < H && ox < W)
-            wn_epilogue<EPI>(P, make_float4(y[a][bq][0], y[a][bq][1], y[a][bq][2], y[a][bq][3]), img_base + (size_t)oy * W + ox, c, cur_img);
+      for (int i = 0; i < 4; ++i)
+        t[i] = bq == 0 ? acc[4 * i + 0][m] + acc[4 * i + 1][m] + acc[4 * i + 2][m] : acc[4 * i + 1][m] - acc[4 * i + 2][m] - acc[4 * i + 3][m];
+      const f32x4 y0 = t[0] + t[1] + t[2], y1 = t[1] - t[2] - t[3];
+      if (c < P.cout) {
+        const int ox = 2 * tx + bq;
+        if (ox < W) {
+          const int oy = 2 * ty;
+          if (oy < H) wn_epilogue<EPI>(P, make_float4(y0[0], y0[1], y0[2], y0[3]), img_base + (size_t)oy * W + ox, c, img);
+          if (oy + 1 < H) wn_epilogue<EPI>(P, make_float4(y1[0], y1[1], y1[2], y1[3]), img_base + (size_t)(oy + 1) * W + ox, c, img);
         }
+      }
     }
   }
-  if (!more_tiles) break;
-  }      // tiles
 }
-#undef P
 
 // weights: packed direct form w[cout_pad][9 * cin_pad] (tap-major, channel-minor) -> U[cin_pad/16][16][cout_pad][16] = G g G^T
 __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int cout_pad, int cin_pad) {
@@ -443,10 +427,10 @@ bool wino_takes(const ConvProblem& q, int epi) {
   return true;
 }
 
-template <int COUT_T, int TH, int EPI>
+template <int COUT_T, int TH, int MW, int EPI>
 static hipError_t launch_wino_t(const ConvLaunch& L, hipStream_t stream) {
-  typedef WinoGeo<COUT_T, TH> G;
-  auto kern = conv_wino_kernel<COUT_T, TH, EPI>;
+  typedef WinoGeo<COUT_T, TH, MW> G;
+  auto kern = conv_wino_kernel<COUT_T, TH, MW, EPI>;
   constexpr int lds = G::LDS_FLOATS * 4;
   static bool attr_done[64] = {};
   int dev = 0;
@@ -458,31 +442,23 @@ static hipError_t launch_wino_t(const ConvLaunch& L, hipStream_t stream) {
   }
   const ConvProblem& P = L.p[0];
   const int tiles_x = (P.Wout + 1) / 2, tiles_y = (P.Hout + 1) / 2;
-  const long n_tiles = (long)P.n_img * ((tiles_y + TH - 1) / TH) * ((tiles_x + G::TW - 1) / G::TW);
-  if (n_tiles > 0x7fffffffL) return hipErrorInvalidValue;
-  // persistent over tiles: one workgroup per CU (the LDS footprint admits one), each walking tiles blockIdx.x, + gridDim.x, ...
-  static int n_cu[64] = {};
-  if (!n_cu[dev] && hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return hipErrorInvalidDevice;
-  const int ct = P.cout_pad / COUT_T;
-  // SF_WINO_OPTS (experiments): bit 0 = staggered wave halves, bit 1 = persistent grid (off: one workgroup per tile)
-  static const int opts = [] { const char* v = std::getenv("SF_WINO_OPTS"); return v ? std::atoi(v) : 3; }();
-  long gx = (opts & 2) ? n_cu[dev] / ct : n_tiles;
-  if (gx < 1) gx = 1;
-  if (gx > n_tiles) gx = n_tiles;
-  ConvLaunch L2 = L;
-  L2.xcd_shift = opts & 1;
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ct, 1), dim3(WN_THREADS), lds, stream, L2);
+  const long blocks = (long)P.n_img * ((tiles_y + TH - 1) / TH) * ((tiles_x + G::TW - 1) / G::TW);
+  if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(P.cout_pad / COUT_T), 1), dim3(WN_THREADS), lds, stream, L);
   return hipGetLastError();
 }
 // one problem per launch
 hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream) {
   if (L.nprob != 1 || !wino_takes(L.p[0], epi)) return hipErrorInvalidValue;
-  // tile: 128 cout x 32 Winograd tiles, or 64 cout x 64 tiles (cout not a multiple of 128; SF_WINO_TILE=64 forces it: experiments)
+  // tile: 128 cout x 32 Winograd tiles (one workgroup per CU), 64 cout x 64 tiles (cout not a multiple of 128), or 64 cout x 32
+  // tiles with two workgroups per CU.  SF_WINO_TILE = 128 | 64 | 2 forces one (experiments).
   static const int force = [] { const char* v = std::getenv("SF_WINO_TILE"); return v ? std::atoi(v) : 0; }();
+  const bool affine = epi == EPI_AFFINE;
+  if (force == 2) return affine ? launch_wino_t<64, 4, 1, EPI_AFFINE>(L, stream) : launch_wino_t<64, 4, 1, EPI_BLEND>(L, stream);
   if (L.p[0].cout_pad % 128 == 0 && force != 64)
-    return epi == EPI_AFFINE ? launch_wino_t<128, 4, EPI_AFFINE>(L, stream) : launch_wino_t<128, 4, EPI_BLEND>(L, stream);
+    return affine ? launch_wino_t<128, 4, 2, EPI_AFFINE>(L, stream) : launch_wino_t<128, 4, 2, EPI_BLEND>(L, stream);
   if (L.p[0].cout_pad % 64 == 0)
-    return epi == EPI_AFFINE ? launch_wino_t<64, 8, EPI_AFFINE>(L, stream) : launch_wino_t<64, 8, EPI_BLEND>(L, stream);
+    return affine ? launch_wino_t<64, 8, 2, EPI_AFFINE>(L, stream) : launch_wino_t<64, 8, 2, EPI_BLEND>(L, stream);
   return hipErrorInvalidValue;
 }
 

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_conv_random.py -x -q -k "winograd" 2>&1 | tail -3 > gpurun_out/r04_j_wino_tests.log
+for O in 1 0; do SF_WINO_OPTS=$O timeout 600 python tools/r04/winobench.py 5 2>&1 | grep '^{"layer' | sed "s/^/OPTS=$O /" ; done > gpurun_out/r04_j_winobench_opts.txt
+timeout 600 python bench.py --steps 5 --warmup 2 --headline-only 2>&1 | grep '^{' > gpurun_out/r04_j_bench_headline.json

@@ -1,0 +1,55 @@
+"""SparseEncoder on the shipped-size synthetic cloud: how much of the dense 27-tap implicit GEMM a per-(tile, tap) skip could drop
+("skip K chunks of a (tile, tap) whose neighbour entries are all -1").  For every convolution: the share of
+(output site, tap) pairs that have an input site, and the share of (tile of T consecutive output rows, tap) pairs in which AT LEAST
+ONE row has one — what a skip at tile granularity still has to compute — for T = 128 / 64 / 32 (the pixel tiles of the kernels).
+Usage: python3 tools/r04/sparse_tile_density.py"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from streamingflow_amd.models.sparse_encoder import SparseEncoder   # noqa: E402
+from streamingflow_amd.voxelize import Voxelization, voxelize   # noqa: E402
+from oracle import cases, hashfill, sparse_encoder_ref as SR   # noqa: E402
+import voxelbench   # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    cfg = SR.default_cfg()
+    m = SparseEncoder(cfg["in_channels"], cfg["sparse_shape"], base_channels=cfg["base_channels"], output_channels=cfg["output_channels"],
+                      encoder_channels=cfg["encoder_channels"], encoder_paddings=cfg["encoder_paddings"], block_type="basicblock").eval()
+    shapes = SR.state_dict_shapes(cfg)
+    m.load_state_dict(hashfill.fill_state_dict({k: torch.empty(v) if v else torch.tensor(0) for k, v in shapes.items()}, seed=83, gain=1.6))
+    m = m.to(dev)
+    vs, rng, mp, mv = cases.VOXEL_SHIPPED
+    vz = Voxelization(list(vs), list(rng), mp, (120000, mv)).eval()
+    feats, coords, sizes = voxelize([voxelbench.cloud().to(dev)], vz)
+    rows = []
+    orig = m._table
+
+    def spy(in_coords, out_coords, batch, shape, k, s, p, subm):
+        t = orig(in_coords, out_coords, batch, shape, k, s, p, subm)
+        live = (t >= 0)
+        n, taps = live.shape
+        r = {"kernel": list(k), "stride": list(s), "subm": bool(subm), "output_sites": int(n), "taps": int(taps), "site_tap_live": float(live.float().mean())}
+        for T in (128, 64, 32):
+            pad = (-n) % T
+            lv = torch.cat([live, torch.zeros((pad, taps), dtype=torch.bool, device=live.device)], 0).view(-1, T, taps).any(1)
+            r[f"tile{T}_tap_live"] = float(lv.float().mean())
+        rows.append(r)
+        return t
+
+    m._table = spy
+    with torch.no_grad():
+        m(feats, coords, 1, nhwc=True)
+    for r in rows:
+        print(json.dumps(r))
+
+
+if __name__ == "__main__":
+    main()
