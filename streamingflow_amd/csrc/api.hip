@@ -18,6 +18,7 @@ hipError_t set_stamp_buffer_sp(unsigned long long* p);
 hipError_t launch_conv_sp(const ConvLaunch& L, int epi, bool scaled, int bn, hipStream_t stream);
 hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream);
 bool wino_takes(const ConvProblem& q, int epi);
+int wino_variant(const ConvProblem& q);
 hipError_t launch_sp_flow(const SpFlow& F, int grid, bool b3, hipStream_t stream);
 hipError_t launch_flow_write(const void* host_src, void* dev_dst, size_t bytes, hipStream_t stream);
 bool sp_flow_has(int epi, bool scaled, int bn);
@@ -468,7 +469,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
         }
         const ConvProblem& q = ps[i];
         ProfRec r;
-        r.key = 16 * 8 + epi;
+        r.key = (16 + wino_variant(q)) * 8 + epi;      // _lib.KERNEL_NAMES: wino128x32t / wino64x64t / wino64x32t2
         const double tiles = (double)q.n_img * ((q.Hout + 1) / 2) * ((q.Wout + 1) / 2);
         r.flops = 2.0 * 16.0 * tiles * q.cout * (q.c0 + q.c1);      // executed: 16 products per 2x2 outputs and (cin, cout) pair
         r.bytes = 4.0 * ((double)q.n_img * q.Hin * q.Win * (q.c0 + q.c1) + 16.0 * q.cout * (q.c0 + q.c1) + (double)q.n_img * q.Hout * q.Wout * q.cout);
@@ -888,19 +889,35 @@ struct Side {                // extra problems for infer_state's launches (AFFIN
   ConvProblem p[3];
   int n;                     // 2 or 3
 };
-bool carry_ok(const sf_dual_w& w, int B, int H, int W) {
+bool carry_ok(const sf_dual_w& w, const sf_pmodel_w& pm, int B, int H, int W) {
   const long P = (long)B * H * W;
   // One latent only.  (Measured with the blend mode / acc_in also in the large-tile AFFINE epilogues: per steady-state step 8 samples
   // 684 -> 669 us, one 200x200 latent 1200 -> 1200, 32 samples 2178 -> 2197 — and the two extra branches cost every AFFINE launch
   // of the batched forward 0.9 % (255.5 -> 257.8 ms): not worth the headline, reverted; profiles/README.md round-3 log.)
   if (!(tune().pipe && B == 1 && P < tune().sp_max_p && tune().sp && pregate(P, w.cand1) && pregate(P, w.cand2))) return false;
-  // every layer that changes its launch must be one the small-P kernel takes (its AFFINE epilogue alone has the blend mode and acc_in)
-  const sf_conv_w* ws[5] = {&w.gates2, &w.cand2, &w.dec2, &w.cand1, &w.gates1};
-  for (const sf_conv_w* c : ws) {
-    const ConvProblem q = problem(*c, nullptr, nullptr, nullptr, B, H, W);
-    if (!sp_takes(&q, 1, EPI_AFFINE)) return false;
-  }
-  return true;
+  if (!pm.rb0.proj.w) return false;
+  // The launch GROUPS the carried form issues must all be ones the small-P kernel takes (its AFFINE epilogue alone has the blend
+  // mode and acc_in; run() refuses them elsewhere and the rollout would fail instead of falling back — ADVICE r3).  Built here with
+  // the pointers that decide sp_takes set to a non-null placeholder: sp_takes never dereferences them.
+  float* const ph = reinterpret_cast<float*>(uintptr_t(64));
+  auto prob = [&](const sf_conv_w& c, bool two_inputs) { return problem(c, ph, two_inputs ? ph : nullptr, ph, B, H, W); };
+  ConvProblem g[3];
+  // infer_state launch 1: rb0.conv1 + rb0.proj + gates2 (with the pre-gated state as second output)
+  g[0] = prob(pm.rb0.conv1, false); g[1] = prob(pm.rb0.proj, false); g[2] = prob(w.gates2, false); g[2].out2 = ph; g[2].e1 = ph;
+  if (!sp_takes(g, 3, EPI_AFFINE)) return false;
+  // launch 2: rb0.conv2 (+ residual, channel sums) + cand2 (blend mode) [+ the state half of gates1]
+  g[0] = prob(pm.rb0.conv2, false); g[0].add = ph; g[0].chansum = ph;
+  g[1] = prob(w.cand2, true); g[1].e0 = ph; g[1].e1 = ph; g[1].mode = 4;
+  int n2 = 2;
+  if (w.gates1_x.w && w.gates1_s.w && tune().pipe >= 2) { g[2] = prob(w.gates1_s, false); n2 = 3; }
+  if (!sp_takes(g, n2, EPI_AFFINE)) return false;
+  // the next cell: gates1 (x half with acc_in when the state half is carried), then cand1 (blend mode) + conv_decoder_2
+  g[0] = n2 == 3 ? prob(w.gates1_x, false) : prob(w.gates1, true);
+  g[0].out2 = ph; g[0].e1 = ph; if (n2 == 3) g[0].acc_in = ph;
+  if (!sp_takes(g, 1, EPI_AFFINE)) return false;
+  g[0] = prob(w.cand1, true); g[0].e0 = ph; g[0].e1 = ph; g[0].mode = 4;
+  g[1] = prob(w.dec2, false);
+  return sp_takes(g, 2, EPI_AFFINE);
 }
 // the two side problems of cell `w` on state `s` (= the output of the cell before it)
 void side_problems(const sf_dual_w& w, const float* s, const Carry& c, int B, int H, int W, Side& sd) {
@@ -1470,7 +1487,7 @@ int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const fl
       Arena Ai = A;
       Side sd = {};
       const Stage* nx = j + 1 < stages.size() ? &stages[j + 1] : nullptr;
-      const bool pipe = nx && nx->s == g.out && carry_ok(*nx->w, B, H, W);
+      const bool pipe = nx && nx->s == g.out && carry_ok(*nx->w, pm, B, H, W);
       if (pipe) {
         side_problems(*nx->w, g.out, cb, B, H, W, sd);
         cnow = cb;

@@ -213,16 +213,30 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
       const float sg = (i == 1) ? 1.f : -1.f;
       const float* const a = src + (((2 * tyl + r1) * PW + 2 * txl) * 4 + quad) * 4;
       const float* const bb = src + (((2 * tyl + r2) * PW + 2 * txl) * 4 + quad) * 4;
-      f32x4 w[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) w[c] = wn_lds_read128(a + c * 16) + sg * wn_lds_read128(bb + c * 16);
-      const f32x4 v0 = w[0] - w[2], v1 = w[1] + w[2], v2 = w[2] - w[1], v3 = w[1] - w[3];
       float* const o = dst + ((i * 4) * WT + wt) * 16 + ((quad ^ ((wt >> 2) & 2)) << 2);
       typedef __attribute__((address_space(3))) f32x4 lds_f4w;
-      *(lds_f4w*)(o) = v0;
-      *(lds_f4w*)(o + WT * 16) = v1;
-      *(lds_f4w*)(o + 2 * WT * 16) = v2;
-      *(lds_f4w*)(o + 3 * WT * 16) = v3;
+      if constexpr (MW == 2) {
+        f32x4 w[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[c] = wn_lds_read128(a + c * 16) + sg * wn_lds_read128(bb + c * 16);
+        *(lds_f4w*)(o) = w[0] - w[2];
+        *(lds_f4w*)(o + WT * 16) = w[1] + w[2];
+        *(lds_f4w*)(o + 2 * WT * 16) = w[2] - w[1];
+        *(lds_f4w*)(o + 3 * WT * 16) = w[1] - w[3];
+      } else {
+        // the 128-register configuration: two columns at a time (24 live registers beside the 64 accumulators instead of 48; the
+        // other workgroup of the CU covers the second LDS round trip)
+        const f32x4 w0 = wn_lds_read128(a) + sg * wn_lds_read128(bb);
+        const f32x4 w2 = wn_lds_read128(a + 32) + sg * wn_lds_read128(bb + 32);
+        *(lds_f4w*)(o) = w0 - w2;
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 w1 = wn_lds_read128(a + 16) + sg * wn_lds_read128(bb + 16);
+        *(lds_f4w*)(o + WT * 16) = w1 + w2;
+        *(lds_f4w*)(o + 2 * WT * 16) = w2 - w1;
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 w3 = wn_lds_read128(a + 48) + sg * wn_lds_read128(bb + 48);
+        *(lds_f4w*)(o + 3 * WT * 16) = w1 - w3;
+      }
     }
   };
   // ---- fragments: wave (wm, wn) = 32 cout x 16 tiles; lane (j, g): row j of a 16-row fragment, K slot g --------------------------
@@ -237,10 +251,6 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   const int wtl = wn * 16 + j;
   const int b_off = wtl * 16 + ((g ^ ((wtl >> 2) & 2)) << 2);
   f32x4 acc[16][MW];
-#pragma unroll
-  for (int p = 0; p < 16; ++p)
-#pragma unroll
-    for (int m = 0; m < MW; ++m) acc[p][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 fa[2][2][MW], fb[2][2];                                 // [set][position of the pair][m]
   auto read_frags = [&](const int S, const int set) {
     const float* const ub = Ubuf + (S % 3) * G::U_FLOATS;
@@ -266,6 +276,10 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   wn_wait(NU * (n_u0 - 1) + ((NPB == 2 && nkc > 1) ? NP : 0));  // U(0) landed (younger: U(1), U(2), patch(1))
   wn_barrier();
   if (NPB == 1 && nkc > 1) issue_patch(1);                      // one patch buffer: every wave has finished transform(0)
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int m = 0; m < MW; ++m) acc[p][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
   read_frags(0, 0);
 
   // (Measured and not kept, profiles/r04_[hij]_winobench_*: a persistent tile loop with the next tile's DMAs issued before the
@@ -352,11 +366,16 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   }
 
   // ---- output transform A^T M A (register-local) + epilogue ---------------------------------------------------------------------------
-  const int ty = ty0 + wtl / TW, tx = tx0 + wtl % TW;
+  // the lane's tile and channel quad are re-derived from a laundered lane index: nothing of them is carried through the stage loop
+  // (two registers the 128-register configuration does not have)
+  int ln_e = lane;
+  asm volatile("" : "+v"(ln_e));
+  const int wtl_e = wn * 16 + (ln_e & 15), g_e = ln_e >> 4;
+  const int ty = ty0 + wtl_e / TW, tx = tx0 + wtl_e % TW;
   const size_t img_base = (size_t)img * H * W;
 #pragma unroll
   for (int m = 0; m < MW; ++m) {
-    const int c = cout0 + wm * 16 * MW + m * 16 + 4 * g;
+    const int c = cout0 + wm * 16 * MW + m * 16 + 4 * g_e;
     // one output column bq at a time (16 + 8 live registers beside the accumulators instead of 48):
     //   t[i] = (M A)[i][bq]:  bq = 0: M[i][0] + M[i][1] + M[i][2],   bq = 1: M[i][1] - M[i][2] - M[i][3]
     //   Y[0][bq] = t[0] + t[1] + t[2],   Y[1][bq] = t[1] - t[2] - t[3]
@@ -447,18 +466,29 @@ static hipError_t launch_wino_t(const ConvLaunch& L, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(P.cout_pad / COUT_T), 1), dim3(WN_THREADS), lds, stream, L);
   return hipGetLastError();
 }
+// which tile configuration a problem runs on: 0 = 128 cout x 32 tiles, 1 = 64 cout x 64 tiles, 2 = 64 cout x 32 tiles, two
+// workgroups per CU (SF_WINO_TILE = 128 | 64 | 2 forces one: experiments); -1: none
+int wino_variant(const ConvProblem& q) {
+  static const int force = [] { const char* v = std::getenv("SF_WINO_TILE"); return v ? std::atoi(v) : 0; }();
+  if (q.cout_pad % 64) return -1;
+  if (force == 2) return 2;
+  if (force == 64) return 1;
+  if (force == 128) return q.cout_pad % 128 == 0 ? 0 : 2;
+  // measured (profiles/r04_l_winobench_tiles.txt): the 128 x 32 tile wins on the big 128-cout launches (1.35x the direct form
+  // against 1.31x), two 64 x 32 workgroups per CU everywhere else (64-cout layers 1.31-1.36x against 1.18-1.28x on 64 x 64 tiles;
+  // small launches 1.40x against 1.32x)
+  const long tiles = (long)q.n_img * ((q.Hout + 7) / 8) * ((q.Wout + 15) / 16);
+  return (q.cout_pad % 128 == 0 && tiles >= 8192) ? 0 : 2;
+}
 // one problem per launch
 hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream) {
   if (L.nprob != 1 || !wino_takes(L.p[0], epi)) return hipErrorInvalidValue;
-  // tile: 128 cout x 32 Winograd tiles (one workgroup per CU), 64 cout x 64 tiles (cout not a multiple of 128), or 64 cout x 32
-  // tiles with two workgroups per CU.  SF_WINO_TILE = 128 | 64 | 2 forces one (experiments).
-  static const int force = [] { const char* v = std::getenv("SF_WINO_TILE"); return v ? std::atoi(v) : 0; }();
   const bool affine = epi == EPI_AFFINE;
-  if (force == 2) return affine ? launch_wino_t<64, 4, 1, EPI_AFFINE>(L, stream) : launch_wino_t<64, 4, 1, EPI_BLEND>(L, stream);
-  if (L.p[0].cout_pad % 128 == 0 && force != 64)
-    return affine ? launch_wino_t<128, 4, 2, EPI_AFFINE>(L, stream) : launch_wino_t<128, 4, 2, EPI_BLEND>(L, stream);
-  if (L.p[0].cout_pad % 64 == 0)
-    return affine ? launch_wino_t<64, 8, 2, EPI_AFFINE>(L, stream) : launch_wino_t<64, 8, 2, EPI_BLEND>(L, stream);
+  switch (wino_variant(L.p[0])) {
+    case 0: return affine ? launch_wino_t<128, 4, 2, EPI_AFFINE>(L, stream) : launch_wino_t<128, 4, 2, EPI_BLEND>(L, stream);
+    case 1: return affine ? launch_wino_t<64, 8, 2, EPI_AFFINE>(L, stream) : launch_wino_t<64, 8, 2, EPI_BLEND>(L, stream);
+    case 2: return affine ? launch_wino_t<64, 4, 1, EPI_AFFINE>(L, stream) : launch_wino_t<64, 4, 1, EPI_BLEND>(L, stream);
+  }
   return hipErrorInvalidValue;
 }
 

@@ -2,7 +2,7 @@
 spilled 244-383 VGPRs and 40-59 SGPRs, which confounded its measurement).  The code objects are cut out of the fat binary and
 read with llvm-readelf --notes:
   * no kernel spills vector registers;
-  * no kernel spills scalar registers, except the three listed below, whose scalar spills (v_writelane into a spare VGPR, no memory
+  * no kernel spills scalar registers, except the few listed below, whose scalar spills (v_writelane into a spare VGPR, no memory
     traffic) sit in cold prologue / epilogue code and are bounded here so that they cannot grow unnoticed;
   * the persistent flow kernel (SF_PERSIST=1) fits the 168-register cap of a 768-thread workgroup without scratch."""
 import os
@@ -18,6 +18,7 @@ READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 SGPR_SPILL_ALLOWED = {
     "sp_flow_kernel": (16, "SE-gate prologue of the two SE-scaled phases of a step (once per item, not in the K loop)"),
     "conv_wino_kernel": (8, "tile decode / epilogue address set-up"),
+    "conv_sp_kernelILi0ELb1ELi2": (1, "SE-gate prologue of the 32-pixel-tile AFFINE kernel (one v_writelane)"),
     "dwconv7_ln_c64_kernel": (40, "row / column addresses kept in scalar registers by design (csrc/aux_kernels.hip)"),
 }
 
@@ -86,4 +87,4 @@ def test_no_kernel_spills_vector_registers_and_scalar_spills_are_bounded():
     # the small-P kernels of the default path (one launch per layer group) too: no scratch at all
     for k in ours:
         if "conv_sp_kernel" in k["name"]:
-            assert int(k["private_segment_fixed_size"]) == 0 and int(k["sgpr_spill_count"]) == 0, k["name"]
+            assert int(k["private_segment_fixed_size"]) == 0, k["name"]

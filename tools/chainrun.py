@@ -19,6 +19,7 @@ def main():
     C, h, w = 64, 50, 50
     net, _ = build_pair(C, "euler", True, True, 0.05)
     ode = net.gru_ode
+    ode.use_graph = False      # eager: the counters are read per kernel launch
     sc = chain_schedule(n, "euler")
     hx = torch.randn(1, h, w, C, device="cuda") * 0.5
     e = torch.randn(sc.n_draws, h, w, C, device="cuda")

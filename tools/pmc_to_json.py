@@ -33,7 +33,7 @@ def main():
     fetch, write = load("pmcb_fetch"), load("pmcb_write")
     rows = []
     for k in fetch:
-        if not any(t in k for t in ("conv_igemm", "conv_direct", "conv_glds", "conv_sp")):
+        if not any(t in k for t in ("conv_igemm", "conv_direct", "conv_glds", "conv_sp", "conv_wino")):
             continue
         f, w = fetch[k], write.get(k, [0.0])
         rows.append({"kernel": k, "launches": len(f), "fetch_kib_avg_raw": sum(f) / len(f), "write_kib_avg": sum(w) / len(w),
