@@ -4,6 +4,7 @@
 #include "sf_device.h"
 #include "../../include/sfnative.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -19,6 +20,7 @@ hipError_t launch_conv_sp(const ConvLaunch& L, int epi, bool scaled, int bn, hip
 hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream);
 bool wino_takes(const ConvProblem& q, int epi);
 int wino_variant(const ConvProblem& q);
+double wino_tiles(const ConvProblem& q);
 hipError_t launch_sp_flow(const SpFlow& F, int grid, bool b3, hipStream_t stream);
 hipError_t launch_flow_write(const void* host_src, void* dev_dst, size_t bytes, hipStream_t stream);
 bool sp_flow_has(int epi, bool scaled, int bn);
@@ -454,11 +456,25 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   // Winograd F(2x2, 3x3) for the 3x3 / stride-1 layers of large launches (conv_wino.hip): 2.25x fewer MACs, exact fp32 arithmetic.
   // Groups are launched problem by problem (the kernel takes one); the profiler prices the launch at its EXECUTED FLOPs (key 16).
   if (tune().wino && P >= tune().wino_min_p && (epi == EPI_AFFINE || epi == EPI_BLEND)) {
-    bool all = true;
-    for (int i = 0; i < n; ++i) all = all && wino_takes(ps[i], epi) && !(tune().b3 && ps[i].w3);
-    if (all) {
+    // the members of a group are independent layers: those the kernel takes run on it one by one, the others stay one group
+    // (the ASPP group: three dilated 3x3 branches + the 1x1 branch)
+    bool takes[SF_MAX_GROUP];
+    int n_wino = 0;
+    for (int i = 0; i < n; ++i) {
+      takes[i] = (double)ps[i].n_img * ps[i].Hout * ps[i].Wout >= tune().wino_min_p && wino_takes(ps[i], epi) && !(tune().b3 && ps[i].w3);
+      n_wino += takes[i] ? 1 : 0;
+    }
+    if (n_wino > 0) {
       SF_TRY(seg_flush());
+      if (n_wino < n) {
+        ConvProblem rest[SF_MAX_GROUP];
+        int nr = 0;
+        for (int i = 0; i < n; ++i)
+          if (!takes[i]) rest[nr++] = ps[i];
+        SF_TRY(run(rest, nr, epi, st));
+      }
       for (int i = 0; i < n; ++i) {
+        if (!takes[i]) continue;
         ConvLaunch W1;
         std::memset(&W1, 0, sizeof(W1));
         W1.p[0] = ps[i];
@@ -469,8 +485,8 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
         }
         const ConvProblem& q = ps[i];
         ProfRec r;
-        r.key = (16 + wino_variant(q)) * 8 + epi;      // _lib.KERNEL_NAMES: wino128x32t / wino64x64t / wino64x32t2
-        const double tiles = (double)q.n_img * ((q.Hout + 1) / 2) * ((q.Wout + 1) / 2);
+        r.key = (16 + wino_variant(q)) * 8 + epi;      // _lib.KERNEL_NAMES: wino128x32t / wino64x64t / wino64x32t2 / wino64x32t2dil
+        const double tiles = wino_tiles(q);
         r.flops = 2.0 * 16.0 * tiles * q.cout * (q.c0 + q.c1);      // executed: 16 products per 2x2 outputs and (cin, cout) pair
         r.bytes = 4.0 * ((double)q.n_img * q.Hin * q.Win * (q.c0 + q.c1) + 16.0 * q.cout * (q.c0 + q.c1) + (double)q.n_img * q.Hout * q.Wout * q.cout);
         r.a = g_prof.get(); r.b = g_prof.get();
@@ -481,6 +497,14 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       }
       return SF_OK;
     }
+    static const bool why = std::getenv("SF_WINO_WHY") != nullptr;      // debugging aid: which large 3x3 launches keep the direct form
+    if (why)
+      for (int i = 0; i < n; ++i)
+        if (ps[i].KH == 3 && !wino_takes(ps[i], epi))
+          std::fprintf(stderr, "[sf] direct 3x3: n=%d/%d %dx%d c=%d+%d->%d stride=%d dil=%d up=%d gather=%d gate=%d in_scale=%d se_sum=%d nsplit=%d chansum=%d acc_in=%d fuse=%d mode=%d wino=%d\n",
+                       i, n, ps[i].Hout, ps[i].Wout, ps[i].c0, ps[i].c1, ps[i].cout, ps[i].stride, ps[i].dil, ps[i].in_up, ps[i].gather != nullptr,
+                       ps[i].gate != nullptr, ps[i].in_scale != nullptr, ps[i].se_sum != nullptr, ps[i].nsplit, ps[i].chansum != nullptr,
+                       ps[i].acc_in != nullptr, ps[i].fuse_w != nullptr, ps[i].mode, ps[i].w_wino != nullptr);
   }
   if (sp_takes(ps, n, epi)) {
     // K ranges are split across workgroups (sc1 slab hand-off) so that the launch has about sp_split_wgs workgroups of

@@ -32,10 +32,15 @@ typedef __attribute__((address_space(3))) void wn_lds_void;
 // MW: 16-row cout tiles per wave (2: wave = 32 cout x 16 tiles, 128 accumulator registers, one workgroup per CU;
 //     1: wave = 16 cout x 16 tiles, 64 accumulator registers, <= 128 registers and <= 80 KB LDS: TWO workgroups per CU, each
 //     one's barriers, transform, prologue and epilogue under the other's MFMAs)
-template <int COUT_T, int TH, int MW>
+// DIL: dilated 3x3 (pad = dilation) as d x d interleaved undilated problems ("phases": output pixel (y, x) belongs to phase
+//     (y mod d, x mod d) and sees only input pixels of its own phase).  The tile grid of a workgroup is the product of two lists —
+//     along x: for every phase p its ceil(len(p) / 2) tiles in turn, along y the same — so a block of TH x 8 tiles may span up to
+//     RY x RX phases, and the patch keeps 2 n + 2 rows / columns per run of n tiles of one phase.
+template <int COUT_T, int TH, int MW, bool DIL = false>
 struct WinoGeo {
   static constexpr int TW = 8, WT = TH * TW;                   // Winograd tiles of a workgroup: TH rows x 8 columns
-  static constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;       // input patch (pixels)
+  static constexpr int RY = 2, RX = 4;                         // DIL: runs (phases) a block may span: >= 3 tiles per phase (wino_takes)
+  static constexpr int PH = 2 * TH + (DIL ? 2 * RY : 2), PW = 2 * TW + (DIL ? 2 * RX : 2);       // input patch (pixels)
   static constexpr int NPX = PH * PW;
   static constexpr int WMW = COUT_T / (16 * MW), WNW = WT / 16; // waves along cout / tiles
   static_assert(WMW * WNW == 8, "eight waves");
@@ -45,8 +50,10 @@ struct WinoGeo {
   static constexpr int NPB = MW == 2 ? 2 : 1;                  // patch buffers (1: the next patch is issued behind the chunk-boundary barrier)
   static constexpr int U_FLOATS = 2 * COUT_T * 16;             // one stage
   static constexpr int V_FLOATS = 16 * WT * 16;                // one chunk
-  static constexpr int P_FLOATS = 8 * NP * 64 * 4;             // one patch, padded to whole DMAs
-  static constexpr int LDS_FLOATS = 3 * U_FLOATS + NVB * V_FLOATS + NPB * P_FLOATS;
+  static constexpr int ND = (NPX * 4 + 63) / 64;               // DIL: patch DMAs of the workgroup (wave w issues pieces w, w + 8, ...)
+  static constexpr int P_FLOATS = DIL ? ND * 256 : 8 * NP * 64 * 4;      // one patch, padded to whole DMAs
+  static constexpr int PARK = DIL ? 512 : 0;                   // DIL: one loop-invariant word per thread kept in LDS instead of a register
+  static constexpr int LDS_FLOATS = 3 * U_FLOATS + NVB * V_FLOATS + NPB * P_FLOATS + PARK;
   static constexpr int WG_PER_CU = MW == 2 ? 1 : 2;
 };
 
@@ -115,10 +122,41 @@ __device__ __forceinline__ void wn_epilogue(const ConvProblem& P, float4 v, cons
   spm_st4(P.out + gp * P.out_cs + P.out_co + c, y);
 }
 
-template <int COUT_T, int TH, int MW, int EPI>
+// one axis of the dilated tile grid: N pixels, dilation d: phases p < r have q + 1 pixels (tb tiles), the others q (ts tiles)
+struct WnAxis {
+  int d, r, tb, ts, nt;
+  __host__ __device__ WnAxis(int N, int dil) : d(dil) {
+    const int q = N / dil;
+    r = N - q * dil; tb = (q + 2) >> 1; ts = (q + 1) >> 1; nt = r * tb + (dil - r) * ts;
+  }
+  __host__ __device__ int tiles(int p) const { return p < r ? tb : ts; }
+  __host__ __device__ void decode(int X, int& p, int& t) const {     // list index -> (phase, tile of the phase)
+    const int nb = r * tb;
+    if (X < nb) { p = X / tb; t = X - p * tb; }
+    else { const int x2 = X - nb; const int pp = x2 / ts; p = r + pp; t = x2 - pp * ts; }
+  }
+  // patch row / column pc of a block that starts at (phase p0, tile t0) and holds n_blk tiles -> pixel coordinate; false: zero fill
+  __host__ __device__ bool patch_coord(int pc, int p0, int t0, int n_blk, int N, int& coord) const {
+    int c = 0, ph = p0, tstart = t0, left = n_blk;
+    for (int run = 0; run < 4 && left > 0; ++run) {
+      const int have = tiles(ph) - tstart;
+      const int n = have < left ? have : left;
+      if (pc < c + 2 * n + 2) {
+        const int xs = 2 * tstart - 1 + (pc - c);
+        coord = ph + d * xs;
+        return ph < d && xs >= 0 && coord < N;
+      }
+      c += 2 * n + 2; left -= n; ph += 1; tstart = 0;
+    }
+    return false;
+  }
+};
+
+template <int COUT_T, int TH, int MW, int EPI, bool DIL = false>
 __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kernel(const ConvLaunch L) {
-  typedef WinoGeo<COUT_T, TH, MW> G;
+  typedef WinoGeo<COUT_T, TH, MW, DIL> G;
   constexpr int TW = G::TW, WT = G::WT, PW = G::PW, NU = G::NU, NP = G::NP, NVB = G::NVB, NPB = G::NPB;
+  static_assert(!DIL || (NVB == 1 && NPB == 1), "the dilated form exists for the two-workgroup configuration");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const Ubuf = smem;
   float* const Vbuf = Ubuf + 3 * G::U_FLOATS;
@@ -126,14 +164,17 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   const ConvProblem& P = L.p[0];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int H = P.Hout, W = P.Wout;                            // stride 1, pad 1: input size = output size
-  const int tiles_x = (W + 1) >> 1, tiles_y = (H + 1) >> 1;
+  const int H = P.Hout, W = P.Wout;                            // stride 1, pad = dilation: input size = output size
+  const WnAxis ax(DIL ? W : 2, DIL ? P.dil : 1), ay(DIL ? H : 2, DIL ? P.dil : 1);      // plain form: constants, folded away
+  const int tiles_x = DIL ? ax.nt : (W + 1) >> 1, tiles_y = DIL ? ay.nt : (H + 1) >> 1;
   const int nbx = (tiles_x + TW - 1) / TW, nby = (tiles_y + TH - 1) / TH;
   int b = (int)blockIdx.x;
   const int bx = b % nbx; b /= nbx;
   const int by = b % nby;
   const int img = b / nby;
-  const int ty0 = by * TH, tx0 = bx * TW;
+  const int ty0 = by * TH, tx0 = bx * TW;                      // DIL: indices into the tile lists of the two axes
+  int px0 = 0, pt0 = 0, py0 = 0, qt0 = 0;                      // DIL: (phase, tile) of the block's first column / row
+  if constexpr (DIL) { ax.decode(tx0, px0, pt0); ay.decode(ty0, py0, qt0); }
   const int cout0 = (int)blockIdx.y * COUT_T;
   const int nkc = P.cin_pad >> 4;                              // 16-channel chunks
   const int NS = nkc * 8;                                      // stages
@@ -150,27 +191,37 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   const __amdgpu_buffer_rsrc_t rsrc_u = make_rsrc(P.w_wino, (size_t)nkc * 16 * P.cout_pad * 16 * sizeof(float));
 #endif
   // ---- patch DMA: element e = (pixel, channel quad) of the (2TH+2) x 18 patch, 16 bytes each, LDS linear in e -----------------
-  int pv0[NP], pv1[NP];
+  // DIL: DMA `idx = d * 8 + wave` of the G::ND the patch needs (wave w issues npw of them); one input tensor (wino_takes)
+  int pv0[NP], pv1[DIL ? 1 : NP];
+  const int npw = DIL ? (G::ND / 8 + (wave < G::ND % 8 ? 1 : 0)) : NP;      // wave-uniform
 #pragma unroll
   for (int d = 0; d < NP; ++d) {
-    const int e = (wave * NP + d) * 64 + lane;
+    const int e = (DIL ? d * 8 + wave : wave * NP + d) * 64 + lane;
     const int pix = e >> 2, quad = e & 3;
     const int py = pix / PW, px = pix - py * PW;
-    const int iy = 2 * ty0 - 1 + py, ix = 2 * tx0 - 1 + px;
-    const bool ok = pix < G::NPX && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    int iy = 2 * ty0 - 1 + py, ix = 2 * tx0 - 1 + px;
+    bool ok = pix < G::NPX && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    if constexpr (DIL) {
+      const bool oky = ay.patch_coord(py, py0, qt0, TH, H, iy), okx = ax.patch_coord(px, px0, pt0, TW, W, ix);
+      ok = pix < G::NPX && oky && okx;
+    }
     const int pofs = iy * W + ix;
     pv0[d] = ok ? (pofs * P.in0_cs + quad * 4) * 4 : (int)0x80000000;      // + the chunk's channel offset stays out of range: zero fill
-    pv1[d] = ok ? (pofs * P.in1_cs - c0 + quad * 4) * 4 : (int)0x80000000;
+    if constexpr (!DIL) pv1[d] = ok ? (pofs * P.in1_cs - c0 + quad * 4) * 4 : (int)0x80000000;
   }
   auto issue_patch = [&](const int kc) {
     float* const dst = Pbuf + (NPB == 2 ? (kc & 1) : 0) * G::P_FLOATS;
-    const bool from1 = kc * 16 >= c0;                           // wave-uniform: the whole chunk reads in1 (c0 % 16 == 0)
+    const bool from1 = !DIL && kc * 16 >= c0;                   // wave-uniform: the whole chunk reads in1 (c0 % 16 == 0)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
     for (int d = 0; d < NP; ++d) {
-      float* const dB = dst + (wave * NP + d) * 256;
-      if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (wn_lds_void*)dB, 16, pv1[d] + kc * 64, 0, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, pv0[d] + kc * 64, 0, 0, 0);
+      if constexpr (DIL) {
+        if (d < npw) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)(dst + (d * 8 + wave) * 256), 16, pv0[d] + kc * 64, 0, 0, 0);
+      } else {
+        float* const dB = dst + (wave * NP + d) * 256;
+        if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (wn_lds_void*)dB, 16, pv1[d] + kc * 64, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, pv0[d] + kc * 64, 0, 0, 0);
+      }
     }
 #else
     (void)dst; (void)from1;
@@ -200,19 +251,36 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   };
   // ---- input transform: task (tile wt, channel quad, row i of B^T d B): 8 reads, 8 add/sub, 4 writes (float4) ------------------
   constexpr int NTASK = WT * 16 / WN_THREADS;                  // 1 (32 tiles) or 2 (64 tiles)
+  float* const Park = Pbuf + NPB * G::P_FLOATS;
+  if constexpr (DIL) {
+    static_assert(!DIL || NTASK == 1, "one transform task per thread");
+    const int quad = tid & 3, wt = (tid >> 2) % WT;
+    const int tyl = wt / TW, txl = wt - tyl * TW;
+    int pX, tX, pY, tY;
+    ax.decode(tx0 + txl, pX, tX);
+    ay.decode(ty0 + tyl, pY, tY);
+    int rx = pX - px0, ry = pY - py0;                          // run of the tile inside the block (clamped: tiles beyond the grid read junk, masked later)
+    rx = rx < G::RX ? rx : G::RX - 1; ry = ry < G::RY ? ry : G::RY - 1;
+    *(__attribute__((address_space(3))) int*)(Park + tid) = ((2 * tyl + 2 * ry) * PW + 2 * txl + 2 * rx) * 16 + quad * 4;
+  }
   auto transform = [&](const int kc) {
     const float* const src = Pbuf + (NPB == 2 ? (kc & 1) : 0) * G::P_FLOATS;
     float* const dst = Vbuf + (NVB == 2 ? (kc & 1) : 0) * G::V_FLOATS;
 #pragma unroll
     for (int t = 0; t < NTASK; ++t) {
+      // task = (row i of B^T d B, tile wt, channel quad): i is the same for a whole wave (its row pair and sign are scalars) and
+      // consecutive lanes walk (quad, tile), so that the four V rows a lane writes — and the eight lanes of a ds_write_b128 group —
+      // are 128 contiguous bytes (with i in the low lane bits the writes were 4-way bank conflicts: 33-40 % of the LDS cycles)
       const int task = tid + t * WN_THREADS;
-      const int i = task & 3, quad = (task >> 2) & 3, wt = task >> 4;
+      const int i = __builtin_amdgcn_readfirstlane(task / (WT * 4)), quad = task & 3, wt = (task >> 2) % WT;
       const int tyl = wt / TW, txl = wt - tyl * TW;
       // B^T rows: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
       const int r1 = (i == 0) ? 0 : (i == 2 ? 2 : 1), r2 = (i == 3) ? 3 : (i == 2 ? 1 : 2);
       const float sg = (i == 1) ? 1.f : -1.f;
-      const float* const a = src + (((2 * tyl + r1) * PW + 2 * txl) * 4 + quad) * 4;
-      const float* const bb = src + (((2 * tyl + r2) * PW + 2 * txl) * 4 + quad) * 4;
+      // the tile's first patch pixel: rows / columns 2 t for the plain form; DIL: 2 t + 2 (run of the tile), parked in LDS
+      const int tp = DIL ? *(const __attribute__((address_space(3))) int*)(Park + tid) : ((2 * tyl) * PW + 2 * txl) * 16 + quad * 4;
+      const float* const a = src + tp + r1 * PW * 16;
+      const float* const bb = src + tp + r2 * PW * 16;
       float* const o = dst + ((i * 4) * WT + wt) * 16 + ((quad ^ ((wt >> 2) & 2)) << 2);
       typedef __attribute__((address_space(3))) f32x4 lds_f4w;
       if constexpr (MW == 2) {
@@ -335,7 +403,7 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (st < 7) {                                               // inside a chunk: as the two-buffer kernel
           const bool patch_young = st <= 1 && more;                 // the patch is issued at the chunk boundary: young for two stages
-          wn_wait(((st < 6 || more) ? NU : 0) + (patch_young ? NP : 0));
+          wn_wait(((st < 6 || more) ? NU : 0) + (patch_young ? npw : 0));
           wn_barrier();
           if (st < 5 || more) issue_u(S + 3);
           read_frags(S + 1, set ^ 1);
@@ -373,6 +441,16 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   const int wtl_e = wn * 16 + (ln_e & 15), g_e = ln_e >> 4;
   const int ty = ty0 + wtl_e / TW, tx = tx0 + wtl_e % TW;
   const size_t img_base = (size_t)img * H * W;
+  // output pixel (2 t + i) of the tile; DIL: pixel 2 t + i of the tile's phase = phase + d (2 t + i)
+  int oy0 = 2 * ty, ox0 = 2 * tx, ostep = 1;
+  if constexpr (DIL) {
+    int pX, tX, pY, tY;
+    ax.decode(tx, pX, tX);
+    ay.decode(ty, pY, tY);
+    ostep = P.dil;
+    ox0 = (tx < ax.nt && pX < ostep) ? pX + ostep * 2 * tX : W;     // beyond the tile list: masked by the range checks below
+    oy0 = (ty < ay.nt && pY < ostep) ? pY + ostep * 2 * tY : H;
+  }
 #pragma unroll
   for (int m = 0; m < MW; ++m) {
     const int c = cout0 + wm * 16 * MW + m * 16 + 4 * g_e;
@@ -387,11 +465,11 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
         t[i] = bq == 0 ? acc[4 * i + 0][m] + acc[4 * i + 1][m] + acc[4 * i + 2][m] : acc[4 * i + 1][m] - acc[4 * i + 2][m] - acc[4 * i + 3][m];
       const f32x4 y0 = t[0] + t[1] + t[2], y1 = t[1] - t[2] - t[3];
       if (c < P.cout) {
-        const int ox = 2 * tx + bq;
+        const int ox = ox0 + bq * ostep;
         if (ox < W) {
-          const int oy = 2 * ty;
+          const int oy = oy0;
           if (oy < H) wn_epilogue<EPI>(P, make_float4(y0[0], y0[1], y0[2], y0[3]), img_base + (size_t)oy * W + ox, c, img);
-          if (oy + 1 < H) wn_epilogue<EPI>(P, make_float4(y1[0], y1[1], y1[2], y1[3]), img_base + (size_t)(oy + 1) * W + ox, c, img);
+          if (oy + ostep < H) wn_epilogue<EPI>(P, make_float4(y1[0], y1[1], y1[2], y1[3]), img_base + (size_t)(oy + ostep) * W + ox, c, img);
         }
       }
     }
@@ -436,20 +514,22 @@ hipError_t launch_wino_weights(const float* w, float* U, int cout_pad, int cin_p
 // in whole 16-channel chunks; transformed weights present; images of at least one workgroup tile
 bool wino_takes(const ConvProblem& q, int epi) {
   if (epi != EPI_AFFINE && epi != EPI_BLEND) return false;
-  if (!q.w_wino || q.KH != 3 || q.KW != 3 || q.stride != 1 || q.dil != 1 || q.pad != 1 || q.in_up || q.gather || q.gate || q.in_scale || q.se_sum ||
+  if (!q.w_wino || q.KH != 3 || q.KW != 3 || q.stride != 1 || q.dil < 1 || q.pad != q.dil || q.in_up || q.gather || q.gate || q.in_scale || q.se_sum ||
       q.nsplit > 1 || q.chansum || q.acc_in || q.fuse_w || (epi == EPI_AFFINE && (q.mode & 4)))
     return false;
   if ((q.c0 % 16) || (q.c1 % 16) || q.c0 + q.c1 != q.cin_pad || (q.cout_pad % 64) || (q.cout % 4)) return false;
   if (q.Hout != q.Hin || q.Wout != q.Win || q.Hout < 16 || q.Wout < 32) return false;
+  // dilated (conv_wino_kernel<.., DIL>): one input tensor, AFFINE epilogue, every phase of both axes at least 5 pixels = 3 tiles long
+  if (q.dil > 1 && (q.c1 != 0 || epi != EPI_AFFINE || q.Hout / q.dil < 5 || q.Wout / q.dil < 5)) return false;
   const double img_bytes = 4.0 * q.Hin * q.Win;
   if (img_bytes * q.in0_cs >= 2147483648.0 || img_bytes * q.in1_cs >= 2147483648.0 || 4.0 * 16 * q.cout_pad * q.cin_pad >= 2147483648.0) return false;
   return true;
 }
 
-template <int COUT_T, int TH, int MW, int EPI>
+template <int COUT_T, int TH, int MW, int EPI, bool DIL = false>
 static hipError_t launch_wino_t(const ConvLaunch& L, hipStream_t stream) {
-  typedef WinoGeo<COUT_T, TH, MW> G;
-  auto kern = conv_wino_kernel<COUT_T, TH, MW, EPI>;
+  typedef WinoGeo<COUT_T, TH, MW, DIL> G;
+  auto kern = conv_wino_kernel<COUT_T, TH, MW, EPI, DIL>;
   constexpr int lds = G::LDS_FLOATS * 4;
   static bool attr_done[64] = {};
   int dev = 0;
@@ -460,7 +540,7 @@ static hipError_t launch_wino_t(const ConvLaunch& L, hipStream_t stream) {
     attr_done[dev] = true;
   }
   const ConvProblem& P = L.p[0];
-  const int tiles_x = (P.Wout + 1) / 2, tiles_y = (P.Hout + 1) / 2;
+  const int tiles_x = DIL ? WnAxis(P.Wout, P.dil).nt : (P.Wout + 1) / 2, tiles_y = DIL ? WnAxis(P.Hout, P.dil).nt : (P.Hout + 1) / 2;
   const long blocks = (long)P.n_img * ((tiles_y + TH - 1) / TH) * ((tiles_x + G::TW - 1) / G::TW);
   if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(P.cout_pad / COUT_T), 1), dim3(WN_THREADS), lds, stream, L);
@@ -471,23 +551,34 @@ static hipError_t launch_wino_t(const ConvLaunch& L, hipStream_t stream) {
 int wino_variant(const ConvProblem& q) {
   static const int force = [] { const char* v = std::getenv("SF_WINO_TILE"); return v ? std::atoi(v) : 0; }();
   if (q.cout_pad % 64) return -1;
-  if (force == 2) return 2;
+  if (q.dil > 1) return 3;      // the dilated form of configuration 2
+#if defined(SF_WINO_ALL_TILES)      // the one-workgroup-per-CU configurations are built for experiments only (tools/r02/build_variant.sh)
   if (force == 64) return 1;
   if (force == 128) return q.cout_pad % 128 == 0 ? 0 : 2;
-  // measured (profiles/r04_l_winobench_tiles.txt): the 128 x 32 tile wins on the big 128-cout launches (1.35x the direct form
-  // against 1.31x), two 64 x 32 workgroups per CU everywhere else (64-cout layers 1.31-1.36x against 1.18-1.28x on 64 x 64 tiles;
-  // small launches 1.40x against 1.32x)
-  const long tiles = (long)q.n_img * ((q.Hout + 7) / 8) * ((q.Wout + 15) / 16);
-  return (q.cout_pad % 128 == 0 && tiles >= 8192) ? 0 : 2;
+#else
+  (void)force;
+#endif
+  // measured (profiles/r04_o_winobench_two_wg_per_cu_vs_128x32.txt): two 64 x 32 workgroups per CU win on every layer — the
+  // 128 -> 128 layer on 224 frames 12.4 ms against 14.3 ms on 128 x 32 tiles (19.4 ms direct), 64-cout layers 1.59-1.62x the direct
+  // form against 1.18-1.28x on 64 x 64 tiles
+  return 2;
+}
+// Winograd tiles a launch executes (the profiler prices 16 products per tile and (cin, cout) pair)
+double wino_tiles(const ConvProblem& q) {
+  if (q.dil > 1) return (double)q.n_img * WnAxis(q.Hout, q.dil).nt * WnAxis(q.Wout, q.dil).nt;
+  return (double)q.n_img * ((q.Hout + 1) / 2) * ((q.Wout + 1) / 2);
 }
 // one problem per launch
 hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream) {
   if (L.nprob != 1 || !wino_takes(L.p[0], epi)) return hipErrorInvalidValue;
   const bool affine = epi == EPI_AFFINE;
   switch (wino_variant(L.p[0])) {
+#if defined(SF_WINO_ALL_TILES)
     case 0: return affine ? launch_wino_t<128, 4, 2, EPI_AFFINE>(L, stream) : launch_wino_t<128, 4, 2, EPI_BLEND>(L, stream);
     case 1: return affine ? launch_wino_t<64, 8, 2, EPI_AFFINE>(L, stream) : launch_wino_t<64, 8, 2, EPI_BLEND>(L, stream);
+#endif
     case 2: return affine ? launch_wino_t<64, 4, 1, EPI_AFFINE>(L, stream) : launch_wino_t<64, 4, 1, EPI_BLEND>(L, stream);
+    case 3: return affine ? launch_wino_t<64, 4, 1, EPI_AFFINE, true>(L, stream) : hipErrorInvalidValue;
   }
   return hipErrorInvalidValue;
 }

@@ -156,7 +156,7 @@ int sf_pack_conv(const float* weight, const float* conv_bias, const float* scale
     hipLaunchKernelGGL(pack_split_bf16_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, wp, groups, reinterpret_cast<unsigned*>(w3));
   }
   float* wu = nullptr;
-  if (wino_packable(cp, ip, cin, kh, kw, flags) && stride == 1 && dil == 1 && (pad < 0 || pad == 1) && (c0 % 16) == 0 && (c1 % 16) == 0) {
+  if (wino_packable(cp, ip, cin, kh, kw, flags) && stride == 1 && (pad < 0 || pad == dil) && (c0 % 16) == 0 && (c1 % 16) == 0) {
     wu = bp + a64((size_t)cp) + ((flags & SF_PACK_BF16X3) ? a64((size_t)total) : 0);
     if (launch_wino_weights(wp, wu, cp, ip, st) != hipSuccess) return SF_ERR_LAUNCH;
   }

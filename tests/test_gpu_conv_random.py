@@ -181,6 +181,15 @@ _WINO = [
     dict(c0=64, c1=64, cout=64, n=5, H=181, W=187),
     dict(c0=128, c1=0, cout=192, n=4, H=150, W=231),
     dict(c0=32, c1=0, cout=64, n=30, H=67, W=70),
+    # dilated (pad = dilation: the ASPP branches): d x d interleaved phases, tile lists per axis, blocks spanning several phases;
+    # phases of two lengths, odd phase lengths (half-used last tile), the largest dilation the kernel takes (5 pixels per phase)
+    dict(c0=64, c1=0, cout=128, n=4, H=200, W=200, dil=12, pad=12),
+    dict(c0=64, c1=0, cout=128, n=4, H=200, W=200, dil=24, pad=24),
+    dict(c0=64, c1=0, cout=128, n=4, H=200, W=200, dil=36, pad=36),
+    dict(c0=32, c1=0, cout=64, n=6, H=157, W=171, dil=7, pad=7),
+    dict(c0=32, c1=0, cout=192, n=3, H=203, W=241, dil=40, pad=40),
+    dict(c0=64, c1=0, cout=64, n=4, H=181, W=187, dil=2, pad=2),
+    dict(c0=48, c1=0, cout=64, n=44, H=50, W=64, dil=3, pad=3),
 ]
 
 

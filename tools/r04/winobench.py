@@ -29,8 +29,16 @@ def main():
              ("128->128, 8 x 200x200", 8, 200, 200, 128, 0, 128),
              ("decoder / encoder 64->64, 224 x 200x200", 224, 200, 200, 64, 0, 64),
              ("GRU candidate cat[64|64]->64, 224 x 200x200", 224, 200, 200, 64, 64, 64),
-             ("128->64, 256 x 100x100", 256, 100, 100, 128, 0, 64)]
-    for name, n, H, W, c0, c1, cout in cases:
+             ("128->64, 256 x 100x100", 256, 100, 100, 128, 0, 64),
+             ("ASPP branch 64->128 dilation 12, 224 x 200x200", 224, 200, 200, 64, 0, 128, 12),
+             ("ASPP branch 64->128 dilation 24, 224 x 200x200", 224, 200, 200, 64, 0, 128, 24),
+             ("ASPP branch 64->128 dilation 36, 224 x 200x200", 224, 200, 200, 64, 0, 128, 36)]
+    only = os.environ.get("WINOBENCH_ONLY")
+    for case in cases:
+        name, n, H, W, c0, c1, cout = case[:7]
+        dil = case[7] if len(case) > 7 else 1
+        if only and only not in name:
+            continue
         g = torch.Generator(device="cuda").manual_seed(1)
         a0 = torch.randn((n, H, W, c0), device=dev, generator=g)
         a1 = torch.randn((n, H, W, c1), device=dev, generator=g) if c1 else None
@@ -40,7 +48,7 @@ def main():
         for mode in ("direct", "winograd"):
             packing.set_winograd(mode == "winograd")
             pk = packing.Pack(None)
-            cw = packing.conv_w(pk, w, c0, c1, act="relu", pad=1)
+            cw = packing.conv_w(pk, w, c0, c1, act="relu", dil=dil, pad=dil)
             args = (ctypes.byref(cw), runtime.ptr(a0), runtime.ptr(a1), None, ctypes.c_void_p(out.data_ptr()), n, H, W, 0)
             _lib.check(L.sf_conv2d_repeat(*args, 2, None, 0, runtime.stream_ptr(dev)), "warm")
             torch.cuda.synchronize()
@@ -53,7 +61,10 @@ def main():
         packing.set_winograd(True)
         P = n * H * W
         flops_direct = 2.0 * P * cout * 9 * (c0 + c1)
-        flops_wino = 2.0 * 16 * n * ((H + 1) // 2) * ((W + 1) // 2) * cout * (c0 + c1)
+        def axis_tiles(N):      # conv_wino.hip WnAxis: phases p < N % d have N // d + 1 pixels
+            q, r = divmod(N, dil)
+            return r * ((q + 2) // 2) + (dil - r) * ((q + 1) // 2)
+        flops_wino = 2.0 * 16 * n * axis_tiles(H) * axis_tiles(W) * cout * (c0 + c1)
         td, tw = res["direct"][0], res["winograd"][0]
         rows.append({"layer": name, "direct_ms": td, "winograd_ms": tw, "speedup": td / tw,
                      "direct_tflops": flops_direct / td * 1e-9, "winograd_executed_tflops": flops_wino / tw * 1e-9,
