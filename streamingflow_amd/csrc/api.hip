@@ -16,6 +16,7 @@ hipError_t launch_conv_glds(const ConvLaunch& L, int epi, int tile, int variant,
 hipError_t set_stamp_buffer(unsigned long long* p);
 int glds_occupancy(int which);
 hipError_t set_stamp_buffer_sp(unsigned long long* p);
+hipError_t set_stamp_buffer_wino(unsigned long long* p);
 hipError_t launch_conv_sp(const ConvLaunch& L, int epi, bool scaled, int bn, hipStream_t stream);
 hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream);
 bool wino_takes(const ConvProblem& q, int epi);
@@ -479,6 +480,8 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
         std::memset(&W1, 0, sizeof(W1));
         W1.p[0] = ps[i];
         W1.nprob = 1;
+        W1.stamp_slot = g_stamp_slot;
+        if (g_stamp_on) g_stamp_slot = (g_stamp_slot + 1) % 64;
         if (!g_prof.on) {
           SF_HIP(launch_conv_wino(W1, epi, st));
           continue;
@@ -1841,7 +1844,9 @@ int sf_set_flow_mode(int on) {
 }
 
 int sf_debug_stamps(void* buf) {
-  if (set_stamp_buffer((unsigned long long*)buf) != hipSuccess || set_stamp_buffer_sp((unsigned long long*)buf) != hipSuccess) return SF_ERR_UNSUPPORTED;
+  if (set_stamp_buffer((unsigned long long*)buf) != hipSuccess || set_stamp_buffer_sp((unsigned long long*)buf) != hipSuccess ||
+      set_stamp_buffer_wino((unsigned long long*)buf) != hipSuccess)
+    return SF_ERR_UNSUPPORTED;
   g_stamp_on = buf != nullptr;
   g_stamp_slot = 0;
   return SF_OK;

@@ -23,8 +23,16 @@
 #include "sf_math.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace sf {
+
+#ifdef SF_STAMP
+static __device__ unsigned long long* g_sf_stamps = nullptr;      // diagnostic builds: in-kernel time stamps (sf_device.h)
+hipError_t set_stamp_buffer_wino(unsigned long long* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_sf_stamps), &p, sizeof(p)); }
+#else
+hipError_t set_stamp_buffer_wino(unsigned long long*) { return hipErrorNotSupported; }
+#endif
 
 constexpr int WN_THREADS = 512;
 typedef __attribute__((address_space(3))) void wn_lds_void;
@@ -50,10 +58,17 @@ struct WinoGeo {
   static constexpr int NPB = MW == 2 ? 2 : 1;                  // patch buffers (1: the next patch is issued behind the chunk-boundary barrier)
   static constexpr int U_FLOATS = 2 * COUT_T * 16;             // one stage
   static constexpr int V_FLOATS = 16 * WT * 16;                // one chunk
-  static constexpr int ND = (NPX * 4 + 63) / 64;               // DIL: patch DMAs of the workgroup (wave w issues pieces w, w + 8, ...)
-  static constexpr int P_FLOATS = DIL ? ND * 256 : 8 * NP * 64 * 4;      // one patch, padded to whole DMAs
+  static constexpr bool COMPACT = DIL || MW == 1;              // patch = exactly ND DMAs (wave w issues pieces w, w + 8, ...) instead of NP per wave
+  static constexpr int ND = (NPX * 4 + 63) / 64;
+  static constexpr int P_FLOATS = COMPACT ? ND * 256 : 8 * NP * 64 * 4;      // one patch, padded to whole DMAs
   static constexpr int PARK = DIL ? 512 : 0;                   // DIL: one loop-invariant word per thread kept in LDS instead of a register
-  static constexpr int LDS_FLOATS = 3 * U_FLOATS + NVB * V_FLOATS + NPB * P_FLOATS + PARK;
+#if defined(SF_WINO_RING)
+  static constexpr int RING = SF_WINO_RING;
+#else
+  static constexpr int RING = (MW == 1 && !DIL) ? 4 : 3;       // U stages in LDS (RING - 1 in flight); what fits twice into a CU's 160 KB
+#endif
+  static constexpr int SB = 2 * COUT_T;                        // the workgroup's scale / bias rows, staged in the prologue for the epilogue
+  static constexpr int LDS_FLOATS = RING * U_FLOATS + NVB * V_FLOATS + NPB * P_FLOATS + PARK + SB;
   static constexpr int WG_PER_CU = MW == 2 ? 1 : 2;
 };
 
@@ -83,12 +98,39 @@ __device__ __forceinline__ void wn_wait(const int n) {
   }
 }
 
-// per-element epilogue: v = the lane's four consecutive output channels c .. c+3 of pixel gp (semantics of conv_igemm.hip run_epilogue)
+// Epilogue arithmetic (semantics of conv_igemm.hip run_epilogue).  fp32 MFMAs and vector-ALU instructions share one issue port, and a
+// tile's epilogue runs beside the partner workgroup's stage loop: every vector instruction here is matrix time (in-kernel stamps,
+// profiles/r04_x_stamps_wino.txt: 27-36 cycles per instruction, 5 us per tile).  So: packed fp32 adds / fmas on register pairs,
+// addresses as a uniform 64-bit base per output pixel + ONE 32-bit lane offset per tensor (scalar arithmetic; the saddr form of
+// global_load / global_store), lane masks as scalar conditions, operand loads requested before the output transform.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 wn_sub2(const f32x2 a, const f32x2 b) { return __builtin_elementwise_fma(b, (f32x2){-1.f, -1.f}, a); }   // v_pk_fma_f32
+__device__ __forceinline__ f32x2 wn_lo(const f32x4 v) { return (f32x2){v[0], v[1]}; }
+__device__ __forceinline__ f32x2 wn_hi(const f32x4 v) { return (f32x2){v[2], v[3]}; }
+struct WnOps { float4 a, b; };      // AFFINE: residual, reset-gate state;  BLEND: update gate, state
+// uniform per-pixel bases of the tensors an epilogue touches, and the lane's element offsets into them
+struct WnPix { const float *ta, *tb; float *out, *out2; };
+struct WnLane { unsigned ea, eb, eo, eo2; };
 template <int EPI>
-__device__ __forceinline__ void wn_epilogue(const ConvProblem& P, float4 v, const size_t gp, const int c, const int img) {
-  const float4 sc = P.scale ? spm_ld4(P.scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
-  const float4 bi = P.bias ? spm_ld4(P.bias + (P.bias_per_img ? (size_t)img * P.cout : 0) + c) : spm_zero4();
-  v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
+__device__ __forceinline__ WnOps wn_epi_load(const ConvProblem& P, const WnPix& px, const WnLane& ln) {
+  WnOps o;
+  o.a = spm_zero4(); o.b = spm_zero4();
+  if constexpr (EPI == EPI_AFFINE) {
+    if (P.add) o.a = spm_ld4(px.ta + (size_t)ln.ea);
+    if (P.out2) o.b = spm_ld4(px.tb + (size_t)ln.eb);
+  } else {
+    o.a = spm_ld4(px.ta + (size_t)ln.ea);
+    o.b = spm_ld4(px.tb + (size_t)ln.eb);
+  }
+  return o;
+}
+// v = the lane's four consecutive output channels c .. c+3 of one pixel; sc / bi = their scale and bias; as = residual scale
+template <int EPI>
+__device__ __forceinline__ void wn_epi_finish(const ConvProblem& P, const f32x2 vlo, const f32x2 vhi, const WnOps& o, const float4 sc, const float4 bi,
+                                              const float4 as, const WnPix& px, const WnLane& ln, const int c) {
+  const f32x2 l = __builtin_elementwise_fma(vlo, (f32x2){sc.x, sc.y}, (f32x2){bi.x, bi.y});
+  const f32x2 h = __builtin_elementwise_fma(vhi, (f32x2){sc.z, sc.w}, (f32x2){bi.z, bi.w});
+  float4 v = make_float4(l[0], l[1], h[0], h[1]);
   float4 y;
   if constexpr (EPI == EPI_AFFINE) {
     const bool act_last = (P.mode & 2) != 0;
@@ -100,28 +142,22 @@ __device__ __forceinline__ void wn_epilogue(const ConvProblem& P, float4 v, cons
       if (c + 3 >= P.clamp_from) y.w = fminf(fmaxf(y.w, P.clamp_lo), P.clamp_hi);
     }
     if (P.add) {
-      float4 ad = spm_ld4(P.add + gp * P.add_cs + c);
-      if (P.add_scale) {
-        const float4 as = spm_ld4(P.add_scale + (size_t)img * P.cout + c);
-        ad.x *= as.x; ad.y *= as.y; ad.z *= as.z; ad.w *= as.w;
-      }
-      y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w;
+      if (P.add_scale) { y.x += o.a.x * as.x; y.y += o.a.y * as.y; y.z += o.a.z * as.z; y.w += o.a.w * as.w; }
+      else { y.x += o.a.x; y.y += o.a.y; y.z += o.a.z; y.w += o.a.w; }
     }
     if (act_last) y = spm_act4(y, P.act);
-    if (P.out2 && c >= P.gate_from) {   // GRU gates, reset half: also emit (1 - r) * s, the candidate conv's input
-      const int cg = c - P.gate_from;
-      const float4 sv = spm_ld4(P.e1 + gp * P.e1_cs + cg);
-      spm_st4(P.out2 + gp * P.out2_cs + cg, make_float4(sv.x * (1.f - y.x), sv.y * (1.f - y.y), sv.z * (1.f - y.z), sv.w * (1.f - y.w)));
-    }
+    if (P.out2 && c >= P.gate_from)     // GRU gates, reset half: also emit (1 - r) * s, the candidate conv's input
+      spm_st4(px.out2 + (size_t)ln.eo2, make_float4(o.b.x * (1.f - y.x), o.b.y * (1.f - y.y), o.b.z * (1.f - y.z), o.b.w * (1.f - y.w)));
   } else {      // EPI_BLEND (temporal.py:56)
     v = spm_act4(v, P.act);
-    const float4 u = spm_ld4(P.e0 + gp * P.e0_cs + c), s = spm_ld4(P.e1 + gp * P.e1_cs + c);
-    if (P.mode & 1) y = make_float4(u.x * (v.x - s.x), u.y * (v.y - s.y), u.z * (v.z - s.z), u.w * (v.w - s.w));
-    else y = make_float4((1.f - u.x) * s.x + u.x * v.x, (1.f - u.y) * s.y + u.y * v.y, (1.f - u.z) * s.z + u.z * v.z, (1.f - u.w) * s.w + u.w * v.w);
+    const float4 u = o.a, st = o.b;
+    if (P.mode & 1) y = make_float4(u.x * (v.x - st.x), u.y * (v.y - st.y), u.z * (v.z - st.z), u.w * (v.w - st.w));
+    else y = make_float4((1.f - u.x) * st.x + u.x * v.x, (1.f - u.y) * st.y + u.y * v.y, (1.f - u.z) * st.z + u.z * v.z, (1.f - u.w) * st.w + u.w * v.w);
   }
-  spm_st4(P.out + gp * P.out_cs + P.out_co + c, y);
+  spm_st4(px.out + (size_t)ln.eo, y);
 }
 
+__device__ inline int nkc_stamp(const ConvProblem& P) { return P.cin_pad >> 4; }
 // one axis of the dilated tile grid: N pixels, dilation d: phases p < r have q + 1 pixels (tb tiles), the others q (ts tiles)
 struct WnAxis {
   int d, r, tb, ts, nt;
@@ -155,11 +191,11 @@ struct WnAxis {
 template <int COUT_T, int TH, int MW, int EPI, bool DIL = false>
 __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kernel(const ConvLaunch L) {
   typedef WinoGeo<COUT_T, TH, MW, DIL> G;
-  constexpr int TW = G::TW, WT = G::WT, PW = G::PW, NU = G::NU, NP = G::NP, NVB = G::NVB, NPB = G::NPB;
+  constexpr int TW = G::TW, WT = G::WT, PW = G::PW, NU = G::NU, NP = G::NP, NVB = G::NVB, NPB = G::NPB, RING = G::RING;
   static_assert(!DIL || (NVB == 1 && NPB == 1), "the dilated form exists for the two-workgroup configuration");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const Ubuf = smem;
-  float* const Vbuf = Ubuf + 3 * G::U_FLOATS;
+  float* const Vbuf = Ubuf + RING * G::U_FLOATS;
   float* const Pbuf = Vbuf + NVB * G::V_FLOATS;
   const ConvProblem& P = L.p[0];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -168,14 +204,28 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   const WnAxis ax(DIL ? W : 2, DIL ? P.dil : 1), ay(DIL ? H : 2, DIL ? P.dil : 1);      // plain form: constants, folded away
   const int tiles_x = DIL ? ax.nt : (W + 1) >> 1, tiles_y = DIL ? ay.nt : (H + 1) >> 1;
   const int nbx = (tiles_x + TW - 1) / TW, nby = (tiles_y + TH - 1) / TH;
-  int b = (int)blockIdx.x;
+  // 1-D grid, XCD-aware: workgroup lin runs on XCD lin % 8 (round-robin dispatch).  Every XCD owns a contiguous range of tile blocks
+  // (neighbouring blocks share their halo rows / columns through that XCD's L2), and the cout blocks of one tile block are
+  // consecutive workgroups of the same XCD: the second one finds the input patch in L2
+  const int ncb = P.cout_pad / COUT_T;
+  const int nblk = nbx * nby * P.n_img, per_xcd = (nblk + 7) >> 3;
+  const int lin = (int)blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+  const int tb_ = slot / ncb;
+  int b = xcd * per_xcd + tb_;
+  if (b >= nblk) return;
   const int bx = b % nbx; b /= nbx;
   const int by = b % nby;
   const int img = b / nby;
   const int ty0 = by * TH, tx0 = bx * TW;                      // DIL: indices into the tile lists of the two axes
   int px0 = 0, pt0 = 0, py0 = 0, qt0 = 0;                      // DIL: (phase, tile) of the block's first column / row
   if constexpr (DIL) { ax.decode(tx0, px0, pt0); ay.decode(ty0, py0, qt0); }
-  const int cout0 = (int)blockIdx.y * COUT_T;
+  SF_STAMP_AT(L, 0);
+#ifdef SF_STAMP
+  SF_STAMP_VAL(L, 8, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));        // HW_ID: wave / SIMD / CU / SH / SE
+  SF_STAMP_VAL(L, 9, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));       // XCC_ID
+  SF_STAMP_VAL(L, 10, (unsigned long long)nkc_stamp(P));
+#endif
+  const int cout0 = (slot - tb_ * ncb) * COUT_T;
   const int nkc = P.cin_pad >> 4;                              // 16-channel chunks
   const int NS = nkc * 8;                                      // stages
   const int c0 = P.c0;
@@ -191,12 +241,13 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   const __amdgpu_buffer_rsrc_t rsrc_u = make_rsrc(P.w_wino, (size_t)nkc * 16 * P.cout_pad * 16 * sizeof(float));
 #endif
   // ---- patch DMA: element e = (pixel, channel quad) of the (2TH+2) x 18 patch, 16 bytes each, LDS linear in e -----------------
+  SF_STAMP_AT(L, 14);
   // DIL: DMA `idx = d * 8 + wave` of the G::ND the patch needs (wave w issues npw of them); one input tensor (wino_takes)
   int pv0[NP], pv1[DIL ? 1 : NP];
-  const int npw = DIL ? (G::ND / 8 + (wave < G::ND % 8 ? 1 : 0)) : NP;      // wave-uniform
+  const int npw = G::COMPACT ? (G::ND / 8 + (wave < G::ND % 8 ? 1 : 0)) : NP;      // wave-uniform
 #pragma unroll
   for (int d = 0; d < NP; ++d) {
-    const int e = (DIL ? d * 8 + wave : wave * NP + d) * 64 + lane;
+    const int e = (G::COMPACT ? d * 8 + wave : wave * NP + d) * 64 + lane;
     const int pix = e >> 2, quad = e & 3;
     const int py = pix / PW, px = pix - py * PW;
     int iy = 2 * ty0 - 1 + py, ix = 2 * tx0 - 1 + px;
@@ -209,16 +260,18 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
     pv0[d] = ok ? (pofs * P.in0_cs + quad * 4) * 4 : (int)0x80000000;      // + the chunk's channel offset stays out of range: zero fill
     if constexpr (!DIL) pv1[d] = ok ? (pofs * P.in1_cs - c0 + quad * 4) * 4 : (int)0x80000000;
   }
+  SF_STAMP_AT(L, 15);
   auto issue_patch = [&](const int kc) {
     float* const dst = Pbuf + (NPB == 2 ? (kc & 1) : 0) * G::P_FLOATS;
     const bool from1 = !DIL && kc * 16 >= c0;                   // wave-uniform: the whole chunk reads in1 (c0 % 16 == 0)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
     for (int d = 0; d < NP; ++d) {
+      if (G::COMPACT && d >= npw) continue;
+      float* const dB = dst + (G::COMPACT ? d * 8 + wave : wave * NP + d) * 256;
       if constexpr (DIL) {
-        if (d < npw) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)(dst + (d * 8 + wave) * 256), 16, pv0[d] + kc * 64, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, pv0[d] + kc * 64, 0, 0, 0);
       } else {
-        float* const dB = dst + (wave * NP + d) * 256;
         if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (wn_lds_void*)dB, 16, pv1[d] + kc * 64, 0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, pv0[d] + kc * 64, 0, 0, 0);
       }
@@ -240,7 +293,7 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   }
   const int u_stage_bytes = 2 * P.cout_pad * 16 * 4;            // two positions
   auto issue_u = [&](const int S) {
-    float* const dst = Ubuf + (S % 3) * G::U_FLOATS;
+    float* const dst = Ubuf + (S % RING) * G::U_FLOATS;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
     for (int u = 0; u < NU; ++u)
@@ -252,6 +305,8 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   // ---- input transform: task (tile wt, channel quad, row i of B^T d B): 8 reads, 8 add/sub, 4 writes (float4) ------------------
   constexpr int NTASK = WT * 16 / WN_THREADS;                  // 1 (32 tiles) or 2 (64 tiles)
   float* const Park = Pbuf + NPB * G::P_FLOATS;
+  float* const SBuf = Park + G::PARK;                          // [scale COUT_T][bias COUT_T]: read behind the stage loop
+
   if constexpr (DIL) {
     static_assert(!DIL || NTASK == 1, "one transform task per thread");
     const int quad = tid & 3, wt = (tid >> 2) % WT;
@@ -321,7 +376,7 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   f32x4 acc[16][MW];
   f32x4 fa[2][2][MW], fb[2][2];                                 // [set][position of the pair][m]
   auto read_frags = [&](const int S, const int set) {
-    const float* const ub = Ubuf + (S % 3) * G::U_FLOATS;
+    const float* const ub = Ubuf + (S % RING) * G::U_FLOATS;
     const int kc = S >> 3, st = S & 7;
     const float* const vb = Vbuf + (NVB == 2 ? (kc & 1) : 0) * G::V_FLOATS + (2 * st) * WT * 16;
 #pragma unroll
@@ -333,27 +388,44 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   };
 
   // ---- prologue: patch 0, three U stages (the ring), transform 0, patch 1 ------------------------------------------------------------
-  const int n_u0 = NS < 3 ? NS : 3;
+  const int n_u0 = NS < RING ? NS : RING;
   issue_patch(0);
   for (int S = 0; S < n_u0; ++S) issue_u(S);
-  wn_wait(NU * n_u0);                                           // the patch is the oldest: everything but the U stages
+  float sbv = tid < COUT_T ? 1.f : 0.f;                         // scale / bias of the cout block: requested behind the DMAs, parked in LDS below
+  if (tid < 2 * COUT_T) {
+    const int co = cout0 + (tid < COUT_T ? tid : tid - COUT_T);
+    if (co < P.cout) {
+      if (tid < COUT_T) { if (P.scale) sbv = P.scale[co]; }
+      else if (P.bias) sbv = P.bias[(P.bias_per_img ? (size_t)img * P.cout : 0) + co];
+    }
+  }
+  SF_STAMP_AT(L, 11);
+  wn_wait(NU * n_u0);                                           // the patch is the oldest: everything but the U stages (a wave that issued the load above also waits for U(0))
   wn_barrier();
+  SF_STAMP_AT(L, 12);
   transform(0);
+  SF_STAMP_AT(L, 13);
+  if (tid < 2 * COUT_T) SBuf[tid] = sbv;                        // published by the barrier below
   if (NPB == 2 && nkc > 1) issue_patch(1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   wn_wait(NU * (n_u0 - 1) + ((NPB == 2 && nkc > 1) ? NP : 0));  // U(0) landed (younger: U(1), U(2), patch(1))
   wn_barrier();
   if (NPB == 1 && nkc > 1) issue_patch(1);                      // one patch buffer: every wave has finished transform(0)
+  if constexpr (NVB == 2) {
 #pragma unroll
-  for (int p = 0; p < 16; ++p)
+    for (int p = 0; p < 16; ++p)
 #pragma unroll
-    for (int m = 0; m < MW; ++m) acc[p][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < MW; ++m) acc[p][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   read_frags(0, 0);
+  SF_STAMP_AT(L, 1);
 
   // (Measured and not kept, profiles/r04_[hij]_winobench_*: a persistent tile loop with the next tile's DMAs issued before the
   // epilogue; the SIMD-partner stagger of MI355X_MICROARCH.md item 9 as a second code path and as a deferred DMA issue.  Each cost
   // more in the compiler's schedule of this loop — 227 -> 239-254 registers, scalar spills in the stage code — than it bought: 14.6 ms
   // for the 128 -> 128 layer on 224 frames with the loop below, 15.3-16.9 ms with them.)
+  // U stages younger than U(S+1) when stage S = (chunk, st) waits for it: RING - 2 of them, fewer at the end of the last chunk
+  auto young = [](const int st, const bool more) { return more ? RING - 2 : (6 - st < RING - 2 ? (6 - st < 0 ? 0 : 6 - st) : RING - 2); };
   if constexpr (NVB == 2) {
     // Conditions are written in (kc, st) so that they fold for st < 5 / 6 / 7 after unrolling: with a run-time branch between a
     // stage's fragment reads and its MFMAs hipcc's wait-count pass loses track of which LDS reads are pending at the merge and
@@ -369,9 +441,9 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
         if (st < 7 || more) {
           // U(S+1) landed: younger DMAs of this wave are U(S+2) and — for two stages behind its issue point — the next patch
           const bool patch_young = (st == 4 || st == 5) && (kc + 2 < nkc);
-          wn_wait(((st < 6 || more) ? NU : 0) + (patch_young ? NP : 0));
-          wn_barrier();                                             // stage S+1 (and, at st == 7, the next chunk's V) published; buffer S % 3 free
-          if (st < 5 || more) issue_u(S + 3);
+          wn_wait(NU * young(st, more) + (patch_young ? NP : 0));
+          wn_barrier();                                             // stage S+1 (and, at st == 7, the next chunk's V) published; buffer S % RING free
+          if (st < 8 - RING || more) issue_u(S + RING);
           read_frags(S + 1, set ^ 1);
         }
         // the next stage's fragment reads stay IN FRONT of this stage's MFMAs (the machine scheduler otherwise sinks them behind the
@@ -392,9 +464,12 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
       }
     }
   } else {
-    // one V buffer (64 tiles x 16 positions x 16 channels = 64 KB): the next chunk's transform sits between the last read of this
-    // chunk's V (behind the barrier of stage 7) and the first read of the next one; stage 7's MFMAs cover its LDS writes
-    for (int kc = 0; kc < nkc; ++kc) {
+    // one V buffer: the next chunk's transform sits between the last read of this chunk's V (behind the barrier of stage 7) and the
+    // first read of the next one; stage 7's MFMAs cover its LDS writes.  The first chunk is its own copy of the body: its MFMAs start
+    // from a zero C operand — no accumulator initialisation (64 vector moves per wave and tile; vector instructions cost matrix
+    // time: see the epilogue)
+    auto chunk = [&](const int kc, auto first_c) {
+      constexpr bool first = decltype(first_c)::value;
       const bool more = kc + 1 < nkc;                               // wave-uniform
 #pragma unroll
       for (int st = 0; st < 8; ++st) {
@@ -403,14 +478,14 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (st < 7) {                                               // inside a chunk: as the two-buffer kernel
           const bool patch_young = st <= 1 && more;                 // the patch is issued at the chunk boundary: young for two stages
-          wn_wait(((st < 6 || more) ? NU : 0) + (patch_young ? npw : 0));
+          wn_wait(NU * young(st, more) + (patch_young ? npw : 0));
           wn_barrier();
-          if (st < 5 || more) issue_u(S + 3);
+          if (st < 8 - RING || more) issue_u(S + RING);
           read_frags(S + 1, set ^ 1);
         } else if (more) {                                          // chunk boundary
-          wn_wait(NU);
+          wn_wait(NU * (RING - 2));
           wn_barrier();                                             // every wave holds this chunk's last fragments: V is free
-          issue_u(S + 3);
+          issue_u(S + RING);
           transform(kc + 1);
           if (NPB == 2 && kc + 2 < nkc) issue_patch(kc + 2);
         }
@@ -420,8 +495,10 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int m = 0; m < MW; ++m)
-              acc[2 * st + p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][p][m][e], fb[set][p][e], acc[2 * st + p][m], 0, 0, 0);
+            for (int m = 0; m < MW; ++m) {
+              const f32x4 cin = (first && e == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[2 * st + p][m];
+              acc[2 * st + p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][p][m][e], fb[set][p][e], cin, 0, 0, 0);
+            }
         __builtin_amdgcn_sched_barrier(0);
         if (st == 7 && more) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -430,9 +507,12 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
           read_frags(S + 1, set ^ 1);
         }
       }
-    }
+    };
+    chunk(0, std::true_type{});
+    for (int kc = 1; kc < nkc; ++kc) chunk(kc, std::false_type{});
   }
 
+  SF_STAMP_AT(L, 2);
   // ---- output transform A^T M A (register-local) + epilogue ---------------------------------------------------------------------------
   // the lane's tile and channel quad are re-derived from a laundered lane index: nothing of them is carried through the stage loop
   // (two registers the 128-register configuration does not have)
@@ -451,29 +531,86 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
     ox0 = (tx < ax.nt && pX < ostep) ? pX + ostep * 2 * tX : W;     // beyond the tile list: masked by the range checks below
     oy0 = (ty < ay.nt && pY < ostep) ? pY + ostep * 2 * tY : H;
   }
+  // uniform bases of the lane-independent part: tensor + (image, pixel (bq, i) of a tile at the image's origin)
+  const bool affine = EPI == EPI_AFFINE;
+  const float* const t_a = affine ? P.add : P.e0;
+  const float* const t_b = P.e1;
+  const int cs_a = affine ? P.add_cs : P.e0_cs, cs_b = P.e1_cs;
+  WnPix px[2][2];
+#pragma unroll
+  for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const size_t p0 = img_base + (size_t)(bq * ostep) + (size_t)(i * ostep) * W;
+      px[bq][i].ta = t_a ? t_a + p0 * cs_a : nullptr;
+      px[bq][i].tb = t_b ? t_b + p0 * cs_b : nullptr;
+      px[bq][i].out = P.out + p0 * P.out_cs + P.out_co;
+      px[bq][i].out2 = P.out2 ? P.out2 + p0 * P.out2_cs : nullptr;
+    }
+  const bool x0 = ox0 < W, x1 = ox0 + ostep < W, y0ok = oy0 < H, y1ok = oy0 + ostep < H;
+  const unsigned pix = (x0 && y0ok) ? (unsigned)(oy0 * W + ox0) : 0u;      // lanes without a tile compute on pixel 0 and store nothing
 #pragma unroll
   for (int m = 0; m < MW; ++m) {
-    const int c = cout0 + wm * 16 * MW + m * 16 + 4 * g_e;
-    // one output column bq at a time (16 + 8 live registers beside the accumulators instead of 48):
-    //   t[i] = (M A)[i][bq]:  bq = 0: M[i][0] + M[i][1] + M[i][2],   bq = 1: M[i][1] - M[i][2] - M[i][3]
-    //   Y[0][bq] = t[0] + t[1] + t[2],   Y[1][bq] = t[1] - t[2] - t[3]
+    const int cl = wm * 16 * MW + m * 16 + 4 * g_e;            // channel inside the workgroup's cout block
+    const int c = cout0 + cl;
+    const bool c_ok = c < P.cout;
+    const int c_ld = c_ok ? c : 0;
+    const bool ok00 = c_ok && x0 && y0ok, ok01 = c_ok && x0 && y1ok, ok10 = c_ok && x1 && y0ok, ok11 = c_ok && x1 && y1ok;
+    WnLane ln;
+    ln.ea = pix * (unsigned)cs_a + (unsigned)c_ld;
+    ln.eb = pix * (unsigned)cs_b + (unsigned)((affine && c_ld >= P.gate_from) ? c_ld - P.gate_from : (affine ? 0 : c_ld));
+    ln.eo = pix * (unsigned)P.out_cs + (unsigned)c_ld;
+    ln.eo2 = pix * (unsigned)P.out2_cs + (unsigned)(c_ld >= P.gate_from ? c_ld - P.gate_from : 0);
+    const float4 sc = *(const float4*)(SBuf + cl), bi = *(const float4*)(SBuf + COUT_T + cl);
+    float4 as = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (affine && P.add && P.add_scale) as = spm_ld4(P.add_scale + (size_t)img * P.cout + c_ld);
+    // one output column bq at a time:  t[i] = (M A)[i][bq]:  bq = 0: M[i][0] + M[i][1] + M[i][2],   bq = 1: M[i][1] - M[i][2] - M[i][3]
+    //                                  Y[0][bq] = t[0] + t[1] + t[2],   Y[1][bq] = t[1] - t[2] - t[3]
+    // column 0's operands are requested before its transform, column 1's before column 0's arithmetic and stores
+    WnOps o00, o01, o10, o11;
+    o00.a = o00.b = o01.a = o01.b = o10.a = o10.b = o11.a = o11.b = spm_zero4();
+    if (ok00) o00 = wn_epi_load<EPI>(P, px[0][0], ln);
+    if (ok01) o01 = wn_epi_load<EPI>(P, px[0][1], ln);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x2 ya[2], yb[2];
 #pragma unroll
-    for (int bq = 0; bq < 2; ++bq) {
-      f32x4 t[4];
+    for (int hh = 0; hh < 2; ++hh) {
+      f32x2 t[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        t[i] = bq == 0 ? acc[4 * i + 0][m] + acc[4 * i + 1][m] + acc[4 * i + 2][m] : acc[4 * i + 1][m] - acc[4 * i + 2][m] - acc[4 * i + 3][m];
-      const f32x4 y0 = t[0] + t[1] + t[2], y1 = t[1] - t[2] - t[3];
-      if (c < P.cout) {
-        const int ox = ox0 + bq * ostep;
-        if (ox < W) {
-          const int oy = oy0;
-          if (oy < H) wn_epilogue<EPI>(P, make_float4(y0[0], y0[1], y0[2], y0[3]), img_base + (size_t)oy * W + ox, c, img);
-          if (oy + ostep < H) wn_epilogue<EPI>(P, make_float4(y1[0], y1[1], y1[2], y1[3]), img_base + (size_t)(oy + ostep) * W + ox, c, img);
-        }
+      for (int i = 0; i < 4; ++i) {
+        const f32x2 a0 = hh ? wn_hi(acc[4 * i + 0][m]) : wn_lo(acc[4 * i + 0][m]), a1 = hh ? wn_hi(acc[4 * i + 1][m]) : wn_lo(acc[4 * i + 1][m]);
+        const f32x2 a2 = hh ? wn_hi(acc[4 * i + 2][m]) : wn_lo(acc[4 * i + 2][m]);
+        t[i] = a0 + a1 + a2;
       }
+      ya[hh] = t[0] + t[1] + t[2]; yb[hh] = wn_sub2(t[1], t[2] + t[3]);
     }
+    if (ok10) o10 = wn_epi_load<EPI>(P, px[1][0], ln);
+    if (ok11) o11 = wn_epi_load<EPI>(P, px[1][1], ln);
+    __builtin_amdgcn_sched_barrier(0);
+    SF_STAMP_AT(L, 5);
+    if (ok00) wn_epi_finish<EPI>(P, ya[0], ya[1], o00, sc, bi, as, px[0][0], ln, c);
+    if (ok01) wn_epi_finish<EPI>(P, yb[0], yb[1], o01, sc, bi, as, px[0][1], ln, c);
+    SF_STAMP_AT(L, 6);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      f32x2 t[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x2 a1 = hh ? wn_hi(acc[4 * i + 1][m]) : wn_lo(acc[4 * i + 1][m]), a2 = hh ? wn_hi(acc[4 * i + 2][m]) : wn_lo(acc[4 * i + 2][m]);
+        const f32x2 a3 = hh ? wn_hi(acc[4 * i + 3][m]) : wn_lo(acc[4 * i + 3][m]);
+        t[i] = wn_sub2(a1, a2 + a3);
+      }
+      ya[hh] = t[0] + t[1] + t[2]; yb[hh] = wn_sub2(t[1], t[2] + t[3]);
+    }
+    SF_STAMP_AT(L, 7);
+    if (ok10) wn_epi_finish<EPI>(P, ya[0], ya[1], o10, sc, bi, as, px[1][0], ln, c);
+    if (ok11) wn_epi_finish<EPI>(P, yb[0], yb[1], o11, sc, bi, as, px[1][1], ln, c);
   }
+  SF_STAMP_AT(L, 3);
+#ifdef SF_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SF_STAMP_AT(L, 4);
+#endif
 }
 
 // weights: packed direct form w[cout_pad][9 * cin_pad] (tap-major, channel-minor) -> U[cin_pad/16][16][cout_pad][16] = G g G^T
@@ -522,6 +659,10 @@ bool wino_takes(const ConvProblem& q, int epi) {
   // dilated (conv_wino_kernel<.., DIL>): one input tensor, AFFINE epilogue, every phase of both axes at least 5 pixels = 3 tiles long
   if (q.dil > 1 && (q.c1 != 0 || epi != EPI_AFFINE || q.Hout / q.dil < 5 || q.Wout / q.dil < 5)) return false;
   const double img_bytes = 4.0 * q.Hin * q.Win;
+  // the epilogue addresses its tensors as a per-image base + a 32-bit element offset
+  if (img_bytes * q.out_cs >= 2147483648.0 || img_bytes * q.add_cs >= 2147483648.0 || img_bytes * q.e0_cs >= 2147483648.0 ||
+      img_bytes * q.e1_cs >= 2147483648.0 || img_bytes * q.out2_cs >= 2147483648.0)
+    return false;
   if (img_bytes * q.in0_cs >= 2147483648.0 || img_bytes * q.in1_cs >= 2147483648.0 || 4.0 * 16 * q.cout_pad * q.cin_pad >= 2147483648.0) return false;
   return true;
 }
@@ -542,8 +683,9 @@ static hipError_t launch_wino_t(const ConvLaunch& L, hipStream_t stream) {
   const ConvProblem& P = L.p[0];
   const int tiles_x = DIL ? WnAxis(P.Wout, P.dil).nt : (P.Wout + 1) / 2, tiles_y = DIL ? WnAxis(P.Hout, P.dil).nt : (P.Hout + 1) / 2;
   const long blocks = (long)P.n_img * ((tiles_y + TH - 1) / TH) * ((tiles_x + G::TW - 1) / G::TW);
-  if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(P.cout_pad / COUT_T), 1), dim3(WN_THREADS), lds, stream, L);
+  const long grid = ((blocks + 7) / 8) * 8 * (P.cout_pad / COUT_T);      // tile blocks in groups of 8 (one per XCD) x cout blocks
+  if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid, 1, 1), dim3(WN_THREADS), lds, stream, L);
   return hipGetLastError();
 }
 // which tile configuration a problem runs on: 0 = 128 cout x 32 tiles, 1 = 64 cout x 64 tiles, 2 = 64 cout x 32 tiles, two

@@ -189,7 +189,7 @@ _WINO = [
     dict(c0=32, c1=0, cout=64, n=6, H=157, W=171, dil=7, pad=7),
     dict(c0=32, c1=0, cout=192, n=3, H=203, W=241, dil=40, pad=40),
     dict(c0=64, c1=0, cout=64, n=4, H=181, W=187, dil=2, pad=2),
-    dict(c0=48, c1=0, cout=64, n=44, H=50, W=64, dil=3, pad=3),
+    dict(c0=64, c1=0, cout=64, n=44, H=50, W=64, dil=3, pad=3),
 ]
 
 

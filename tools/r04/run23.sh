@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+export SF_LIB_PATH=build_r02/stamp/libsfnative.so
+( timeout 300 python tools/r04/stamps_wino.py 128 128 32 200 200
+  timeout 300 python tools/r04/stamps_wino.py 64 64 32 200 200
+  timeout 300 python tools/r04/stamps_wino.py 64 64 32 200 200 1 1
+  timeout 300 python tools/r04/stamps_wino.py 128 64 32 200 200 12 ) > gpurun_out/r04_v_stamps_wino.txt 2>&1
