@@ -563,19 +563,19 @@ def main():
         tot = sum(pms)
         k = max(range(NK), key=lambda i: pms[i])
         achieved = pfl[k] / (pms[k] * 1e-3) / 1e12
-        traffic, traffic_commit = None, None
+        traffic, traffic_commit, traffic_kernel = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
         if os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
-                traffic, traffic_commit = pj.get("hbm_bytes_per_launch"), pj.get("commit")
+                traffic, traffic_commit, traffic_kernel = pj.get("hbm_bytes_per_launch"), pj.get("commit"), pj.get("kernel")
             except Exception:
                 traffic = None
         roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                 # PMC counters need their own rocprofv3 passes: the figure is the committed summary of the same command,
                 # never a measurement of this run
-                "traffic_source": {"file": "profiles/pmc_dominant.json", "measured_in_this_run": False, "commit": traffic_commit},
+                "traffic_source": {"file": "profiles/pmc_dominant.json", "measured_in_this_run": False, "commit": traffic_commit, "kernel": traffic_kernel},
                 "kernel": _lib.KERNEL_NAMES.get(k, str(k)), "launches_per_forward": calls[k] // 2,
                 # Winograd launches are priced at their EXECUTED FLOPs (16 products per 2x2 outputs and (cin, cout) pair; the direct
                 # form the reference computes has 36): `achieved` / `frac` are what the matrix pipe did, the direct-form figure what

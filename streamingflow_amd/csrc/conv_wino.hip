@@ -35,6 +35,13 @@ hipError_t set_stamp_buffer_wino(unsigned long long*) { return hipErrorNotSuppor
 #endif
 
 constexpr int WN_THREADS = 512;
+// -DSF_WINO_ROLL builds the rolling input transform (conv_wino_kernel, "ROLLING INPUT TRANSFORM"): measured 1-4 % slower than the
+// one-shot transform at the chunk boundary (profiles/r04_z5_winobench_rolling_vs_one_shot_transform.txt), kept for experiments
+#if defined(SF_WINO_ROLL)
+constexpr bool WN_ROLL_BUILD = true;
+#else
+constexpr bool WN_ROLL_BUILD = false;
+#endif
 typedef __attribute__((address_space(3))) void wn_lds_void;
 
 // MW: 16-row cout tiles per wave (2: wave = 32 cout x 16 tiles, 128 accumulator registers, one workgroup per CU;
@@ -61,7 +68,8 @@ struct WinoGeo {
   static constexpr bool COMPACT = DIL || MW == 1;              // patch = exactly ND DMAs (wave w issues pieces w, w + 8, ...) instead of NP per wave
   static constexpr int ND = (NPX * 4 + 63) / 64;
   static constexpr int P_FLOATS = COMPACT ? ND * 256 : 8 * NP * 64 * 4;      // one patch, padded to whole DMAs
-  static constexpr int PARK = DIL ? 512 : 0;                   // DIL: one loop-invariant word per thread kept in LDS instead of a register
+  static constexpr int PARK = DIL ? 512 : ((MW == 1 && WN_ROLL_BUILD) ? ((NPX * 4 + 63) / 64) * 64 : 0);      // loop-invariant words kept in LDS instead of registers:
+                                                               // DIL: a patch offset per thread; two workgroups per CU: the pixel offset of every patch piece
 #if defined(SF_WINO_RING)
   static constexpr int RING = SF_WINO_RING;
 #else
@@ -75,6 +83,13 @@ struct WinoGeo {
 __device__ __forceinline__ f32x4 wn_lds_read128(const float* p) {
   typedef const __attribute__((address_space(3))) f32x4 lds_f4;
   return *(lds_f4*)p;
+}
+// the lane index without a live register: two vector instructions where it is needed
+// (volatile: otherwise everything derived from it is hoisted out of the stage loop and kept in registers the loop does not have)
+__device__ __forceinline__ int wn_lane_id() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
 }
 __device__ __forceinline__ void wn_barrier() {
   asm volatile("" ::: "memory");
@@ -111,8 +126,8 @@ struct WnOps { float4 a, b; };      // AFFINE: residual, reset-gate state;  BLEN
 // uniform per-pixel bases of the tensors an epilogue touches, and the lane's element offsets into them
 struct WnPix { const float *ta, *tb; float *out, *out2; };
 struct WnLane { unsigned ea, eb, eo, eo2; };
-template <int EPI>
-__device__ __forceinline__ WnOps wn_epi_load(const ConvProblem& P, const WnPix& px, const WnLane& ln) {
+template <int EPI, class PT>
+__device__ __forceinline__ WnOps wn_epi_load(const PT& P, const WnPix& px, const WnLane& ln) {
   WnOps o;
   o.a = spm_zero4(); o.b = spm_zero4();
   if constexpr (EPI == EPI_AFFINE) {
@@ -125,9 +140,15 @@ __device__ __forceinline__ WnOps wn_epi_load(const ConvProblem& P, const WnPix& 
   return o;
 }
 // v = the lane's four consecutive output channels c .. c+3 of one pixel; sc / bi = their scale and bias; as = residual scale
-template <int EPI>
-__device__ __forceinline__ void wn_epi_finish(const ConvProblem& P, const f32x2 vlo, const f32x2 vhi, const WnOps& o, const float4 sc, const float4 bi,
-                                              const float4 as, const WnPix& px, const WnLane& ln, const int c) {
+// returns the output value (and the reset-gate by-product in y2): the caller stores all four pixels of the tile at the very end —
+// a store in the middle made the next pixel's arithmetic wait for its completion (hipcc guards the reuse of a store's data
+// registers with s_waitcnt vmcnt(0): one memory round trip per pixel, seen in the ISA and in the in-kernel stamps)
+struct WnOut { float4 y, y2; };
+template <int EPI, class PT>
+__device__ __forceinline__ WnOut wn_epi_finish(const PT& P, const f32x2 vlo, const f32x2 vhi, const WnOps& o, const float4 sc, const float4 bi,
+                                               const float4 as, const int c) {
+  WnOut r;
+  r.y2 = spm_zero4();
   const f32x2 l = __builtin_elementwise_fma(vlo, (f32x2){sc.x, sc.y}, (f32x2){bi.x, bi.y});
   const f32x2 h = __builtin_elementwise_fma(vhi, (f32x2){sc.z, sc.w}, (f32x2){bi.z, bi.w});
   float4 v = make_float4(l[0], l[1], h[0], h[1]);
@@ -147,17 +168,18 @@ __device__ __forceinline__ void wn_epi_finish(const ConvProblem& P, const f32x2 
     }
     if (act_last) y = spm_act4(y, P.act);
     if (P.out2 && c >= P.gate_from)     // GRU gates, reset half: also emit (1 - r) * s, the candidate conv's input
-      spm_st4(px.out2 + (size_t)ln.eo2, make_float4(o.b.x * (1.f - y.x), o.b.y * (1.f - y.y), o.b.z * (1.f - y.z), o.b.w * (1.f - y.w)));
+      r.y2 = make_float4(o.b.x * (1.f - y.x), o.b.y * (1.f - y.y), o.b.z * (1.f - y.z), o.b.w * (1.f - y.w));
   } else {      // EPI_BLEND (temporal.py:56)
     v = spm_act4(v, P.act);
     const float4 u = o.a, st = o.b;
     if (P.mode & 1) y = make_float4(u.x * (v.x - st.x), u.y * (v.y - st.y), u.z * (v.z - st.z), u.w * (v.w - st.w));
     else y = make_float4((1.f - u.x) * st.x + u.x * v.x, (1.f - u.y) * st.y + u.y * v.y, (1.f - u.z) * st.z + u.z * v.z, (1.f - u.w) * st.w + u.w * v.w);
   }
-  spm_st4(px.out + (size_t)ln.eo, y);
+  r.y = y;
+  return r;
 }
 
-__device__ inline int nkc_stamp(const ConvProblem& P) { return P.cin_pad >> 4; }
+template <class PT> __device__ inline int nkc_stamp(const PT& P) { return P.cin_pad >> 4; }
 // one axis of the dilated tile grid: N pixels, dilation d: phases p < r have q + 1 pixels (tb tiles), the others q (ts tiles)
 struct WnAxis {
   int d, r, tb, ts, nt;
@@ -193,6 +215,7 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   typedef WinoGeo<COUT_T, TH, MW, DIL> G;
   constexpr int TW = G::TW, WT = G::WT, PW = G::PW, NU = G::NU, NP = G::NP, NVB = G::NVB, NPB = G::NPB, RING = G::RING;
   static_assert(!DIL || (NVB == 1 && NPB == 1), "the dilated form exists for the two-workgroup configuration");
+  constexpr bool ROLL = WN_ROLL_BUILD && NVB == 1 && NPB == 1 && WT == 32 && MW == 1 && !DIL;      // rolling input transform (below; the dilated form has no registers for it)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const Ubuf = smem;
   float* const Vbuf = Ubuf + RING * G::U_FLOATS;
@@ -206,7 +229,9 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   const int nbx = (tiles_x + TW - 1) / TW, nby = (tiles_y + TH - 1) / TH;
   // 1-D grid, XCD-aware: workgroup lin runs on XCD lin % 8 (round-robin dispatch).  Every XCD owns a contiguous range of tile blocks
   // (neighbouring blocks share their halo rows / columns through that XCD's L2), and the cout blocks of one tile block are
-  // consecutive workgroups of the same XCD: the second one finds the input patch in L2
+  // consecutive workgroups of the same XCD: the second one finds the input patch in L2.
+  // (A persistent form — two workgroups per CU looping over the items of their XCD, argument pointer and thread index laundered per
+  // tile against hoisting — measured 5 % SLOWER than one workgroup per item: profiles/r04_z7_winobench_persistent_vs_per_tile.txt.)
   const int ncb = P.cout_pad / COUT_T;
   const int nblk = nbx * nby * P.n_img, per_xcd = (nblk + 7) >> 3;
   const int lin = (int)blockIdx.x, xcd = lin & 7, slot = lin >> 3;
@@ -243,7 +268,11 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   // ---- patch DMA: element e = (pixel, channel quad) of the (2TH+2) x 18 patch, 16 bytes each, LDS linear in e -----------------
   SF_STAMP_AT(L, 14);
   // DIL: DMA `idx = d * 8 + wave` of the G::ND the patch needs (wave w issues npw of them); one input tensor (wino_takes)
-  int pv0[NP], pv1[DIL ? 1 : NP];
+  // PQ (two workgroups per CU, two inputs possible): only the pixel offset is kept per DMA (one register instead of two); the byte
+  // offset into the chunk's input tensor is formed when the DMA is issued (3 vector instructions, once per chunk)
+  constexpr bool PQ = !DIL && G::COMPACT && WN_ROLL_BUILD;
+  int pv0[PQ ? 1 : NP], pv1[(DIL || PQ) ? 1 : NP];
+  float* const PqPark = Pbuf + NPB * G::P_FLOATS;              // = Park below (PQ only)
   const int npw = G::COMPACT ? (G::ND / 8 + (wave < G::ND % 8 ? 1 : 0)) : NP;      // wave-uniform
 #pragma unroll
   for (int d = 0; d < NP; ++d) {
@@ -257,8 +286,10 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
       ok = pix < G::NPX && oky && okx;
     }
     const int pofs = iy * W + ix;
-    pv0[d] = ok ? (pofs * P.in0_cs + quad * 4) * 4 : (int)0x80000000;      // + the chunk's channel offset stays out of range: zero fill
-    if constexpr (!DIL) pv1[d] = ok ? (pofs * P.in1_cs - c0 + quad * 4) * 4 : (int)0x80000000;
+    if constexpr (PQ) {
+      if (d < npw) *(__attribute__((address_space(3))) int*)(PqPark + e) = ok ? pofs : -1;      // read back by the same lane when it issues the DMA
+    } else pv0[d] = ok ? (pofs * P.in0_cs + quad * 4) * 4 : (int)0x80000000;      // + the chunk's channel offset stays out of range: zero fill
+    if constexpr (!DIL && !PQ) pv1[d] = ok ? (pofs * P.in1_cs - c0 + quad * 4) * 4 : (int)0x80000000;
   }
   SF_STAMP_AT(L, 15);
   auto issue_patch = [&](const int kc) {
@@ -271,6 +302,13 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
       float* const dB = dst + (G::COMPACT ? d * 8 + wave : wave * NP + d) * 256;
       if constexpr (DIL) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, pv0[d] + kc * 64, 0, 0, 0);
+      } else if constexpr (PQ) {
+        const int cs4 = (from1 ? P.in1_cs : P.in0_cs) * 4, base = (from1 ? -c0 * 4 : 0) + kc * 64;      // scalars
+        const int ln_ = wn_lane_id();
+        const int pq = *(const __attribute__((address_space(3))) int*)(PqPark + (d * 8 + wave) * 64 + ln_);
+        const int off = pq >= 0 ? pq * cs4 + base + (ln_ & 3) * 16 : (int)0x80000000;
+        if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (wn_lds_void*)dB, 16, off, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, off, 0, 0, 0);
       } else {
         if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (wn_lds_void*)dB, 16, pv1[d] + kc * 64, 0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, pv0[d] + kc * 64, 0, 0, 0);
@@ -387,6 +425,13 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
     }
   };
 
+  auto read_frag = [&](const int S, const int set, const int p) {      // one position of a stage (MW == 1)
+    const float* const ub = Ubuf + (S % RING) * G::U_FLOATS;
+    const int kc = S >> 3, st = S & 7;
+    const float* const vb = Vbuf + (NVB == 2 ? (kc & 1) : 0) * G::V_FLOATS + (2 * st) * WT * 16;
+    fa[set][p][0] = wn_lds_read128(ub + p * COUT_T * 16 + a_off[0]);
+    fb[set][p] = wn_lds_read128(vb + p * WT * 16 + b_off);
+  };
   // ---- prologue: patch 0, three U stages (the ring), transform 0, patch 1 ------------------------------------------------------------
   const int n_u0 = NS < RING ? NS : RING;
   issue_patch(0);
@@ -410,8 +455,8 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   wn_wait(NU * (n_u0 - 1) + ((NPB == 2 && nkc > 1) ? NP : 0));  // U(0) landed (younger: U(1), U(2), patch(1))
   wn_barrier();
-  if (NPB == 1 && nkc > 1) issue_patch(1);                      // one patch buffer: every wave has finished transform(0)
-  if constexpr (NVB == 2) {
+  if (!ROLL && NPB == 1 && nkc > 1) issue_patch(1);             // one patch buffer: every wave has finished transform(0)
+  if constexpr (NVB == 2 || ROLL) {      // (the one-buffer, one-shot-transform loop starts its first chunk from a zero C operand instead)
 #pragma unroll
     for (int p = 0; p < 16; ++p)
 #pragma unroll
@@ -460,6 +505,78 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
         if (st == 3 && more) {                                      // next chunk's transform beside this chunk's stages (its patch landed a chunk ago)
           transform(kc + 1);
           if (kc + 2 < nkc) issue_patch(kc + 2);                    // into the buffer transform(kc) read: every wave passed >= 4 barriers since
+        }
+      }
+    }
+  } else if constexpr (ROLL) {
+    // ROLLING INPUT TRANSFORM.  With the whole transform of chunk kc+1 at the chunk boundary the matrix pipe of this workgroup drains
+    // there — barrier, 3 dependent LDS round trips, barrier, and the first fragment reads of the new chunk with nothing to cover them:
+    // in-kernel stamps showed a workgroup's stage loop at 52 % of the MFMA rate while its partner was in its prologue / epilogue
+    // (profiles/r04_x_stamps_wino.txt).  V[4 i .. 4 i + 3] (row i of B^T d B) is read by stages 2 i and 2 i + 1 only, so the rows of the
+    // next chunk are written IN PLACE as they fall free, one row per stage, each thread one (tile, channel quad, output column):
+    //     row 0 in stage 5, row 1 in stage 6, row 2 in stage 7 of chunk kc, row 3 in stage 0 of chunk kc + 1
+    // (4 LDS reads in front of the stage's MFMAs, 6 packed adds and 1 LDS write behind them).  The single patch buffer is read in
+    // those four stages; the next patch is requested in stage 1 and is older than every U stage that stage 5 still has in flight,
+    // so the stage's own vmcnt wait + barrier publish it.  Same sums in the same order as the one-shot transform: bitwise equal.
+    const int tj = wave >> 1;                                         // output column of this wave's transform tasks
+    const int cA = tj == 0 ? 0 : (tj == 2 ? 2 : 1), cB = tj == 0 ? 2 : (tj == 1 ? 2 : (tj == 2 ? 1 : 3));     // columns w[cA] +- w[cB]
+    const float sB = tj == 1 ? 1.f : -1.f;
+    // the lane's two offsets (patch pixel of its tile / its V row) live in two registers through the loop
+    int tp_l, vo_l;
+    {
+      const int quad = tid & 3, wt = (tid >> 2) & (WT - 1);
+      tp_l = ((2 * (wt / TW)) * PW + 2 * (wt % TW)) * 16 + quad * 4;
+      vo_l = (tj * WT + wt) * 16 + ((quad ^ ((wt >> 2) & 2)) << 2);
+    }
+    // half h of a task: column cA (h = 0) or cB (h = 1) of patch rows r1, r2 -> w = d[r1] +- d[r2]
+    auto trow_read = [&](const int i, const int h, f32x4 (&r)[2]) {
+      const int r1 = (i == 0) ? 0 : (i == 2 ? 2 : 1), r2 = (i == 3) ? 3 : (i == 2 ? 1 : 2);
+      const float* const pc = Pbuf + tp_l + (h ? cB : cA) * 16;
+      r[0] = wn_lds_read128(pc + r1 * PW * 16); r[1] = wn_lds_read128(pc + r2 * PW * 16);
+    };
+    auto trow_w = [&](const int i, const f32x4 (&r)[2]) { return (i == 1) ? r[0] + r[1] : r[0] - r[1]; };    // B^T rows: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+    auto trow_write = [&](const int i, const f32x4 wA, const f32x4 wB) {
+      typedef __attribute__((address_space(3))) f32x4 lds_f4w;
+      *(lds_f4w*)(Vbuf + i * 4 * WT * 16 + vo_l) = wA + sB * wB;
+    };
+    for (int kc = 0; kc < nkc; ++kc) {
+      const bool more = kc + 1 < nkc;                               // wave-uniform
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const int S = kc * 8 + st;
+        const int set = st & 1;
+        // a transform row rides in this stage (stage 0 of chunk 0 rewrites row 3 with the values the prologue wrote: no special case)
+        const bool t_now = st == 0 || (st >= 5 && more);
+        const int ti = st == 0 ? 3 : st - 5;
+        f32x4 tr[2], wA;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // fragments of stage S in registers, this wave's V row written
+        if (st < 7 || more) {
+          const bool patch_young = more && st >= 2 && st <= RING;   // requested in stage 1: behind U(S+1) for these stages, in front of it later
+          wn_wait(NU * young(st, more) + (patch_young ? npw : 0));
+          wn_barrier();                                             // U(S+1) and the V rows written in stage S-1 published; buffer S % RING, and the
+                                                                    // patch after stage 0, free
+          if (st < 8 - RING || more) issue_u(S + RING);
+          if (st == 1 && more) issue_patch(kc + 1);
+          read_frag(S + 1, set ^ 1, 0);
+          if (t_now) trow_read(ti, 0, tr);
+        }
+        // The stage's MFMAs in two halves.  The next stage's fragments are read one position ahead of each half (24 fragment
+        // registers live instead of 32), the transform task's second pair of reads and its arithmetic sit between / behind the
+        // halves (8 + 4 registers instead of 16 + 4): the kernel has 128 registers for two workgroups per CU.
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[2 * st + p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][p][0][e], fb[set][p][e], acc[2 * st + p][0], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st < 7 || more) {
+            if (p == 0) read_frag(S + 1, set ^ 1, 1);
+            if (t_now) {
+              if (p == 0) { wA = trow_w(ti, tr); trow_read(ti, 1, tr); }
+              else trow_write(ti, wA, trow_w(ti, tr));
+            }
+          }
         }
       }
     }
@@ -588,8 +705,9 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
     if (ok11) o11 = wn_epi_load<EPI>(P, px[1][1], ln);
     __builtin_amdgcn_sched_barrier(0);
     SF_STAMP_AT(L, 5);
-    if (ok00) wn_epi_finish<EPI>(P, ya[0], ya[1], o00, sc, bi, as, px[0][0], ln, c);
-    if (ok01) wn_epi_finish<EPI>(P, yb[0], yb[1], o01, sc, bi, as, px[0][1], ln, c);
+    WnOut r00, r01, r10, r11;
+    r00 = wn_epi_finish<EPI>(P, ya[0], ya[1], o00, sc, bi, as, c);
+    r01 = wn_epi_finish<EPI>(P, yb[0], yb[1], o01, sc, bi, as, c);
     SF_STAMP_AT(L, 6);
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
@@ -603,8 +721,20 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
       ya[hh] = t[0] + t[1] + t[2]; yb[hh] = wn_sub2(t[1], t[2] + t[3]);
     }
     SF_STAMP_AT(L, 7);
-    if (ok10) wn_epi_finish<EPI>(P, ya[0], ya[1], o10, sc, bi, as, px[1][0], ln, c);
-    if (ok11) wn_epi_finish<EPI>(P, yb[0], yb[1], o11, sc, bi, as, px[1][1], ln, c);
+    r10 = wn_epi_finish<EPI>(P, ya[0], ya[1], o10, sc, bi, as, c);
+    r11 = wn_epi_finish<EPI>(P, yb[0], yb[1], o11, sc, bi, as, c);
+    // all stores of the tile back to back: no register of a store in flight is written again
+    __builtin_amdgcn_sched_barrier(0);
+    if (ok00) spm_st4(px[0][0].out + (size_t)ln.eo, r00.y);
+    if (ok01) spm_st4(px[0][1].out + (size_t)ln.eo, r01.y);
+    if (ok10) spm_st4(px[1][0].out + (size_t)ln.eo, r10.y);
+    if (ok11) spm_st4(px[1][1].out + (size_t)ln.eo, r11.y);
+    if (affine && P.out2 && c >= P.gate_from) {
+      if (ok00) spm_st4(px[0][0].out2 + (size_t)ln.eo2, r00.y2);
+      if (ok01) spm_st4(px[0][1].out2 + (size_t)ln.eo2, r01.y2);
+      if (ok10) spm_st4(px[1][0].out2 + (size_t)ln.eo2, r10.y2);
+      if (ok11) spm_st4(px[1][1].out2 + (size_t)ln.eo2, r11.y2);
+    }
   }
   SF_STAMP_AT(L, 3);
 #ifdef SF_STAMP

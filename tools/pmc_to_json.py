@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load(d):
-    f = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", d, "*", "*counter_collection.csv")))[-1]
+    f = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", d, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1]      # newest (file names start with a pid)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
@@ -21,7 +21,7 @@ def load(d):
 
 def durations(d):
     """total ns per kernel name from the kernel trace written beside the counters"""
-    fs = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", d, "*", "*kernel_trace.csv")))
+    fs = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", d, "*", "*kernel_trace.csv")), key=os.path.getmtime)
     tot = collections.defaultdict(float)
     if fs:
         for r in csv.DictReader(open(fs[-1])):
