@@ -161,6 +161,10 @@ static_assert(sizeof(ConvProblem) % 8 == 0, "problems are stored back to back in
 // table writer: up to SP_WRITER_BYTES of a table per launch, passed by value (one or two launches per rollout)
 #define SP_WRITER_BYTES 61440     /* measured on this runtime (tools/r04/kernarg_probe.hip): kernel arguments of 64 KB launch and capture fine */
 struct FlowBlob { unsigned char b[SP_WRITER_BYTES]; };
+// every struct that travels as a kernel argument, against the sizes the launch paths were measured with
+static_assert(sizeof(ConvLaunch) <= 4096, "ConvLaunch is passed by value: one 4-KB kernarg page");
+static_assert(sizeof(SpFlow) <= 64, "SpFlow is passed by value");
+static_assert(sizeof(FlowBlob) + 64 <= 65536, "table writer: blob + the scalar arguments beside it stay below the probed 64 KB");
 
 // Diagnostic builds only (-DSF_STAMP, tools/r02/stamps.py): wave 0 of every workgroup records s_memrealtime (100 MHz)
 // at fixed points of the kernel into a debug buffer no other code reads.  The product build compiles none of it.
