@@ -215,3 +215,36 @@ def test_winograd_conv(i):
     # ... and agrees with the direct form of the same layer far inside the tolerance both have against torch
     direct = _run(c, 300 + i, wino=False)
     assert maxabs(got, direct) <= 5e-5, maxabs(got, direct)
+
+
+@pytest.mark.parametrize("i", [0, 1, 7, 11, 13])
+def test_winograd_conv_is_bitwise_reproducible(i):
+    """Two workgroups per CU, LDS-DMA rings with counted waits, transform buffers reused chunk after chunk: a race would show up as
+    run-to-run differences.  12 launches of the same layer (other work interleaved) must agree bit for bit — plain and dilated."""
+    from streamingflow_amd import _lib, packing, runtime
+    c = dict(dil=1)
+    c.update(_WINO[i])
+    n, H, W, c0, c1, cout, dil = c["n"], c["H"], c["W"], c["c0"], c["c1"], c["cout"], c["dil"]
+    g = torch.Generator(device="cuda").manual_seed(4321 + i)
+    a0 = torch.randn((n, H, W, c0), device="cuda", generator=g)
+    a1 = torch.randn((n, H, W, c1), device="cuda", generator=g) if c1 else None
+    w = torch.randn((cout, c0 + c1, 3, 3), device="cuda", generator=g) * 0.05
+    packing.set_winograd(True)
+    pk = packing.Pack(None)
+    cw = packing.conv_w(pk, w, c0, c1, act="lrelu", dil=dil, stride=1, pad=dil)
+    assert cw.w_wino, "the layer must have been packed with Winograd weights"
+    L = _lib.lib()
+    ws = runtime.workspace(L.sf_conv2d_ex_ws_bytes(), "cuda")
+    outs = []
+    for r in range(12):
+        out = torch.empty((n, H, W, cout), device="cuda")
+        _lib.check(L.sf_conv2d_ex_fwd(ctypes.byref(cw), runtime.ptr(a0), c0, runtime.ptr(a1), c1, None, cout, 0,
+                                      ctypes.c_void_p(out.data_ptr()), cout, 0, n, H, W, 0, runtime.ptr(ws), ws.numel() * 4,
+                                      runtime.stream_ptr()), "conv2d_ex")
+        if r % 3 == 1:
+            torch.randn(1 << (12 + r), device="cuda").sum()      # unrelated work in between
+        outs.append(out)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
