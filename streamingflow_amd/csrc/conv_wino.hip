@@ -255,12 +255,14 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   const int NS = nkc * 8;                                      // stages
   const int c0 = P.c0;
 
+  const int up = DIL ? 0 : P.in_up;                            // nearest x2 upsampling on read (plain form): input pixel (y >> 1, x >> 1)
+  const int Win = P.Win;
 #if defined(__HIP_DEVICE_COMPILE__)
   auto make_rsrc = [](const float* base, size_t bytes) {
     const unsigned nrec = bytes < 0x7fffffffull ? (unsigned)bytes : 0x7fffffffu;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (int)nrec, 0x00020000);
   };
-  const size_t img_px = (size_t)H * W;
+  const size_t img_px = (size_t)P.Hin * P.Win;
   const __amdgpu_buffer_rsrc_t rsrc0 = make_rsrc(P.in0 + (size_t)img * img_px * P.in0_cs, img_px * P.in0_cs * sizeof(float));
   const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(P.in1 ? P.in1 + (size_t)img * img_px * P.in1_cs : P.in0, P.in1 ? img_px * P.in1_cs * sizeof(float) : 0);
   const __amdgpu_buffer_rsrc_t rsrc_u = make_rsrc(P.w_wino, (size_t)nkc * 16 * P.cout_pad * 16 * sizeof(float));
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
       const bool oky = ay.patch_coord(py, py0, qt0, TH, H, iy), okx = ax.patch_coord(px, px0, pt0, TW, W, ix);
       ok = pix < G::NPX && oky && okx;
     }
-    const int pofs = iy * W + ix;
+    const int pofs = DIL ? iy * W + ix : (iy >> up) * Win + (ix >> up);
     if constexpr (PQ) {
       if (d < npw) *(__attribute__((address_space(3))) int*)(PqPark + e) = ok ? pofs : -1;      // read back by the same lane when it issues the DMA
     } else pv0[d] = ok ? (pofs * P.in0_cs + quad * 4) * 4 : (int)0x80000000;      // + the chunk's channel offset stays out of range: zero fill
@@ -781,11 +783,11 @@ hipError_t launch_wino_weights(const float* w, float* U, int cout_pad, int cin_p
 // in whole 16-channel chunks; transformed weights present; images of at least one workgroup tile
 bool wino_takes(const ConvProblem& q, int epi) {
   if (epi != EPI_AFFINE && epi != EPI_BLEND) return false;
-  if (!q.w_wino || q.KH != 3 || q.KW != 3 || q.stride != 1 || q.dil < 1 || q.pad != q.dil || q.in_up || q.gather || q.gate || q.in_scale || q.se_sum ||
+  if (!q.w_wino || q.KH != 3 || q.KW != 3 || q.stride != 1 || q.dil < 1 || q.pad != q.dil || (q.in_up && q.dil != 1) || q.gather || q.gate || q.in_scale || q.se_sum ||
       q.nsplit > 1 || q.chansum || q.acc_in || q.fuse_w || (epi == EPI_AFFINE && (q.mode & 4)))
     return false;
   if ((q.c0 % 16) || (q.c1 % 16) || q.c0 + q.c1 != q.cin_pad || (q.cout_pad % 64) || (q.cout % 4)) return false;
-  if (q.Hout != q.Hin || q.Wout != q.Win || q.Hout < 16 || q.Wout < 32) return false;
+  if (q.Hout != (q.Hin << q.in_up) || q.Wout != (q.Win << q.in_up) || q.Hout < 16 || q.Wout < 32) return false;      // in_up: nearest x2 upsampling on read
   // dilated (conv_wino_kernel<.., DIL>): one input tensor, AFFINE epilogue, every phase of both axes at least 5 pixels = 3 tiles long
   if (q.dil > 1 && (q.c1 != 0 || epi != EPI_AFFINE || q.Hout / q.dil < 5 || q.Wout / q.dil < 5)) return false;
   const double img_bytes = 4.0 * q.Hin * q.Win;

@@ -190,6 +190,9 @@ _WINO = [
     dict(c0=32, c1=0, cout=192, n=3, H=203, W=241, dil=40, pad=40),
     dict(c0=64, c1=0, cout=64, n=4, H=181, W=187, dil=2, pad=2),
     dict(c0=64, c1=0, cout=64, n=44, H=50, W=64, dil=3, pad=3),
+    # nearest x2 upsampling on read (the decoder's upsampling layers): H, W are the INPUT size here
+    dict(c0=128, c1=0, cout=128, n=3, H=100, W=100, in_up=1),
+    dict(c0=32, c1=32, cout=64, n=4, H=67, W=71, in_up=1),
 ]
 
 
