@@ -76,7 +76,8 @@ struct WinoGeo {
   static constexpr int RING = (MW == 1 && !DIL) ? 4 : 3;       // U stages in LDS (RING - 1 in flight); what fits twice into a CU's 160 KB
 #endif
   static constexpr int SB = 2 * COUT_T;                        // the workgroup's scale / bias rows, staged in the prologue for the epilogue
-  static constexpr int LDS_FLOATS = RING * U_FLOATS + NVB * V_FLOATS + NPB * P_FLOATS + PARK + SB;
+  static constexpr int SC = (MW == 1 && !DIL) ? 256 : 0;       // per-channel input scale of the image (SE gate on in0, <= 256 channels), staged in the prologue
+  static constexpr int LDS_FLOATS = RING * U_FLOATS + NVB * V_FLOATS + NPB * P_FLOATS + PARK + SB + SC;
   static constexpr int WG_PER_CU = MW == 2 ? 1 : 2;
 };
 
@@ -267,6 +268,9 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(P.in1 ? P.in1 + (size_t)img * img_px * P.in1_cs : P.in0, P.in1 ? img_px * P.in1_cs * sizeof(float) : 0);
   const __amdgpu_buffer_rsrc_t rsrc_u = make_rsrc(P.w_wino, (size_t)nkc * 16 * P.cout_pad * 16 * sizeof(float));
 #endif
+  float* const SCbuf = Pbuf + NPB * G::P_FLOATS + G::PARK + G::SB;      // [c0] input scales (SCALED), behind Park and SBuf
+  constexpr bool SCALED = G::SC > 0 && EPI == EPI_AFFINE;      // the SE-scaled layers of p_model: the patch is multiplied per channel before the transform
+  const bool scaled = SCALED && P.in_scale != nullptr;
   // ---- patch DMA: element e = (pixel, channel quad) of the (2TH+2) x 18 patch, 16 bytes each, LDS linear in e -----------------
   SF_STAMP_AT(L, 14);
   // DIL: DMA `idx = d * 8 + wave` of the G::ND the patch needs (wave w issues npw of them); one input tensor (wino_takes)
@@ -319,6 +323,23 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
 #else
     (void)dst; (void)from1;
 #endif
+  };
+  // SCALED (SE gate on in0): every lane multiplies the patch pieces IT fetched by the four channel scales of its quad, in place, once
+  // its DMAs have landed — no register lives across the stage loop for it, and the transform stays as it is
+  auto scale_patch = [&](const int kc) {
+    if constexpr (SCALED) {
+      if (scaled && kc * 16 < c0) {
+        const int ln_ = wn_lane_id();
+        const f32x4 s4 = wn_lds_read128(SCbuf + kc * 16 + (ln_ & 3) * 4);
+        typedef __attribute__((address_space(3))) f32x4 lds_f4w;
+#pragma unroll
+        for (int d = 0; d < NP; ++d) {
+          if (d >= npw) continue;
+          float* const q = Pbuf + ((d * 8 + wave) * 64 + ln_) * 4;
+          *(lds_f4w*)q = wn_lds_read128(q) * s4;
+        }
+      }
+    }
   };
   // ---- U DMA: stage S = (chunk kc, position pair st): rows r of [2 positions][COUT_T], 64 B each; piece q = 16 rows ------------
   int uv[NU];
@@ -436,6 +457,9 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   };
   // ---- prologue: patch 0, three U stages (the ring), transform 0, patch 1 ------------------------------------------------------------
   const int n_u0 = NS < RING ? NS : RING;
+  float scv = 1.f;                                              // this thread's input-scale channel: requested in front of the DMAs (older: done when they are)
+  if constexpr (SCALED)
+    if (scaled && tid < c0) scv = P.in_scale[(size_t)img * c0 + tid];
   issue_patch(0);
   for (int S = 0; S < n_u0; ++S) issue_u(S);
   float sbv = tid < COUT_T ? 1.f : 0.f;                         // scale / bias of the cout block: requested behind the DMAs, parked in LDS below
@@ -448,6 +472,15 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   }
   SF_STAMP_AT(L, 11);
   wn_wait(NU * n_u0);                                           // the patch is the oldest: everything but the U stages (a wave that issued the load above also waits for U(0))
+  if constexpr (SCALED) {
+    if (scaled) {
+      if (tid < G::SC) SCbuf[tid] = scv;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wn_barrier();                                             // the scales are in LDS
+      scale_patch(0);                                           // this lane's own pieces (landed: wn_wait above)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
   wn_barrier();
   SF_STAMP_AT(L, 12);
   transform(0);
@@ -619,6 +652,7 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
               acc[2 * st + p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][p][m][e], fb[set][p][e], cin, 0, 0, 0);
             }
         __builtin_amdgcn_sched_barrier(0);
+        if (st == 3 && more) scale_patch(kc + 1);                   // its DMAs landed at stage 2's wait; published by the barriers of stages 4 .. 7
         if (st == 7 && more) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           wn_barrier();                                             // the next chunk's V is visible (and every wave is done with the patch)
@@ -783,7 +817,8 @@ hipError_t launch_wino_weights(const float* w, float* U, int cout_pad, int cin_p
 // in whole 16-channel chunks; transformed weights present; images of at least one workgroup tile
 bool wino_takes(const ConvProblem& q, int epi) {
   if (epi != EPI_AFFINE && epi != EPI_BLEND) return false;
-  if (!q.w_wino || q.KH != 3 || q.KW != 3 || q.stride != 1 || q.dil < 1 || q.pad != q.dil || (q.in_up && q.dil != 1) || q.gather || q.gate || q.in_scale || q.se_sum ||
+  if (!q.w_wino || q.KH != 3 || q.KW != 3 || q.stride != 1 || q.dil < 1 || q.pad != q.dil || (q.in_up && q.dil != 1) || q.gather || q.gate || q.se_sum ||
+      (q.in_scale && (epi != EPI_AFFINE || q.dil != 1 || q.c0 > 256)) ||      // SE-scaled input: plain AFFINE form, scales staged in LDS
       q.nsplit > 1 || q.chansum || q.acc_in || q.fuse_w || (epi == EPI_AFFINE && (q.mode & 4)))
     return false;
   if ((q.c0 % 16) || (q.c1 % 16) || q.c0 + q.c1 != q.cin_pad || (q.cout_pad % 64) || (q.cout % 4)) return false;
