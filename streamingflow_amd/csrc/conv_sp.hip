@@ -56,7 +56,11 @@ struct SpGeo {
   static constexpr int BUFF = 2 * SUBF;       // floats per chunk buffer
   static constexpr int RING = SP_NB * BUFF;   // NT 2: 72 KB, NT 4: 96 KB
   static constexpr int NBI = BN / 32;         // pixel row blocks (8 rows) per loader and sub-chunk
+#if defined(SF_ABL_NO_PIXEL_DMA)      // timing-only ablation (results are garbage): the loaders issue the weight DMAs only — what a pixel operand
+  static constexpr int DPC = 2 * 2;           // that is LDS-resident could save at most (tools/r04/abl_pixel_dma.sh)
+#else
   static constexpr int DPC = 2 * (2 + NBI);   // DMA instructions per loader and chunk
+#endif
   static constexpr int NPX = BN / 32;         // epilogue items (pixel, channel quad) per consumer lane
   static_assert(4 * BN * SP_RED_PITCH + 512 <= RING, "reduction buffer + channel-sum scratch live in the ring");
 };
@@ -697,6 +701,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * lw) * 32), 16, a_voff[0], sc * 128, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * (lw + 4)) * 32), 16, a_voff[1], sc * 128, 0, 0);
           }
+#if !defined(SF_ABL_NO_PIXEL_DMA)
 #pragma unroll
           for (int i = 0; i < G::NBI; ++i) {
             float* const dB = blk + (SP_BM + 8 * (lw + 4 * i)) * 32;
@@ -708,14 +713,17 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
             if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (sp_lds_void*)dB, 16, vob, 0, 0, PX_AUX);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (sp_lds_void*)dB, 16, vob, 0, 0, PX_AUX);
           }
+#endif
         } else {      // offset -1 fails the buffer range check: the DMA writes zeros
           if (with_w) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * lw) * 32), 16, minus1, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * (lw + 4)) * 32), 16, minus1, 0, 0, 0);
           }
+#if !defined(SF_ABL_NO_PIXEL_DMA)
 #pragma unroll
           for (int i = 0; i < G::NBI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (sp_lds_void*)(blk + (SP_BM + 8 * (lw + 4 * i)) * 32), 16, minus1, 0, 0, 0);
+#endif
         }
 #else
         (void)blk; (void)koff; (void)from1; (void)live; (void)whole_chunks; (void)minus1;
