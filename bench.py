@@ -384,7 +384,13 @@ def main():
                     "algorithmic_bytes_per_step": by / Bs, "algorithmic_gbs": by / t / 1e9,
                     "hbm_frac": by / t / 1e9 / PEAK_HBM_GBS}
         step_only = {"single_sample": time_step(1, H // 4, W // 4, 50), "batch8": time_step(8, H // 4, W // 4, 20),
-                     "stress_latent_200x200": time_step(1, H, W, 5)}
+                     "stress_latent_200x200": time_step(1, H, W, 5),
+                     # `tflops` / `mfma_frac` here divide the reference's (direct-form) FLOPs of a step by its time.  From 14 000 pixels per
+                     # launch the gates / candidates of a step run in Winograd form (2.25x fewer executed products): for batch8 and the
+                     # 200x200 latent these are direct-form-EQUIVALENT rates, not matrix-pipe utilisation; the single latent runs no
+                     # Winograd layer
+                     "flop_accounting": "algorithmic (direct-form) FLOPs / time; batch8 and stress_latent_200x200 include Winograd layers "
+                                        "(SF_WINO_MIN_P = 14000): direct-form-equivalent rates"}
         if rank == 0 and world == 1 and not a.no_cpu_baseline:      # the same unit of work on the host cores (oracle, 16 threads)
             from oracle import ref_torch as R
             torch.set_num_threads(min(os.cpu_count() or 1, 16))

@@ -165,7 +165,8 @@ const Tune& tune() {
     x.wide64 = geti("SF_WIDE64", 0);               // 1: 64-cout layers at >= 131072 pixels on 64 x 256 tiles (variant 10) instead of 64 x 128
     x.seg_maxph = geti("SF_SEG_MAXPH", 1 << 30);   // diagnostic: at most this many phases per persistent flow launch (1: every phase its own launch of the flow kernel)
     x.wino = geti("SF_WINO", 1);                   // layers packed with Winograd weights run conv_wino.hip from wino_min_p pixels (0: direct form everywhere)
-    x.wino_min_p = geti("SF_WINO_MIN_P", 65536);       // measured: 32 latents of 50x50 (80 000 pixels) gain 1.6 % on the headline, profiles/r04_zz_wino_min_p_sweep.txt
+    x.wino_min_p = geti("SF_WINO_MIN_P", 14000);       // measured (profiles/r04_zz_wino_min_p_sweep.txt, r04_zz_step_min_p_batched_latents.txt): 6 or more batched 50x50 latents
+                                                     // and one 200x200 latent gain 6-11 % per ODE step, 5 latents / one 100x100 latent lose 4-7 %; 32 latents +1.6 % on the headline
     x.flow_timeout = geti("SF_FLOW_TIMEOUT", 1 << 22);   // polls before a dependency wait of the flow kernel gives up (~1 us each: seconds); bring-up runs use a small value
     x.flow_sc1 = geti("SF_FLOW_SC1", 0);           // experiment: flow kernel without the acquire fence (every load of handed-off bytes an sc1 load)
     x.fenced = geti("SF_HANDOFF_FENCED", 0);       // 1: split-K hand-offs also run the agent-scope release / acquire fences of round 1 (known-good reference for the fence-free sc1 form; gfx950 only either way)
