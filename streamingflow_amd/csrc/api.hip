@@ -489,7 +489,8 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
         }
         const ConvProblem& q = ps[i];
         ProfRec r;
-        r.key = (16 + wino_variant(q)) * 8 + epi;      // _lib.KERNEL_NAMES: wino128x32t / wino64x64t / wino64x32t2 / wino64x32t2dil
+        const int wv = wino_variant(q);
+        r.key = (16 + (wv == 4 ? 2 : wv)) * 8 + epi;   // _lib.KERNEL_NAMES: wino128x32t / wino64x64t / wino64x32t2 (also its form with concatenated images) / wino64x32t2dil
         const double tiles = wino_tiles(q);
         r.flops = 2.0 * 16.0 * tiles * q.cout * (q.c0 + q.c1);      // executed: 16 products per 2x2 outputs and (cin, cout) pair
         r.bytes = 4.0 * ((double)q.n_img * q.Hin * q.Win * (q.c0 + q.c1) + 16.0 * q.cout * (q.c0 + q.c1) + (double)q.n_img * q.Hout * q.Wout * q.cout);

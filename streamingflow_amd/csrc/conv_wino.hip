@@ -51,11 +51,16 @@ typedef __attribute__((address_space(3))) void wn_lds_void;
 //     (y mod d, x mod d) and sees only input pixels of its own phase).  The tile grid of a workgroup is the product of two lists —
 //     along x: for every phase p its ceil(len(p) / 2) tiles in turn, along y the same — so a block of TH x 8 tiles may span up to
 //     RY x RX phases, and the patch keeps 2 n + 2 rows / columns per run of n tiles of one phase.
-template <int COUT_T, int TH, int MW, bool DIL = false>
+// CAT: narrow images (a 50x50 latent is 25 tiles wide: blocks of 8 tile columns would be 28 % empty) are concatenated along x — the
+//     tile columns of all images form one list, a block of 8 columns may span two images, and the patch keeps a halo column on either
+//     side of each image's run (2 n + 2 columns per run, as DIL).  One input scale / bias set per workgroup: layers with per-image
+//     epilogue operands keep the plain form.
+template <int COUT_T, int TH, int MW, bool DIL = false, bool CAT = false>
 struct WinoGeo {
+  static_assert(!(DIL && CAT), "one run structure at a time");
   static constexpr int TW = 8, WT = TH * TW;                   // Winograd tiles of a workgroup: TH rows x 8 columns
   static constexpr int RY = 2, RX = 4;                         // DIL: runs (phases) a block may span: >= 3 tiles per phase (wino_takes)
-  static constexpr int PH = 2 * TH + (DIL ? 2 * RY : 2), PW = 2 * TW + (DIL ? 2 * RX : 2);       // input patch (pixels)
+  static constexpr int PH = 2 * TH + (DIL ? 2 * RY : 2), PW = 2 * TW + (DIL ? 2 * RX : (CAT ? 4 : 2));       // input patch (pixels)
   static constexpr int NPX = PH * PW;
   static constexpr int WMW = COUT_T / (16 * MW), WNW = WT / 16; // waves along cout / tiles
   static_assert(WMW * WNW == 8, "eight waves");
@@ -211,9 +216,9 @@ struct WnAxis {
   }
 };
 
-template <int COUT_T, int TH, int MW, int EPI, bool DIL = false>
+template <int COUT_T, int TH, int MW, int EPI, bool DIL = false, bool CAT = false>
 __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kernel(const ConvLaunch L) {
-  typedef WinoGeo<COUT_T, TH, MW, DIL> G;
+  typedef WinoGeo<COUT_T, TH, MW, DIL, CAT> G;
   constexpr int TW = G::TW, WT = G::WT, PW = G::PW, NU = G::NU, NP = G::NP, NVB = G::NVB, NPB = G::NPB, RING = G::RING;
   static_assert(!DIL || (NVB == 1 && NPB == 1), "the dilated form exists for the two-workgroup configuration");
   constexpr bool ROLL = WN_ROLL_BUILD && NVB == 1 && NPB == 1 && WT == 32 && MW == 1 && !DIL;      // rolling input transform (below; the dilated form has no registers for it)
@@ -227,22 +232,26 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   const int H = P.Hout, W = P.Wout;                            // stride 1, pad = dilation: input size = output size
   const WnAxis ax(DIL ? W : 2, DIL ? P.dil : 1), ay(DIL ? H : 2, DIL ? P.dil : 1);      // plain form: constants, folded away
   const int tiles_x = DIL ? ax.nt : (W + 1) >> 1, tiles_y = DIL ? ay.nt : (H + 1) >> 1;
-  const int nbx = (tiles_x + TW - 1) / TW, nby = (tiles_y + TH - 1) / TH;
+  const int tpi = tiles_x;                                     // CAT: tile columns per image; the column list has n_img * tpi entries
+  const int nbx = ((CAT ? P.n_img * tiles_x : tiles_x) + TW - 1) / TW, nby = (tiles_y + TH - 1) / TH;
   // 1-D grid, XCD-aware: workgroup lin runs on XCD lin % 8 (round-robin dispatch).  Every XCD owns a contiguous range of tile blocks
   // (neighbouring blocks share their halo rows / columns through that XCD's L2), and the cout blocks of one tile block are
   // consecutive workgroups of the same XCD: the second one finds the input patch in L2.
   // (A persistent form — two workgroups per CU looping over the items of their XCD, argument pointer and thread index laundered per
   // tile against hoisting — measured 5 % SLOWER than one workgroup per item: profiles/r04_z7_winobench_persistent_vs_per_tile.txt.)
   const int ncb = P.cout_pad / COUT_T;
-  const int nblk = nbx * nby * P.n_img, per_xcd = (nblk + 7) >> 3;
+  const int nblk = nbx * nby * (CAT ? 1 : P.n_img), per_xcd = (nblk + 7) >> 3;
   const int lin = (int)blockIdx.x, xcd = lin & 7, slot = lin >> 3;
   const int tb_ = slot / ncb;
   int b = xcd * per_xcd + tb_;
   if (b >= nblk) return;
   const int bx = b % nbx; b /= nbx;
   const int by = b % nby;
-  const int img = b / nby;
-  const int ty0 = by * TH, tx0 = bx * TW;                      // DIL: indices into the tile lists of the two axes
+  // CAT: the block's first column is tile ct0 of image img; its columns from cn0 on belong to image img + 1 (tiles 0 ..)
+  const int img = CAT ? (bx * TW) / tpi : b / nby;
+  const int ct0 = CAT ? bx * TW - img * tpi : 0;
+  const int cn0 = CAT ? (tpi - ct0 < TW ? tpi - ct0 : TW) : TW;
+  const int ty0 = by * TH, tx0 = CAT ? ct0 : bx * TW;          // DIL: indices into the tile lists of the two axes
   int px0 = 0, pt0 = 0, py0 = 0, qt0 = 0;                      // DIL: (phase, tile) of the block's first column / row
   if constexpr (DIL) { ax.decode(tx0, px0, pt0); ay.decode(ty0, py0, qt0); }
   SF_STAMP_AT(L, 0);
@@ -256,6 +265,7 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   const int NS = nkc * 8;                                      // stages
   const int c0 = P.c0;
 
+  const int img_px_i = P.Hin * P.Win;                          // CAT: pixel offset of the next image inside the buffer
   const int up = DIL ? 0 : P.in_up;                            // nearest x2 upsampling on read (plain form): input pixel (y >> 1, x >> 1)
   const int Win = P.Win;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -264,8 +274,9 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (int)nrec, 0x00020000);
   };
   const size_t img_px = (size_t)P.Hin * P.Win;
-  const __amdgpu_buffer_rsrc_t rsrc0 = make_rsrc(P.in0 + (size_t)img * img_px * P.in0_cs, img_px * P.in0_cs * sizeof(float));
-  const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(P.in1 ? P.in1 + (size_t)img * img_px * P.in1_cs : P.in0, P.in1 ? img_px * P.in1_cs * sizeof(float) : 0);
+  const size_t n_in = (CAT && img + 1 < P.n_img) ? 2 : 1;      // CAT: the buffer covers this image and the next
+  const __amdgpu_buffer_rsrc_t rsrc0 = make_rsrc(P.in0 + (size_t)img * img_px * P.in0_cs, n_in * img_px * P.in0_cs * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(P.in1 ? P.in1 + (size_t)img * img_px * P.in1_cs : P.in0, P.in1 ? n_in * img_px * P.in1_cs * sizeof(float) : 0);
   const __amdgpu_buffer_rsrc_t rsrc_u = make_rsrc(P.w_wino, (size_t)nkc * 16 * P.cout_pad * 16 * sizeof(float));
 #endif
   float* const SCbuf = Pbuf + NPB * G::P_FLOATS + G::PARK + G::SB;      // [c0] input scales (SCALED), behind Park and SBuf
@@ -286,12 +297,17 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
     const int pix = e >> 2, quad = e & 3;
     const int py = pix / PW, px = pix - py * PW;
     int iy = 2 * ty0 - 1 + py, ix = 2 * tx0 - 1 + px;
-    bool ok = pix < G::NPX && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    int run = 0;                                                // CAT: columns from 2 cn0 + 2 on are the next image's run, starting at its halo column x = -1
+    if constexpr (CAT) {
+      run = px >= 2 * cn0 + 2 ? 1 : 0;
+      ix = run ? px - (2 * cn0 + 2) - 1 : ix;
+    }
+    bool ok = pix < G::NPX && iy >= 0 && iy < H && ix >= 0 && ix < W && (!CAT || (img + run < P.n_img && (run == 0 || cn0 < TW)));
     if constexpr (DIL) {
       const bool oky = ay.patch_coord(py, py0, qt0, TH, H, iy), okx = ax.patch_coord(px, px0, pt0, TW, W, ix);
       ok = pix < G::NPX && oky && okx;
     }
-    const int pofs = DIL ? iy * W + ix : (iy >> up) * Win + (ix >> up);
+    const int pofs = DIL ? iy * W + ix : (iy >> up) * Win + (ix >> up) + (CAT ? run * img_px_i : 0);
     if constexpr (PQ) {
       if (d < npw) *(__attribute__((address_space(3))) int*)(PqPark + e) = ok ? pofs : -1;      // read back by the same lane when it issues the DMA
     } else pv0[d] = ok ? (pofs * P.in0_cs + quad * 4) * 4 : (int)0x80000000;      // + the chunk's channel offset stays out of range: zero fill
@@ -394,7 +410,8 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
       const int r1 = (i == 0) ? 0 : (i == 2 ? 2 : 1), r2 = (i == 3) ? 3 : (i == 2 ? 1 : 2);
       const float sg = (i == 1) ? 1.f : -1.f;
       // the tile's first patch pixel: rows / columns 2 t for the plain form; DIL: 2 t + 2 (run of the tile), parked in LDS
-      const int tp = DIL ? *(const __attribute__((address_space(3))) int*)(Park + tid) : ((2 * tyl) * PW + 2 * txl) * 16 + quad * 4;
+      const int tp = DIL ? *(const __attribute__((address_space(3))) int*)(Park + tid)
+                         : ((2 * tyl) * PW + 2 * txl + ((CAT && txl >= cn0) ? 2 : 0)) * 16 + quad * 4;      // CAT: the next image's run sits two columns further
       const float* const a = src + tp + r1 * PW * 16;
       const float* const bb = src + tp + r2 * PW * 16;
       float* const o = dst + ((i * 4) * WT + wt) * 16 + ((quad ^ ((wt >> 2) & 2)) << 2);
@@ -672,7 +689,9 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
   int ln_e = lane;
   asm volatile("" : "+v"(ln_e));
   const int wtl_e = wn * 16 + (ln_e & 15), g_e = ln_e >> 4;
-  const int ty = ty0 + wtl_e / TW, tx = tx0 + wtl_e % TW;
+  const int txl_e = wtl_e % TW;
+  const bool run_e = CAT && txl_e >= cn0;                      // CAT: the lane's tile belongs to the next image
+  const int ty = ty0 + wtl_e / TW, tx = run_e ? txl_e - cn0 : tx0 + txl_e;
   const size_t img_base = (size_t)img * H * W;
   // output pixel (2 t + i) of the tile; DIL: pixel 2 t + i of the tile's phase = phase + d (2 t + i)
   int oy0 = 2 * ty, ox0 = 2 * tx, ostep = 1;
@@ -700,8 +719,9 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
       px[bq][i].out = P.out + p0 * P.out_cs + P.out_co;
       px[bq][i].out2 = P.out2 ? P.out2 + p0 * P.out2_cs : nullptr;
     }
-  const bool x0 = ox0 < W, x1 = ox0 + ostep < W, y0ok = oy0 < H, y1ok = oy0 + ostep < H;
-  const unsigned pix = (x0 && y0ok) ? (unsigned)(oy0 * W + ox0) : 0u;      // lanes without a tile compute on pixel 0 and store nothing
+  const bool img_ok = !CAT || img + (run_e ? 1 : 0) < P.n_img;
+  const bool x0 = img_ok && ox0 < W, x1 = img_ok && ox0 + ostep < W, y0ok = oy0 < H, y1ok = oy0 + ostep < H;
+  const unsigned pix = (x0 && y0ok) ? (unsigned)(oy0 * W + ox0 + (run_e ? H * W : 0)) : 0u;      // lanes without a tile compute on pixel 0 and store nothing
 #pragma unroll
   for (int m = 0; m < MW; ++m) {
     const int cl = wm * 16 * MW + m * 16 + 4 * g_e;            // channel inside the workgroup's cout block
@@ -834,10 +854,10 @@ bool wino_takes(const ConvProblem& q, int epi) {
   return true;
 }
 
-template <int COUT_T, int TH, int MW, int EPI, bool DIL = false>
+template <int COUT_T, int TH, int MW, int EPI, bool DIL = false, bool CAT = false>
 static hipError_t launch_wino_t(const ConvLaunch& L, hipStream_t stream) {
-  typedef WinoGeo<COUT_T, TH, MW, DIL> G;
-  auto kern = conv_wino_kernel<COUT_T, TH, MW, EPI, DIL>;
+  typedef WinoGeo<COUT_T, TH, MW, DIL, CAT> G;
+  auto kern = conv_wino_kernel<COUT_T, TH, MW, EPI, DIL, CAT>;
   constexpr int lds = G::LDS_FLOATS * 4;
   static bool attr_done[64] = {};
   int dev = 0;
@@ -849,11 +869,26 @@ static hipError_t launch_wino_t(const ConvLaunch& L, hipStream_t stream) {
   }
   const ConvProblem& P = L.p[0];
   const int tiles_x = DIL ? WnAxis(P.Wout, P.dil).nt : (P.Wout + 1) / 2, tiles_y = DIL ? WnAxis(P.Hout, P.dil).nt : (P.Hout + 1) / 2;
-  const long blocks = (long)P.n_img * ((tiles_y + TH - 1) / TH) * ((tiles_x + G::TW - 1) / G::TW);
+  const long blocks = CAT ? (long)((tiles_y + TH - 1) / TH) * (((long)P.n_img * tiles_x + G::TW - 1) / G::TW)
+                          : (long)P.n_img * ((tiles_y + TH - 1) / TH) * ((tiles_x + G::TW - 1) / G::TW);
   const long grid = ((blocks + 7) / 8) * 8 * (P.cout_pad / COUT_T);      // tile blocks in groups of 8 (one per XCD) x cout blocks
   if (grid > 0x7fffffffL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid, 1, 1), dim3(WN_THREADS), lds, stream, L);
   return hipGetLastError();
+}
+// CAT pays where blocks of 8 tile columns fit the image badly and no epilogue operand is per image (SF_WINO_CAT=0: never)
+static bool wino_cat(const ConvProblem& q) {
+  static const int on = [] { const char* v = std::getenv("SF_WINO_CAT"); return v ? std::atoi(v) : 1; }();
+  const int tpi = (q.Wout + 1) / 2;
+  if (!on || q.dil != 1 || q.in_up || q.n_img < 2 || tpi < 8 || q.in_scale || q.bias_per_img || q.add_scale) return false;
+  const int plain = (tpi + 7) / 8 * 8;
+  if (plain * 100 < tpi * 110) return false;      // less than 10 % empty columns: keep the plain form
+  const double img_bytes = 4.0 * q.Hin * q.Win;
+  const int cs = q.in0_cs > q.in1_cs ? q.in0_cs : q.in1_cs;
+  const int co = q.out_cs > q.add_cs ? q.out_cs : q.add_cs;
+  const int ce = q.e0_cs > q.e1_cs ? q.e0_cs : q.e1_cs;
+  const int cm = co > ce ? (co > q.out2_cs ? co : q.out2_cs) : (ce > q.out2_cs ? ce : q.out2_cs);
+  return 2.0 * img_bytes * cs < 2147483648.0 && 2.0 * img_bytes * cm < 2147483648.0;      // two images behind one base
 }
 // which tile configuration a problem runs on: 0 = 128 cout x 32 tiles, 1 = 64 cout x 64 tiles, 2 = 64 cout x 32 tiles, two
 // workgroups per CU (SF_WINO_TILE = 128 | 64 | 2 forces one: experiments); -1: none
@@ -861,6 +896,7 @@ int wino_variant(const ConvProblem& q) {
   static const int force = [] { const char* v = std::getenv("SF_WINO_TILE"); return v ? std::atoi(v) : 0; }();
   if (q.cout_pad % 64) return -1;
   if (q.dil > 1) return 3;      // the dilated form of configuration 2
+  if (wino_cat(q)) return 4;    // configuration 2 with the images concatenated along x
 #if defined(SF_WINO_ALL_TILES)      // the one-workgroup-per-CU configurations are built for experiments only (tools/r02/build_variant.sh)
   if (force == 64) return 1;
   if (force == 128) return q.cout_pad % 128 == 0 ? 0 : 2;
@@ -888,6 +924,7 @@ hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream) {
 #endif
     case 2: return affine ? launch_wino_t<64, 4, 1, EPI_AFFINE>(L, stream) : launch_wino_t<64, 4, 1, EPI_BLEND>(L, stream);
     case 3: return affine ? launch_wino_t<64, 4, 1, EPI_AFFINE, true>(L, stream) : hipErrorInvalidValue;
+    case 4: return affine ? launch_wino_t<64, 4, 1, EPI_AFFINE, false, true>(L, stream) : launch_wino_t<64, 4, 1, EPI_BLEND, false, true>(L, stream);
   }
   return hipErrorInvalidValue;
 }
