@@ -223,10 +223,11 @@ def test_winograd_conv(i):
     assert maxabs(got, direct) <= 5e-5, maxabs(got, direct)
 
 
-@pytest.mark.parametrize("i", [0, 1, 7, 11, 13])
+@pytest.mark.parametrize("i", [0, 1, 4, 5, 7, 11, 13])
 def test_winograd_conv_is_bitwise_reproducible(i):
     """Two workgroups per CU, LDS-DMA rings with counted waits, transform buffers reused chunk after chunk: a race would show up as
-    run-to-run differences.  12 launches of the same layer (other work interleaved) must agree bit for bit — plain and dilated."""
+    run-to-run differences.  12 launches of the same layer (other work interleaved) must agree bit for bit — plain, dilated, and narrow
+    images concatenated along x (cases 4 and 5)."""
     from streamingflow_amd import _lib, packing, runtime
     c = dict(dil=1)
     c.update(_WINO[i])
