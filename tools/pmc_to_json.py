@@ -43,8 +43,12 @@ def main():
     dur = durations("pmcb_write")
     for r in rows:
         r["total_ms_under_pmc"] = dur.get(r["kernel"], 0.0) / 1e6
-    if len(sys.argv) > 1:
-        dom = next((r for r in rows if sys.argv[1] in r["kernel"]), rows[0])
+    if len(sys.argv) > 1:      # every instantiation whose name contains the fragment, merged (bench.py's profiler key groups the plain form of the
+        #                        Winograd kernel and its form with concatenated images: "conv_wino_kernel<64, 4, 1, 0, false, ")
+        grp = [r for r in rows if sys.argv[1] in r["kernel"]] or rows[:1]
+        n = sum(r["launches"] for r in grp)
+        dom = {"kernel": " + ".join(r["kernel"] for r in grp), "launches": n,
+               "hbm_bytes_per_launch": sum(r["total_hbm_bytes"] for r in grp) / max(1, n)}
     else:       # the kernel template that takes the most time in the forward (bench.py's `roofline.kernel` groups by tile shape)
         dom = max(rows, key=lambda r: r["total_ms_under_pmc"]) if dur else rows[0]
     out = {"kernel": dom["kernel"], "hbm_bytes_per_launch": dom["hbm_bytes_per_launch"],

@@ -7,7 +7,7 @@ export SF_COMMIT=${SF_COMMIT:-unknown}
 export SF_FLOW_TIMEOUT=65536
 # 1. dominant kernel of the forward
 bash $R/tools/pmc_bench.sh > /dev/null 2>&1
-python3 $R/tools/pmc_to_json.py "conv_wino_kernel<64, 4, 1, 0, false>" > $R/gpurun_out/pmc_dominant.log 2>&1      # bench.py's dominant kernel (most time in the batched forward)
+python3 $R/tools/pmc_to_json.py "conv_wino_kernel<64, 4, 1, 0, false, " > $R/gpurun_out/pmc_dominant.log 2>&1      # bench.py's dominant kernel (most time in the batched forward)
 cp $R/profiles/pmc_dominant.json $R/gpurun_out/pmc_dominant.json
 # 2. the single latent inside a rollout: chains of 10 and 30 steps, both forms
 for n in 10 30; do
