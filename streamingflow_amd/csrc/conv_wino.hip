@@ -126,6 +126,7 @@ __device__ __forceinline__ void wn_wait(const int n) {
 // global_load / global_store), lane masks as scalar conditions, operand loads requested before the output transform.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 wn_sub2(const f32x2 a, const f32x2 b) { return __builtin_elementwise_fma(b, (f32x2){-1.f, -1.f}, a); }   // v_pk_fma_f32
+__device__ __forceinline__ f32x4 wn_sub4(const f32x4 a, const f32x4 b) { return __builtin_elementwise_fma(b, (f32x4){-1.f, -1.f, -1.f, -1.f}, a); }       // two v_pk_fma_f32 (a - b, exact: one rounding)
 __device__ __forceinline__ f32x2 wn_lo(const f32x4 v) { return (f32x2){v[0], v[1]}; }
 __device__ __forceinline__ f32x2 wn_hi(const f32x4 v) { return (f32x2){v[2], v[3]}; }
 struct WnOps { float4 a, b; };      // AFFINE: residual, reset-gate state;  BLEND: update gate, state
@@ -799,6 +800,420 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
 #endif
 }
 
+
+// =====================================================================================================================================
+// Round 5: the same arithmetic (bitwise: same products, same summation orders) on a different decomposition.
+//
+// What bounded conv_wino_kernel (tools/r05/mfma_cost.hip, profiles/r05_a_mfma_cost.txt): the fp32 MFMA and every other vector-side
+// instruction share one issue port, and at two waves per SIMD and workgroup a 1-KB LDS-DMA piece costs ~20 cycles of matrix time, a
+// ds_read_b128 ~7, a vector instruction ~5.5, a global load into registers ~4.  Per tile of a 64 -> 64 layer the old kernel spends 8192
+// cycles per wave in MFMAs, ~2800 in 520 vector instructions of prologue / epilogue, ~1700 in 40 DMA pieces + 128 fragment reads, ~1100 in
+// the input transform: 0.59 of the peak by the issue port alone (measured 0.57-0.58).  Here:
+//   * wave (i, h) owns positions 4 i .. 4 i + 3 (row i of B^T d B) of 32 cout x 32 tiles: 2 A + 2 B fragments feed 16 MFMAs (1 + 1 feed 4
+//     in the old kernel: half the LDS reads), and row i is exactly what the two waves (i, 0), (i, 1) write in the input transform;
+//   * U never touches LDS: every lane loads its A fragments straight into registers (buffer_load_dwordx4, 1 KB contiguous per
+//     fragment, two steps ahead, the next-but-one fragment into the registers the current half-step has just released) — no U ring, no
+//     per-stage barrier (two barriers per 16-channel chunk instead of nine), and the freed LDS double-buffers V;
+//   * the output transform is split: T[i][b] = (M A)[i][b] in registers (4 positions -> 2 values), exchanged through LDS (64 KB over the
+//     V buffers, a swizzle that is conflict-free for the writers' and the readers' lane groups), Y = A^T T by the thread that stores it:
+//     lane = (tile, channel quad) with the 16 channel quads of a pixel in consecutive lanes — 256 contiguous bytes per pixel and store;
+//   * prologue index arithmetic cut to what is per-lane by nature.
+// Mode A (plain / concatenated images): V double-buffered, one patch buffer — barriers per chunk: B (chunk start: V(kc) published, patch
+// free) and M (patch(kc+1) landed, before the transform that runs between steps 1 and 2).  Mode B (dilated: its patch is 18 KB): one V, two
+// patch buffers, the transform at the chunk boundary between two barriers.
+template <bool DIL, bool CAT>
+struct Wino5Geo {
+  static_assert(!(DIL && CAT), "one run structure at a time");
+  static constexpr int COUT_T = 64, TH = 4, TW = 8, WT = TH * TW;
+  static constexpr int RY = 2, RX = 4;
+  static constexpr int PH = 2 * TH + (DIL ? 2 * RY : 2), PW = 2 * TW + (DIL ? 2 * RX : (CAT ? 4 : 2));
+  static constexpr int NPX = PH * PW;
+  static constexpr int ND = (NPX * 4 + 63) / 64;                // 1-KB DMA pieces of a patch; wave w issues pieces w, w + 8, ...
+  static constexpr int NP = (ND + 7) / 8;
+  static constexpr int P_FLOATS = ND * 256;
+  static constexpr int V_FLOATS = 16 * WT * 16;
+  static constexpr int NVB = DIL ? 1 : 2, NPB = DIL ? 2 : 1;
+  static constexpr int PARK = DIL ? 512 : 0;                    // DIL: the patch offset of every transform task
+  static constexpr int SB = 2 * COUT_T, SC = DIL ? 0 : 256;
+  static constexpr int T_FLOATS = 4 * 2 * WT * COUT_T;          // the exchange of the output transform: [row i][b][tile][cout]
+  static_assert(NVB * V_FLOATS + NPB * P_FLOATS >= T_FLOATS, "the exchange lives over V and the patch");
+  static constexpr int LDS_FLOATS = NVB * V_FLOATS + NPB * P_FLOATS + PARK + SB + SC;
+  static_assert(2 * LDS_FLOATS * 4 <= 160 * 1024, "two workgroups per CU");
+};
+
+template <int EPI, bool DIL = false, bool CAT = false>
+__global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLaunch L) {
+  typedef Wino5Geo<DIL, CAT> G;
+  constexpr int COUT_T = G::COUT_T, TH = G::TH, TW = G::TW, WT = G::WT, PW = G::PW, NP = G::NP;
+  constexpr bool MODE_A = G::NVB == 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const Vbuf = smem;
+  float* const Pbuf = Vbuf + G::NVB * G::V_FLOATS;
+  float* const Park = Pbuf + G::NPB * G::P_FLOATS;
+  float* const SBuf = Park + G::PARK;                          // [scale COUT_T][bias COUT_T]
+  float* const SCbuf = SBuf + G::SB;                           // [c0] input scales (SCALED)
+  const ConvProblem& P = L.p[0];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = P.Hout, W = P.Wout;
+  const WnAxis ax(DIL ? W : 2, DIL ? P.dil : 1), ay(DIL ? H : 2, DIL ? P.dil : 1);
+  const int tiles_x = DIL ? ax.nt : (W + 1) >> 1, tiles_y = DIL ? ay.nt : (H + 1) >> 1;
+  const int tpi = tiles_x;
+  const int nbx = ((CAT ? P.n_img * tiles_x : tiles_x) + TW - 1) / TW, nby = (tiles_y + TH - 1) / TH;
+  // 1-D grid, XCD-aware (as conv_wino_kernel): every XCD owns a contiguous range of tile blocks, the cout blocks of a tile block are
+  // consecutive workgroups of that XCD
+  const int ncb = P.cout_pad / COUT_T;
+  const int nblk = nbx * nby * (CAT ? 1 : P.n_img), per_xcd = (nblk + 7) >> 3;
+  const int lin = (int)blockIdx.x, xcd = lin & 7, slot_ = lin >> 3;
+  const int tb_ = slot_ / ncb;
+  int b = xcd * per_xcd + tb_;
+  if (b >= nblk) return;
+  const int bx = b % nbx; b /= nbx;
+  const int by = b % nby;
+  const int img = CAT ? (bx * TW) / tpi : b / nby;
+  const int ct0 = CAT ? bx * TW - img * tpi : 0;
+  const int cn0 = CAT ? (tpi - ct0 < TW ? tpi - ct0 : TW) : TW;
+  const int ty0 = by * TH, tx0 = CAT ? ct0 : bx * TW;
+  int px0 = 0, pt0 = 0, py0 = 0, qt0 = 0;
+  if constexpr (DIL) { ax.decode(tx0, px0, pt0); ay.decode(ty0, py0, qt0); }
+  SF_STAMP_AT(L, 0);
+#ifdef SF_STAMP
+  SF_STAMP_VAL(L, 8, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));
+  SF_STAMP_VAL(L, 9, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));
+  SF_STAMP_VAL(L, 10, (unsigned long long)nkc_stamp(P));
+#endif
+  const int cout0 = (slot_ - tb_ * ncb) * COUT_T;
+  const int nkc = P.cin_pad >> 4;                              // 16-channel chunks (>= 2: cin_pad is a multiple of 32)
+  const int NS = nkc * 4;                                      // steps: (chunk, position of the wave's row)
+  const int c0 = P.c0;
+  const int img_px_i = P.Hin * P.Win;
+  const int up = DIL ? 0 : P.in_up;
+  const int Win = P.Win;
+#if defined(__HIP_DEVICE_COMPILE__)
+  auto make_rsrc = [](const float* base, size_t bytes) {
+    const unsigned nrec = bytes < 0x7fffffffull ? (unsigned)bytes : 0x7fffffffu;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (int)nrec, 0x00020000);
+  };
+  const size_t img_px = (size_t)P.Hin * P.Win;
+  const size_t n_in = (CAT && img + 1 < P.n_img) ? 2 : 1;
+  const __amdgpu_buffer_rsrc_t rsrc0 = make_rsrc(P.in0 + (size_t)img * img_px * P.in0_cs, n_in * img_px * P.in0_cs * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(P.in1 ? P.in1 + (size_t)img * img_px * P.in1_cs : P.in0, P.in1 ? n_in * img_px * P.in1_cs * sizeof(float) : 0);
+  const __amdgpu_buffer_rsrc_t rsrc_u = make_rsrc(P.w_wino, (size_t)nkc * 16 * P.cout_pad * 16 * sizeof(float));
+#endif
+  constexpr bool SCALED = G::SC > 0 && EPI == EPI_AFFINE;
+  const bool scaled = SCALED && P.in_scale != nullptr;
+  // ---- patch DMA: element e = (pixel, channel quad) of the patch, 16 bytes each, LDS linear in e; piece idx = d * 8 + wave --------------
+  SF_STAMP_AT(L, 14);
+  int pv0[NP], pv1[DIL ? 1 : NP];
+  const int npw = G::ND / 8 + (wave < G::ND % 8 ? 1 : 0);      // wave-uniform
+#pragma unroll
+  for (int d = 0; d < NP; ++d) {
+    const int e = (d * 8 + wave) * 64 + lane;
+    const int pix = e >> 2, quad = e & 3;
+    const int py = pix / PW, px = pix - py * PW;
+    int iy = 2 * ty0 - 1 + py, ix = 2 * tx0 - 1 + px;
+    int run = 0;
+    if constexpr (CAT) {
+      run = px >= 2 * cn0 + 2 ? 1 : 0;
+      ix = run ? px - (2 * cn0 + 2) - 1 : ix;
+    }
+    bool ok = pix < G::NPX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && (!CAT || (img + run < P.n_img && (run == 0 || cn0 < TW)));
+    if constexpr (DIL) {
+      const bool oky = ay.patch_coord(py, py0, qt0, TH, H, iy), okx = ax.patch_coord(px, px0, pt0, TW, W, ix);
+      ok = pix < G::NPX && oky && okx;
+    }
+    const int pofs = DIL ? iy * W + ix : (iy >> up) * Win + (ix >> up) + (CAT ? run * img_px_i : 0);
+    pv0[d] = ok ? (pofs * P.in0_cs + quad * 4) * 4 : (int)0x80000000;
+    if constexpr (!DIL) pv1[d] = ok ? (pofs * P.in1_cs - c0 + quad * 4) * 4 : (int)0x80000000;
+  }
+  SF_STAMP_AT(L, 15);
+  auto issue_patch = [&](const int kc) {
+    float* const dst = Pbuf + (G::NPB == 2 ? (kc & 1) : 0) * G::P_FLOATS;
+    const bool from1 = !DIL && kc * 16 >= c0;                   // wave-uniform: the whole chunk reads in1 (c0 % 16 == 0)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int d = 0; d < NP; ++d) {
+      if (d >= npw) continue;
+      float* const dB = dst + (d * 8 + wave) * 256;
+      if constexpr (DIL) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, pv0[d] + kc * 64, 0, 0, 0);
+      } else {
+        if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (wn_lds_void*)dB, 16, pv1[d] + kc * 64, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, pv0[d] + kc * 64, 0, 0, 0);
+      }
+    }
+#else
+    (void)dst; (void)from1;
+#endif
+  };
+  auto scale_patch = [&](const int kc) {
+    if constexpr (SCALED) {
+      if (scaled && kc * 16 < c0) {
+        const f32x4 s4 = wn_lds_read128(SCbuf + kc * 16 + (lane & 3) * 4);
+        typedef __attribute__((address_space(3))) f32x4 lds_f4w;
+#pragma unroll
+        for (int d = 0; d < NP; ++d) {
+          if (d >= npw) continue;
+          float* const q = Pbuf + ((d * 8 + wave) * 64 + lane) * 4;
+          *(lds_f4w*)q = wn_lds_read128(q) * s4;
+        }
+      }
+    }
+  };
+  // ---- roles: wave (ih, hh) = row ih of B^T d B (positions 4 ih .. 4 ih + 3), cout half hh; lane (j, g) of a 16-row fragment -------------
+  const int ih = wave >> 1, hh = wave & 1;
+  const int j = lane & 15, g = lane >> 4;
+  // A fragments (U[chunk][position][cout_pad][16]) straight from global memory: 16 rows x 64 B = 1 KB contiguous per fragment
+  const int u_voff = ((cout0 + hh * 32 + j) * 16 + g * 4) * 4;
+  const int u_pos_bytes = P.cout_pad * 64;
+  auto load_A = [&](const int s, const int mb) -> f32x4 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int sc = s < NS ? s : NS - 1;                         // the tail re-loads the last step (no branch in the MFMA stream)
+    const int so = (((sc >> 2) * 16 + ih * 4 + (sc & 3)) * u_pos_bytes);
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, u_voff + mb * 1024, so, 0));
+#else
+    (void)s; (void)mb; return (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
+  };
+  // B fragments: V[position][tile][16], slot swizzle as conv_wino_kernel
+  const int b_off = (ih * 4 * WT + j) * 16 + ((g ^ ((j >> 2) & 2)) << 2);
+  // ---- input transform: task (row ih, tile wt, channel quad): 8 reads, 8 add / sub, 4 writes (float4) -------------------------------------
+  if constexpr (DIL) {
+    const int quad = tid & 3, wt = (tid >> 2) % WT;
+    const int tyl = wt / TW, txl = wt - tyl * TW;
+    int pX, tX, pY, tY;
+    ax.decode(tx0 + txl, pX, tX);
+    ay.decode(ty0 + tyl, pY, tY);
+    int rx = pX - px0, ry = pY - py0;
+    rx = rx < G::RX ? rx : G::RX - 1; ry = ry < G::RY ? ry : G::RY - 1;
+    *(__attribute__((address_space(3))) int*)(Park + tid) = ((2 * tyl + 2 * ry) * PW + 2 * txl + 2 * rx) * 16 + quad * 4;
+  }
+  auto transform = [&](const int kc) {
+    const float* const src = Pbuf + (G::NPB == 2 ? (kc & 1) : 0) * G::P_FLOATS;
+    float* const dst = Vbuf + (G::NVB == 2 ? (kc & 1) : 0) * G::V_FLOATS;
+    const int quad = lane & 3, wt = (tid >> 2) & (WT - 1);
+    const int tyl = wt / TW, txl = wt - tyl * TW;
+    // B^T rows: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+    const int r1 = (ih == 0) ? 0 : (ih == 2 ? 2 : 1), r2 = (ih == 3) ? 3 : (ih == 2 ? 1 : 2);
+    const float sg = (ih == 1) ? 1.f : -1.f;
+    const int tp = DIL ? *(const __attribute__((address_space(3))) int*)(Park + tid)
+                       : ((2 * tyl) * PW + 2 * txl + ((CAT && txl >= cn0) ? 2 : 0)) * 16 + quad * 4;
+    const float* const a = src + tp + r1 * PW * 16;
+    const float* const bb = src + tp + r2 * PW * 16;
+    float* const o = dst + ((ih * 4) * WT + wt) * 16 + ((quad ^ ((wt >> 2) & 2)) << 2);
+    typedef __attribute__((address_space(3))) f32x4 lds_f4w;
+    const f32x4 w0 = wn_lds_read128(a) + sg * wn_lds_read128(bb);
+    const f32x4 w2 = wn_lds_read128(a + 32) + sg * wn_lds_read128(bb + 32);
+    *(lds_f4w*)(o) = wn_sub4(w0, w2);
+    const f32x4 w1 = wn_lds_read128(a + 16) + sg * wn_lds_read128(bb + 16);
+    *(lds_f4w*)(o + WT * 16) = w1 + w2;
+    *(lds_f4w*)(o + 2 * WT * 16) = wn_sub4(w2, w1);
+    const f32x4 w3 = wn_lds_read128(a + 48) + sg * wn_lds_read128(bb + 48);
+    *(lds_f4w*)(o + 3 * WT * 16) = wn_sub4(w1, w3);
+  };
+  // ---- prologue -----------------------------------------------------------------------------------------------------------------------------
+  float scv = 1.f;
+  if constexpr (SCALED)
+    if (scaled && tid < c0) scv = P.in_scale[(size_t)img * c0 + tid];
+  issue_patch(0);
+  f32x4 A[2][2];                                                // [ring slot = step & 1][mb]
+  A[0][0] = load_A(0, 0); A[0][1] = load_A(0, 1);
+  A[1][0] = load_A(1, 0); A[1][1] = load_A(1, 1);
+  float sbv = tid < COUT_T ? 1.f : 0.f;
+  if (tid < 2 * COUT_T) {
+    const int co = cout0 + (tid < COUT_T ? tid : tid - COUT_T);
+    if (co < P.cout) {
+      if (tid < COUT_T) { if (P.scale) sbv = P.scale[co]; }
+      else if (P.bias) sbv = P.bias[(P.bias_per_img ? (size_t)img * P.cout : 0) + co];
+    }
+  }
+  SF_STAMP_AT(L, 11);
+  wn_wait(4);                                                   // the patch is older than the four A loads (a wave that loaded scale / bias waits for one of them too)
+  if constexpr (SCALED) {
+    if (scaled) {
+      if (tid < G::SC) SCbuf[tid] = scv;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wn_barrier();
+      scale_patch(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  wn_barrier();                                                 // patch(0) complete
+  SF_STAMP_AT(L, 12);
+  transform(0);
+  SF_STAMP_AT(L, 13);
+  if (tid < 2 * COUT_T) SBuf[tid] = sbv;
+  if (!MODE_A) issue_patch(1);                                  // second patch buffer
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  wn_barrier();                                                 // V(0) published; Mode A: the patch buffer is free
+  SF_STAMP_AT(L, 1);
+
+  f32x4 acc[4][2][2];
+  auto step = [&](const int kc, auto p_c, auto first_c) {
+    constexpr int p = decltype(p_c)::value, slot = p & 1;
+    constexpr bool first = decltype(first_c)::value;
+    const float* const vb = Vbuf + (G::NVB == 2 ? (kc & 1) : 0) * G::V_FLOATS + p * WT * 16 + b_off;
+    f32x4 Bf[2];
+    Bf[0] = wn_lds_read128(vb);
+    Bf[1] = wn_lds_read128(vb + 256);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const f32x4 cin = (first && e == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[p][mb][nb];
+          acc[p][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[slot][mb][e], Bf[nb][e], cin, 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      A[slot][mb] = load_A(kc * 4 + p + 2, mb);                 // into the registers this half-step has released
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto chunk = [&](const int kc, auto first_c, auto more_c) {
+    constexpr bool more = decltype(more_c)::value;
+    if (MODE_A && more) issue_patch(kc + 1);                    // behind barrier B: every wave is done with transform(kc)
+    step(kc, std::integral_constant<int, 0>{}, first_c);
+    step(kc, std::integral_constant<int, 1>{}, first_c);
+    if (MODE_A && more) {
+      wn_wait(4);                                               // younger than the patch: the A loads of steps 0 and 1
+      scale_patch(kc + 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wn_barrier();                                             // M: patch(kc + 1) complete
+      transform(kc + 1);
+    }
+    step(kc, std::integral_constant<int, 2>{}, first_c);
+    step(kc, std::integral_constant<int, 3>{}, first_c);
+    if (more) {
+      if constexpr (MODE_A) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wn_barrier();                                           // B: V(kc + 1) published, patch buffer free
+      } else {
+        wn_wait(4);                                             // patch(kc + 1) is older than this chunk's A loads
+        wn_barrier();                                           // E: every wave holds its last fragments of V(kc); patch(kc + 1) complete
+        transform(kc + 1);
+        if (kc + 2 < nkc) issue_patch(kc + 2);                  // into the buffer transform(kc) read
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wn_barrier();                                           // F: V(kc + 1) published
+      }
+    }
+  };
+  chunk(0, std::true_type{}, std::true_type{});
+  for (int kc = 1; kc + 1 < nkc; ++kc) chunk(kc, std::false_type{}, std::true_type{});
+  chunk(nkc - 1, std::false_type{}, std::false_type{});
+  SF_STAMP_AT(L, 2);
+
+  // ---- output transform, first half in registers: T[ih][b] = (M A)[ih][b] -------------------------------------------------------------------
+  //   b = 0: (M0 + M1) + M2      b = 1: M1 - (M2 + M3)        (the orders of conv_wino_kernel)
+  float* const Tb = Vbuf;                                      // [ih][b][tile][64 cout], 16-byte slot cq of a tile's row at cq ^ (tile & 15)
+  wn_barrier();                                                 // every wave is done with V (and nothing is in flight into the patch)
+  {
+    typedef __attribute__((address_space(3))) f32x4 lds_f4w;
+    const int tw_base = ((ih * 2) * WT + j) * 64;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int tw = tw_base + (((hh * 8 + mb * 4 + g) ^ j) << 2);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const f32x4 m0 = acc[0][mb][nb], m1 = acc[1][mb][nb], m2 = acc[2][mb][nb], m3 = acc[3][mb][nb];
+        *(lds_f4w*)(Tb + tw + nb * 16 * 64) = (m0 + m1) + m2;
+        *(lds_f4w*)(Tb + tw + nb * 16 * 64 + WT * 64) = wn_sub4(m1, m2 + m3);
+      }
+    }
+  }
+  // ---- second half + epilogue: thread = (tile wt, channel quad cq), the 16 quads of a pixel in consecutive lanes --------------------------------
+  const int cq = tid & 15, wt_e = tid >> 4;
+  const int tyl_e = wt_e >> 3, txl_e = wt_e & 7;
+  const bool run_e = CAT && txl_e >= cn0;
+  const int ty = ty0 + tyl_e, tx = run_e ? txl_e - cn0 : tx0 + txl_e;
+  const size_t img_base = (size_t)img * H * W;
+  int oy0 = 2 * ty, ox0 = 2 * tx, ostep = 1;
+  if constexpr (DIL) {
+    int pX, tX, pY, tY;
+    ax.decode(tx, pX, tX);
+    ay.decode(ty, pY, tY);
+    ostep = P.dil;
+    ox0 = (tx < ax.nt && pX < ostep) ? pX + ostep * 2 * tX : W;
+    oy0 = (ty < ay.nt && pY < ostep) ? pY + ostep * 2 * tY : H;
+  }
+  const bool affine = EPI == EPI_AFFINE;
+  const float* const t_a = affine ? P.add : P.e0;
+  const float* const t_b = P.e1;
+  const int cs_a = affine ? P.add_cs : P.e0_cs, cs_b = P.e1_cs;
+  WnPix px[2][2];
+#pragma unroll
+  for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const size_t p0 = img_base + (size_t)(bq * ostep) + (size_t)(i * ostep) * W;
+      px[bq][i].ta = t_a ? t_a + p0 * cs_a : nullptr;
+      px[bq][i].tb = t_b ? t_b + p0 * cs_b : nullptr;
+      px[bq][i].out = P.out + p0 * P.out_cs + P.out_co;
+      px[bq][i].out2 = P.out2 ? P.out2 + p0 * P.out2_cs : nullptr;
+    }
+  const bool img_ok = !CAT || img + (run_e ? 1 : 0) < P.n_img;
+  const bool x0 = img_ok && ox0 < W, x1 = img_ok && ox0 + ostep < W, y0ok = oy0 < H, y1ok = oy0 + ostep < H;
+  const unsigned pix = (x0 && y0ok) ? (unsigned)(oy0 * W + ox0 + (run_e ? H * W : 0)) : 0u;
+  const int cl = cq * 4;
+  const int c = cout0 + cl;
+  const bool c_ok = c < P.cout;
+  const int c_ld = c_ok ? c : 0;
+  const bool ok00 = c_ok && x0 && y0ok, ok01 = c_ok && x0 && y1ok, ok10 = c_ok && x1 && y0ok, ok11 = c_ok && x1 && y1ok;
+  WnLane ln;
+  ln.ea = pix * (unsigned)cs_a + (unsigned)c_ld;
+  ln.eb = pix * (unsigned)cs_b + (unsigned)((affine && c_ld >= P.gate_from) ? c_ld - P.gate_from : (affine ? 0 : c_ld));
+  ln.eo = pix * (unsigned)P.out_cs + (unsigned)c_ld;
+  ln.eo2 = pix * (unsigned)P.out2_cs + (unsigned)(c_ld >= P.gate_from ? c_ld - P.gate_from : 0);
+  // epilogue operands requested before the exchange is read
+  WnOps o00, o01, o10, o11;
+  o00.a = o00.b = o01.a = o01.b = o10.a = o10.b = o11.a = o11.b = spm_zero4();
+  if (ok00) o00 = wn_epi_load<EPI>(P, px[0][0], ln);
+  if (ok01) o01 = wn_epi_load<EPI>(P, px[0][1], ln);
+  if (ok10) o10 = wn_epi_load<EPI>(P, px[1][0], ln);
+  if (ok11) o11 = wn_epi_load<EPI>(P, px[1][1], ln);
+  float4 as = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (affine && P.add && P.add_scale) as = spm_ld4(P.add_scale + (size_t)img * P.cout + c_ld);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  wn_barrier();                                                 // the exchange is complete
+  const float4 sc = *(const float4*)(SBuf + cl), bi = *(const float4*)(SBuf + COUT_T + cl);
+  const int tr = wt_e * 64 + ((cq ^ (wt_e & 15)) << 2);
+  SF_STAMP_AT(L, 5);
+  WnOut r00, r01, r10, r11;
+  {
+    const f32x4 t0 = wn_lds_read128(Tb + tr), t1 = wn_lds_read128(Tb + 2 * WT * 64 + tr);
+    const f32x4 t2 = wn_lds_read128(Tb + 4 * WT * 64 + tr), t3 = wn_lds_read128(Tb + 6 * WT * 64 + tr);
+    const f32x4 ya = (t0 + t1) + t2, yb = wn_sub4(t1, t2 + t3);
+    r00 = wn_epi_finish<EPI>(P, wn_lo(ya), wn_hi(ya), o00, sc, bi, as, c);
+    r01 = wn_epi_finish<EPI>(P, wn_lo(yb), wn_hi(yb), o01, sc, bi, as, c);
+  }
+  SF_STAMP_AT(L, 6);
+  {
+    const f32x4 t0 = wn_lds_read128(Tb + WT * 64 + tr), t1 = wn_lds_read128(Tb + 3 * WT * 64 + tr);
+    const f32x4 t2 = wn_lds_read128(Tb + 5 * WT * 64 + tr), t3 = wn_lds_read128(Tb + 7 * WT * 64 + tr);
+    const f32x4 ya = (t0 + t1) + t2, yb = wn_sub4(t1, t2 + t3);
+    r10 = wn_epi_finish<EPI>(P, wn_lo(ya), wn_hi(ya), o10, sc, bi, as, c);
+    r11 = wn_epi_finish<EPI>(P, wn_lo(yb), wn_hi(yb), o11, sc, bi, as, c);
+  }
+  SF_STAMP_AT(L, 7);
+  __builtin_amdgcn_sched_barrier(0);
+  if (ok00) spm_st4(px[0][0].out + (size_t)ln.eo, r00.y);
+  if (ok01) spm_st4(px[0][1].out + (size_t)ln.eo, r01.y);
+  if (ok10) spm_st4(px[1][0].out + (size_t)ln.eo, r10.y);
+  if (ok11) spm_st4(px[1][1].out + (size_t)ln.eo, r11.y);
+  if (affine && P.out2 && c >= P.gate_from) {
+    if (ok00) spm_st4(px[0][0].out2 + (size_t)ln.eo2, r00.y2);
+    if (ok01) spm_st4(px[0][1].out2 + (size_t)ln.eo2, r01.y2);
+    if (ok10) spm_st4(px[1][0].out2 + (size_t)ln.eo2, r10.y2);
+    if (ok11) spm_st4(px[1][1].out2 + (size_t)ln.eo2, r11.y2);
+  }
+  SF_STAMP_AT(L, 3);
+#ifdef SF_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SF_STAMP_AT(L, 4);
+#endif
+}
+
 // weights: packed direct form w[cout_pad][9 * cin_pad] (tap-major, channel-minor) -> U[cin_pad/16][16][cout_pad][16] = G g G^T
 __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int cout_pad, int cin_pad) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (co, ci)
@@ -913,10 +1328,40 @@ double wino_tiles(const ConvProblem& q) {
   if (q.dil > 1) return (double)q.n_img * WnAxis(q.Hout, q.dil).nt * WnAxis(q.Wout, q.dil).nt;
   return (double)q.n_img * ((q.Hout + 1) / 2) * ((q.Wout + 1) / 2);
 }
+template <int EPI, bool DIL = false, bool CAT = false>
+static hipError_t launch_wino5_t(const ConvLaunch& L, hipStream_t stream) {
+  typedef Wino5Geo<DIL, CAT> G;
+  auto kern = conv_wino5_kernel<EPI, DIL, CAT>;
+  constexpr int lds = G::LDS_FLOATS * 4;
+  static bool attr_done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_done[dev] = true;
+  }
+  const ConvProblem& P = L.p[0];
+  const int tiles_x = DIL ? WnAxis(P.Wout, P.dil).nt : (P.Wout + 1) / 2, tiles_y = DIL ? WnAxis(P.Hout, P.dil).nt : (P.Hout + 1) / 2;
+  const long blocks = CAT ? (long)((tiles_y + G::TH - 1) / G::TH) * (((long)P.n_img * tiles_x + G::TW - 1) / G::TW)
+                          : (long)P.n_img * ((tiles_y + G::TH - 1) / G::TH) * ((tiles_x + G::TW - 1) / G::TW);
+  const long grid = ((blocks + 7) / 8) * 8 * (P.cout_pad / G::COUT_T);
+  if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid, 1, 1), dim3(WN_THREADS), lds, stream, L);
+  return hipGetLastError();
+}
 // one problem per launch
 hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream) {
   if (L.nprob != 1 || !wino_takes(L.p[0], epi)) return hipErrorInvalidValue;
   const bool affine = epi == EPI_AFFINE;
+  static const int ver = [] { const char* v = std::getenv("SF_WINO_V"); return v ? std::atoi(v) : 5; }();      // 4: the round-4 kernel (A/B runs)
+  if (ver >= 5) {
+    switch (wino_variant(L.p[0])) {
+      case 2: return affine ? launch_wino5_t<EPI_AFFINE>(L, stream) : launch_wino5_t<EPI_BLEND>(L, stream);
+      case 3: return affine ? launch_wino5_t<EPI_AFFINE, true>(L, stream) : hipErrorInvalidValue;
+      case 4: return affine ? launch_wino5_t<EPI_AFFINE, false, true>(L, stream) : launch_wino5_t<EPI_BLEND, false, true>(L, stream);
+    }
+  }
   switch (wino_variant(L.p[0])) {
 #if defined(SF_WINO_ALL_TILES)
     case 0: return affine ? launch_wino_t<128, 4, 2, EPI_AFFINE>(L, stream) : launch_wino_t<128, 4, 2, EPI_BLEND>(L, stream);

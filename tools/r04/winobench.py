@@ -71,7 +71,8 @@ def main():
                      "winograd_frac_of_fp32_mfma_peak_executed": flops_wino / tw * 1e-9 / PEAK,
                      "winograd_direct_equivalent_tflops": flops_direct / tw * 1e-9,
                      "max_abs_direct_vs_winograd": float((res["direct"][1] - res["winograd"][1]).abs().max()),
-                     "abs_max_of_output": float(res["direct"][1].abs().max())})
+                     "abs_max_of_output": float(res["direct"][1].abs().max()),
+                     "winograd_out_checksum": int(res["winograd"][1].view(torch.int32).to(torch.int64).sum())})
         print(json.dumps(rows[-1]), flush=True)
     print(json.dumps({"winobench": rows}))
 
