@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--timeset", default="shipped", help="oracle.cases.TIMESETS key (default: BASELINE config 2)")
+    ap.add_argument("--timeset", default="shipped", help="workloads.synthetic.TIMESETS key (default: BASELINE config 2)")
     ap.add_argument("--solver", default="euler")
     ap.add_argument("--batch", type=int, default=32, help="samples per forward on each GPU (the reference API "
                     "takes a batch and loops over it; here same-structure samples run through the kernels together)")
@@ -178,11 +178,11 @@ def main():
 
     import streamingflow_amd as sfa
     from streamingflow_amd import _lib, schedule as S
-    from oracle import cases, hashfill, refimport
+    from workloads import hashfill, synthetic as cases
 
     C, H, W = 64, 200, 200
     cts, lts, tts, dt = cases.timeset(a.timeset)
-    cfg = refimport.make_cfg(C, impute=True, solver=a.solver, variable=True)
+    cfg = cases.make_cfg(C, impute=True, solver=a.solver, variable=True)
     net = sfa.FuturePredictionODE(C, C, 4, cfg, n_gru_blocks=2, n_res_layers=1, delta_t=dt).eval()
     sd = cases.fpode_state_dict(net.state_dict())        # random-init weights (hashed, reproducible)
     net.load_state_dict(sd)

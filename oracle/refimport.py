@@ -59,13 +59,7 @@ def install():
             sys.modules[name] = m
 
 
-def make_cfg(C, impute=True, solver="euler", variable=True, filter_size=None, skipco=False):
-    """The 7 config keys the hot path reads (SURVEY.md §5 "Config / flags")."""
-    return SimpleNamespace(MODEL=SimpleNamespace(
-        IMPUTE=impute, SOLVER=solver,
-        FUTURE_PRED=SimpleNamespace(USE_VARIABLE_ODE_STEP=variable),
-        SMALL_ENCODER=SimpleNamespace(FILTER_SIZE=filter_size or C, SKIPCO=skipco),
-        ENCODER=SimpleNamespace(OUT_CHANNELS=C)))
+from workloads.synthetic import make_cfg       # noqa: E402,F401  (re-exported: tests and gen_golden use refimport.make_cfg)
 
 
 def modules():

@@ -31,9 +31,9 @@ def flops_per_frame(C=64, H=200, W=200, head_couts=(2, 2, 1, 2)):
 def run(reps=10, cpu=False, dev=None, frames=7):
     from streamingflow_amd import _lib, runtime
     from streamingflow_amd.models.decoder import Decoder
-    from oracle import cases, decoder_ref as DR
+    from workloads import synthetic as cases
     dev = dev or torch.device("cuda", 0)
-    cin, ncls, npres, nhd, gate, _ = cases.DECODER_CASES["shipped_gates_small"]
+    cin, ncls, npres, nhd, gate = cases.DECODER_SHIPPED
     m = Decoder(cin, ncls, npres, nhd, gate).eval()
     sd = cases.decoder_state_dict(m.state_dict())
     m.load_state_dict(sd)
@@ -57,6 +57,7 @@ def run(reps=10, cpu=False, dev=None, frames=7):
            "ms_per_call": t * 1e3, "frames_per_s": frames / t, "gflop_per_frame_reference_order": flops_per_frame() / 1e9,
            "tflops_reference_flops": fl / t / 1e12, "mfma_frac": fl / t / 1e12 / PEAK}
     if cpu:
+        from oracle import decoder_ref as DR      # the checker, timed as the reported CPU baseline only
         torch.set_num_threads(min(os.cpu_count() or 1, 16))
         xc = x[:, :1].cpu()
         with torch.no_grad():

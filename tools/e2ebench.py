@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 def run(reps=3, dev=None):
     from streamingflow_amd import _lib, runtime
     from streamingflow_amd.models.streamingflow import default_cfg, streamingflow
-    from oracle import cases, hashfill
+    from workloads import hashfill, synthetic as cases
     import liftbench
     import voxelbench
     dev = dev or torch.device("cuda", 0)

@@ -17,15 +17,13 @@ def run(reps=5, cpu=False, dev=None):
     from streamingflow_amd import _lib, runtime
     from streamingflow_amd.models.sparse_encoder import SparseEncoder
     from streamingflow_amd.voxelize import Voxelization, voxelize
-    from oracle import cases, sparse_encoder_ref as SR
+    from workloads import hashfill, synthetic as cases
     import voxelbench
     dev = dev or torch.device("cuda", 0)
-    cfg = SR.default_cfg()
+    cfg = dict(cases.SPARSE_SHIPPED)
     m = SparseEncoder(cfg["in_channels"], cfg["sparse_shape"], base_channels=cfg["base_channels"], output_channels=cfg["output_channels"],
                       encoder_channels=cfg["encoder_channels"], encoder_paddings=cfg["encoder_paddings"], block_type="basicblock").eval()
-    shapes = SR.state_dict_shapes(cfg)
-    from oracle import hashfill
-    sd = hashfill.fill_state_dict({k: torch.empty(v) if v else torch.tensor(0) for k, v in shapes.items()}, seed=83, gain=1.6)
+    sd = hashfill.fill_state_dict(m.state_dict(), seed=83, gain=1.6)      # same (key, shape, seed) -> same weights as oracle.cases.sparse_state_dict
     m.load_state_dict(sd)
     m = m.to(dev)
     vs, rng, mp, mv = cases.VOXEL_SHIPPED
@@ -54,6 +52,7 @@ def run(reps=5, cpu=False, dev=None):
          "sparse_encoder_ms": enc_ms, "voxelize_plus_encoder_ms": all_ms, "clouds_per_s": 1e3 / all_ms,
          "occupied_bev_fraction": float((out.abs().amax(1) > 0).float().mean())}
     if cpu:
+        from oracle import sparse_encoder_ref as SR      # the checker, timed as the reported CPU baseline only
         n = 20000                     # bounded sample: the numpy oracle is ~linear in the number of voxels
         t0 = time.perf_counter()
         SR.sparse_encoder_forward(sd, feats[:n].cpu().numpy(), coords[:n].cpu().numpy(), 1, cfg)

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 def run(reps=10, cpu=False, dev=None):
     from streamingflow_amd import _lib, runtime
     from streamingflow_amd.models.temporal_model import TemporalModel
-    from oracle import cases, temporal_model_ref as TR
+    from workloads import synthetic as cases
     dev = dev or torch.device("cuda", 0)
     L = _lib.lib()
     e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
@@ -38,6 +38,7 @@ def run(reps=10, cpu=False, dev=None):
         L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
         r = {"ms_per_call": ms.value / reps, "samples_per_s": 1e3 * reps / ms.value}
         if cpu and name == "camera_c70":
+            from oracle import temporal_model_ref as TR      # the checker, timed as the reported CPU baseline only
             torch.set_num_threads(min(os.cpu_count() or 1, 16))
             with torch.no_grad():
                 t0 = time.perf_counter()
