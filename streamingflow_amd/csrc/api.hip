@@ -483,6 +483,24 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
         W1.nprob = 1;
         W1.stamp_slot = g_stamp_slot;
         if (g_stamp_on) g_stamp_slot = (g_stamp_slot + 1) % 64;
+        static const bool list = std::getenv("SF_WINO_LIST") != nullptr;      // debugging aid (tools/r05/wino_layers.py): every launch timed by itself
+        if (list && !g_prof.on) {
+          const ConvProblem& q = ps[i];
+          hipEvent_t a, b;
+          SF_HIP(hipEventCreate(&a)); SF_HIP(hipEventCreate(&b));
+          SF_HIP(hipEventRecord(a, st));
+          SF_HIP(launch_conv_wino(W1, epi, st));
+          SF_HIP(hipEventRecord(b, st));
+          SF_HIP(hipEventSynchronize(b));
+          float ms = 0.f;
+          SF_HIP(hipEventElapsedTime(&ms, a, b));
+          (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+          std::fprintf(stderr, "[sf-wino] n=%d %dx%d c=%d+%d->%d epi=%d act=%d mode=%d add=%d add_scale=%d out2=%d in_scale=%d bias_img=%d clamp=%d dil=%d up=%d var=%d us=%.1f gflop=%.3f\n",
+                       q.n_img, q.Hout, q.Wout, q.c0, q.c1, q.cout, epi, q.act, q.mode, q.add != nullptr, q.add_scale != nullptr, q.out2 != nullptr,
+                       q.in_scale != nullptr, q.bias_per_img, q.clamp_from >= 0, q.dil, q.in_up, wino_variant(q), ms * 1e3,
+                       2.0 * 16.0 * wino_tiles(q) * q.cout * (q.c0 + q.c1) * 1e-9);
+          continue;
+        }
         if (!g_prof.on) {
           SF_HIP(launch_conv_wino(W1, epi, st));
           continue;

@@ -821,6 +821,45 @@ __global__ __launch_bounds__(WN_THREADS, (MW == 2 ? 2 : 4)) void conv_wino_kerne
 // Mode A (plain / concatenated images): V double-buffered, one patch buffer — barriers per chunk: B (chunk start: V(kc) published, patch
 // free) and M (patch(kc+1) landed, before the transform that runs between steps 1 and 2).  Mode B (dilated: its patch is 18 KB): one V, two
 // patch buffers, the transform at the chunk boundary between two barriers.
+
+// packed subtraction a - b (v_pk_add_f32 with the second operand negated: hipcc turns fma(b, -1, a) and a - b on vectors into four
+// scalar v_sub_f32; every vector-side instruction costs ~5.5 cycles of matrix time beside the fp32 MFMAs)
+__device__ __forceinline__ f32x2 wn5_sub2(const f32x2 a, const f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x4 wn5_sub4(const f32x4 a, const f32x4 b) {
+  const f32x2 lo = wn5_sub2(wn_lo(a), wn_lo(b)), hi = wn5_sub2(wn_hi(a), wn_hi(b));
+  return (f32x4){lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ f32x4 wn5_undef4() {      // a register nobody has to initialise (lanes that do not load do not store either)
+  f32x4 v;
+  return __builtin_nondeterministic_value(v);
+}
+__device__ __forceinline__ f32x4 wn5_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void wn5_st4(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// activation of the tile's 16 values under ONE uniform switch (per element the switch costs a chain of scalar branches and copies)
+__device__ __forceinline__ void wn5_act16(f32x4 (&y)[4], const int act) {
+  switch (act) {
+    case ACT_RELU:
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = __builtin_elementwise_max(y[k], (f32x4){0.f, 0.f, 0.f, 0.f});
+      break;
+    case ACT_LRELU:
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[k][q] = y[k][q] > 0.f ? y[k][q] : 0.1f * y[k][q];
+      break;
+    case ACT_NONE: break;
+    default:
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[k][q] = spm_act(y[k][q], act);
+  }
+}
 template <bool DIL, bool CAT>
 struct Wino5Geo {
   static_assert(!(DIL && CAT), "one run structure at a time");
@@ -841,6 +880,11 @@ struct Wino5Geo {
   static_assert(2 * LDS_FLOATS * 4 <= 160 * 1024, "two workgroups per CU");
 };
 
+// timing-only ablations (tools/r05/ablate.sh; wrong results by construction): -DSF_W5_ABL=<bits>  1: no input transform in the loop,
+// 2: no patch DMAs in the loop, 4: no A loads in the loop, 8: no barriers in the loop, 16: no MFMAs, 32: minimal epilogue
+#if !defined(SF_W5_ABL)
+#define SF_W5_ABL 0
+#endif
 template <int EPI, bool DIL = false, bool CAT = false>
 __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLaunch L) {
   typedef Wino5Geo<DIL, CAT> G;
@@ -924,7 +968,7 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
     }
     const int pofs = DIL ? iy * W + ix : (iy >> up) * Win + (ix >> up) + (CAT ? run * img_px_i : 0);
     pv0[d] = ok ? (pofs * P.in0_cs + quad * 4) * 4 : (int)0x80000000;
-    if constexpr (!DIL) pv1[d] = ok ? (pofs * P.in1_cs - c0 + quad * 4) * 4 : (int)0x80000000;
+    if constexpr (!DIL) pv1[d] = ok ? (pofs * P.in1_cs + quad * 4) * 4 : (int)0x80000000;
   }
   SF_STAMP_AT(L, 15);
   auto issue_patch = [&](const int kc) {
@@ -935,11 +979,18 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
     for (int d = 0; d < NP; ++d) {
       if (d >= npw) continue;
       float* const dB = dst + (d * 8 + wave) * 256;
+      // the chunk's channel offset rides in the scalar operand (not part of the range check: an invalid lane stays out of range);
+      // the two inputs are two branches (the asm comments keep hipcc from merging them into lane selects: vector instructions)
       if constexpr (DIL) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, pv0[d] + kc * 64, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, pv0[d], kc * 64, 0, 0);
       } else {
-        if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (wn_lds_void*)dB, 16, pv1[d] + kc * 64, 0, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, pv0[d] + kc * 64, 0, 0, 0);
+        if (from1) {
+          asm volatile("; patch from in1");
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (wn_lds_void*)dB, 16, pv1[d], (kc * 16 - c0) * 4, 0, 0);
+        } else {
+          asm volatile("; patch from in0");
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, pv0[d], kc * 64, 0, 0);
+        }
       }
     }
 #else
@@ -1004,12 +1055,12 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
     typedef __attribute__((address_space(3))) f32x4 lds_f4w;
     const f32x4 w0 = wn_lds_read128(a) + sg * wn_lds_read128(bb);
     const f32x4 w2 = wn_lds_read128(a + 32) + sg * wn_lds_read128(bb + 32);
-    *(lds_f4w*)(o) = wn_sub4(w0, w2);
+    *(lds_f4w*)(o) = wn5_sub4(w0, w2);
     const f32x4 w1 = wn_lds_read128(a + 16) + sg * wn_lds_read128(bb + 16);
     *(lds_f4w*)(o + WT * 16) = w1 + w2;
-    *(lds_f4w*)(o + 2 * WT * 16) = wn_sub4(w2, w1);
+    *(lds_f4w*)(o + 2 * WT * 16) = wn5_sub4(w2, w1);
     const f32x4 w3 = wn_lds_read128(a + 48) + sg * wn_lds_read128(bb + 48);
-    *(lds_f4w*)(o + 3 * WT * 16) = wn_sub4(w1, w3);
+    *(lds_f4w*)(o + 3 * WT * 16) = wn5_sub4(w1, w3);
   };
   // ---- prologue -----------------------------------------------------------------------------------------------------------------------------
   float scv = 1.f;
@@ -1064,31 +1115,32 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
           const f32x4 cin = (first && e == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[p][mb][nb];
-          acc[p][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[slot][mb][e], Bf[nb][e], cin, 0, 0, 0);
+          if (SF_W5_ABL & 16) acc[p][mb][nb] = (e == 0 && nb == 0 && mb == 0) ? cin + A[slot][mb] * Bf[nb] : cin;
+          else acc[p][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[slot][mb][e], Bf[nb][e], cin, 0, 0, 0);
         }
       __builtin_amdgcn_sched_barrier(0);
-      A[slot][mb] = load_A(kc * 4 + p + 2, mb);                 // into the registers this half-step has released
+      if (!(SF_W5_ABL & 4)) A[slot][mb] = load_A(kc * 4 + p + 2, mb);                 // into the registers this half-step has released
       __builtin_amdgcn_sched_barrier(0);
     }
   };
   auto chunk = [&](const int kc, auto first_c, auto more_c) {
     constexpr bool more = decltype(more_c)::value;
-    if (MODE_A && more) issue_patch(kc + 1);                    // behind barrier B: every wave is done with transform(kc)
+    if (MODE_A && more && !(SF_W5_ABL & 2)) issue_patch(kc + 1);                    // behind barrier B: every wave is done with transform(kc)
     step(kc, std::integral_constant<int, 0>{}, first_c);
     step(kc, std::integral_constant<int, 1>{}, first_c);
     if (MODE_A && more) {
       wn_wait(4);                                               // younger than the patch: the A loads of steps 0 and 1
       scale_patch(kc + 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      wn_barrier();                                             // M: patch(kc + 1) complete
-      transform(kc + 1);
+      if (!(SF_W5_ABL & 8)) wn_barrier();                                             // M: patch(kc + 1) complete
+      if (!(SF_W5_ABL & 1)) transform(kc + 1);
     }
     step(kc, std::integral_constant<int, 2>{}, first_c);
     step(kc, std::integral_constant<int, 3>{}, first_c);
     if (more) {
       if constexpr (MODE_A) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wn_barrier();                                           // B: V(kc + 1) published, patch buffer free
+        if (!(SF_W5_ABL & 8)) wn_barrier();                                           // B: V(kc + 1) published, patch buffer free
       } else {
         wn_wait(4);                                             // patch(kc + 1) is older than this chunk's A loads
         wn_barrier();                                           // E: every wave holds its last fragments of V(kc); patch(kc + 1) complete
@@ -1106,6 +1158,17 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
 
   // ---- output transform, first half in registers: T[ih][b] = (M A)[ih][b] -------------------------------------------------------------------
   //   b = 0: (M0 + M1) + M2      b = 1: M1 - (M2 + M3)        (the orders of conv_wino_kernel)
+  if (SF_W5_ABL & 32) {
+    f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) sacc += acc[p][mb][nb];
+    if (sacc[0] + sacc[1] + sacc[2] + sacc[3] == 1.2345f) P.out[tid] = sacc[0];
+    return;
+  }
   float* const Tb = Vbuf;                                      // [ih][b][tile][64 cout], 16-byte slot cq of a tile's row at cq ^ (tile & 15)
   wn_barrier();                                                 // every wave is done with V (and nothing is in flight into the patch)
   {
@@ -1118,7 +1181,7 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
       for (int nb = 0; nb < 2; ++nb) {
         const f32x4 m0 = acc[0][mb][nb], m1 = acc[1][mb][nb], m2 = acc[2][mb][nb], m3 = acc[3][mb][nb];
         *(lds_f4w*)(Tb + tw + nb * 16 * 64) = (m0 + m1) + m2;
-        *(lds_f4w*)(Tb + tw + nb * 16 * 64 + WT * 64) = wn_sub4(m1, m2 + m3);
+        *(lds_f4w*)(Tb + tw + nb * 16 * 64 + WT * 64) = wn5_sub4(m1, m2 + m3);
       }
     }
   }
@@ -1127,7 +1190,6 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   const int tyl_e = wt_e >> 3, txl_e = wt_e & 7;
   const bool run_e = CAT && txl_e >= cn0;
   const int ty = ty0 + tyl_e, tx = run_e ? txl_e - cn0 : tx0 + txl_e;
-  const size_t img_base = (size_t)img * H * W;
   int oy0 = 2 * ty, ox0 = 2 * tx, ostep = 1;
   if constexpr (DIL) {
     int pX, tX, pY, tY;
@@ -1137,76 +1199,114 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
     ox0 = (tx < ax.nt && pX < ostep) ? pX + ostep * 2 * tX : W;
     oy0 = (ty < ay.nt && pY < ostep) ? pY + ostep * 2 * tY : H;
   }
-  const bool affine = EPI == EPI_AFFINE;
+  constexpr bool affine = EPI == EPI_AFFINE;
   const float* const t_a = affine ? P.add : P.e0;
   const float* const t_b = P.e1;
   const int cs_a = affine ? P.add_cs : P.e0_cs, cs_b = P.e1_cs;
-  WnPix px[2][2];
-#pragma unroll
-  for (int bq = 0; bq < 2; ++bq)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const size_t p0 = img_base + (size_t)(bq * ostep) + (size_t)(i * ostep) * W;
-      px[bq][i].ta = t_a ? t_a + p0 * cs_a : nullptr;
-      px[bq][i].tb = t_b ? t_b + p0 * cs_b : nullptr;
-      px[bq][i].out = P.out + p0 * P.out_cs + P.out_co;
-      px[bq][i].out2 = P.out2 ? P.out2 + p0 * P.out2_cs : nullptr;
-    }
   const bool img_ok = !CAT || img + (run_e ? 1 : 0) < P.n_img;
   const bool x0 = img_ok && ox0 < W, x1 = img_ok && ox0 + ostep < W, y0ok = oy0 < H, y1ok = oy0 + ostep < H;
-  const unsigned pix = (x0 && y0ok) ? (unsigned)(oy0 * W + ox0 + (run_e ? H * W : 0)) : 0u;
+  const unsigned pix = (x0 && y0ok) ? (unsigned)(oy0 * W + ox0 + (run_e ? H * W : 0)) : 0u;      // lanes without a tile compute on pixel 0 and store nothing
   const int cl = cq * 4;
   const int c = cout0 + cl;
   const bool c_ok = c < P.cout;
   const int c_ld = c_ok ? c : 0;
-  const bool ok00 = c_ok && x0 && y0ok, ok01 = c_ok && x0 && y1ok, ok10 = c_ok && x1 && y0ok, ok11 = c_ok && x1 && y1ok;
-  WnLane ln;
-  ln.ea = pix * (unsigned)cs_a + (unsigned)c_ld;
-  ln.eb = pix * (unsigned)cs_b + (unsigned)((affine && c_ld >= P.gate_from) ? c_ld - P.gate_from : (affine ? 0 : c_ld));
-  ln.eo = pix * (unsigned)P.out_cs + (unsigned)c_ld;
-  ln.eo2 = pix * (unsigned)P.out2_cs + (unsigned)(c_ld >= P.gate_from ? c_ld - P.gate_from : 0);
-  // epilogue operands requested before the exchange is read
-  WnOps o00, o01, o10, o11;
-  o00.a = o00.b = o01.a = o01.b = o10.a = o10.b = o11.a = o11.b = spm_zero4();
-  if (ok00) o00 = wn_epi_load<EPI>(P, px[0][0], ln);
-  if (ok01) o01 = wn_epi_load<EPI>(P, px[0][1], ln);
-  if (ok10) o10 = wn_epi_load<EPI>(P, px[1][0], ln);
-  if (ok11) o11 = wn_epi_load<EPI>(P, px[1][1], ln);
-  float4 as = make_float4(1.f, 1.f, 1.f, 1.f);
-  if (affine && P.add && P.add_scale) as = spm_ld4(P.add_scale + (size_t)img * P.cout + c_ld);
+  // pixel k of the tile: (b, a) = (k >> 1, k & 1) = (x offset, y offset).  Operands and results move through raw buffer accesses on
+  // the image (CAT: the image and the next one): one shared lane offset per tensor, the pixel's offset in the scalar operand, and a
+  // lane without that pixel gets an offset beyond the range — its load returns 0, its store is dropped: no lane masks, no registers to
+  // initialise, no 64-bit lane arithmetic
+  const bool okk[4] = {c_ok && x0 && y0ok, c_ok && x0 && y1ok, c_ok && x1 && y0ok, c_ok && x1 && y1ok};
+  const size_t img_base = (size_t)img * H * W;
+  const size_t img_span = (size_t)((CAT && img + 1 < P.n_img) ? 2 : 1) * H * W;
+  const int pk_[4] = {0, ostep * W, ostep, ostep * W + ostep};      // pixel offset of pixel k
+  constexpr int OOB = (int)0x80000000;
+  const bool has_a = affine ? P.add != nullptr : true, has_b = affine ? P.out2 != nullptr : true;
+  const bool gate_lane = affine && P.out2 != nullptr && c >= P.gate_from;      // GRU gates, reset half: also emits (1 - r) * s
+  f32x4 oa[4], ob[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (has_a) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(t_a + img_base * cs_a, img_span * cs_a * sizeof(float));
+    const int v = (int)(pix * (unsigned)cs_a + (unsigned)c_ld) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) oa[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, okk[k] ? v : OOB, pk_[k] * cs_a * 4, 0));
+  }
+  if (has_b) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(t_b + img_base * cs_b, img_span * cs_b * sizeof(float));
+    const int v = (int)(pix * (unsigned)cs_b + (unsigned)(affine ? (c_ld >= P.gate_from ? c_ld - P.gate_from : 0) : c_ld)) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ob[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (okk[k] && (!affine || gate_lane)) ? v : OOB, pk_[k] * cs_b * 4, 0));
+  }
+#endif
+  f32x4 as = (f32x4){1.f, 1.f, 1.f, 1.f};
+  if (affine && P.add && P.add_scale) as = wn5_ld4(P.add_scale + (size_t)img * P.cout + c_ld);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   wn_barrier();                                                 // the exchange is complete
-  const float4 sc = *(const float4*)(SBuf + cl), bi = *(const float4*)(SBuf + COUT_T + cl);
+  const f32x4 sc = wn_lds_read128(SBuf + cl), bi = wn_lds_read128(SBuf + COUT_T + cl);
   const int tr = wt_e * 64 + ((cq ^ (wt_e & 15)) << 2);
   SF_STAMP_AT(L, 5);
-  WnOut r00, r01, r10, r11;
-  {
-    const f32x4 t0 = wn_lds_read128(Tb + tr), t1 = wn_lds_read128(Tb + 2 * WT * 64 + tr);
-    const f32x4 t2 = wn_lds_read128(Tb + 4 * WT * 64 + tr), t3 = wn_lds_read128(Tb + 6 * WT * 64 + tr);
-    const f32x4 ya = (t0 + t1) + t2, yb = wn_sub4(t1, t2 + t3);
-    r00 = wn_epi_finish<EPI>(P, wn_lo(ya), wn_hi(ya), o00, sc, bi, as, c);
-    r01 = wn_epi_finish<EPI>(P, wn_lo(yb), wn_hi(yb), o01, sc, bi, as, c);
+  f32x4 y[4];
+#pragma unroll
+  for (int bq = 0; bq < 2; ++bq) {
+    const float* const tb = Tb + bq * WT * 64 + tr;
+    const f32x4 t0 = wn_lds_read128(tb), t1 = wn_lds_read128(tb + 2 * WT * 64), t2 = wn_lds_read128(tb + 4 * WT * 64), t3 = wn_lds_read128(tb + 6 * WT * 64);
+    y[2 * bq] = (t0 + t1) + t2;
+    y[2 * bq + 1] = wn5_sub4(t1, t2 + t3);
   }
   SF_STAMP_AT(L, 6);
-  {
-    const f32x4 t0 = wn_lds_read128(Tb + WT * 64 + tr), t1 = wn_lds_read128(Tb + 3 * WT * 64 + tr);
-    const f32x4 t2 = wn_lds_read128(Tb + 5 * WT * 64 + tr), t3 = wn_lds_read128(Tb + 7 * WT * 64 + tr);
-    const f32x4 ya = (t0 + t1) + t2, yb = wn_sub4(t1, t2 + t3);
-    r10 = wn_epi_finish<EPI>(P, wn_lo(ya), wn_hi(ya), o10, sc, bi, as, c);
-    r11 = wn_epi_finish<EPI>(P, wn_lo(yb), wn_hi(yb), o11, sc, bi, as, c);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) y[k] = __builtin_elementwise_fma(y[k], sc, bi);
+  f32x4 y2[4];
+  if constexpr (affine) {
+    const bool act_last = (P.mode & 2) != 0;
+    if (!act_last) wn5_act16(y, P.act);
+    if (P.clamp_from >= 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (c + q >= P.clamp_from) y[k][q] = fminf(fmaxf(y[k][q], P.clamp_lo), P.clamp_hi);
+    }
+    if (P.add) {
+      if (P.add_scale) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = __builtin_elementwise_fma(oa[k], as, y[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = y[k] + oa[k];
+      }
+    }
+    if (act_last) wn5_act16(y, P.act);
+    if (P.out2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y2[k] = ob[k] * ((f32x4){1.f, 1.f, 1.f, 1.f} - y[k]);
+    }
+  } else {      // EPI_BLEND (temporal.py:56)
+    wn5_act16(y, P.act);
+    if (P.mode & 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = oa[k] * (y[k] - ob[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = ((f32x4){1.f, 1.f, 1.f, 1.f} - oa[k]) * ob[k] + oa[k] * y[k];
+    }
   }
   SF_STAMP_AT(L, 7);
   __builtin_amdgcn_sched_barrier(0);
-  if (ok00) spm_st4(px[0][0].out + (size_t)ln.eo, r00.y);
-  if (ok01) spm_st4(px[0][1].out + (size_t)ln.eo, r01.y);
-  if (ok10) spm_st4(px[1][0].out + (size_t)ln.eo, r10.y);
-  if (ok11) spm_st4(px[1][1].out + (size_t)ln.eo, r11.y);
-  if (affine && P.out2 && c >= P.gate_from) {
-    if (ok00) spm_st4(px[0][0].out2 + (size_t)ln.eo2, r00.y2);
-    if (ok01) spm_st4(px[0][1].out2 + (size_t)ln.eo2, r01.y2);
-    if (ok10) spm_st4(px[1][0].out2 + (size_t)ln.eo2, r10.y2);
-    if (ok11) spm_st4(px[1][1].out2 + (size_t)ln.eo2, r11.y2);
+#if defined(__HIP_DEVICE_COMPILE__)
+  {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(P.out + img_base * P.out_cs + P.out_co, img_span * P.out_cs * sizeof(float) - (size_t)P.out_co * sizeof(float));
+    const int v = (int)(pix * (unsigned)P.out_cs + (unsigned)c_ld) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, y[k]), rs, okk[k] ? v : OOB, pk_[k] * P.out_cs * 4, 0);
   }
+  if (affine && P.out2) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(P.out2 + img_base * P.out2_cs, img_span * P.out2_cs * sizeof(float));
+    const int v = (int)(pix * (unsigned)P.out2_cs + (unsigned)(c_ld >= P.gate_from ? c_ld - P.gate_from : 0)) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, y2[k]), rs, (okk[k] && gate_lane) ? v : OOB, pk_[k] * P.out2_cs * 4, 0);
+  }
+#endif
   SF_STAMP_AT(L, 3);
 #ifdef SF_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
