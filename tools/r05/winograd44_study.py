@@ -1,0 +1,156 @@
+"""Accuracy study for VERDICT r4 item 2: Winograd F(4x4, 3x3) in fp32 for the non-recurrent-chain 3x3 layers — CPU, test infrastructure only.
+
+Every 3x3 / stride-1 convolution of the oracle (oracle/ref_torch.py) at >= 100x100 pixels per image — encoder, decoder, SpatialGRU,
+DeepLab head incl. the dilated ASPP branches through their polyphase components — is re-evaluated as
+    U = G g G^T (6x6 per cout, cin),  V = B^T d B (per 6x6 input tile, stride 4),  M = sum_cin U (.) V,  Y = A^T M A (4x4 outputs)
+in fp32 with Lavin's F(4x4, 3x3) matrices: 4x fewer multiplies than the direct form, 1.78x fewer than F(2x2, 3x3), transform constants up
+to 8 / 5 / (1/24): rounding ~10x F(2x2)'s.  The layers of the GRU-ODE chain (50x50 latents) keep F(2x2, 3x3) ("chain_f22") or the direct
+form ("chain_direct").  Output compared with the exact direct-convolution oracle on the same inputs / weights / noise: max-abs on the
+BEV output.  Gate: <= 2e-4 (north star 1e-3).
+Usage: python3 tools/r05/winograd44_study.py [quick]"""
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools", "r04"))
+from oracle import cases, hashfill, ref_torch as R  # noqa: E402
+from util import build_pair  # noqa: E402
+import winograd_study as W22  # noqa: E402  (F(2x2, 3x3) restatement; importing it installs ITS shim, replaced below)
+
+MODE = {"head": None, "chain": None, "n44": 0, "n22": 0, "direct": 0}
+_conv2d, _convT = W22._conv2d, W22._convT
+
+BT = torch.tensor([[4., 0., -5., 0., 1., 0.], [0., -4., -4., 1., 1., 0.], [0., 4., -4., -1., 1., 0.],
+                   [0., -2., -1., 2., 1., 0.], [0., 2., -1., -2., 1., 0.], [0., 4., 0., -5., 0., 1.]])
+G = torch.tensor([[1 / 4., 0., 0.], [-1 / 6., -1 / 6., -1 / 6.], [-1 / 6., 1 / 6., -1 / 6.],
+                  [1 / 24., 1 / 12., 1 / 6.], [1 / 24., -1 / 12., 1 / 6.], [0., 0., 1.]])
+AT = torch.tensor([[1., 1., 1., 1., 1., 0.], [0., 1., -1., 2., -2., 0.], [0., 1., 1., 4., 4., 0.], [0., 1., -1., 8., -8., 1.]])
+
+
+def winograd44_3x3(x, w):
+    """conv2d(x, w, padding=1) for 3x3 w, stride 1, via F(4x4, 3x3) in fp32.  x [N, C, H, W], w [O, C, 3, 3]."""
+    N, C, H, Wd = x.shape
+    He, We = (H + 3) // 4 * 4, (Wd + 3) // 4 * 4
+    xp = F.pad(x, (1, 1 + We - Wd, 1, 1 + He - H))
+    d = xp.unfold(2, 6, 4).unfold(3, 6, 4)                       # [N, C, Th, Tw, 6, 6]
+    V = torch.einsum("ai,nctuij,bj->nctuab", BT, d, BT)
+    U = torch.einsum("ai,ocij,bj->ocab", G, w, G)                # computed once per layer (pack time)
+    Th, Tw = V.shape[2], V.shape[3]
+    Vm = V.permute(4, 5, 1, 0, 2, 3).reshape(36, C, N * Th * Tw)
+    Um = U.permute(2, 3, 0, 1).reshape(36, w.shape[0], C)
+    M = torch.bmm(Um, Vm).reshape(6, 6, w.shape[0], N, Th, Tw)
+    Y = torch.einsum("ai,ijontu,bj->notuab", AT, M, AT)          # [N, O, Th, Tw, 4, 4]
+    Y = Y.permute(0, 1, 2, 4, 3, 5).reshape(N, w.shape[0], 4 * Th, 4 * Tw)
+    return Y[:, :, :H, :Wd].contiguous()
+
+
+def conv3x3(x, w, dil, fn):
+    if dil == 1:
+        return fn(x, w)
+    y = x.new_empty((x.shape[0], w.shape[0], x.shape[2], x.shape[3]))
+    for a in range(dil):
+        for b in range(dil):
+            sub = x[:, :, a::dil, b::dil]
+            if sub.numel():
+                y[:, :, a::dil, b::dil] = fn(sub.contiguous(), w)
+    return y
+
+
+def pick(x, w, stride, padding, dilation, groups):
+    s = stride if isinstance(stride, int) else stride[0]
+    p = padding if isinstance(padding, int) else padding[0]
+    d = dilation if isinstance(dilation, int) else dilation[0]
+    if groups != 1 or tuple(w.shape[2:]) != (3, 3) or s != 1 or p != d:
+        return None, 0
+    head = x.shape[2] * x.shape[3] >= 100 * 100
+    return (MODE["head"] if head else MODE["chain"]), d
+
+
+class Shim:
+    def __getattr__(self, k):
+        return getattr(F, k)
+
+    def _run(self, x, w, b, form, d):
+        fn = winograd44_3x3 if form == "f44" else W22.winograd_3x3
+        MODE["n44" if form == "f44" else "n22"] += 1
+        y = conv3x3(x, w, d, fn)
+        return y if b is None else y + b.view(1, -1, 1, 1)
+
+    def conv2d(self, x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
+        form, d = pick(x, w, stride, padding, dilation, groups)
+        if form in (None, "direct"):
+            MODE["direct"] += 1
+            return _conv2d(x, w, b, stride, padding, dilation, groups)
+        return self._run(x, w, b, form, d)
+
+    def conv_transpose2d(self, x, w, b=None, stride=1, padding=0, *a, **k):
+        ok = tuple(w.shape[2:]) == (3, 3) and stride == 1 and padding == 1 and not a and not k
+        form = (MODE["head"] if x.shape[2] * x.shape[3] >= 100 * 100 else MODE["chain"]) if ok else None
+        if form in (None, "direct"):
+            MODE["direct"] += 1
+            return _convT(x, w, b, stride, padding, *a, **k)
+        return self._run(x, w.flip(2, 3).transpose(0, 1).contiguous(), b, form, 1)
+
+
+R.F = Shim()
+
+
+def forward(C, H, W, ts, solver):
+    cts, lts, tts, dt = cases.timeset(ts)
+    _, sd = build_pair(C, solver, True, True, dt, device="cpu")
+    cam, lid = cases.bev_inputs(C, H, W, cts.shape[1], lts.shape[1])
+    with torch.no_grad():
+        y, _ = R.future_prediction_ode_forward(sd, cases.present_input(cam, lid), cam, lid, cts, lts, tts, dt, 2, solver, True, True,
+                                                hashfill.HashedNoise(cases.EPS_SEED))
+    return y
+
+
+def selfcheck():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 5, 11, 14, generator=g)
+    w = torch.randn(7, 5, 3, 3, generator=g)
+    for d in (1, 2, 3):
+        e = (conv3x3(x, w, d, winograd44_3x3) - _conv2d(x, w, None, 1, d, d)).abs().max()
+        assert e < 1e-4, (d, float(e))
+    return float(e)
+
+
+def main():
+    quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+    torch.set_num_threads(8)
+    selfcheck()
+    runs = [("C=64 BEV 200x200 config 2 shipped euler", 64, 200, 200, "shipped", "euler"),
+            ("C=32 BEV 200x200 config 1 euler", 32, 200, 200, "config1", "euler")]
+    if not quick:
+        runs += [("C=64 BEV 200x200 config 4 future16 euler", 64, 200, 200, "future16", "euler"),
+                 ("C=64 BEV 200x200 config 5 stream40 (46 steps) euler", 64, 200, 200, "stream40", "euler")]
+    rows = []
+    out_path = os.path.join(ROOT, "profiles", "r05_winograd44_accuracy_study.json")
+    for name, C, H, W, ts, solver in runs:
+        t0 = time.time()
+        MODE.update(head="direct", chain="direct")
+        ref = forward(C, H, W, ts, solver)
+        row = {"case": name, "absmax_of_output": float(ref.abs().max())}
+        for tag, head, chain in (("head_f44_chain_f22", "f44", "f22"), ("head_f44_chain_direct", "f44", "direct"), ("head_f22_chain_f22", "f22", "f22")):
+            if quick and tag != "head_f44_chain_f22":
+                continue
+            MODE.update(head=head, chain=chain, n44=0, n22=0, direct=0)
+            y = forward(C, H, W, ts, solver)
+            row[tag] = {"maxabs": float((y - ref).abs().max()), "layers_f44": MODE["n44"], "layers_f22": MODE["n22"], "layers_direct": MODE["direct"],
+                        "frames_maxabs": [float(v) for v in (y - ref).abs().flatten(2).max(2)[0][0]][:: max(1, y.shape[1] // 8)]}
+        row["seconds"] = time.time() - t0
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+        json.dump({"what": __doc__.split("Usage")[0], "gate": "<= 2e-4 max-abs on the BEV output (VERDICT r4 item 2; north-star tolerance 1e-3)", "rows": rows},
+                  open(out_path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
