@@ -157,9 +157,14 @@ const char* sf_status_string(int status);
 /* Persistent "flow" form of the single-latent rollout (csrc/conv_sp.hip: sp_flow_kernel): every launch group of sf_nnfo_rollout_* runs
  * as a phase of ONE resident launch ordered by tile-level dataflow — bitwise the results of the launch-per-layer form, ~5 % less time
  * per ODE step.  It needs every CU of an otherwise IDLE device (one workgroup per CU must be resident at once; waits are bounded, so a
- * device shared with another process or stream ends the launch with wrong results instead of hanging): opt-in.  on: 1 / 0, -1 = the
+ * device shared with another process or stream ends the launch with NaN results — see sf_flow_errors — instead of hanging): opt-in.  on: 1 / 0, -1 = the
  * SF_PERSIST environment variable (default 0).  Returns the previous setting.  Process-wide; set it before capturing a graph. */
 int sf_set_flow_mode(int on);
+/* Every dependency wait of the flow kernel is bounded (SF_FLOW_TIMEOUT polls).  A rollout in which one gave up does NOT return its
+ * half-finished results: a tail kernel of the same call (captured with it in a graph) overwrites out_states / final_state with NaN.
+ * sf_flow_errors synchronises `stream` and returns the number of timed-out waits of the calling thread's most recent persistent
+ * rollout (0 = healthy), SF_ERR_INVALID if the thread has not run one.  The launch-per-layer form (the default) has no such waits. */
+int sf_flow_errors(void* stream);
 
 /* ---- ABI guard ---------------------------------------------------------------------------------------------------------
  * The structs above are passed by pointer and sf_conv_w is embedded by value in every composite, so a host compiled

@@ -86,6 +86,7 @@ _f6 = C.POINTER(C.c_float * 6)
 SIGNATURES = {
     "sf_version": (_i, []),
     "sf_set_flow_mode": (_i, [_i]),
+    "sf_flow_errors": (_i, [_vp]),
     "sf_abi_version": (_i, []),
     "sf_abi_sizeof": (_sz, [_i]),
     "sf_abi_check": (_i, [_i, C.POINTER(_sz), _i]),

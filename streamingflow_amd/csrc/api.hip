@@ -69,6 +69,17 @@ hipError_t copy_floats(const float* src, float* dst, size_t n, hipStream_t st) {
   hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n4);
   return hipGetLastError();
 }
+// persistent flow: a dependency wait that timed out leaves err[0] != 0 and the rollout's results undefined — make that loud instead of
+// silent: every output of the call becomes NaN.  A kernel, so a captured graph carries the check with it.
+__global__ void flow_poison_kernel(const unsigned* __restrict__ err, float* __restrict__ a, size_t na, float* __restrict__ b, size_t nb) {
+  if (__builtin_nontemporal_load(err) == 0) return;
+  const float q = __builtin_nanf("");
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += (size_t)gridDim.x * blockDim.x) {
+    if (i < na) a[i] = q;
+    else b[i - na] = q;
+  }
+}
+thread_local const unsigned* g_flow_err_last = nullptr;      // error word of this thread's most recent persistent rollout (sf_flow_errors)
 hipError_t zero_fill(void* p, size_t bytes, hipStream_t st) {     // p 16-byte aligned, bytes a multiple of 16 (arena blocks are)
   const size_t n4 = bytes / 16;
   if (n4 == 0) return hipSuccess;
@@ -155,7 +166,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int wino, wino_min_p, flow_timeout, flow_sc1, b3_small_tiles, wide64, seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int wino, wino_min_p, flow_timeout, b3_small_tiles, wide64, seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -168,7 +179,6 @@ const Tune& tune() {
     x.wino_min_p = geti("SF_WINO_MIN_P", 14000);       // measured (profiles/r04_zz_wino_min_p_sweep.txt, r04_zz_step_min_p_batched_latents.txt): 6 or more batched 50x50 latents
                                                      // and one 200x200 latent gain 6-11 % per ODE step, 5 latents / one 100x100 latent lose 4-7 %; 32 latents +1.6 % on the headline
     x.flow_timeout = geti("SF_FLOW_TIMEOUT", 1 << 22);   // polls before a dependency wait of the flow kernel gives up (~1 us each: seconds); bring-up runs use a small value
-    x.flow_sc1 = geti("SF_FLOW_SC1", 0);           // experiment: flow kernel without the acquire fence (every load of handed-off bytes an sc1 load)
     x.fenced = geti("SF_HANDOFF_FENCED", 0);       // 1: split-K hand-offs also run the agent-scope release / acquire fences of round 1 (known-good reference for the fence-free sc1 form; gfx950 only either way)
     x.b3 = geti("SF_BF16X3", 1);                   // layers packed with split-bf16 weights (opt-in at pack time) run the bf16x3 K loop where a kernel has one (0: exact fp32 even then)
     x.pipe = geti("SF_PIPE", 2);                   // one latent: branch 2 of the NEXT dual cell (gates2 -> cand2, functions of the state only) rides in the launches of infer_state, its conv_decoder_2 in the candidate launch (0: every cell on its own, 5 launches)
@@ -274,6 +284,7 @@ struct FlowBuilder {
   unsigned* done;                // device: tile counters (zeroed at the start of the rollout), done[-64 .. -1] = error words
   unsigned* err;
   int next_done = 0;
+  int recorded = 0;              // phases recorded so far in this rollout (never reset: picks the split-K scratch half of the next phase)
   bool b3 = false;
   int grid = 0;
   int launches = 0;
@@ -313,7 +324,6 @@ struct FlowBuilder {
     F.p = reinterpret_cast<const ConvProblem*>(table + pb);
     F.done = done;
     F.err = err;
-    F.sc1_loads = tune().flow_sc1;
     if (launch_sp_flow(F, grid, b3, st) != hipSuccess) return SF_ERR_LAUNCH;
     ++launches;
     phases.clear(); probs.clear();
@@ -384,6 +394,7 @@ struct FlowBuilder {
       ph.lag_tot_base = a.tot_base; ph.lag_tot_expect = a.tot_expect;
     }
     phases.push_back(ph);
+    ++recorded;
     return SF_OK;
   }
   int add_copy(const float* src, float* dst, size_t nfloats) {
@@ -566,7 +577,9 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     // inside a persistent flow consecutive phases overlap in time (a slice of phase q+1 may start while a last arriver of phase q
     // still reads its slabs): slabs and tickets alternate between the two halves of the scratch by phase parity (phase q+2 starts
     // only when phase q is complete)
-    const int parity = g_seg ? (int)(g_seg->phases.size() & 1) : 0;
+    // (a running count of recorded phases, NOT the index inside the flow under construction: add() may flush first and the phase then
+    // opens a new flow — with the index, the phase before the flush and the one after it could land on the same half)
+    const int parity = g_seg ? (g_seg->recorded & 1) : 0;
     const size_t slab_lim = g_split ? (g_seg ? (parity + 1) * (g_split->slab_floats / 2) : g_split->slab_floats) : 0;
     const int cnt_lim = g_split ? (g_seg ? (parity + 1) * (g_split->ncounters / 2) : g_split->ncounters) : 0;
     size_t slab_off = (g_seg && g_split) ? parity * (g_split->slab_floats / 2) : 0;
@@ -1495,11 +1508,14 @@ struct Stage {
 
 size_t rollout_ws_floats(int C, int P) {
   const size_t cellw = dual_ws_floats(C, P), inf = infer_ws_floats(C, P);
-  return (cellw > inf ? cellw : inf) + 15 * al((size_t)P * C) + SPLIT_WS_FLOATS + FLOW_WS_FLOATS + 256;
+  // the persistent flow's tables and counters (5 MB) only where the flow form is switched on at the time of the query: the size query and
+  // the call see the same setting (a workspace sized without them makes a flow-mode call fail with SF_ERR_WORKSPACE, not overrun)
+  const bool flow = g_flow_mode < 0 ? tune().persist != 0 : g_flow_mode != 0;
+  return (cellw > inf ? cellw : inf) + 15 * al((size_t)P * C) + SPLIT_WS_FLOATS + (flow ? FLOW_WS_FLOATS : 0) + 256;
 }
 
 int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const float* eps, const unsigned long long* philox, int coef_stride,
-               const int32_t* sel_nops, int n_targets, float* out_states, int B, int H, int W, Arena& A, hipStream_t st) {
+               const int32_t* sel_nops, int n_targets, float* out_states, int B, int H, int W, Arena& A, hipStream_t st, const unsigned** flow_err) {
   const size_t PC = (size_t)B * H * W * pm.C;
   // buffers of the carried branch 2 (outside the per-stage arenas: written during one stage's infer_state, read by the next cell)
   Carry cb, cnow;
@@ -1516,6 +1532,7 @@ int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const fl
     ~SegScope() { if (on) g_seg = nullptr; }
   } seg_scope(&seg, persist);
   if (persist) SF_HIP(zero_fill(done, (FLOW_DONE_COUNTERS + 64) * sizeof(unsigned), st));
+  *flow_err = persist ? done + FLOW_DONE_COUNTERS : nullptr;
   bool carried = false;
   for (size_t j = 0; j < stages.size(); ++j) {
     const Stage& g = stages[j];
@@ -1618,8 +1635,14 @@ static int rollout_core(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const 
       return SF_ERR_INVALID;
     }
   }
-  SF_TRY(run_stages(stages, *pm, eps, philox, cstride, sel_nops, n_targets, out_states, B, H, W, A, st));
+  const unsigned* flow_err = nullptr;
+  SF_TRY(run_stages(stages, *pm, eps, philox, cstride, sel_nops, n_targets, out_states, B, H, W, A, st, &flow_err));
   if (final_state) SF_HIP(copy_floats(sbuf[si], final_state, PC, st));
+  if (flow_err) {      // the flow kernel's bounded waits: a timeout must not pass as a result
+    hipLaunchKernelGGL(flow_poison_kernel, dim3(256), dim3(256), 0, st, flow_err, out_states, (size_t)n_targets * PC, final_state, final_state ? PC : 0);
+    SF_HIP(hipGetLastError());
+    g_flow_err_last = flow_err;
+  }
   return SF_OK;
 }
 int sf_nnfo_rollout_fwd(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const sf_pmodel_w* pm, int solver, int impute,
@@ -1861,6 +1884,15 @@ int sf_set_flow_mode(int on) {
   const int was = g_flow_mode < 0 ? tune().persist : g_flow_mode;
   g_flow_mode = on < 0 ? -1 : (on ? 1 : 0);
   return was;
+}
+// number of timed-out dependency waits of the calling thread's most recent persistent-flow rollout (0 = healthy; > 0: its outputs were
+// overwritten with NaN).  Synchronises `stream`.  SF_ERR_INVALID: this thread has not run one.
+int sf_flow_errors(void* stream) {
+  if (!g_flow_err_last) return SF_ERR_INVALID;
+  unsigned v = 0;
+  if (hipMemcpyAsync(&v, g_flow_err_last, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return SF_ERR_LAUNCH;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return SF_ERR_LAUNCH;
+  return (int)(v > 0x3fffffffu ? 0x3fffffffu : v);
 }
 
 int sf_debug_stamps(void* buf) {

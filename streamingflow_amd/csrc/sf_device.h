@@ -155,7 +155,6 @@ struct SpFlow {
   const ConvProblem* p;
   unsigned int* done;            // tile counters of the flow (zero at its start)
   unsigned int* err;             // [0]: number of timed-out waits (0 after a healthy run)
-  int sc1_loads;                 // experiment: 1 = no acquire fence; every load of handed-off bytes is an sc1 load / sc1 LDS-DMA
 };
 static_assert(sizeof(ConvProblem) % 8 == 0, "problems are stored back to back in the table");
 // table writer: up to SP_WRITER_BYTES of a table per launch, passed by value (one or two launches per rollout)

@@ -31,12 +31,14 @@ def run_sharded(model_fn, samples):
     return {i: model_fn(samples[i]) for i in shard_indices(len(samples))}
 
 
-def gather_predictions(local, n_samples, like=None):
+def gather_predictions(local, n_samples, like=None, force_collective=False):
     """All-gather per-sample outputs (same shape on every rank) so that every rank holds the full,
     index-ordered list.  ``local``: {sample index: tensor}.  One collective for the whole shard:
-    the shard is stacked (padded to ceil(n/W) rows) and gathered with all_gather_into_tensor."""
+    the shard is stacked (padded to ceil(n/W) rows) and gathered with all_gather_into_tensor.
+    A single rank returns its own tensors without a collective unless ``force_collective`` (a
+    one-rank process group then runs the same device all-gather: tests/test_gpu_rccl.py)."""
     rank, w = world()
-    if w == 1:
+    if w == 1 and not (force_collective and dist.is_available() and dist.is_initialized()):
         return [local[i] for i in range(n_samples)]
     per = (n_samples + w - 1) // w
     mine = shard_indices(n_samples)
@@ -59,9 +61,9 @@ def gather_predictions(local, n_samples, like=None):
     return [out[i % w, i // w] for i in range(n_samples)]
 
 
-def reduce_counters(t):
+def reduce_counters(t, force_collective=False):
     """Sum metric counters (IoU intersection/union, PQ tp/fp/fn/iou — reference metrics.py:32-35,
     89-92 declare them with dist_reduce_fx='sum') over all ranks, in place."""
-    if world()[1] > 1:
+    if world()[1] > 1 or (force_collective and dist.is_available() and dist.is_initialized()):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t

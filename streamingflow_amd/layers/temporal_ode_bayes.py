@@ -12,6 +12,7 @@ Differences a caller can observe (all documented in DESIGN.md):
   * ``solver='rk4'`` is accepted in addition to the reference's 'euler' / 'midpoint';
   * inference only (no autograd), batch 1 per call as in the reference.
 """
+import collections
 import ctypes
 
 import numpy as np
@@ -249,14 +250,23 @@ class NNFOwithBayesianJumps(nn.Module):
         # (noise_seed, call counter)); no eps tensor exists.  Same distribution, its own stream; ignored when eps is given
         # None = auto: on whenever no `noise` source was injected (nothing to replay), True / False force it
         self.in_kernel_noise = None
-        self.noise_seed = 0x5EED5F10
+        # None = derived at the first draw from torch's global seed (torch.manual_seed reaches the in-kernel noise as it reaches the
+        # reference's torch.randn) mixed with the distributed rank and a per-module serial number: ranks and module instances draw
+        # different streams.  `seed_noise(seed)` pins it (and restarts the call counter); neither is part of state_dict.
+        self.noise_seed = None
         self._noise_calls = 0
+        NNFOwithBayesianJumps._serial = getattr(NNFOwithBayesianJumps, "_serial", 0) + 1
+        self._noise_serial = NNFOwithBayesianJumps._serial
         # capture the rollout of each schedule structure into a hipGraph and replay it.  None = auto: on for rollouts that
         # run on the launch-bound single-latent kernels (B*h*w < 4096), where ~9 short launches per step are replayed from one
         # graph; the results are cloned out of the graph's static buffers.  True: always, and the returned tensors ARE the
         # static buffers (valid until the next replay); False: never
         self.use_graph = None
-        self._graphs = {}
+        # at most GRAPH_CACHE_MAX captured rollouts are kept, least recently used first out (a stream of variable timestamps produces a
+        # new schedule structure per call: each entry pins its own buffers and a rollout workspace); when auto mode sees more than
+        # GRAPH_AUTO_MAX_STRUCTURES distinct structures it stops capturing and runs eagerly
+        self._graphs = collections.OrderedDict()
+        self._graph_structures_seen = set()
         self._graph_gens = None
         self.apply(init_weights)
 
@@ -334,6 +344,22 @@ class NNFOwithBayesianJumps(nn.Module):
             ptr(hx_obs), ptr(eps), ptr(coef), int(per_image), sel.ctypes.data_as(_lib.i32p), len(sel), ptr(out),
             ptr(final), B, h, w, ptr(ws), ws.numel() * 4, runtime.stream_ptr(hx_obs.device)), "nnfo_rollout")
 
+    GRAPH_CACHE_MAX = 4
+    GRAPH_AUTO_MAX_STRUCTURES = 16
+
+    def seed_noise(self, seed):
+        """Pin the seed of the in-kernel (Philox) noise and restart its call counter."""
+        self.noise_seed = int(seed) & 0x7FFFFFFFFFFFFFFF
+        self._noise_calls = 0
+
+    def _philox_seed(self):
+        if self.noise_seed is None:
+            rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+            x = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + rank * 0xBF58476D1CE4E5B9 + self._noise_serial * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+            x ^= x >> 31
+            self.noise_seed = x & 0x7FFFFFFFFFFFFFFF
+        return self.noise_seed
+
     def drop_graphs(self):
         """Destroy every captured rollout graph of this module and release its static buffers."""
         L = _lib.lib()
@@ -341,6 +367,7 @@ class NNFOwithBayesianJumps(nn.Module):
             if g.get("exec") is not None:
                 L.sf_graph_destroy(g["exec"])
         self._graphs.clear()
+        self._graph_structures_seen.clear()
 
     def rollout_nhwc(self, hx_obs, sc, eps=None):
         """hx_obs: [n_obs, B, h, w, C] (or [n_obs, h, w, C] for one sample) encoded observations in
@@ -366,9 +393,15 @@ class NNFOwithBayesianJumps(nn.Module):
         philox = None
         in_kernel = self.noise is None if self.in_kernel_noise is None else bool(self.in_kernel_noise)
         auto_graph = self.use_graph is None and B * h * w < 4096
+        if auto_graph:
+            # not from inside somebody else's capture (warm-up, synchronize and a nested capture would break it), and not for an
+            # endless variety of schedule structures
+            self._graph_structures_seen.add(s0.key())
+            if torch.cuda.is_current_stream_capturing() or len(self._graph_structures_seen) > self.GRAPH_AUTO_MAX_STRUCTURES:
+                auto_graph = False
         if eps is None and in_kernel and self.noise is None:
             self._noise_calls += 1
-            philox = torch.tensor([self.noise_seed, self._noise_calls], dtype=torch.int64, device=dev)
+            philox = torch.tensor([self._philox_seed(), self._noise_calls], dtype=torch.int64, device=dev)
             eps = torch.empty((0, B, h, w, C), dtype=torch.float32, device=dev)      # placeholder (shape key of the graph cache)
         elif eps is None:
             eps = self._draw_eps(need, B, h, w, dev)
@@ -419,6 +452,12 @@ class NNFOwithBayesianJumps(nn.Module):
                         _lib.check(L.sf_graph_end(sp, ctypes.byref(ex)), "graph_end")
                 g["exec"] = ex
                 self._graphs[key] = g
+                while len(self._graphs) > self.GRAPH_CACHE_MAX:      # least recently used out: its graph is destroyed, its buffers released
+                    _, old_g = self._graphs.popitem(last=False)
+                    if old_g.get("exec") is not None:
+                        L.sf_graph_destroy(old_g["exec"])
+            else:
+                self._graphs.move_to_end(key)
             g["hx"].copy_(hx_obs); g["eps"].copy_(eps); g["coef"].copy_(coef)
             if philox is not None:
                 g["philox"].copy_(philox)

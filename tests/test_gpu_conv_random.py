@@ -166,8 +166,8 @@ def test_dma_conv_is_bitwise_reproducible(i):
         assert torch.equal(o, outs[0])
 
 
-# Layers that qualify for the Winograd F(2x2, 3x3) kernel (csrc/conv_wino.hip: 3x3, stride 1, pad 1, inputs in whole 16-channel
-# chunks, cout a multiple of 128, >= 131072 pixels): one and two sources, odd sizes (ragged tile blocks at the right / bottom
+# Layers that qualify for the Winograd F(2x2, 3x3) kernel (csrc/conv_wino.hip: 3x3, stride 1, pad = dilation, inputs in whole
+# 16-channel chunks, cout a multiple of 64, >= 14000 pixels): one and two sources, odd sizes (ragged tile blocks at the right / bottom
 # edge, odd H / W: a half-used last Winograd tile), two cout tiles, many small images, channel-sliced inputs / outputs, every
 # activation, the residual before and after it.  Same oracle and tolerance as the direct form.
 _WINO = [
@@ -236,9 +236,13 @@ def test_winograd_conv_is_bitwise_reproducible(i):
     a0 = torch.randn((n, H, W, c0), device="cuda", generator=g)
     a1 = torch.randn((n, H, W, c1), device="cuda", generator=g) if c1 else None
     w = torch.randn((cout, c0 + c1, 3, 3), device="cuda", generator=g) * 0.05
+    was = packing.winograd()
     packing.set_winograd(True)
-    pk = packing.Pack(None)
-    cw = packing.conv_w(pk, w, c0, c1, act="lrelu", dil=dil, stride=1, pad=dil)
+    try:
+        pk = packing.Pack(None)
+        cw = packing.conv_w(pk, w, c0, c1, act="lrelu", dil=dil, stride=1, pad=dil)
+    finally:
+        packing.set_winograd(was)
     assert cw.w_wino, "the layer must have been packed with Winograd weights"
     L = _lib.lib()
     ws = runtime.workspace(L.sf_conv2d_ex_ws_bytes(), "cuda")
@@ -255,3 +259,58 @@ def test_winograd_conv_is_bitwise_reproducible(i):
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
 
+
+
+def _wino_calls(fn):
+    """run fn() under the library profiler: (result, names of the kernels that ran)"""
+    from streamingflow_amd import _lib
+    L = _lib.lib()
+    NK = _lib.SF_PROF_KEYS
+    calls, ms = (ctypes.c_int32 * NK)(), (ctypes.c_double * NK)()
+    fl, by = (ctypes.c_double * NK)(), (ctypes.c_double * NK)()
+    L.sf_prof_enable(1)
+    try:
+        r = fn()
+        torch.cuda.synchronize()
+        L.sf_prof_collect(calls, ms, fl, by)
+    finally:
+        L.sf_prof_enable(0)
+    return r, {_lib.KERNEL_NAMES[k]: calls[k] for k in range(NK) if calls[k]}
+
+
+def test_winograd_epilogues_of_the_batched_latents_against_the_direct_form():
+    """the epilogue variants the unit cases above do not reach, at kernel level on the launches of 8 batched 50x50 latents
+    (images concatenated along x): the conv-GRU cell = [update ; reset] gates with the reset-gate second output (AFFINE + out2 /
+    gate_from), then the candidate with the state blend (BLEND); and infer_state = SE-scaled input (the plain form: per-image scales
+    staged in LDS), residual with an SE scale (add_scale), the clamped last layer.  Each module runs twice — packed with and without
+    Winograd weights — on the same inputs: the profiler must show the Winograd kernel in the first run only, and the two results must
+    agree far inside the 1e-3 end-to-end tolerance that would otherwise be the only check of a masked-lane or offset bug."""
+    from util import build_pair, cases
+    from streamingflow_amd import packing
+    C, B, h, w = 64, 8, 50, 50
+    cts, lts, tts, dt = cases.timeset("shipped")
+
+    def build(wino):
+        was = packing.winograd()
+        packing.set_winograd(wino)
+        try:
+            net, _ = build_pair(C, "euler", True, True, dt)
+            gru, ode = net.spatial_grus[0], net.gru_ode
+            x = (hashfill.normal("wl_x", (3, B, h, w, C), 11) * 0.5).cuda()          # [T, B, h, w, C] NHWC frames
+            s0 = (hashfill.normal("wl_s", (B, h, w, C), 12) * 0.5).cuda()
+            ode.noise = hashfill.HashedNoise(3)
+
+            def run():
+                y = gru.forward_nhwc(x, s0)
+                p, q = ode.infer_state(s0.permute(0, 3, 1, 2).contiguous())
+                return y, p, q
+            return _wino_calls(run)
+        finally:
+            packing.set_winograd(was)
+    (ya, pa, qa), used_a = build(True)
+    (yb, pb, qb), used_b = build(False)
+    assert any(k.startswith("conv_wino") and k.endswith("blend>") for k in used_a), used_a
+    assert any(k.startswith("conv_wino") and k.endswith("affine>") for k in used_a), used_a
+    assert not any(k.startswith("conv_wino") for k in used_b), used_b
+    for a, b in ((ya, yb), (pa, pb), (qa, qb)):
+        assert a.shape == b.shape and maxabs(a, b) <= 2e-5, maxabs(a, b)

@@ -53,3 +53,42 @@ def test_persistent_segments_equal_launch_per_layer_bitwise(tmp_path, solver, ts
     for x, y in zip(a, b):
         assert torch.isfinite(x).all()
         assert torch.equal(x, y), (solver, ts, mode, float((x - y).abs().max()))
+
+
+ERR_SCRIPT = r"""
+import sys, ctypes, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from util import build_pair, cases, hashfill
+from streamingflow_amd import schedule as S, _lib, runtime
+C, h, w = 64, 50, 50
+cts, lts, tts, dt = cases.timeset("shipped")
+net, _ = build_pair(C, "euler", True, True, dt)
+ode = net.gru_ode
+ode.use_graph = False
+times, _ = S.merge_observations(cts[0].tolist(), lts[0].tolist())
+sc = S.build_schedule(times, tts[0].tolist(), dt, True, "euler")
+hx = (hashfill.normal("pshx0", (len(times), h, w, C), 61) * 0.5).cuda()
+eps = hashfill.normal("pseps0", (sc.n_draws, h, w, C), 62).cuda()
+a, fa = ode.rollout_nhwc(hx, sc, eps)
+errs = _lib.lib().sf_flow_errors(runtime.stream_ptr(hx.device))
+print("ERRS", errs, int(torch.isnan(a).all()), int(torch.isnan(fa).all()), int(torch.isfinite(a).all()))
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+
+def test_flow_timeouts_are_loud():
+    """every dependency wait of the flow kernel is bounded; a wait that gave up must not pass as a result.  With the bound
+    at ONE poll waits do time out: the rollout's outputs are NaN and sf_flow_errors reports them.  With the default bound the same
+    rollout is healthy: zero errors, finite outputs."""
+    def run(timeout):
+        env = dict(os.environ)
+        env["SF_PERSIST"] = "1"
+        if timeout is not None:
+            env["SF_FLOW_TIMEOUT"] = str(timeout)
+        r = subprocess.run([sys.executable, "-c", ERR_SCRIPT], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("ERRS")][-1].split()
+        return [int(v) for v in line[1:]]
+    errs, nan_a, nan_f, finite = run(1)
+    assert errs > 0 and nan_a == 1 and nan_f == 1, (errs, nan_a, nan_f)
+    errs, nan_a, nan_f, finite = run(None)
+    assert errs == 0 and finite == 1, (errs, finite)
