@@ -633,7 +633,7 @@ def main():
             import voxelbench
             vox = voxelbench.run(reps=10, cpu=(world == 1 and not a.no_cpu_baseline), dev=dev)
             import sparsebench
-            vox["sparse_encoder"] = sparsebench.run(reps=3, cpu=False, dev=dev)
+            vox["sparse_encoder"] = sparsebench.run(reps=3, cpu=(world == 1 and not a.no_cpu_baseline), dev=dev)
         except Exception as ex:
             vox = {"error": repr(ex)}
 

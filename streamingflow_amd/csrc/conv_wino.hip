@@ -138,6 +138,13 @@ __device__ __forceinline__ void wn5_act16(f32x4 (&y)[4], const int act) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) y[k][q] = y[k][q] > 0.f ? y[k][q] : 0.1f * y[k][q];
       break;
+    case ACT_SIGMOID:      // 1 / (1 + 2^(-x log2 e)) on the hardware exp2 / reciprocal (1 ulp each: ~2e-7 from the expf / division form of the
+                           // direct-form kernels, 4 instructions instead of 25 per element: the GRU gates' epilogue is 16 of them per lane)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[k][q] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y[k][q]));
+      break;
     case ACT_NONE: break;
     default:
 #pragma unroll
@@ -158,7 +165,7 @@ struct Wino5Geo {
   static constexpr int P_FLOATS = ND * 256;
   static constexpr int V_FLOATS = 16 * WT * 16;
   static constexpr int NVB = DIL ? 1 : 2, NPB = DIL ? 2 : 1;
-  static constexpr int PARK = DIL ? 512 : 0;                    // DIL: the patch offset of every transform task
+  static constexpr int PARK = DIL ? 512 + 64 : 0;               // DIL: the patch offset of every transform task + the per-axis tables of the block
   static constexpr int SB = 2 * COUT_T, SC = DIL ? 0 : 256;
   static constexpr int T_FLOATS = 4 * 2 * WT * COUT_T;          // the exchange of the output transform: [row i][b][tile][cout]
   static_assert(NVB * V_FLOATS + NPB * P_FLOATS >= T_FLOATS, "the exchange lives over V and the patch");
@@ -232,6 +239,38 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
 #endif
   constexpr bool SCALED = G::SC > 0 && EPI == EPI_AFFINE;
   const bool scaled = SCALED && P.in_scale != nullptr;
+  // DIL: what depends on one axis only is computed once per block by 36 + 12 lanes and shared through LDS (every lane walking the run
+  // lists itself — twice per patch element, twice for its transform task, twice for its output tile — was 300 of the kernel's ~650
+  // vector instructions per wave and tile): Tab[0..PW) input x of patch column c (-1: zero fill), [32..32+PH) input y of patch row r,
+  // [48..56) first output x of tile column t (W: none), [56..60) first output y of tile row t, [60..68) / [68..72) run of tile column / row
+  typedef __attribute__((address_space(3))) int lds_int;
+  float* const TabF = Park + 512;
+  auto tab = [&](const int i) -> int { return *(const lds_int*)(TabF + i); };
+  if constexpr (DIL) {
+    if (tid < 72) {
+      int v = 0;
+      if (tid < PW) { int ix; v = ax.patch_coord(tid, px0, pt0, TW, W, ix) ? ix : -1; }
+      else if (tid >= 32 && tid < 32 + G::PH) { int iy; v = ay.patch_coord(tid - 32, py0, qt0, TH, H, iy) ? iy : -1; }
+      else if (tid >= 48 && tid < 60) {
+        const bool isx = tid < 56;
+        const int t = isx ? tx0 + (tid - 48) : ty0 + (tid - 56);
+        const WnAxis& a = isx ? ax : ay;
+        int pp, tt;
+        a.decode(t, pp, tt);
+        v = (t < a.nt && pp < P.dil) ? pp + P.dil * 2 * tt : (isx ? W : H);
+      } else if (tid >= 60) {
+        const bool isx = tid < 68;
+        const int t = isx ? tx0 + (tid - 60) : ty0 + (tid - 68);
+        int pp, tt;
+        (isx ? ax : ay).decode(t, pp, tt);
+        const int r = pp - (isx ? px0 : py0), lim = isx ? G::RX : G::RY;
+        v = r < lim ? r : lim - 1;
+      }
+      *(lds_int*)(TabF + tid) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wn_barrier();
+  }
   // ---- patch DMA: element e = (pixel, channel quad) of the patch, 16 bytes each, LDS linear in e; piece idx = d * 8 + wave --------------
   SF_STAMP_AT(L, 14);
   int pv0[NP], pv1[DIL ? 1 : NP];
@@ -249,8 +288,9 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
     }
     bool ok = pix < G::NPX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && (!CAT || (img + run < P.n_img && (run == 0 || cn0 < TW)));
     if constexpr (DIL) {
-      const bool oky = ay.patch_coord(py, py0, qt0, TH, H, iy), okx = ax.patch_coord(px, px0, pt0, TW, W, ix);
-      ok = pix < G::NPX && oky && okx;
+      const int pyc = py < G::PH ? py : 0;                      // (pieces are padded to whole DMAs: elements beyond the patch)
+      ix = tab(px); iy = tab(32 + pyc);
+      ok = pix < G::NPX && ix >= 0 && iy >= 0;
     }
     const int pofs = DIL ? iy * W + ix : (iy >> up) * Win + (ix >> up) + (CAT ? run * img_px_i : 0);
     pv0[d] = ok ? (pofs * P.in0_cs + quad * 4) * 4 : (int)0x80000000;
@@ -319,11 +359,7 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   if constexpr (DIL) {
     const int quad = tid & 3, wt = (tid >> 2) % WT;
     const int tyl = wt / TW, txl = wt - tyl * TW;
-    int pX, tX, pY, tY;
-    ax.decode(tx0 + txl, pX, tX);
-    ay.decode(ty0 + tyl, pY, tY);
-    int rx = pX - px0, ry = pY - py0;
-    rx = rx < G::RX ? rx : G::RX - 1; ry = ry < G::RY ? ry : G::RY - 1;
+    const int rx = tab(60 + txl), ry = tab(68 + tyl);
     *(__attribute__((address_space(3))) int*)(Park + tid) = ((2 * tyl + 2 * ry) * PW + 2 * txl + 2 * rx) * 16 + quad * 4;
   }
   auto transform = [&](const int kc) {
@@ -479,12 +515,9 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   const int ty = ty0 + tyl_e, tx = run_e ? txl_e - cn0 : tx0 + txl_e;
   int oy0 = 2 * ty, ox0 = 2 * tx, ostep = 1;
   if constexpr (DIL) {
-    int pX, tX, pY, tY;
-    ax.decode(tx, pX, tX);
-    ay.decode(ty, pY, tY);
     ostep = P.dil;
-    ox0 = (tx < ax.nt && pX < ostep) ? pX + ostep * 2 * tX : W;
-    oy0 = (ty < ay.nt && pY < ostep) ? pY + ostep * 2 * tY : H;
+    ox0 = tab(48 + txl_e);
+    oy0 = tab(56 + tyl_e);
   }
   constexpr bool affine = EPI == EPI_AFFINE;
   const float* const t_a = affine ? P.add : P.e0;

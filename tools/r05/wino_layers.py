@@ -22,7 +22,7 @@ def summarise(path):
     tot = sum(a[1] for a in agg.values())
     print(f"total {tot / 1e3:.2f} ms in {sum(a[0] for a in agg.values())} launches")
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        print(f"{a[1] / 1e3:8.2f} ms {100 * a[1] / tot:5.1f}%  x{a[0]:3d}  {a[2] / a[1] * 1e-3 / 157.3:5.3f} of peak  {k}")
+        print(f"{a[1] / 1e3:8.2f} ms {100 * a[1] / tot:5.1f}%  x{a[0]:3d}  {a[2] / a[1] * 1e3 / 157.3:5.3f} of peak  {k}")
 
 
 def main():

@@ -13,6 +13,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
+PEAK = 157.3      # fp32 MFMA, TFLOP/s (MI355X_MICROARCH.md)
+
+
 def run(reps=5, cpu=False, dev=None):
     from streamingflow_amd import _lib, runtime
     from streamingflow_amd.models.sparse_encoder import SparseEncoder
@@ -45,12 +48,38 @@ def run(reps=5, cpu=False, dev=None):
         L.sf_event_record(e1, runtime.stream_ptr(dev))
         L.sf_event_elapsed_ms(e0, e1, ctypes.byref(ms))
         return ms.value / r
+    # FLOPs of the encoder's convolutions on this cloud: "dense-tap" = what the kernels execute (every output row x all 27 / 3 taps,
+    # the implicit GEMM gathers a zero row for a missing neighbour), "useful" = only the (output site, tap) pairs that have an input site
+    # (what spconv's rule-based gather / GEMM / scatter would multiply: spconv_ops.h:302-348)
+    fl = {"dense": 0.0, "useful": 0.0, "convs": 0}
+    orig_conv = m._conv
+
+    def spy_conv(w, f, nbr, n_out, add=None, act_after_add=False):
+        taps = nbr.shape[1]
+        live = float((nbr[:n_out] >= 0).sum().item())
+        cin = w.c0 + w.c1
+        fl["dense"] += 2.0 * n_out * taps * cin * w.cout
+        fl["useful"] += 2.0 * live * cin * w.cout
+        fl["convs"] += 1
+        return orig_conv(w, f, nbr, n_out, add, act_after_add)
+    m._conv = spy_conv
+    with torch.no_grad():
+        m(feats, coords, 1, nhwc=True)
+    m._conv = orig_conv
     enc_ms = timed(lambda: m(feats, coords, 1, nhwc=True), reps)
     all_ms = timed(lambda: m(*voxelize([pts], vz)[:2], 1, nhwc=True), reps)
     out = m(feats, coords, 1)
     r = {"workload": f"350000x5 points -> {feats.shape[0]} voxels on 1600x1600x41 -> BEV {tuple(out.shape)}",
          "sparse_encoder_ms": enc_ms, "voxelize_plus_encoder_ms": all_ms, "clouds_per_s": 1e3 / all_ms,
-         "occupied_bev_fraction": float((out.abs().amax(1) > 0).float().mean())}
+         "occupied_bev_fraction": float((out.abs().amax(1) > 0).float().mean()),
+         # the whole encoder call (index kernels: out sites + neighbour tables, and the convolutions) against the fp32 MFMA peak
+         "roofline": {"bound": "mfma", "kernel": "SparseEncoder.forward: sf_sparse_out_sites / sf_sparse_table + %d sf_sparse_conv_fwd (conv_glds gather tiles)" % fl["convs"],
+                      "flops_executed_dense_taps": fl["dense"], "flops_useful_site_tap_pairs": fl["useful"],
+                      "achieved": fl["dense"] / (enc_ms * 1e-3) / 1e12, "achieved_useful": fl["useful"] / (enc_ms * 1e-3) / 1e12,
+                      "peak": PEAK, "unit": "TFLOP/s", "frac": fl["dense"] / (enc_ms * 1e-3) / 1e12 / PEAK,
+                      "frac_useful": fl["useful"] / (enc_ms * 1e-3) / 1e12 / PEAK, "traffic": None,
+                      "note": "dense-tap execution: %.1f %% of the executed products have an input site; a 16-row fragment x tap skip would drop "
+                              "nothing on the heavy stages (profiles/r05_sparse_fragment_density.jsonl)" % (100.0 * fl["useful"] / max(fl["dense"], 1.0))}}
     if cpu:
         from oracle import sparse_encoder_ref as SR      # the checker, timed as the reported CPU baseline only
         n = 20000                     # bounded sample: the numpy oracle is ~linear in the number of voxels
@@ -59,7 +88,8 @@ def run(reps=5, cpu=False, dev=None):
         tc = time.perf_counter() - t0
         r["cpu_baseline"] = {"value": 1.0 / (tc * feats.shape[0] / n), "unit": "clouds/s", "cores": 1, "kind": "port",
                              "sample": f"first {n} of {feats.shape[0]} voxels through oracle/sparse_encoder_ref.py (numpy), {tc:.1f} s, "
-                                       "scaled linearly to the full cloud"}
+                                       "scaled linearly to the full cloud",
+                             "parity": "unpinned: spconv cannot be built here (CUDA headers), the oracle restates spconv 1.x twice (DESIGN.md, parity caveats)"}
     return r
 
 
