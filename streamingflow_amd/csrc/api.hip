@@ -1921,6 +1921,8 @@ int sf_prof_collect(int32_t* calls, double* ms, double* flops, double* bytes) {
     SF_HIP(hipEventSynchronize(r.b));
     SF_HIP(hipEventElapsedTime(&t, r.a, r.b));
     if (r.key >= 0 && r.key < SF_PROF_KEYS) { calls[r.key] += 1; ms[r.key] += t; flops[r.key] += r.flops; bytes[r.key] += r.bytes; }
+    static const bool dump = std::getenv("SF_PROF_DUMP") != nullptr;      // debugging aid: one line per profiled launch, in launch order
+    if (dump) std::fprintf(stderr, "[sf-prof] key=%d us=%.1f gflop=%.3f mbytes=%.2f\n", r.key, t * 1e3, r.flops * 1e-9, r.bytes * 1e-6);
     g_prof.pool.push_back(r.a);
     g_prof.pool.push_back(r.b);
   }

@@ -39,12 +39,12 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     case ACT_RELU:    return v > 0.f ? v : 0.f;
     case ACT_TANH:    return tanhf(v);
     case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
-    case ACT_GELU:    return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    case ACT_GELU:    return 0.5f * v * (1.f + spm_erf(v * 0.70710678118654752440f));
     default:          return v;
   }
 }
 
-__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + spm_erf(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float softplus_f(float v) { return v > 20.f ? v : log1pf(expf(v)); }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -58,6 +58,8 @@ struct SpGeo {
   static constexpr int NBI = BN / 32;         // pixel row blocks (8 rows) per loader and sub-chunk
 #if defined(SF_ABL_NO_PIXEL_DMA)      // timing-only ablation (results are garbage): the loaders issue the weight DMAs only — what a pixel operand
   static constexpr int DPC = 2 * 2;           // that is LDS-resident could save at most (tools/r04/abl_pixel_dma.sh)
+#elif defined(SF_ABL_NO_WEIGHT_DMA)   // timing-only (garbage results): the pixel DMAs only — what weights that never had to be fetched per workgroup (one
+  static constexpr int DPC = 2 * NBI;         // copy per XCD L2, a weight-stationary slice) could save at most (tools/r05/abl_weight_dma.sh)
 #else
   static constexpr int DPC = 2 * (2 + NBI);   // DMA instructions per loader and chunk
 #endif
@@ -67,6 +69,11 @@ struct SpGeo {
 template <int NT>
 constexpr int sp_lds_bytes(bool scale) { return (SpGeo<NT>::RING + SP_MISC + (scale ? SP_SC_FLOATS : 0)) * 4; }
 
+#if defined(SF_ABL_NO_WEIGHT_DMA)
+#define SP_ABL_NO_W 1
+#else
+#define SP_ABL_NO_W 0
+#endif
 typedef __attribute__((address_space(3))) void sp_lds_void;
 
 
@@ -697,7 +704,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
         float* const blk = smem + buf * G::BUFF + s2 * G::SUBF;
 #if defined(__HIP_DEVICE_COMPILE__)
         if (live) {
-          if (with_w) {
+          if (with_w && !SP_ABL_NO_W) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * lw) * 32), 16, a_voff[0], sc * 128, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * (lw + 4)) * 32), 16, a_voff[1], sc * 128, 0, 0);
           }
@@ -715,7 +722,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
           }
 #endif
         } else {      // offset -1 fails the buffer range check: the DMA writes zeros
-          if (with_w) {
+          if (with_w && !SP_ABL_NO_W) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * lw) * 32), 16, minus1, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (sp_lds_void*)(blk + (8 * (lw + 4)) * 32), 16, minus1, 0, 0, 0);
           }
