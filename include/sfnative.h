@@ -316,6 +316,9 @@ size_t sf_deeplab_head_ws_bytes(int C, int hid, int n, int H, int W);
 int sf_bottleneck_fwd(const sf_bottleneck_w* w, const float* x, float* out, int n, int H, int W, float* ws,
                       size_t ws_bytes, void* stream);
 size_t sf_bottleneck_ws_bytes(int Cin, int Cout, int n, int H, int W);
+/* elementwise LogSigmoid, min(x, 0) - log1p(exp(-|x|)): the decoder of DistributionModule(method='BERNOULLI')
+ * (streamingflow/models/distributions.py:29-33, :46-47) */
+int sf_logsigmoid_fwd(const float* x, float* out, size_t n, void* stream);
 /* last_conv of DistributionModule / SpatialDistributionModule — beverse motion_modules.py:34-46,74-88
  * (and streamingflow/models/distributions.py:35-49 with clamp == 0): [global avg-pool +] 1x1 conv + bias,
  * second half of the channels clamped to [lo, hi] */
@@ -403,6 +406,11 @@ int sf_depth_softmax_fwd(const float* logits, float* prob, int rows, int D, int 
  * coors [max_voxels][3] = (x, y, z), num_points_per_voxel [max_voxels]; voxel_num: device int = the
  * reference's return value.  mean_feats (may be NULL) [max_voxels][F] = sum over the voxel's points /
  * their number — the reduction streamingflow.voxelize applies right after (streamingflow.py:190-195). */
+/* Dynamic voxelisation (mmdet3d/ops/voxel/voxelize.py:46-49, the max_points == -1 / max_voxels == -1 branch of _Voxelization.forward ->
+ * dynamic_voxelize; src/voxelization_cpu.cpp:8-43, src/voxelization_cuda.cu:25-60): coors [num_points][3] int32 = the (x, y, z) voxel of
+ * every point, floor((p - min) / size) in fp32, or (-1, -1, -1) for a point outside the range on any axis. */
+int sf_dynamic_voxelize_fwd(const float* points, int num_points, int num_features, const float* voxel_size, const float* coors_range,
+                            int32_t* coors, void* stream);
 size_t sf_hard_voxelize_ws_bytes(int num_points);
 int sf_hard_voxelize_fwd(const float* points, int num_points, int num_features, const float* voxel_size,
                          const float* coors_range, int max_points, int max_voxels, float* voxels, int32_t* coors,

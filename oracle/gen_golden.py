@@ -206,6 +206,10 @@ def gen_beverse(m):
             mu, ls = dm(s_t)
             out[tag + "/dist_mu"], out[tag + "/dist_log_sigma"] = _np(mu), _np(ls)
             out[tag + "/sf_dist"] = _np(sfd(s_t))
+            for meth, key in (("MIXGAUSSIAN", "sf_dist_mix"), ("BERNOULLI", "sf_dist_bern")):
+                mod = RD.DistributionModule(C, lat, method=meth).eval()
+                mod.load_state_dict(hashfill.fill_state_dict(mod.state_dict(), seed=2, gain=2.0))
+                out[tag + "/" + key] = _np(mod(s_t))
         print(tag, {k.split("/")[1]: v.shape for k, v in out.items() if k.startswith(tag)})
     # a16: single-branch cells defined (unused) in temporal_ode_bayes.py
     tob = m.tob
@@ -370,6 +374,10 @@ def gen_voxel():
         out["voxels_" + tag], out["coors_" + tag], out["num_" + tag] = _np(v), c.numpy().astype(np.int32), k.numpy().astype(np.int32)
         v2, c2, k2 = VZ.hard_voxelize(pts.numpy(), vs, rng, mp, mv)
         assert np.array_equal(v.numpy(), v2) and np.array_equal(c.numpy(), c2) and np.array_equal(k.numpy(), k2), tag
+        # the dynamic branch of the same module (max_points = -1): per-point coordinates
+        dc = R.Voxelization(list(vs), list(rng), -1, (mv, mv)).eval()(pts)
+        out["dyn_coors_" + tag] = dc.numpy().astype(np.int32)
+        assert np.array_equal(out["dyn_coors_" + tag], VZ.dynamic_voxelize(pts.numpy(), vs, rng)), tag
         print("voxel", tag, tuple(v.shape), int(k.sum()), "points kept of", n)
     np.savez_compressed(os.path.join(OUT, "voxelize.npz"), **out)
 

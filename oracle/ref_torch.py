@@ -398,11 +398,15 @@ def beverse_distribution(sd, s_t, latent_dim, lo, hi, p=""):
     return o[:, :, :latent_dim], torch.clamp(o[:, :, latent_dim:], lo, hi)
 
 
-def sf_distribution(sd, s_t, latent_dim, p=""):
-    """streamingflow/models/distributions.py:35-51, method GAUSSIAN."""
+def sf_distribution(sd, s_t, latent_dim, p="", method="GAUSSIAN"):
+    """streamingflow/models/distributions.py:35-51: GAUSSIAN / MIXGAUSSIAN (encoder, global average pool, 1x1 conv) or BERNOULLI
+    (one Bottleneck + LogSigmoid, :29-33)."""
     b = s_t.shape[0]
+    if method == "BERNOULLI":
+        return F.logsigmoid(bottleneck(sd, p + "encoder.0", s_t[:, 0], downsample=False))
     e = _dist_encoder(sd, p + "encoder", s_t[:, 0], 4)
-    return _conv(sd, p + "decoder.1", e.mean(dim=(2, 3), keepdim=True)).view(b, 1, 2 * latent_dim)
+    n_out = 2 * latent_dim if method == "GAUSSIAN" else 6 * latent_dim + 3
+    return _conv(sd, p + "decoder.1", e.mean(dim=(2, 3), keepdim=True)).view(b, 1, n_out)
 
 
 def single_gru_cell(sd, x, state, ode, p=""):

@@ -36,6 +36,12 @@ def point_coors(points, voxel_size, coors_range):
     return c, ok
 
 
+def dynamic_voxelize(points, voxel_size, coors_range):
+    """voxelize.py:46-49 -> dynamic_voxelize (voxelization_cpu.cpp:8-43): coors [N, 3] int32, (-1, -1, -1) for points outside the range."""
+    c, _ = point_coors(points, voxel_size, coors_range)
+    return c.astype(np.int32)
+
+
 def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels):
     """-> (voxels [M, max_points, F] f32, coors [M, 3] int32 (x, y, z), num_points_per_voxel [M] int32).
     Voxels are numbered in the order their first point appears; a new voxel after max_voxels is

@@ -145,6 +145,8 @@ SIGNATURES = {
     "sf_lift_pool_fused_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, C.c_float, _vp, _vp]),
     "sf_depth_softmax_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sf_hard_voxelize_ws_bytes": (_sz, [_i]),
+    "sf_logsigmoid_fwd": (_i, [_vp, _vp, _sz, _vp]),
+    "sf_dynamic_voxelize_fwd": (_i, [_vp, _i, _i, _f3, _f6, _vp, _vp]),
     "sf_hard_voxelize_fwd": (_i, [_vp, _i, _i, _f3, _f6, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sf_sparse_index_ws_bytes": (_sz, [_i, _i]),
     "sf_sparse_out_sites_fwd": (_i, [_vp, _i, _i, _i3, _i3, _i3, _i3, _vp, _i, _vp, _vp, _sz, _vp]),

@@ -31,6 +31,7 @@ hipError_t launch_transpose_strided(const float* in, float* out, int n, int rows
                                     hipStream_t s);
 hipError_t launch_maxpool2(const float* in, float* out, int n, int Hin, int Win, int C, int ceil_pad, hipStream_t s);
 hipError_t launch_mean_from_partials(const float* part, float* out, int n, int nslab, int C, int hw, hipStream_t s);
+hipError_t launch_logsigmoid(const float* in, float* out, size_t n, hipStream_t s);
 hipError_t launch_upsample2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s);
 hipError_t launch_broadcast_channels(const float* vec, float* out, int n, int HW, int k, int out_cs, int out_co, hipStream_t s);
 hipError_t launch_upsample_bilinear2_add(const float* in, const float* skip, float* out, int n, int Hin, int Win, int C,
@@ -1328,6 +1329,13 @@ int sf_channel_mean_fwd(const float* x, float* out, int n, int HW, int C, float*
   if (!A.ok() || !part) return SF_ERR_WORKSPACE;
   SF_HIP(launch_chan_partial(x, part, n, HW, C, 64, (hipStream_t)stream));
   SF_HIP(launch_mean_from_partials(part, out, n, 64, C, HW, (hipStream_t)stream));
+  return SF_OK;
+}
+/* elementwise LogSigmoid (DistributionModule(method='BERNOULLI'), streamingflow/models/distributions.py:33, :47) */
+int sf_logsigmoid_fwd(const float* x, float* out, size_t n, void* stream) {
+  if (!x || !out) return SF_ERR_INVALID;
+  if (n == 0) return SF_OK;
+  SF_HIP(launch_logsigmoid(x, out, n, (hipStream_t)stream));
   return SF_OK;
 }
 /* out[img][pixel][out_co .. out_co+k) = vec[img][0..k) for every pixel (k, out_cs, out_co multiples of 4) */

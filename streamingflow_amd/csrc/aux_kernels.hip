@@ -136,6 +136,18 @@ hipError_t launch_upsample_bilinear2_add(const float* in, const float* skip, flo
   hipLaunchKernelGGL(upsample_bilinear2_add_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, skip, out, n, Hin, Win, C);
   return hipGetLastError();
 }
+// LogSigmoid (the decoder of DistributionModule(method='BERNOULLI'), streamingflow/models/distributions.py:33): min(x, 0) - log1p(exp(-|x|))
+__global__ __launch_bounds__(256) void logsigmoid_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float x = in[i];
+    out[i] = fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+  }
+}
+hipError_t launch_logsigmoid(const float* in, float* out, size_t n, hipStream_t s) {
+  const size_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(logsigmoid_kernel, dim3((unsigned)(blocks < 65536 ? (blocks ? blocks : 1) : 65536)), dim3(256), 0, s, in, out, n);
+  return hipGetLastError();
+}
 hipError_t launch_upsample2(const float* in, float* out, int n, int Hin, int Win, int C, hipStream_t s) {
   size_t total = (size_t)n * Hin * 2 * Win * 2 * (C / 4);
   if (!total) return hipSuccess;

@@ -56,6 +56,24 @@ __global__ void vox_key_kernel(const float* __restrict__ points, int n, int F, V
   val[i] = (unsigned)i;
 }
 
+// dynamic voxelisation (voxelize.py:46-49 -> dynamic_voxelize; voxelization_cpu.cpp:8-43 / voxelization_cuda.cu:25-60): the voxel coordinate
+// of every point, (-1, -1, -1) for a point outside the range on any axis — no voxel numbering, no caps
+__global__ void vox_dynamic_kernel(const float* __restrict__ points, int n, int F, VoxGrid G, int* __restrict__ coors) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = points + (size_t)i * F;
+  bool ok = true;
+  int c[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float f = floorf(__fdiv_rn(__fsub_rn(p[a], G.lo[a]), G.vs[a]));
+    ok = ok && (f >= 0.f) && (f < (float)G.g[a]);
+    c[a] = ok ? (int)f : 0;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) coors[(size_t)i * 3 + a] = ok ? c[a] : -1;
+}
+
 __global__ void vox_head_kernel(const unsigned* __restrict__ keys, const unsigned* __restrict__ order, int n, unsigned sentinel,
                                 int* __restrict__ flag) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -142,6 +160,24 @@ size_t sf_hard_voxelize_ws_bytes(int num_points) {
   if (num_points < 1) return 0;
   const size_t a = a256((size_t)num_points * 4);
   return 6 * a + a256(vox_sort_tmp(num_points, 32, nullptr)) + a256(vox_scan_tmp(num_points, nullptr)) + 256;
+}
+
+int sf_dynamic_voxelize_fwd(const float* points, int num_points, int num_features, const float* voxel_size, const float* coors_range,
+                            int32_t* coors, void* stream) {
+  if (!voxel_size || !coors_range || !coors || num_points < 0 || num_features < 3) return SF_ERR_INVALID;
+  if (num_points == 0) return SF_OK;
+  if (!points) return SF_ERR_INVALID;
+  VoxGrid G;
+  for (int a = 0; a < 3; ++a) {
+    G.vs[a] = voxel_size[a];
+    G.lo[a] = coors_range[a];
+    if (!(voxel_size[a] > 0.f)) return SF_ERR_INVALID;
+    G.g[a] = (int)roundf((coors_range[3 + a] - coors_range[a]) / voxel_size[a]);       // voxelization_cpu.cpp:157-160
+    if (G.g[a] < 1) return SF_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(vox_dynamic_kernel, dim3((unsigned)((num_points + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), points,
+                     num_points, num_features, G, coors);
+  return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
 }
 
 int sf_hard_voxelize_fwd(const float* points, int num_points, int num_features, const float* voxel_size, const float* coors_range,

@@ -38,6 +38,19 @@ def hard_voxelize_padded(points, voxel_size, coors_range, max_points, max_voxels
     return {"voxels": voxels, "coors": coors, "num": num, "mean": mean, "voxel_num": vnum}
 
 
+def dynamic_voxelize(points, voxel_size, coors_range):
+    """[N, F>=3] points -> coors [N, 3] int32: the (x, y, z) voxel of every point, (-1, -1, -1) outside the range
+    (voxelize.py:46-49; mmdet3d/ops/voxel/src/voxelization_cpu.cpp:8-43)."""
+    runtime.require_cuda(points)
+    pts = points.contiguous().float()
+    n, F = pts.shape
+    coors = torch.empty((n, 3), dtype=torch.int32, device=pts.device)
+    vs = (C.c_float * 3)(*[float(v) for v in voxel_size])
+    cr = (C.c_float * 6)(*[float(v) for v in coors_range])
+    _lib.check(_lib.lib().sf_dynamic_voxelize_fwd(ptr(pts), n, F, vs, cr, ptr(coors), runtime.stream_ptr(pts.device)), "dynamic_voxelize")
+    return coors
+
+
 class Voxelization(nn.Module):
     """Same constructor, attributes and ``forward`` as the reference module (voxelize.py:75-139)."""
 
@@ -57,8 +70,8 @@ class Voxelization(nn.Module):
     def forward(self, input):
         """input [N, F>=3] -> (voxels [M, max_points, F], coors [M, 3] int32 (x, y, z), num_points_per_voxel [M])."""
         max_voxels = self.max_voxels[0] if self.training else self.max_voxels[1]
-        if self.max_num_points == -1 or max_voxels == -1:
-            raise NotImplementedError("dynamic voxelisation (max_points == -1) is not on the shipped path")
+        if self.max_num_points == -1 or max_voxels == -1:      # voxelize.py:46-49: the coordinates only
+            return dynamic_voxelize(input, self.voxel_size, self.point_cloud_range)
         r = hard_voxelize_padded(input, self.voxel_size, self.point_cloud_range, self.max_num_points, max_voxels)
         m = int(r["voxel_num"].item())        # the reference slices too (voxelize.py:68-71): one host sync
         return r["voxels"][:m], r["coors"][:m], r["num"][:m]

@@ -24,7 +24,8 @@ def _build(device):
     def mk(tag):
         C, lat, *_ = cases.BEVERSE_CASES[tag]
         mods = {"fp": (M.FuturePrediction(C, lat, 3, 3), 1.0), "sdm": (M.SpatialDistributionModule(C, lat, -5.0, 5.0), 3.0),
-                "dm": (M.DistributionModule(C, lat, -0.05, 0.05), 3.0), "sfd": (D.DistributionModule(C, lat), 2.0)}
+                "dm": (M.DistributionModule(C, lat, -0.05, 0.05), 3.0), "sfd": (D.DistributionModule(C, lat), 2.0),
+                "sfd_mix": (D.DistributionModule(C, lat, method="MIXGAUSSIAN"), 2.0), "sfd_bern": (D.DistributionModule(C, lat, method="BERNOULLI"), 2.0)}
         out = {}
         for k, (mod, gain) in mods.items():
             sd = hashfill.fill_state_dict(mod.state_dict(), seed=2, gain=gain)
@@ -46,6 +47,8 @@ def test_oracle_matches_reference_fixture(tag):
         mu, ls = R.beverse_distribution(mods["dm"][1], s_t, lat, -0.05, 0.05)
         assert maxabs(mu, g[tag + "/dist_mu"]) <= 1e-5 and maxabs(ls, g[tag + "/dist_log_sigma"]) <= 1e-5
         assert maxabs(R.sf_distribution(mods["sfd"][1], s_t, lat), g[tag + "/sf_dist"]) <= 1e-5
+        assert maxabs(R.sf_distribution(mods["sfd_mix"][1], s_t, lat, method="MIXGAUSSIAN"), g[tag + "/sf_dist_mix"]) <= 1e-5
+        assert maxabs(R.sf_distribution(mods["sfd_bern"][1], s_t, lat, method="BERNOULLI"), g[tag + "/sf_dist_bern"]) <= 1e-5
 
 
 def _close(a, ref, rel=2e-5, scale_ref=None):
@@ -70,6 +73,9 @@ def test_gpu_matches_reference_fixture(tag):
     assert _close(mu, g[tag + "/dist_mu"]) and _close(ls, g[tag + "/dist_log_sigma"], scale_ref=g[tag + "/dist_mu"])
     assert float(ls.abs().max()) <= 0.05 + 1e-7            # the clamp is exercised
     assert _close(mods["sfd"][0](s_t.cuda()), g[tag + "/sf_dist"])
+    mix = mods["sfd_mix"][0](s_t.cuda())                     # the unused methods of distributions.py:24-33 (6 * latent + 3 outputs / LogSigmoid map)
+    assert tuple(mix.shape) == (1, 1, 6 * lat + 3) and _close(mix, g[tag + "/sf_dist_mix"])
+    assert _close(mods["sfd_bern"][0](s_t.cuda()), g[tag + "/sf_dist_bern"])
 
 
 def _single(device):

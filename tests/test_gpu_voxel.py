@@ -67,3 +67,25 @@ def test_shipped_size_exact_and_reproducible():
     w, d, q = VZ.hard_voxelize(pts.numpy(), vs, rng, mp, mv)
     assert v.shape[0] == w.shape[0]
     assert np.array_equal(c.cpu().numpy(), d) and np.array_equal(k.cpu().numpy(), q) and np.array_equal(v.cpu().numpy(), w)
+
+
+@pytest.mark.parametrize("tag", list(cases.VOXEL_CASES))
+def test_dynamic_voxelization_module(tag):
+    """max_num_points == -1 (voxelize.py:46-49): the module returns the per-point coordinates only — bit-exact against the fixture from
+    the reference module on its own C++ kernel; also at the shipped grid against the oracle, with points outside the range on every axis."""
+    from streamingflow_amd.voxelize import Voxelization, dynamic_voxelize
+    G = gold("voxelize.npz")
+    n, F, vs, rng, mp, mv = cases.VOXEL_CASES[tag]
+    pts = cases.voxel_points(tag)
+    c = Voxelization(list(vs), list(rng), -1, (mv, mv)).eval()(pts.cuda())
+    assert c.dtype == torch.int32 and tuple(c.shape) == (pts.shape[0], 3)
+    assert np.array_equal(c.cpu().numpy(), G["dyn_coors_" + tag])
+    with pytest.raises(RuntimeError):
+        dynamic_voxelize(pts, vs, rng)                   # CPU tensor: no fallback
+    if tag == "cube16":
+        vs2, rng2, _, _ = cases.VOXEL_SHIPPED
+        g = torch.Generator().manual_seed(5)
+        big = torch.cat([torch.randn((350000, 3), generator=g) * torch.tensor([30.0, 30.0, 3.0]), torch.rand((350000, 2), generator=g)], 1)
+        got = dynamic_voxelize(big.cuda(), vs2, rng2).cpu().numpy()
+        want = VZ.dynamic_voxelize(big.numpy(), vs2, rng2)
+        assert np.array_equal(got, want) and (want == -1).any() and (want >= 0).any()

@@ -52,3 +52,25 @@ def test_shipped_grid_properties():
     assert idx == sorted(idx)
     feats, coords, sizes = VZ.sf_voxelize([torch.from_numpy(pts), torch.from_numpy(pts[:1000])], vs, rng, mp, mv)
     assert feats.shape[0] == coords.shape[0] == sizes.shape[0] and set(coords[:, 0].tolist()) == {0, 1}
+
+
+@pytest.mark.parametrize("tag", list(cases.VOXEL_CASES))
+def test_dynamic_voxelize_oracle_matches_reference_fixture(tag):
+    """the max_points == -1 branch (voxelize.py:46-49): per-point coordinates from the reference module on its own C++ kernel"""
+    G = gold("voxelize.npz")
+    n, F, vs, rng, mp, mv = cases.VOXEL_CASES[tag]
+    c = VZ.dynamic_voxelize(cases.voxel_points(tag).numpy(), vs, rng)
+    assert c.dtype == np.int32 and np.array_equal(c, G["dyn_coors_" + tag])
+    assert ((c == -1).all(1) | (c >= 0).all(1)).all()          # a point is inside on every axis or marked on every axis
+
+
+def test_dynamic_voxelize_oracle_matches_compiled_reference_live():
+    from oracle import build_ref
+    ext = build_ref.load_voxel_layer()
+    if ext is None:
+        pytest.skip("oracle/_ref/voxel_layer not built (needs /root/reference)")
+    pts = torch.rand((4000, 5), generator=torch.Generator().manual_seed(9)) * 12 - 6
+    vs, rng = [0.75, 0.75, 0.75], [-4.5, -4.5, -4.5, 4.5, 4.5, 4.5]
+    coors = pts.new_zeros((pts.shape[0], 3), dtype=torch.int)
+    ext.dynamic_voxelize(pts, coors, vs, rng, 3)
+    assert np.array_equal(coors.numpy(), VZ.dynamic_voxelize(pts.numpy(), vs, rng))
