@@ -487,7 +487,7 @@ int sf_event_destroy(void* ev);
 /* Per-launch profiler for bench.py (off by default): when enabled every implicit-GEMM launch is
  * bracketed by hipEvents on its own stream.  sf_prof_collect fills SF_PROF_KEYS-entry arrays indexed by
  * kernel key = tile_config*8 + epilogue (calls, total ms, algorithmic flops, algorithmic bytes). */
-#define SF_PROF_KEYS 160
+#define SF_PROF_KEYS 168
 int sf_prof_enable(int on);
 int sf_prof_collect(int32_t* calls, double* ms, double* flops, double* bytes);
 

@@ -14,7 +14,7 @@ i32p = C.POINTER(C.c_int32)
 
 SF_COEF_STRIDE = 12
 SF_ABI_VERSION = 5       # include/sfnative.h: changes whenever a public struct changes layout
-SF_PROF_KEYS = 160
+SF_PROF_KEYS = 168
 PACK_TRANSPOSED, PACK_FOLD_DUP, PACK_INTERLEAVE, PACK_BF16X3, PACK_WINOGRAD = 1, 2, 4, 8, 16      # SF_PACK_* of sfnative.h
 ACT = {"none": 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4, "gelu": 5}
 SOLVER = {"euler": 0, "midpoint": 1, "rk4": 2}
@@ -178,9 +178,10 @@ SIGNATURES = {
 }
 
 # kernel key = tile_config*8 + epilogue  (csrc/conv_igemm.hip launch_conv; configs 10..13: the LDS-DMA kernel conv_glds_kernel)
-KERNEL_NAMES = {c * 8 + e: (f"conv_wino<{cn[4:]},{en}>" if cn.startswith("wino") else f"conv_glds<{cn[3:]},{en}>" if cn.startswith("dma") else f"conv_sp<{cn[2:]},{en}>" if cn.startswith("sp") else f"conv_igemm<{cn},{en}>")
+KERNEL_NAMES = {c * 8 + e: (f"convnext_mlp<{cn[3:]},gelu+residual>" if cn.startswith("mlp") else f"conv_wino<{cn[4:]},{en}>" if cn.startswith("wino") else f"conv_glds<{cn[3:]},{en}>" if cn.startswith("dma") else f"conv_sp<{cn[2:]},{en}>" if cn.startswith("sp") else f"conv_igemm<{cn},{en}>")
                 for c, cn in enumerate(("S16x64k4", "L64x64", "LN64x128", "direct16px", "T64x64splitK", "dmaLN128x64", "L64x128", "L128x128w4", "L64x128w8", "L128x128w8",
-                                        "dma128x128w8", "dma64x64", "dma64x128w8", "dmaLN64x128", "sp64x32", "dmaT64x64splitK", "wino128x32t", "wino64x64t", "wino64x32t2", "wino64x32t2dil"))
+                                        "dma128x128w8", "dma64x64", "dma64x128w8", "dmaLN64x128", "sp64x32", "dmaT64x64splitK", "wino128x32t", "wino64x64t", "wino64x32t2", "wino64x32t2dil",
+                                        "mlp64-256-64"))
                 for e, en in enumerate(("affine", "blend", "ln_gelu", "trust", "sample"))}
 
 _LIB = None

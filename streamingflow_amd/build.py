@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsfnative.so")
-SOURCES = ["conv_igemm.hip", "conv_sp.hip", "conv_wino.hip", "aux_kernels.hip", "api.hip", "lift_splat.hip", "voxelize.hip", "sparse_index.hip", "eval_kernels.hip", "pack.hip"]
+SOURCES = ["conv_igemm.hip", "conv_sp.hip", "conv_wino.hip", "convnext_mlp.hip", "aux_kernels.hip", "api.hip", "lift_splat.hip", "voxelize.hip", "sparse_index.hip", "eval_kernels.hip", "pack.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 

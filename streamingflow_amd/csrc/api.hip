@@ -26,6 +26,8 @@ hipError_t launch_sp_flow(const SpFlow& F, int grid, bool b3, hipStream_t stream
 hipError_t launch_flow_write(const void* host_src, void* dev_dst, size_t bytes, hipStream_t stream);
 bool sp_flow_has(int epi, bool scaled, int bn);
 int sp_flow_capacity(bool b3);
+hipError_t launch_convnext_mlp(const float* t, const float* x, float* out, const float* w1, const float* s1, const float* b1, const float* w2,
+                               const float* s2, const float* b2, long P, hipStream_t stream);
 hipError_t launch_transpose(const float* in, float* out, int n, int rows, int cols, hipStream_t s);
 hipError_t launch_transpose_strided(const float* in, float* out, int n, int rows, int cols, size_t in_stride, size_t out_stride,
                                     hipStream_t s);
@@ -1822,6 +1824,30 @@ int sf_convnext_block_fwd(const sf_convnext_w* w, const float* x, float* out, in
   if (!A.ok()) return SF_ERR_WORKSPACE;
   if (launch_dwconv7_ln(x, t, w->dw_w, w->dw_b, w->ln_w, w->ln_b, n, H, W, C, 1e-6f, st) != hipSuccess)
     return SF_ERR_UNSUPPORTED;
+  // 64 -> 256 -> 64 (every ConvNeXt block of the reference's configs): the two pointwise layers in one launch, the hidden tensor
+  // never written (convnext_mlp.hip).  Exact fp32 only: the bf16x3 mode keeps its own K loop on the two-launch path
+  static const bool fuse = [] { const char* v = std::getenv("SF_MLP_FUSED"); return v ? std::atoi(v) != 0 : true; }();
+  const sf_conv_w &a = w->pw1, &b = w->pw2;
+  const bool one_by_one = a.kh == 1 && a.kw == 1 && b.kh == 1 && b.kw == 1 && a.stride == 1 && b.stride == 1 && a.pad == 0 && b.pad == 0;
+  if (fuse && one_by_one && C == 64 && a.c0 == 64 && a.c1 == 0 && a.cin_pad == 64 && a.cout == 256 && a.cout_pad == 256 && a.act == ACT_GELU &&
+      b.c0 == 256 && b.c1 == 0 && b.cin_pad == 256 && b.cout == 64 && b.cout_pad == 64 && b.act == ACT_NONE && a.w && b.w &&
+      !(tune().b3 && a.w_bf16x3 && b.w_bf16x3)) {
+    SF_TRY(seg_flush());
+    if (!g_prof.on) {
+      SF_HIP(launch_convnext_mlp(t, x, out, a.w, a.scale, a.bias, b.w, b.scale, b.bias, (long)P, st));
+      return SF_OK;
+    }
+    ProfRec r;
+    r.key = 20 * 8 + EPI_AFFINE;
+    r.flops = 2.0 * (double)P * (64.0 * 256.0 + 256.0 * 64.0);
+    r.bytes = 4.0 * ((double)P * 64.0 * 3.0 + 2.0 * 64.0 * 256.0);     // t and x once, out once, both weight matrices once
+    r.a = g_prof.get(); r.b = g_prof.get();
+    SF_HIP(hipEventRecord(r.a, st));
+    SF_HIP(launch_convnext_mlp(t, x, out, a.w, a.scale, a.bias, b.w, b.scale, b.bias, (long)P, st));
+    SF_HIP(hipEventRecord(r.b, st));
+    g_prof.recs.push_back(r);
+    return SF_OK;
+  }
   SF_TRY(run1(problem(w->pw1, t, nullptr, u, n, H, W), EPI_AFFINE, st));
   ConvProblem p2 = problem(w->pw2, u, nullptr, out, n, H, W);
   p2.add = x;

@@ -115,6 +115,47 @@ def test_convnext_block_c64_vs_torch(n, H, W):
     assert maxabs(got, ref) <= TOL
 
 
+@pytest.mark.parametrize("n,H,W", [(1, 5, 5), (1, 8, 8), (3, 37, 41), (2, 100, 100)])
+def test_convnext_mlp_in_one_launch(n, H, W):
+    """pwconv1 -> GELU -> pwconv2 -> gamma -> residual of a 64-channel block runs as ONE launch (convnext_mlp.hip: the 256-channel
+    hidden tensor stays in registers): the profiler must see that kernel and no other GEMM launch, and the block must agree with the
+    reference formulation (convolutions.py:333-346) in torch fp64 far inside the 1e-3 bar — sizes below one 64-pixel wave tile, an
+    exact multiple of it, and ragged ones; random gamma, LayerNorm affine and biases so that no term is scaled away."""
+    import ctypes
+    import streamingflow_amd.layers.convolutions as Cv
+    from streamingflow_amd import _lib
+    torch.manual_seed(1000 * n + H)
+    blk = Cv.Block(64, layer_scale_init_value=1.0).eval()
+    with torch.no_grad():
+        blk.norm.weight.uniform_(0.5, 1.5); blk.norm.bias.uniform_(-0.5, 0.5)
+        blk.gamma.uniform_(-1.5, 1.5); blk.pwconv1.bias.uniform_(-1.0, 1.0); blk.pwconv2.bias.uniform_(-1.0, 1.0)
+        blk.pwconv1.weight.mul_(3.0)          # hidden values out to |v| ~ 6: both tails of the GELU
+    x = torch.randn(n, 64, H, W)
+    with torch.no_grad():
+        d = blk.double()
+        xd = x.double()
+        y = F.conv2d(xd, d.dwconv.weight, d.dwconv.bias, padding=3, groups=64).permute(0, 2, 3, 1)
+        y = F.layer_norm(y, (64,), d.norm.weight, d.norm.bias, 1e-6)
+        y = d.pwconv2(F.gelu(d.pwconv1(y)))
+        ref = (xd + (d.gamma * y).permute(0, 3, 1, 2)).float()
+        blk = blk.float().cuda()
+        L = _lib.lib()
+        NK = _lib.SF_PROF_KEYS
+        calls, ms = (ctypes.c_int32 * NK)(), (ctypes.c_double * NK)()
+        fl, by = (ctypes.c_double * NK)(), (ctypes.c_double * NK)()
+        blk(x.cuda())                          # packs
+        L.sf_prof_enable(1)
+        try:
+            got = blk(x.cuda())
+            torch.cuda.synchronize()
+            L.sf_prof_collect(calls, ms, fl, by)
+        finally:
+            L.sf_prof_enable(0)
+    used = [_lib.KERNEL_NAMES[k] for k in range(NK) if calls[k]]
+    assert used == ["convnext_mlp<64-256-64,gelu+residual>"], used
+    assert maxabs(got, ref) <= 2e-5, maxabs(got, ref)
+
+
 @pytest.mark.parametrize("solver", ["euler", "midpoint"])
 @pytest.mark.parametrize("impute", [True, False])
 def test_golden_ode_step(pair8, solver, impute):
