@@ -93,6 +93,10 @@ def test_no_kernel_spills_vector_registers_and_scalar_spills_are_bounded():
     assert len(wino) == 5                        # AFFINE / BLEND x (plain, concatenated images) + the dilated AFFINE form
     for k in wino:
         assert int(k["vgpr_count"]) <= 128 and int(k["private_segment_fixed_size"]) == 0, k
+    # the fused ConvNeXt MLP: two waves per SIMD (<= 256 registers between the vector and accumulator files), no scratch
+    mlp = [k for k in ours if "convnext_mlp_kernel" in k["name"]]
+    assert len(mlp) == 1
+    assert int(mlp[0]["vgpr_count"]) + int(mlp[0]["agpr_count"]) <= 256 and int(mlp[0]["private_segment_fixed_size"]) == 0, mlp[0]
     # the small-P kernels of the default path (one launch per layer group) too: no scratch at all
     for k in ours:
         if "conv_sp_kernel" in k["name"]:
