@@ -105,7 +105,7 @@ def _run_packed(c, i, tol):
     y = F.conv2d(xin, w, None, c["stride"], c["pad"], c["dil"]) * sc.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
     Ho, Wo = y.shape[-2:]
     add = hashfill.normal(f"rc_a_{i}", (n, cout, Ho, Wo), 6) if c["add"] else None
-    act = {"none": lambda t: t, "relu": F.relu, "lrelu": lambda t: F.leaky_relu(t, 0.1), "tanh": torch.tanh}[c["act"]]
+    act = {"none": lambda t: t, "relu": F.relu, "lrelu": lambda t: F.leaky_relu(t, 0.1), "tanh": torch.tanh, "gelu": F.gelu}[c["act"]]
     want = act(y + add) if (c["add"] and c["after"]) else (act(y) + add if c["add"] else act(y))
 
     pk = packing.Pack(None)
@@ -133,6 +133,25 @@ def _run_packed(c, i, tol):
         rest = torch.cat([out[..., :oco], out[..., oco + cout:]], -1)
         assert float((rest - 7.0).abs().max()) == 0.0
     return got.clone()
+
+
+# Large plain 1x1 layers (the ASPP projection and its 1x1 branch, classifiers, SpatialGRU decoders): K from 32 to 512, ragged pixel
+# counts, inputs inside wider tensors, outputs into channel slices, residual before and after the activation, GELU included.
+_PW = [
+    dict(c0=64, cout=64, n=2, H=181, W=187, act="none"),
+    dict(c0=64, cout=128, n=2, H=200, W=200, act="relu"),
+    dict(c0=512, cout=128, n=2, H=200, W=173, act="relu"),
+    dict(c0=128, cout=64, n=3, H=150, W=150, act="lrelu"),
+    dict(c0=32, cout=64, n=1, H=256, W=257, act="gelu"),
+    dict(c0=96, cout=128, n=5, H=120, W=131, act="none"),
+]
+
+
+@pytest.mark.parametrize("i", range(len(_PW)))
+def test_large_pointwise_conv(i):
+    c = dict(k=1, stride=1, dil=1, c1=0, pad=0, add=i % 3 != 1, after=i % 2 == 0, in_slack=8 * (i % 2), out_slack=[0, 4, 16][i % 3])
+    c.update(_PW[i])
+    _run(c, 500 + i, tol=5e-5)
 
 
 @pytest.mark.parametrize("i", [0, 1, 3, 8])

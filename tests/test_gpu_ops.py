@@ -115,6 +115,45 @@ def test_convnext_block_c64_vs_torch(n, H, W):
     assert maxabs(got, ref) <= TOL
 
 
+def test_deeplab_head_c64_vs_torch():
+    """DeepLabHead(64, 64, 128) on 2 x 200 x 173 frames against the reference formulation (convolutions.py:217-280) in torch fp32 on
+    the CPU at the shipped width: the projection takes the pooled branch as a per-IMAGE bias (the two frames get different rows), the
+    dilated branches and the 3x3 run the Winograd kernel."""
+    import ctypes
+    import streamingflow_amd.layers.convolutions as Cv
+    from streamingflow_amd import _lib
+    torch.manual_seed(77)
+    head = Cv.DeepLabHead(64, 64, 128).eval()
+    with torch.no_grad():
+        for m in head.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.7, 1.3); m.bias.uniform_(-0.2, 0.2)
+                m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(2, 64, 200, 173)
+    x[1] += 0.7                      # different pooled vectors per frame
+    with torch.no_grad():
+        aspp = head[0]
+        outs = [b(x) for b in list(aspp.convs)[:4]]
+        outs.append(F.interpolate(aspp.convs[4](x), size=x.shape[-2:], mode="bilinear", align_corners=False))
+        ref = head[4](head[3](head[2](head[1](aspp.project(torch.cat(outs, 1))))))
+        head = head.cuda()
+        head(x.cuda())               # packs
+        L = _lib.lib()
+        NK = _lib.SF_PROF_KEYS
+        calls, ms = (ctypes.c_int32 * NK)(), (ctypes.c_double * NK)()
+        fl, by = (ctypes.c_double * NK)(), (ctypes.c_double * NK)()
+        L.sf_prof_enable(1)
+        try:
+            got = head(x.cuda())
+            torch.cuda.synchronize()
+            L.sf_prof_collect(calls, ms, fl, by)
+        finally:
+            L.sf_prof_enable(0)
+    used = {_lib.KERNEL_NAMES[k]: calls[k] for k in range(NK) if calls[k]}
+    assert used.get("conv_wino<64x32t2dil,affine>", 0) >= 2 and used.get("conv_wino<64x32t2,affine>", 0) >= 1, used
+    assert maxabs(got, ref) <= 2e-4, maxabs(got, ref)
+
+
 @pytest.mark.parametrize("n,H,W", [(1, 5, 5), (1, 8, 8), (3, 37, 41), (2, 100, 100)])
 def test_convnext_mlp_in_one_launch(n, H, W):
     """pwconv1 -> GELU -> pwconv2 -> gamma -> residual of a 64-channel block runs as ONE launch (convnext_mlp.hip: the 256-channel
