@@ -311,6 +311,12 @@ size_t sf_convnext_block_ws_bytes(int C, int n, int H, int W);
 int sf_deeplab_head_fwd(const sf_deeplab_w* w, const float* x, float* out, int n, int H, int W,
                         float* ws, size_t ws_bytes, void* stream);
 size_t sf_deeplab_head_ws_bytes(int C, int hid, int n, int H, int W);
+/* the same, the classifier writing the boundary's planar layout itself: image i as [cout][H][W] planes at
+ * out + (i / group) * stride_major + (i % group) * stride_minor floats.  Frames (t, b) of a [T][B] run into the reference's
+ * [B][T][C][H][W] result (future_prediction_ode.py:62-64): group = B, stride_major = C*H*W, stride_minor = T*C*H*W — no
+ * transpose launches after the head.  Same workspace as sf_deeplab_head_fwd. */
+int sf_deeplab_head_planar_fwd(const sf_deeplab_w* w, const float* x, float* out, int n, int H, int W, int group,
+                               size_t stride_major, size_t stride_minor, float* ws, size_t ws_bytes, void* stream);
 
 /* Bottleneck.forward — convolutions.py:164-172: [n][H][W][Cin] -> [n][Ho][Wo][Cout] */
 int sf_bottleneck_fwd(const sf_bottleneck_w* w, const float* x, float* out, int n, int H, int W, float* ws,

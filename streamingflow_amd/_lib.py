@@ -125,6 +125,7 @@ SIGNATURES = {
     "sf_convnext_block_fwd": (_i, [C.POINTER(ConvNextW), _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sf_convnext_block_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "sf_deeplab_head_fwd": (_i, [C.POINTER(DeepLabW), _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sf_deeplab_head_planar_fwd": (_i, [C.POINTER(DeepLabW), _vp, _vp, _i, _i, _i, _i, _sz, _sz, _vp, _sz, _vp]),
     "sf_deeplab_head_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "sf_bottleneck_fwd": (_i, [C.POINTER(BottleneckW), _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sf_bottleneck_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),

@@ -245,7 +245,7 @@ bool sp_takes(const ConvProblem* ps, int n, int epi) {
   for (int i = 0; i < n; ++i) {
     const ConvProblem& q = ps[i];
     const long Pi = (long)q.n_img * q.Hout * q.Wout;
-    if (Pi >= tune().sp_max_p || q.gather || q.gate || !one_source_per_chunk(q)) return false;
+    if (Pi >= tune().sp_max_p || q.gather || q.gate || q.out_planar || !one_source_per_chunk(q)) return false;
     if ((epi == EPI_LNG || epi == EPI_TRUST) && q.cout_pad > 64) return false;
     if (q.in_scale || q.se_sum) {
       ++scaled;
@@ -431,6 +431,8 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     const double e0 = 2.0 * ps[i].Hin * ps[i].Win * ps[i].in0_cs, e1 = 2.0 * ps[i].Hin * ps[i].Win * ps[i].in1_cs;
     if (!ps[i].gather && (e0 >= 2147483648.0 || e1 >= 2147483648.0)) return SF_ERR_UNSUPPORTED;
   }
+  for (int i = 0; i < n; ++i)      // planar output: the AFFINE epilogue of the LDS-staged kernels only (never silently ignored)
+    if (ps[i].out_planar && (epi != EPI_AFFINE || ps[i].pl_div < 1 || ps[i].out2 || ps[i].chansum)) return SF_ERR_UNSUPPORTED;
   bool has_acc = false;      // K-partial inputs and the blend mode of the AFFINE epilogue: small-P kernel only (never silently ignored)
   for (int i = 0; i < n; ++i) has_acc = has_acc || ps[i].acc_in != nullptr || (epi == EPI_AFFINE && (ps[i].mode & 4));
   if (has_acc && (wide_ln || !sp_takes(ps, n, epi))) return SF_ERR_UNSUPPORTED;
@@ -1858,8 +1860,8 @@ size_t sf_deeplab_head_ws_bytes(int C, int hid, int n, int H, int W) {
   size_t P = (size_t)n * H * W;
   return (al(P * 4 * hid) + 2 * al(P * hid) + al((size_t)n * ASPP_SLABS * C) + al((size_t)n * hid)) * sizeof(float);
 }
-int sf_deeplab_head_fwd(const sf_deeplab_w* w, const float* x, float* out, int n, int H, int W, float* ws,
-                        size_t ws_bytes, void* stream) {
+static int deeplab_head(const sf_deeplab_w* w, const float* x, float* out, int n, int H, int W, int planar_group, size_t stride_major,
+                        size_t stride_minor, float* ws, size_t ws_bytes, void* stream) {
   if (!w || !x || !out) return SF_ERR_INVALID;
   const int C = w->C, hid = w->hid;
   hipStream_t st = (hipStream_t)stream;
@@ -1883,7 +1885,21 @@ int sf_deeplab_head_fwd(const sf_deeplab_w* w, const float* x, float* out, int n
   pj.bias = bimg; pj.bias_per_img = 1;
   SF_TRY(run1(pj, EPI_AFFINE, st));
   SF_TRY(run1(problem(w->conv3, y, nullptr, z, n, H, W), EPI_AFFINE, st));
-  return run1(problem(w->cls, z, nullptr, out, n, H, W), EPI_AFFINE, st);
+  ConvProblem pc = problem(w->cls, z, nullptr, out, n, H, W);
+  if (planar_group > 0) { pc.out_planar = 1; pc.pl_div = planar_group; pc.pl_sa = stride_major; pc.pl_sb = stride_minor; }
+  return run1(pc, EPI_AFFINE, st);
+}
+int sf_deeplab_head_fwd(const sf_deeplab_w* w, const float* x, float* out, int n, int H, int W, float* ws,
+                        size_t ws_bytes, void* stream) {
+  return deeplab_head(w, x, out, n, H, W, 0, 0, 0, ws, ws_bytes, stream);
+}
+// the same with the classifier writing the boundary layout itself: image i as [cout][H][W] planes at
+// out + (i / group) * stride_major + (i % group) * stride_minor floats (frames (t, b) of a [T][B] run into a [B][T][C][H][W] tensor:
+// group = B, stride_major = C*H*W, stride_minor = T*C*H*W) — no transpose launches after the head (future_prediction_ode.py:62-64)
+int sf_deeplab_head_planar_fwd(const sf_deeplab_w* w, const float* x, float* out, int n, int H, int W, int group, size_t stride_major,
+                               size_t stride_minor, float* ws, size_t ws_bytes, void* stream) {
+  if (group < 1 || !w || stride_major < (size_t)w->cls.cout * H * W || stride_minor < (size_t)w->cls.cout * H * W) return SF_ERR_INVALID;
+  return deeplab_head(w, x, out, n, H, W, group, stride_major, stride_minor, ws, ws_bytes, stream);
 }
 
 // ---- graphs / events ------------------------------------------------------------------------------

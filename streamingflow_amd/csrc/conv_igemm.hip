@@ -194,7 +194,14 @@ __device__ __forceinline__ void run_epilogue(const ConvProblem& P, f32x4 (&acc)[
               y.z = (1.f - u.z) * s.z + u.z * v.z; y.w = (1.f - u.w) * s.w + u.w * v.w;
             }
           }
-          st4(P.out + (size_t)gp * P.out_cs + P.out_co + c, y);
+          bool planar = false;
+          if constexpr (EPI == EPI_AFFINE) planar = P.out_planar != 0;      // block-uniform
+          if (planar) {      // 16 consecutive pixels of a channel per lane row: 64-byte runs
+            float* o = P.out + (size_t)(img / P.pl_div) * P.pl_sa + (size_t)(img % P.pl_div) * P.pl_sb + (size_t)c * HWout + (gp - img * HWout);
+            o[0] = y.x; o[(size_t)HWout] = y.y; o[2 * (size_t)HWout] = y.z; o[3 * (size_t)HWout] = y.w;
+          } else {
+            st4(P.out + (size_t)gp * P.out_cs + P.out_co + c, y);
+          }
         }
         if constexpr (EPI == EPI_AFFINE) {
           if (P.chansum) {   // block-uniform branch; all lanes take part in the shuffles

@@ -676,7 +676,7 @@ bool wino_takes(const ConvProblem& q, int epi) {
   if (epi != EPI_AFFINE && epi != EPI_BLEND) return false;
   if (!q.w_wino || q.KH != 3 || q.KW != 3 || q.stride != 1 || q.dil < 1 || q.pad != q.dil || (q.in_up && q.dil != 1) || q.gather || q.gate || q.se_sum ||
       (q.in_scale && (epi != EPI_AFFINE || q.dil != 1 || q.c0 > 256)) ||      // SE-scaled input: plain AFFINE form, scales staged in LDS
-      q.nsplit > 1 || q.chansum || q.acc_in || q.fuse_w || (epi == EPI_AFFINE && (q.mode & 4)))
+      q.nsplit > 1 || q.chansum || q.acc_in || q.fuse_w || q.out_planar || (epi == EPI_AFFINE && (q.mode & 4)))
     return false;
   if ((q.c0 % 16) || (q.c1 % 16) || q.c0 + q.c1 != q.cin_pad || (q.cout_pad % 64) || (q.cout % 4)) return false;
   if (q.Hout != (q.Hin << q.in_up) || q.Wout != (q.Win << q.in_up) || q.Hout < 16 || q.Wout < 32) return false;      // in_up: nearest x2 upsampling on read

@@ -60,6 +60,10 @@ struct ConvProblem {
   int coef_stride;        // floats between per-image coefficient records (0: shared)
   int clamp_from;         // AFFINE: output channels >= clamp_from are clamped to [clamp_lo, clamp_hi] (<0: off)
   float clamp_lo, clamp_hi;
+  // AFFINE, LDS-staged kernels only: planar output (the boundary's [C][H][W] layout written by the last layer itself instead of a
+  // transpose launch): element (image i, pixel p, channel c) goes to out + (i / pl_div) * pl_sa + (i % pl_div) * pl_sb + c * HW + p
+  int out_planar, pl_div;
+  size_t pl_sa, pl_sb;
   int gate_from;          // AFFINE with out2: output channels c >= gate_from are reset gates; out2[c - gate_from] = (1 - y) * e1[c - gate_from]
   // sparse (gather) convolution: the input row of output row p under kernel tap t is gather[p*KH + t]
   // (-1: inactive site); geometry is then n_img = 1, Hout = 1, Wout = number of output rows, KW = 1

@@ -250,5 +250,17 @@ class DeepLabHead(nn.Sequential, PackedModule):
                                          runtime.stream_ptr(x.device)), "deeplab_head")
         return out
 
+    def forward_nhwc_into_planar(self, x, out, group, stride_major, stride_minor):
+        """The same head, its classifier writing the reference's planar layout itself: image i of x [n, h, w, C] lands as
+        [cout][h][w] planes at ``out.data_ptr() + 4 * ((i // group) * stride_major + (i % group) * stride_minor)`` (strides in
+        floats) — FuturePredictionODE writes frames (t, b) straight into its [B, T, C, H, W] result, no transpose launches."""
+        n, h, w, c = x.shape
+        L = _lib.lib()
+        st = self.packed().struct
+        ws = runtime.workspace(L.sf_deeplab_head_ws_bytes(c, self.hidden_channel, n, h, w), x.device)
+        _lib.check(L.sf_deeplab_head_planar_fwd(st, ptr(x), ptr(out), n, h, w, int(group), int(stride_major), int(stride_minor),
+                                                ptr(ws), ws.numel() * 4, runtime.stream_ptr(x.device)), "deeplab_head_planar")
+        return out
+
     def forward(self, x):
         return runtime.to_nchw(self.forward_nhwc(runtime.to_nhwc(x)))

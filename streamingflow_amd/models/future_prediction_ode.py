@@ -6,6 +6,8 @@ Drop-in for the reference module (same constructor, ``forward`` signature, retur
 arithmetic runs on libsfnative (HIP, gfx950).  Internally everything is NHWC fp32; the NCHW
 reference layout exists only at ``forward``'s boundary.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -13,6 +15,10 @@ from .. import _lib, runtime, schedule as sched
 from ..layers.convolutions import Block, DeepLabHead
 from ..layers.temporal import SpatialGRU
 from ..layers.temporal_ode_bayes import NNFOwithBayesianJumps
+
+
+# SF_HEAD_PLANAR=0: the head writes [pixel][channel] frames and T strided transposes follow (the form before round 5; A/B aid)
+_HEAD_PLANAR = os.environ.get("SF_HEAD_PLANAR", "1") != "0"
 
 
 class FuturePredictionODE(nn.Module):
@@ -41,13 +47,18 @@ class FuturePredictionODE(nn.Module):
         frames = [(camera_states if src == 0 else lidar_states)[bs, i] for src, i in order]
         return (times, frames, order) if with_order else (times, frames)
 
-    def head_nhwc(self, x):
-        """x: [T, B, H, W, C] decoded predictions -> [T, B, H, W, C] (:56-62)."""
+    def head_nhwc(self, x, res=None):
+        """x: [T, B, H, W, C] decoded predictions -> [T, B, H, W, C] (:56-62).  With ``res`` (a [B, T, C, H, W] tensor) the last
+        block's classifier writes frame (t, b) straight into res[b, t] in the reference's layout and None is returned."""
         T, B, H, W, C = x.shape
         hidden = x[0]
-        for gru, blk in zip(self.spatial_grus, self.res_blocks):
+        last = len(self.spatial_grus) - 1
+        for i, (gru, blk) in enumerate(zip(self.spatial_grus, self.res_blocks)):
             x = gru.forward_nhwc(x, hidden).view(T * B, H, W, C)
             if isinstance(blk, DeepLabHead):
+                if res is not None and i == last:
+                    blk.forward_nhwc_into_planar(x, res, B, C * H * W, T * C * H * W)
+                    return None
                 x = blk.forward_nhwc(x)
             else:
                 for b in blk:
@@ -92,6 +103,13 @@ class FuturePredictionODE(nn.Module):
             obs = runtime.to_nhwc(stacked)
             obs = obs.view(n_obs, B, *obs.shape[1:])
         _, x = self.gru_ode.forward_nhwc(scs if B > 1 else scs[0], obs)
+        if (out is True and _HEAD_PLANAR and isinstance(self.res_blocks[-1], DeepLabHead)
+                and self.res_blocks[-1][4].out_channels == x.shape[-1]):
+            # the group is the whole batch, in order: the head's classifier writes [B, T, C, H, W] itself
+            T, _, H, W, C = x.shape
+            res = torch.empty((B, T, C, H, W), dtype=torch.float32, device=x.device)
+            self.head_nhwc(x, res)
+            return res
         y = self.head_nhwc(x)                                   # [T, B, H, W, C]
         T, _, H, W, C = y.shape
         if out is True:          # the group is the whole batch, in order: write [B, T, C, H, W] directly

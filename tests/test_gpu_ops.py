@@ -154,6 +154,28 @@ def test_deeplab_head_c64_vs_torch():
     assert maxabs(got, ref) <= 2e-4, maxabs(got, ref)
 
 
+@pytest.mark.parametrize("T,B,H,W", [(3, 2, 64, 72), (2, 3, 33, 47), (1, 1, 200, 173)])
+def test_deeplab_head_writes_the_boundary_layout_itself(T, B, H, W):
+    """sf_deeplab_head_planar_fwd: frames (t, b) of a [T][B] run land in a [B, T, C, H, W] tensor as the reference returns it
+    (future_prediction_ode.py:62-64), written by the classifier's own epilogue.  Same arithmetic as the [pixel][channel] form followed
+    by a transpose, so the two must agree to the last bit when the same kernel runs both (and to rounding when the small-P kernel,
+    which has no planar store, ran the [pixel][channel] form); nothing outside the frames may be touched."""
+    import streamingflow_amd.layers.convolutions as Cv
+    from streamingflow_amd import runtime
+    torch.manual_seed(T * 100 + B)
+    head = Cv.DeepLabHead(64, 64, 128).eval().cuda()
+    x = torch.randn(T * B, H, W, 64, device="cuda")
+    with torch.no_grad():
+        want = runtime.to_nchw(head.forward_nhwc(x)).view(T, B, 64, H, W).permute(1, 0, 2, 3, 4)
+        res = torch.full((B, T + 1, 64, H, W), 7.0, device="cuda")            # one spare frame per sample: must stay untouched
+        head.forward_nhwc_into_planar(x, res, B, 64 * H * W, (T + 1) * 64 * H * W)
+    if T * B * H * W >= 12288:
+        assert torch.equal(res[:, :T], want)
+    else:
+        assert maxabs(res[:, :T], want) <= 1e-5
+    assert float((res[:, T] - 7.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("n,H,W", [(1, 5, 5), (1, 8, 8), (3, 37, 41), (2, 100, 100)])
 def test_convnext_mlp_in_one_launch(n, H, W):
     """pwconv1 -> GELU -> pwconv2 -> gamma -> residual of a 64-channel block runs as ONE launch (convnext_mlp.hip: the 256-channel
