@@ -217,18 +217,32 @@ class DeepLabHead(nn.Sequential, PackedModule):
         self.in_channels, self.hidden_channel = in_channels, hidden_channel
 
     def _pack(self):
+        return self.pack_after(None)
+
+    def pack_after(self, pre):
+        """The packed head, optionally for an input that is still to go through a bias-free 1x1 convolution ``pre``
+        ([C][C_in][1][1] weight): every consumer of the head's input is linear in it (the four branch convolutions, the mean of
+        the pooling branch) and a bias-free 1x1 maps the zero padding to zeros, so W_branch . (pre . h) = (W_branch o pre) . h —
+        the composition is formed once in fp64 and the 1x1 launches never run (FuturePredictionODE: SpatialGRU.conv_decoder)."""
         if self.training:
             raise RuntimeError("streamingflow_amd is inference-only: call .eval() (BatchNorm uses running statistics)")
         pk = packing.Pack(_lib.DeepLabW())
         s, aspp, C, hid = pk.struct, self[0], self.in_channels, self.hidden_channel
         if len(aspp.convs) != 5:
             raise NotImplementedError
+        if pre is not None:
+            assert pre.shape[0] == C and tuple(pre.shape[2:]) == (1, 1), tuple(pre.shape)
+            C = pre.shape[1]
+            pd = pre.detach()[:, :, 0, 0].double()
+            fold = lambda w: torch.einsum("ockl,ci->oikl", w.detach().double(), pd).float()
+        else:
+            fold = lambda w: w
         for i in range(4):
             conv, bn = aspp.convs[i][0], aspp.convs[i][1]
             sc, bi = packing.bn_fold(bn)
-            s.branch[i] = packing.conv_w(pk, conv.weight, C, scale=sc, bias=bi, act="relu", dil=conv.dilation[0])
+            s.branch[i] = packing.conv_w(pk, fold(conv.weight), C, scale=sc, bias=bi, act="relu", dil=conv.dilation[0])
         sc, bi = packing.bn_fold(aspp.convs[4][2])
-        s.pool_w = pk.hold(aspp.convs[4][1].weight.reshape(hid, C))
+        s.pool_w = pk.hold(fold(aspp.convs[4][1].weight).reshape(hid, C))
         s.pool_scale, s.pool_bias = pk.hold(sc), pk.hold(bi)
         wproj = aspp.project[0].weight                                    # [hid][5*hid][1][1]
         s.proj_pool_w = pk.hold(wproj[:, 4 * hid:, 0, 0])
@@ -240,23 +254,23 @@ class DeepLabHead(nn.Sequential, PackedModule):
         s.C, s.hid = C, hid
         return pk
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, st=None):
         n, h, w, c = x.shape
         L = _lib.lib()
-        st = self.packed().struct
+        st = self.packed().struct if st is None else st
         ws = runtime.workspace(L.sf_deeplab_head_ws_bytes(c, self.hidden_channel, n, h, w), x.device)
         out = torch.empty((n, h, w, st.cls.cout), dtype=torch.float32, device=x.device)
         _lib.check(L.sf_deeplab_head_fwd(st, ptr(x), ptr(out), n, h, w, ptr(ws), ws.numel() * 4,
                                          runtime.stream_ptr(x.device)), "deeplab_head")
         return out
 
-    def forward_nhwc_into_planar(self, x, out, group, stride_major, stride_minor):
+    def forward_nhwc_into_planar(self, x, out, group, stride_major, stride_minor, st=None):
         """The same head, its classifier writing the reference's planar layout itself: image i of x [n, h, w, C] lands as
         [cout][h][w] planes at ``out.data_ptr() + 4 * ((i // group) * stride_major + (i % group) * stride_minor)`` (strides in
         floats) — FuturePredictionODE writes frames (t, b) straight into its [B, T, C, H, W] result, no transpose launches."""
         n, h, w, c = x.shape
         L = _lib.lib()
-        st = self.packed().struct
+        st = self.packed().struct if st is None else st
         ws = runtime.workspace(L.sf_deeplab_head_ws_bytes(c, self.hidden_channel, n, h, w), x.device)
         _lib.check(L.sf_deeplab_head_planar_fwd(st, ptr(x), ptr(out), n, h, w, int(group), int(stride_major), int(stride_minor),
                                                 ptr(ws), ws.numel() * 4, runtime.stream_ptr(x.device)), "deeplab_head_planar")

@@ -47,17 +47,25 @@ class SpatialGRU(PackedModule):
                              self.hidden_size, self.conv_decoder, gate_bias=self.gru_bias_init)
         return pk
 
-    def forward_nhwc(self, x, state):
+    def pack_states_only(self):
+        """The cell without its decoder: the library then returns the hidden states themselves (a consumer that folds
+        ``conv_decoder`` into its own weights reads them: DeepLabHead.pack_after)."""
+        pk = packing.Pack(None)
+        pk.struct = pack_gru(pk, self.conv_update, self.conv_reset, self.conv_state_tilde, self.input_size, self.hidden_size, None,
+                             gate_bias=self.gru_bias_init)
+        return pk
+
+    def forward_nhwc(self, x, state, st=None):
         """x: [T, B, H, W, Cx] (or [T, H, W, Cx] for one sample), state: [B, H, W, C] (or [H, W, C]).
-        Returns the decoded outputs with the shape of x."""
+        Returns the decoded outputs with the shape of x (the hidden states [.., C] with the struct of ``pack_states_only``)."""
         one = x.dim() == 4
         if one:
             x, state = x[:, None], state[None]
         T, B, h, w, _ = x.shape
         L = _lib.lib()
         ws = runtime.workspace(L.sf_spatial_gru_ws_bytes(self.hidden_size, B, h, w), x.device)
-        out = torch.empty((T, B, h, w, self.input_size), dtype=torch.float32, device=x.device)
-        _lib.check(L.sf_spatial_gru_fwd(self.packed().struct, ptr(x), ptr(state), ptr(out), T, B, h, w, ptr(ws),
+        out = torch.empty((T, B, h, w, self.input_size if st is None else self.hidden_size), dtype=torch.float32, device=x.device)
+        _lib.check(L.sf_spatial_gru_fwd(self.packed().struct if st is None else st, ptr(x), ptr(state), ptr(out), T, B, h, w, ptr(ws),
                                         ws.numel() * 4, runtime.stream_ptr(x.device)), "spatial_gru")
         return out[:, 0] if one else out
 

@@ -21,6 +21,39 @@ from ..layers.temporal_ode_bayes import NNFOwithBayesianJumps
 _HEAD_PLANAR = os.environ.get("SF_HEAD_PLANAR", "1") != "0"
 
 
+# SF_FOLD_DECODER=0: the last SpatialGRU runs its 1x1 conv_decoder on every frame (T launches) instead of handing its hidden states
+# to a DeepLabHead packed with the decoder folded into its input convolutions (A/B aid)
+_FOLD_DECODER = os.environ.get("SF_FOLD_DECODER", "1") != "0"
+
+
+class _FoldedTail(runtime.PackedModule):
+    """Packed copies for the last (SpatialGRU, DeepLabHead) pair of the head: the GRU without its decoder and the head with
+    ``conv_decoder`` composed into its branch and pooling weights (DeepLabHead.pack_after).  Holds no parameters of its own — the two
+    modules are referenced, not registered — and re-packs when any of theirs changes."""
+
+    def __init__(self, gru, head):
+        super().__init__()
+        self.__dict__["_gru"], self.__dict__["_head"] = gru, head
+
+    def _param_signature(self):
+        from .. import packing
+        sig = [packing.math_mode(), packing.winograd(), self._head.training]
+        for m in (self._gru, self._head):
+            for t in list(m.parameters()) + list(m.buffers()):
+                sig.append((t.data_ptr(), t._version, t.device))
+        return tuple(sig)
+
+    def packed(self):
+        sig = self._param_signature()
+        cache = self.__dict__.get("_sf_pack")
+        if cache is None or cache[0] != sig:
+            runtime.require_cuda(self._gru.conv_decoder.weight)
+            with torch.no_grad():
+                pk = (self._gru.pack_states_only(), self._head.pack_after(self._gru.conv_decoder.weight))
+            self.__dict__["_sf_pack"] = cache = (sig, pk, 0)
+        return cache[1]
+
+
 class FuturePredictionODE(nn.Module):
     def __init__(self, in_channels, latent_dim, n_future, cfg, mixture=True, n_gru_blocks=2, n_res_layers=1,
                  delta_t=0.05):
@@ -54,12 +87,22 @@ class FuturePredictionODE(nn.Module):
         hidden = x[0]
         last = len(self.spatial_grus) - 1
         for i, (gru, blk) in enumerate(zip(self.spatial_grus, self.res_blocks)):
-            x = gru.forward_nhwc(x, hidden).view(T * B, H, W, C)
+            gst = hst = None
+            if (_FOLD_DECODER and i == last and isinstance(blk, DeepLabHead) and gru.conv_decoder.bias is None
+                    and gru.input_size == blk.in_channels):
+                # the decoder of the last GRU is linear and only the head reads it: composed into the head's input weights
+                tail = self.__dict__.get("_folded_tail")
+                if tail is None or tail._gru is not gru or tail._head is not blk:
+                    tail = self.__dict__["_folded_tail"] = _FoldedTail(gru, blk)
+                gpk, hpk = tail.packed()
+                gst, hst = gpk.struct, hpk.struct
+            x = gru.forward_nhwc(x, hidden, gst)
+            x = x.view(T * B, H, W, x.shape[-1])
             if isinstance(blk, DeepLabHead):
                 if res is not None and i == last:
-                    blk.forward_nhwc_into_planar(x, res, B, C * H * W, T * C * H * W)
+                    blk.forward_nhwc_into_planar(x, res, B, C * H * W, T * C * H * W, hst)
                     return None
-                x = blk.forward_nhwc(x)
+                x = blk.forward_nhwc(x, hst)
             else:
                 for b in blk:
                     x = b.forward_nhwc(x)

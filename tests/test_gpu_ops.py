@@ -154,6 +154,31 @@ def test_deeplab_head_c64_vs_torch():
     assert maxabs(got, ref) <= 2e-4, maxabs(got, ref)
 
 
+@pytest.mark.parametrize("which", ["pair8", "pair64"])
+def test_head_with_the_last_decoder_folded_into_the_aspp(which, request, monkeypatch):
+    """FuturePredictionODE.head_nhwc (future_prediction_ode.py:56-62) hands the hidden states of the last SpatialGRU to a
+    DeepLabHead whose branch and pooling weights carry conv_decoder (bias-free 1x1: linear, maps the zero padding to zeros), so the
+    decoder launches never run.  Against the same head with the decoder run per frame: equal to fp32 rounding of the composed
+    weights, far inside the 1e-3 bar; the planar-output form of both too."""
+    import streamingflow_amd.models.future_prediction_ode as M
+    net, _ = request.getfixturevalue(which)
+    C = 8 if which == "pair8" else 64
+    T, B, H, W = 3, 2, 48, 40
+    x = hashfill.normal("head_fold_x", (T, B, H, W, C), 21).cuda()
+    outs = {}
+    for fold in (False, True):
+        monkeypatch.setattr(M, "_FOLD_DECODER", fold)
+        with torch.no_grad():
+            y = net.head_nhwc(x)
+            res = torch.empty((B, T, C, H, W), device="cuda")
+            assert net.head_nhwc(x, res) is None
+        outs[fold] = (y, res)
+    scale = float(outs[False][0].abs().max())
+    assert maxabs(outs[True][0], outs[False][0]) <= 2e-5 * max(1.0, scale)
+    assert maxabs(outs[True][1], outs[False][1]) <= 2e-5 * max(1.0, scale)
+    assert maxabs(outs[True][1], outs[True][0].permute(1, 0, 4, 2, 3)) <= 1e-5 * max(1.0, scale)
+
+
 @pytest.mark.parametrize("T,B,H,W", [(3, 2, 64, 72), (2, 3, 33, 47), (1, 1, 200, 173)])
 def test_deeplab_head_writes_the_boundary_layout_itself(T, B, H, W):
     """sf_deeplab_head_planar_fwd: frames (t, b) of a [T][B] run land in a [B, T, C, H, W] tensor as the reference returns it
