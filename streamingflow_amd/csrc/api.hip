@@ -433,6 +433,10 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   }
   for (int i = 0; i < n; ++i)      // planar output: the AFFINE epilogue of the LDS-staged kernels only (never silently ignored)
     if (ps[i].out_planar && (epi != EPI_AFFINE || ps[i].pl_div < 1 || ps[i].out2 || ps[i].chansum)) return SF_ERR_UNSUPPORTED;
+  for (int i = 0; i < n; ++i)      // pooled output: the Winograd kernel only (callers ask pool_fusable() first; never silently ignored)
+    if (ps[i].pool2 && !(tune().wino && (double)ps[i].n_img * ps[i].Hout * ps[i].Wout >= tune().wino_min_p && wino_takes(ps[i], epi) &&
+                         !(tune().b3 && ps[i].w3)))
+      return SF_ERR_UNSUPPORTED;
   bool has_acc = false;      // K-partial inputs and the blend mode of the AFFINE epilogue: small-P kernel only (never silently ignored)
   for (int i = 0; i < n; ++i) has_acc = has_acc || ps[i].acc_in != nullptr || (epi == EPI_AFFINE && (ps[i].mode & 4));
   if (has_acc && (wide_ln || !sp_takes(ps, n, epi))) return SF_ERR_UNSUPPORTED;
@@ -1187,8 +1191,10 @@ size_t ode_step_ws_floats(int C, int P) {
 }
 
 // ResBlock (res_models.py:74-79) on n images; t: [P][cin] scratch, pr: [P][cout] scratch (if proj)
+// `pooled` (optional): MaxPool2d(2) of the block's output, [n][H/2][W/2][C]; written by the last convolution's own epilogue where the
+// Winograd kernel runs it (`out` is then not written at all), by a pooling launch after it otherwise
 int res_block(const sf_res_w& w, const float* x, float* out, float* t, float* pr, int n, int Hin, int Win, int in_up,
-              hipStream_t st) {
+              hipStream_t st, float* pooled = nullptr) {
   ConvProblem ps[2];
   ps[0] = problem(w.conv1, x, nullptr, t, n, Hin, Win, in_up);
   int np = 1;
@@ -1197,6 +1203,16 @@ int res_block(const sf_res_w& w, const float* x, float* out, float* t, float* pr
   if (!w.proj.w && in_up) return SF_ERR_INVALID;   // residual of an upsampled input needs it materialised
   ConvProblem c2 = problem(w.conv2, t, nullptr, out, n, Hin << in_up, Win << in_up);
   c2.add = w.proj.w ? pr : x;
+  if (pooled) {
+    static const bool fuse = [] { const char* v = std::getenv("SF_POOL_FUSED"); return v ? std::atoi(v) != 0 : true; }();
+    ConvProblem cp = c2;
+    cp.pool2 = 1; cp.out = pooled;
+    if (fuse && tune().wino && (double)cp.n_img * cp.Hout * cp.Wout >= tune().wino_min_p && wino_takes(cp, EPI_AFFINE) && !(tune().b3 && cp.w3))
+      return run1(cp, EPI_AFFINE, st);
+    SF_TRY(run1(c2, EPI_AFFINE, st));
+    SF_HIP(launch_maxpool2(out, pooled, n, c2.Hout, c2.Wout, c2.cout, 0, st));
+    return SF_OK;
+  }
   return run1(c2, EPI_AFFINE, st);
 }
 
@@ -1706,10 +1722,8 @@ int sf_small_encoder_fwd(const sf_encoder_w* w, const float* x, float* out, int 
   float* q2 = A.take(P2 * 2 * F); float* t2 = A.take(P2 * 4 * F); float* pr2 = A.take(P2 * 4 * F);
   float* o2 = A.take(P2 * 4 * F); float* o3 = A.take(P2 * 4 * F); float* o4 = A.take(P2 * 4 * F);
   if (!A.ok()) return SF_ERR_WORKSPACE;
-  SF_TRY(res_block(w->blocks[0], x, o0, t0, pr0, n, H, W, 0, st));            // res_models.py:101-105
-  SF_HIP(launch_maxpool2(o0, q1, n, H, W, F, 0, st));
-  SF_TRY(res_block(w->blocks[1], q1, o1, t1, pr1, n, H1, W1, 0, st));
-  SF_HIP(launch_maxpool2(o1, q2, n, H1, W1, 2 * F, 0, st));
+  SF_TRY(res_block(w->blocks[0], x, o0, t0, pr0, n, H, W, 0, st, q1));        // res_models.py:101-105: block, MaxPool2d(2)
+  SF_TRY(res_block(w->blocks[1], q1, o1, t1, pr1, n, H1, W1, 0, st, q2));
   SF_TRY(res_block(w->blocks[2], q2, o2, t2, pr2, n, H2, W2, 0, st));
   SF_TRY(res_block(w->blocks[3], o2, o3, t2, pr2, n, H2, W2, 0, st));
   SF_TRY(res_block(w->blocks[4], o3, o4, t2, pr2, n, H2, W2, 0, st));

@@ -614,7 +614,15 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   SF_STAMP_AT(L, 7);
   __builtin_amdgcn_sched_barrier(0);
 #if defined(__HIP_DEVICE_COMPILE__)
-  {
+  if (affine && !DIL && P.pool2) {      // block-uniform: the tile IS the 2x2 pooling window (H, W even: a tile is whole or absent)
+    const size_t pimg = (size_t)(H >> 1) * (W >> 1);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(P.out + (size_t)img * pimg * P.out_cs + P.out_co,
+                                                (img_span / ((size_t)H * W)) * pimg * P.out_cs * sizeof(float) - (size_t)P.out_co * sizeof(float));
+    const unsigned ppix = (unsigned)(ty * (W >> 1) + tx) + (run_e ? (unsigned)pimg : 0u);
+    const f32x4 m = __builtin_elementwise_max(__builtin_elementwise_max(y[0], y[1]), __builtin_elementwise_max(y[2], y[3]));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, m), rs,
+                                           okk[0] ? (int)(ppix * (unsigned)P.out_cs + (unsigned)c_ld) * 4 : OOB, 0, 0);
+  } else {
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(P.out + img_base * P.out_cs + P.out_co, img_span * P.out_cs * sizeof(float) - (size_t)P.out_co * sizeof(float));
     const int v = (int)(pix * (unsigned)P.out_cs + (unsigned)c_ld) * 4;
 #pragma unroll
@@ -678,6 +686,7 @@ bool wino_takes(const ConvProblem& q, int epi) {
       (q.in_scale && (epi != EPI_AFFINE || q.dil != 1 || q.c0 > 256)) ||      // SE-scaled input: plain AFFINE form, scales staged in LDS
       q.nsplit > 1 || q.chansum || q.acc_in || q.fuse_w || q.out_planar || (epi == EPI_AFFINE && (q.mode & 4)))
     return false;
+  if (q.pool2 && (epi != EPI_AFFINE || q.dil != 1 || q.out2 || (q.Hout & 1) || (q.Wout & 1))) return false;
   if ((q.c0 % 16) || (q.c1 % 16) || q.c0 + q.c1 != q.cin_pad || (q.cout_pad % 64) || (q.cout % 4)) return false;
   if (q.Hout != (q.Hin << q.in_up) || q.Wout != (q.Win << q.in_up) || q.Hout < 16 || q.Wout < 32) return false;      // in_up: nearest x2 upsampling on read
   // dilated (conv_wino_kernel<.., DIL>): one input tensor, AFFINE epilogue, every phase of both axes at least 5 pixels = 3 tiles long

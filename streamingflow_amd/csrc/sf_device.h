@@ -64,6 +64,11 @@ struct ConvProblem {
   // transpose launch): element (image i, pixel p, channel c) goes to out + (i / pl_div) * pl_sa + (i % pl_div) * pl_sb + c * HW + p
   int out_planar, pl_div;
   size_t pl_sa, pl_sb;
+  // AFFINE, Winograd kernel only (even Hout, Wout): `out` is the 2x2 max-pooled tensor [n][Hout/2][Wout/2][out_cs] — a thread of the
+  // epilogue holds exactly one pooling window (its tile), so the pool costs three maxima and the full-size tensor is never written
+  // (res_models.py:101-105: every encoder block is followed by MaxPool2d(2))
+  int pool2;
+  int pad_;
   int gate_from;          // AFFINE with out2: output channels c >= gate_from are reset gates; out2[c - gate_from] = (1 - y) * e1[c - gate_from]
   // sparse (gather) convolution: the input row of output row p under kernel tap t is gather[p*KH + t]
   // (-1: inactive site); geometry is then n_img = 1, Hout = 1, Wout = number of output rows, KW = 1

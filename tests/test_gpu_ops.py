@@ -154,6 +154,35 @@ def test_deeplab_head_c64_vs_torch():
     assert maxabs(got, ref) <= 2e-4, maxabs(got, ref)
 
 
+@pytest.mark.parametrize("n,H,W", [(2, 104, 120), (3, 96, 64), (2, 102, 118)])
+def test_encoder_pools_in_the_winograd_epilogue(pair64, n, H, W):
+    """SmallEncoder (res_models.py:98-109) at the shipped width on frames large enough for the Winograd kernel: the MaxPool2d(2)
+    after blocks 0 and 1 is taken over the epilogue's own 2x2 tile (no full-size tensor, no pooling launch) — asserted through the
+    profiler (no direct-form 3x3 launch) and against the oracle's encoder with the same weights.  (2, 102, 118): 51 x 59 after the
+    first pool, odd: the second pool falls back to the pooling launch (floor mode)."""
+    import ctypes
+    from streamingflow_amd import _lib
+    net, sd = pair64
+    x = hashfill.normal("enc_pool_x", (n, 64, H, W), 31)
+    want = R.small_encoder(sd, "gru_ode.srvp_encoder", x)
+    L = _lib.lib()
+    NK = _lib.SF_PROF_KEYS
+    calls, ms = (ctypes.c_int32 * NK)(), (ctypes.c_double * NK)()
+    fl, by = (ctypes.c_double * NK)(), (ctypes.c_double * NK)()
+    with torch.no_grad():
+        net.gru_ode.srvp_encoder(x.cuda())          # packs
+        L.sf_prof_enable(1)
+        try:
+            got = net.gru_ode.srvp_encoder(x.cuda())
+            torch.cuda.synchronize()
+            L.sf_prof_collect(calls, ms, fl, by)
+        finally:
+            L.sf_prof_enable(0)
+    used = {_lib.KERNEL_NAMES[k]: calls[k] for k in range(NK) if calls[k]}
+    assert any(k.startswith("conv_wino") for k in used), used
+    assert maxabs(got, want) <= 2e-4, maxabs(got, want)
+
+
 @pytest.mark.parametrize("which", ["pair8", "pair64"])
 def test_head_with_the_last_decoder_folded_into_the_aspp(which, request, monkeypatch):
     """FuturePredictionODE.head_nhwc (future_prediction_ode.py:56-62) hands the hidden states of the last SpatialGRU to a
