@@ -433,8 +433,8 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   }
   for (int i = 0; i < n; ++i)      // planar output: the AFFINE epilogue of the LDS-staged kernels only (never silently ignored)
     if (ps[i].out_planar && (epi != EPI_AFFINE || ps[i].pl_div < 1 || ps[i].out2 || ps[i].chansum)) return SF_ERR_UNSUPPORTED;
-  for (int i = 0; i < n; ++i)      // pooled output: the Winograd kernel only (callers ask pool_fusable() first; never silently ignored)
-    if (ps[i].pool2 && !(tune().wino && (double)ps[i].n_img * ps[i].Hout * ps[i].Wout >= tune().wino_min_p && wino_takes(ps[i], epi) &&
+  for (int i = 0; i < n; ++i)      // pooled output / half-size residual: the Winograd kernel only (res_block checks first; never silently ignored)
+    if ((ps[i].pool2 || ps[i].add_up) && !(tune().wino && (double)ps[i].n_img * ps[i].Hout * ps[i].Wout >= tune().wino_min_p && wino_takes(ps[i], epi) &&
                          !(tune().b3 && ps[i].w3)))
       return SF_ERR_UNSUPPORTED;
   bool has_acc = false;      // K-partial inputs and the blend mode of the AFFINE epilogue: small-P kernel only (never silently ignored)
@@ -1195,14 +1195,21 @@ size_t ode_step_ws_floats(int C, int P) {
 // Winograd kernel runs it (`out` is then not written at all), by a pooling launch after it otherwise
 int res_block(const sf_res_w& w, const float* x, float* out, float* t, float* pr, int n, int Hin, int Win, int in_up,
               hipStream_t st, float* pooled = nullptr) {
+  ConvProblem c2 = problem(w.conv2, t, nullptr, out, n, Hin << in_up, Win << in_up);
+  c2.add = w.proj.w ? pr : x;
+  if (!w.proj.w && in_up) {
+    // identity skip of an input that is upsampled on read: the Winograd epilogue reads the half-size tensor itself (one source pixel
+    // per tile); anywhere else the caller has to materialise the upsampled input (SF_ERR_UNSUPPORTED before anything is launched)
+    static const bool fuse = [] { const char* v = std::getenv("SF_UPSAMPLE_FUSED"); return v ? std::atoi(v) != 0 : true; }();
+    c2.add_up = 1;
+    if (!(fuse && tune().wino && (double)c2.n_img * c2.Hout * c2.Wout >= tune().wino_min_p && wino_takes(c2, EPI_AFFINE) && !(tune().b3 && c2.w3)))
+      return SF_ERR_UNSUPPORTED;
+  }
   ConvProblem ps[2];
   ps[0] = problem(w.conv1, x, nullptr, t, n, Hin, Win, in_up);
   int np = 1;
   if (w.proj.w) { ps[1] = problem(w.proj, x, nullptr, pr, n, Hin, Win, in_up); np = 2; }
   SF_TRY(run(ps, np, EPI_AFFINE, st));
-  if (!w.proj.w && in_up) return SF_ERR_INVALID;   // residual of an upsampled input needs it materialised
-  ConvProblem c2 = problem(w.conv2, t, nullptr, out, n, Hin << in_up, Win << in_up);
-  c2.add = w.proj.w ? pr : x;
   if (pooled) {
     static const bool fuse = [] { const char* v = std::getenv("SF_POOL_FUSED"); return v ? std::atoi(v) != 0 : true; }();
     ConvProblem cp = c2;
@@ -1752,8 +1759,14 @@ int sf_small_decoder_fwd(const sf_decoder_w* w, const float* z, float* out, int 
   SF_TRY(res_block(w->blocks[2], a0, a1, a2, a3, n, h, wd, 0, st));                     // 2F -> 2F
   // upsample(x2) is applied on read by block 3 (conv_1 and projection), :142-143
   SF_TRY(res_block(w->blocks[3], a1, b0, b1, b2, n, h, wd, 1, st));                     // 2F -> F @2h
-  SF_HIP(launch_upsample2(b0, c0, n, 2 * h, 2 * wd, F, st));
-  SF_TRY(res_block(w->blocks[4], c0, c1, c2, c3, n, 4 * h, 4 * wd, 0, st));             // F -> F @4h
+  // block 4 (F -> F @4h) reads block 3's output upsampled: on read where its second convolution runs on the Winograd kernel (the
+  // identity skip then comes from the half-size tensor too), from a materialised copy otherwise
+  int rc = res_block(w->blocks[4], b0, c1, c2, c3, n, 2 * h, 2 * wd, 1, st);
+  if (rc == SF_ERR_UNSUPPORTED) {
+    SF_HIP(launch_upsample2(b0, c0, n, 2 * h, 2 * wd, F, st));
+    rc = res_block(w->blocks[4], c0, c1, c2, c3, n, 4 * h, 4 * wd, 0, st);
+  }
+  SF_TRY(rc);
   SF_TRY(run1(problem(w->last0, c1, nullptr, c2, n, 4 * h, 4 * wd), EPI_AFFINE, st));
   return run1(problem(w->last1, c2, nullptr, out, n, 4 * h, 4 * wd), EPI_AFFINE, st);
 }

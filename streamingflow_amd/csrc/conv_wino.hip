@@ -545,7 +545,13 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   (void)img_span; (void)pk_; (void)OOB; (void)has_a; (void)has_b; (void)gate_lane;
   f32x4 oa[4], ob[4];
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (has_a) {
+  if (has_a && affine && !DIL && P.add_up) {      // block-uniform: the tile's four pixels read source pixel (ty, tx) of the half-size tensor
+    const size_t pimg = (size_t)(H >> 1) * (W >> 1);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(t_a + (size_t)img * pimg * cs_a, (img_span / ((size_t)H * W)) * pimg * cs_a * sizeof(float));
+    const unsigned ppix = (unsigned)(ty * (W >> 1) + tx) + (run_e ? (unsigned)pimg : 0u);
+    oa[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, okk[0] ? (int)(ppix * (unsigned)cs_a + (unsigned)c_ld) * 4 : OOB, 0, 0));
+    oa[1] = oa[0]; oa[2] = oa[0]; oa[3] = oa[0];
+  } else if (has_a) {
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(t_a + img_base * cs_a, img_span * cs_a * sizeof(float));
     const int v = (int)(pix * (unsigned)cs_a + (unsigned)c_ld) * 4;
 #pragma unroll
@@ -687,6 +693,7 @@ bool wino_takes(const ConvProblem& q, int epi) {
       q.nsplit > 1 || q.chansum || q.acc_in || q.fuse_w || q.out_planar || (epi == EPI_AFFINE && (q.mode & 4)))
     return false;
   if (q.pool2 && (epi != EPI_AFFINE || q.dil != 1 || q.out2 || (q.Hout & 1) || (q.Wout & 1))) return false;
+  if (q.add_up && (epi != EPI_AFFINE || q.dil != 1 || !q.add || (q.Hout & 1) || (q.Wout & 1))) return false;
   if ((q.c0 % 16) || (q.c1 % 16) || q.c0 + q.c1 != q.cin_pad || (q.cout_pad % 64) || (q.cout % 4)) return false;
   if (q.Hout != (q.Hin << q.in_up) || q.Wout != (q.Win << q.in_up) || q.Hout < 16 || q.Wout < 32) return false;      // in_up: nearest x2 upsampling on read
   // dilated (conv_wino_kernel<.., DIL>): one input tensor, AFFINE epilogue, every phase of both axes at least 5 pixels = 3 tiles long

@@ -68,7 +68,9 @@ struct ConvProblem {
   // epilogue holds exactly one pooling window (its tile), so the pool costs three maxima and the full-size tensor is never written
   // (res_models.py:101-105: every encoder block is followed by MaxPool2d(2))
   int pool2;
-  int pad_;
+  // AFFINE, Winograd kernel only: `add` is a half-resolution tensor [n][Hout/2][Wout/2][add_cs] read with nearest x2 upsampling — the
+  // four pixels of a tile share one source pixel (the identity skip of a residual block whose input is upsampled on read)
+  int add_up;
   int gate_from;          // AFFINE with out2: output channels c >= gate_from are reset gates; out2[c - gate_from] = (1 - y) * e1[c - gate_from]
   // sparse (gather) convolution: the input row of output row p under kernel tap t is gather[p*KH + t]
   // (-1: inactive site); geometry is then n_img = 1, Hout = 1, Wout = number of output rows, KW = 1

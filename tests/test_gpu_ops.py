@@ -183,6 +183,20 @@ def test_encoder_pools_in_the_winograd_epilogue(pair64, n, H, W):
     assert maxabs(got, want) <= 2e-4, maxabs(got, want)
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 26, 30), (5, 25, 25), (1, 50, 50)])
+def test_decoder_reads_the_upsampled_skip_in_the_winograd_epilogue(pair64, n, h, w):
+    """SmallDecoder (res_models.py:131-145) at the shipped width on latents whose 4x output is large enough for the Winograd kernel:
+    the last residual block reads its input upsampled on the fly — the first convolution in its patch loads, the identity skip in
+    the second convolution's epilogue (one half-size source pixel per 2x2 tile) — so no upsampled copy is written.  Against the
+    oracle's decoder with the same weights."""
+    net, sd = pair64
+    z = hashfill.normal("dec_up_z", (n, 64, h, w), 32) * 0.5
+    want = R.small_decoder(sd, "gru_ode.srvp_decoder", z)
+    with torch.no_grad():
+        got = net.gru_ode.srvp_decoder(z.cuda())
+    assert maxabs(got, want) <= 2e-4, maxabs(got, want)
+
+
 @pytest.mark.parametrize("which", ["pair8", "pair64"])
 def test_head_with_the_last_decoder_folded_into_the_aspp(which, request, monkeypatch):
     """FuturePredictionODE.head_nhwc (future_prediction_ode.py:56-62) hands the hidden states of the last SpatialGRU to a
