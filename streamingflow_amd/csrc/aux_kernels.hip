@@ -393,8 +393,106 @@ __global__ __launch_bounds__(256, 3) void dwconv7_ln_c64_kernel(const float* __r
   }
 }
 
+// The same with TWO channels per lane (v_pk_fma_f32: the 49 taps of both in one instruction each) and two strips per wave: lanes 0-31
+// work on strip 2w, lanes 32-63 on strip 2w + 1 (a strip = 2 output rows x `seg` columns of one image; both strips of a wave lie in
+// the same image, the host checks that the strips of an image come in pairs).  Window 8 rows x 7 columns (+ one prefetched) of
+// channel pairs in registers, 8-byte loads through a buffer descriptor on the image — a row or column outside it gets an offset
+// beyond the descriptor's range and reads zero, no masks — the LayerNorm sums over the 32 lanes of a half by DPP + four lane reads.
+// Taps accumulate in the same (ky, kx) order as the one-channel kernel: the convolution is bitwise the same, the LayerNorm sums
+// associate differently (last-bit differences).  Vector work per pixel 2.3x less: the one-channel kernel is bound by it.
+typedef float dw_f2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256, 2) void dwconv7_ln_c64_pk_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                const float* __restrict__ wdw, const float* __restrict__ bdw,
+                                                                const float* __restrict__ lnw, const float* __restrict__ lnb, int n,
+                                                                int H, int W, float eps, int seg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int C = 64, R = 2;
+  constexpr unsigned BAD = 0x40000000u;      // added to an offset: beyond any image (the host keeps images below 1 GB)
+  const int lane = threadIdx.x & 63, half = lane >> 5, cp = lane & 31;
+  const long wv = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nseg = (W + seg - 1) / seg, nrb = (H + R - 1) / R;
+  const int per_img = nrb * nseg;             // even (host)
+  if (2 * wv >= (long)n * per_img) return;
+  const int img = (int)((2 * wv) / per_img);  // wave-uniform
+  const int si = (int)((2 * wv) % per_img) + half;
+  const int sg = si % nseg, rb = si / nseg;
+  const int y0 = rb * R, x0 = sg * seg, x1 = (x0 + seg < W) ? x0 + seg : W;
+  const size_t img_off = (size_t)img * H * W * C;
+  const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + img_off), (short)0, (int)((unsigned)H * W * C * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(out + img_off, (short)0, (int)((unsigned)H * W * C * 4), 0x00020000);
+  dw_f2 w[49];
+#pragma unroll
+  for (int k = 0; k < 49; ++k) w[k] = *reinterpret_cast<const dw_f2*>(wdw + k * C + 2 * cp);
+  const dw_f2 bias = *reinterpret_cast<const dw_f2*>(bdw + 2 * cp), gam = *reinterpret_cast<const dw_f2*>(lnw + 2 * cp),
+              bet = *reinterpret_cast<const dw_f2*>(lnb + 2 * cp);
+  unsigned rowb[R + 6];                       // byte offset of (row, column 0, channel pair) or BAD
+#pragma unroll
+  for (int r = 0; r < R + 6; ++r) {
+    const int y = y0 - 3 + r;
+    rowb[r] = (y >= 0 && y < H) ? (unsigned)(y * W) * (C * 4) + (unsigned)cp * 8 : BAD;
+  }
+  dw_f2 win[R + 6][8];
+  auto load_col = [&](const int x, const int slot) {
+    const unsigned xo = (x >= 0 && x < W) ? (unsigned)x * (C * 4) : BAD;
+#pragma unroll
+    for (int r = 0; r < R + 6; ++r)
+      win[r][slot] = __builtin_bit_cast(dw_f2, __builtin_amdgcn_raw_buffer_load_b64(rs_i, (int)(rowb[r] + xo), 0, 0));
+  };
+  // sum over the 32 lanes of the half (two values per lane): DPP inside each row of 16, then the two rows of the half
+  auto half_sum = [&](const dw_f2 v) {
+    float t = v.x + v.y;
+    t += dpp_mov<0xB1>(t);
+    t += dpp_mov<0x4E>(t);
+    t += dpp_mov<0x141>(t);
+    t += dpp_mov<0x140>(t);
+    const int it = __float_as_int(t);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(it, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(it, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(it, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(it, 48));
+    return half ? r2 + r3 : r0 + r1;
+  };
+#pragma unroll
+  for (int kx = 0; kx < 7; ++kx) load_col(x0 - 3 + kx, kx);
+  for (int xb = 0; xb < seg; xb += 8) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {             // window position kx lives in slot (p + kx) % 8; slot (p + 7) % 8 is filled one step ahead
+      const int x = x0 + xb + p;
+      if (xb + p >= seg) break;               // wave-uniform (seg not a multiple of 8); also keeps the scheduler from hoisting the next columns' loads over this one's products (132 spills without it)
+      load_col(x + 4, (p + 7) % 8);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        dw_f2 acc = bias;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 7; ++kx) acc = __builtin_elementwise_fma(win[r + ky][(p + kx) % 8], w[ky * 7 + kx], acc);
+        const float mean = half_sum(acc) * (1.f / C);
+        const dw_f2 d = acc - mean;
+        const float rstd = 1.f / sqrtf(half_sum(d * d) * (1.f / C) + eps);
+        const dw_f2 o = d * rstd * gam + bet;
+        const bool ok = (y0 + r < H) && (x < x1);
+        const unsigned off = ok ? (unsigned)((y0 + r) * W + x) * (C * 4) + (unsigned)cp * 8 : BAD;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, o), rs_o, (int)off, 0, 0);
+      }
+    }
+  }
+#endif
+}
+
 hipError_t launch_dwconv7_ln(const float* in, float* out, const float* wdw, const float* bdw, const float* lnw,
                              const float* lnb, int n, int H, int W, int C, float eps, hipStream_t s) {
+  static const bool pk = [] { const char* v = std::getenv("SF_DWCONV_PK"); return v ? std::atoi(v) != 0 : true; }();
+  if (pk && C == 64 && (long)n * H * W >= 65536 && (double)H * W * C * 4.0 < 1073741824.0) {
+    // two channels per lane, two strips per wave: strips of an image must come in pairs
+    int seg = 40;
+    const int nrb = (H + 1) / 2;
+    if ((nrb * ((W + seg - 1) / seg)) & 1) seg = W;      // one strip per row pair ...
+    if (((nrb * ((W + seg - 1) / seg)) & 1) == 0) {      // ... (an odd number of row pairs of one strip each keeps the one-channel kernel)
+      const long waves = ((long)n * nrb * ((W + seg - 1) / seg)) / 2;
+      hipLaunchKernelGGL(dwconv7_ln_c64_pk_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, in, out, wdw, bdw, lnw, lnb, n, H, W, eps,
+                         seg);
+      return hipGetLastError();
+    }
+  }
   if (C == 64 && (long)n * H * W >= 65536) {   // large maps: register-window kernel (below that the LDS-tile kernel has more waves)
     const int seg = 40;
     const long waves = (long)n * ((H + 3) / 4) * ((W + seg - 1) / seg);

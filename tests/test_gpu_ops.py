@@ -95,11 +95,12 @@ def test_golden_head_blocks(pair8):
     assert maxabs(net.spatial_grus[1](seq, seq[:, 0]), g["spatial_gru_seq"]) <= TOL
 
 
-@pytest.mark.parametrize("n,H,W", [(2, 181, 187), (1, 256, 260), (1, 64, 64)])
+@pytest.mark.parametrize("n,H,W", [(2, 181, 187), (1, 256, 260), (1, 64, 64), (2, 200, 200), (1, 255, 300)])
 def test_convnext_block_c64_vs_torch(n, H, W):
-    """C == 64 maps of >= 65536 pixels take the register-window depthwise + LayerNorm kernel, smaller ones the LDS-tile
-    kernel; both against the reference formulation (convolutions.py:310-346) in torch fp32 on the CPU, with
-    gamma = 1 so that the block's body is not scaled away."""
+    """C == 64 maps of >= 65536 pixels take a register-window depthwise + LayerNorm kernel — two channels per lane and two strips
+    per wave where the strips of an image come in pairs ((1, 256, 260), (2, 200, 200), and (1, 255, 300): odd height, ragged last
+    segment), one channel per lane otherwise ((2, 181, 187)) — smaller ones the LDS-tile kernel; all against the reference
+    formulation (convolutions.py:310-346) in torch fp32 on the CPU, with gamma = 1 so that the block's body is not scaled away."""
     import streamingflow_amd.layers.convolutions as Cv
     torch.manual_seed(H * 7 + W)
     blk = Cv.Block(64, layer_scale_init_value=1.0).eval()
