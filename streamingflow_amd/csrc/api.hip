@@ -20,6 +20,7 @@ hipError_t set_stamp_buffer_wino(unsigned long long* p);
 hipError_t launch_conv_sp(const ConvLaunch& L, int epi, bool scaled, int bn, hipStream_t stream);
 hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream);
 bool wino_takes(const ConvProblem& q, int epi);
+bool wino_same_geometry(const ConvProblem& a, const ConvProblem& b);
 int wino_variant(const ConvProblem& q);
 double wino_tiles(const ConvProblem& q);
 hipError_t launch_sp_flow(const SpFlow& F, int grid, bool b3, hipStream_t stream);
@@ -494,6 +495,44 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
         for (int i = 0; i < n; ++i)
           if (!takes[i]) rest[nr++] = ps[i];
         SF_TRY(run(rest, nr, epi, st));
+      }
+      // layers of identical geometry (the two branches of a dual cell) share ONE launch: their tails merge
+      static const bool group_on = [] { const char* v = std::getenv("SF_WINO_GROUP"); return v ? std::atoi(v) != 0 : true; }();
+      static const bool list_on = std::getenv("SF_WINO_LIST") != nullptr;
+      if (group_on && !list_on && n_wino >= 2) {
+        ConvLaunch WG;
+        std::memset(&WG, 0, sizeof(WG));
+        bool same = true;
+        int first = -1;
+        for (int i = 0; i < n; ++i) {
+          if (!takes[i]) continue;
+          if (first < 0) first = i;
+          same = same && wino_same_geometry(ps[first], ps[i]);
+          WG.p[WG.nprob++] = ps[i];
+        }
+        if (same) {
+          WG.stamp_slot = g_stamp_slot;
+          if (g_stamp_on) g_stamp_slot = (g_stamp_slot + 1) % 64;
+          if (!g_prof.on) {
+            SF_HIP(launch_conv_wino(WG, epi, st));
+            return SF_OK;
+          }
+          ProfRec r;
+          const int wv = wino_variant(ps[first]);
+          r.key = (16 + (wv == 4 ? 2 : wv)) * 8 + epi;
+          r.flops = 0; r.bytes = 0;
+          for (int i = 0; i < WG.nprob; ++i) {
+            const ConvProblem& q = WG.p[i];
+            r.flops += 2.0 * 16.0 * wino_tiles(q) * q.cout * (q.c0 + q.c1);
+            r.bytes += 4.0 * ((double)q.n_img * q.Hin * q.Win * (q.c0 + q.c1) + 16.0 * q.cout * (q.c0 + q.c1) + (double)q.n_img * q.Hout * q.Wout * q.cout);
+          }
+          r.a = g_prof.get(); r.b = g_prof.get();
+          SF_HIP(hipEventRecord(r.a, st));
+          SF_HIP(launch_conv_wino(WG, epi, st));
+          SF_HIP(hipEventRecord(r.b, st));
+          g_prof.recs.push_back(r);
+          return SF_OK;
+        }
       }
       for (int i = 0; i < n; ++i) {
         if (!takes[i]) continue;

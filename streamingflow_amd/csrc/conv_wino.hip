@@ -189,7 +189,16 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   float* const Park = Pbuf + G::NPB * G::P_FLOATS;
   float* const SBuf = Park + G::PARK;                          // [scale COUT_T][bias COUT_T]
   float* const SCbuf = SBuf + G::SB;                           // [c0] input scales (SCALED)
-  const ConvProblem& P = L.p[0];
+  // a group of layers of identical geometry (the two branches of a dual cell) shares one launch: problem i owns the workgroups
+  // [i * wg_base[1], (i + 1) * wg_base[1]) (a multiple of 8 each, so that workgroup -> XCD stays blockIdx & 7); the tails of the
+  // single launches (625 - 1250 workgroups over 512 slots) merge into one
+  int lin_ = (int)blockIdx.x, pi_ = 0;
+  if (L.nprob > 1) {      // block-uniform
+    pi_ = lin_ / L.wg_base[1];
+    lin_ -= pi_ * L.wg_base[1];
+  }
+  const ConvProblem& P = L.p[0];       // geometry, strides, flags: the same for every problem of the group
+  const ConvProblem& PX = L.p[pi_];     // tensors: this workgroup's problem
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = P.Hout, W = P.Wout;
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   // consecutive workgroups of that XCD
   const int ncb = P.cout_pad / COUT_T;
   const int nblk = nbx * nby * (CAT ? 1 : P.n_img), per_xcd = (nblk + 7) >> 3;
-  const int lin = (int)blockIdx.x, xcd = lin & 7, slot_ = lin >> 3;
+  const int lin = lin_, xcd = lin & 7, slot_ = lin >> 3;
   const int tb_ = slot_ / ncb;
   int b = xcd * per_xcd + tb_;
   if (b >= nblk) return;
@@ -233,12 +242,12 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   };
   const size_t img_px = (size_t)P.Hin * P.Win;
   const size_t n_in = (CAT && img + 1 < P.n_img) ? 2 : 1;
-  const __amdgpu_buffer_rsrc_t rsrc0 = make_rsrc(P.in0 + (size_t)img * img_px * P.in0_cs, n_in * img_px * P.in0_cs * sizeof(float));
-  const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(P.in1 ? P.in1 + (size_t)img * img_px * P.in1_cs : P.in0, P.in1 ? n_in * img_px * P.in1_cs * sizeof(float) : 0);
-  const __amdgpu_buffer_rsrc_t rsrc_u = make_rsrc(P.w_wino, (size_t)nkc * 16 * P.cout_pad * 16 * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rsrc0 = make_rsrc(PX.in0 + (size_t)img * img_px * P.in0_cs, n_in * img_px * P.in0_cs * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(PX.in1 ? PX.in1 + (size_t)img * img_px * P.in1_cs : PX.in0, PX.in1 ? n_in * img_px * P.in1_cs * sizeof(float) : 0);
+  const __amdgpu_buffer_rsrc_t rsrc_u = make_rsrc(PX.w_wino, (size_t)nkc * 16 * P.cout_pad * 16 * sizeof(float));
 #endif
   constexpr bool SCALED = G::SC > 0 && EPI == EPI_AFFINE;
-  const bool scaled = SCALED && P.in_scale != nullptr;
+  const bool scaled = SCALED && PX.in_scale != nullptr;
   // DIL: what depends on one axis only is computed once per block by 36 + 12 lanes and shared through LDS (every lane walking the run
   // lists itself — twice per patch element, twice for its transform task, twice for its output tile — was 300 of the kernel's ~650
   // vector instructions per wave and tile): Tab[0..PW) input x of patch column c (-1: zero fill), [32..32+PH) input y of patch row r,
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   // ---- prologue -----------------------------------------------------------------------------------------------------------------------------
   float scv = 1.f;
   if constexpr (SCALED)
-    if (scaled && tid < c0) scv = P.in_scale[(size_t)img * c0 + tid];
+    if (scaled && tid < c0) scv = PX.in_scale[(size_t)img * c0 + tid];
   issue_patch(0);
   f32x4 A[2][2];                                                // [ring slot = step & 1][mb]
   A[0][0] = load_A(0, 0); A[0][1] = load_A(0, 1);
@@ -397,8 +406,8 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   if (tid < 2 * COUT_T) {
     const int co = cout0 + (tid < COUT_T ? tid : tid - COUT_T);
     if (co < P.cout) {
-      if (tid < COUT_T) { if (P.scale) sbv = P.scale[co]; }
-      else if (P.bias) sbv = P.bias[(P.bias_per_img ? (size_t)img * P.cout : 0) + co];
+      if (tid < COUT_T) { if (PX.scale) sbv = PX.scale[co]; }
+      else if (PX.bias) sbv = PX.bias[(P.bias_per_img ? (size_t)img * P.cout : 0) + co];
     }
   }
   SF_STAMP_AT(L, 11);
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) sacc += acc[p][mb][nb];
-    if (sacc[0] + sacc[1] + sacc[2] + sacc[3] == 1.2345f) P.out[tid] = sacc[0];
+    if (sacc[0] + sacc[1] + sacc[2] + sacc[3] == 1.2345f) PX.out[tid] = sacc[0];
     return;
   }
   float* const Tb = Vbuf;                                      // [ih][b][tile][64 cout], 16-byte slot cq of a tile's row at cq ^ (tile & 15)
@@ -520,8 +529,8 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
     oy0 = tab(56 + tyl_e);
   }
   constexpr bool affine = EPI == EPI_AFFINE;
-  const float* const t_a = affine ? P.add : P.e0;
-  const float* const t_b = P.e1;
+  const float* const t_a = affine ? PX.add : PX.e0;
+  const float* const t_b = PX.e1;
   const int cs_a = affine ? P.add_cs : P.e0_cs, cs_b = P.e1_cs;
   const bool img_ok = !CAT || img + (run_e ? 1 : 0) < P.n_img;
   const bool x0 = img_ok && ox0 < W, x1 = img_ok && ox0 + ostep < W, y0ok = oy0 < H, y1ok = oy0 + ostep < H;
@@ -540,8 +549,8 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   const size_t img_span = (size_t)((CAT && img + 1 < P.n_img) ? 2 : 1) * H * W;
   const int pk_[4] = {0, ostep * W, ostep, ostep * W + ostep};      // pixel offset of pixel k
   constexpr int OOB = (int)0x80000000;
-  const bool has_a = affine ? P.add != nullptr : true, has_b = affine ? P.out2 != nullptr : true;
-  const bool gate_lane = affine && P.out2 != nullptr && c >= P.gate_from;      // GRU gates, reset half: also emits (1 - r) * s
+  const bool has_a = affine ? PX.add != nullptr : true, has_b = affine ? PX.out2 != nullptr : true;
+  const bool gate_lane = affine && PX.out2 != nullptr && c >= P.gate_from;      // GRU gates, reset half: also emits (1 - r) * s
   (void)img_span; (void)pk_; (void)OOB; (void)has_a; (void)has_b; (void)gate_lane;
   f32x4 oa[4], ob[4];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -565,7 +574,7 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   }
 #endif
   f32x4 as = (f32x4){1.f, 1.f, 1.f, 1.f};
-  if (affine && P.add && P.add_scale) as = wn5_ld4(P.add_scale + (size_t)img * P.cout + c_ld);
+  if (affine && PX.add && PX.add_scale) as = wn5_ld4(PX.add_scale + (size_t)img * P.cout + c_ld);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   wn_barrier();                                                 // the exchange is complete
   const f32x4 sc = wn_lds_read128(SBuf + cl), bi = wn_lds_read128(SBuf + COUT_T + cl);
@@ -593,8 +602,8 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
         for (int q = 0; q < 4; ++q)
           if (c + q >= P.clamp_from) y[k][q] = fminf(fmaxf(y[k][q], P.clamp_lo), P.clamp_hi);
     }
-    if (P.add) {
-      if (P.add_scale) {
+    if (PX.add) {
+      if (PX.add_scale) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) y[k] = __builtin_elementwise_fma(oa[k], as, y[k]);
       } else {
@@ -603,7 +612,7 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
       }
     }
     if (act_last) wn5_act16(y, P.act);
-    if (P.out2) {
+    if (PX.out2) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) y2[k] = ob[k] * ((f32x4){1.f, 1.f, 1.f, 1.f} - y[k]);
     }
@@ -622,21 +631,21 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
 #if defined(__HIP_DEVICE_COMPILE__)
   if (affine && !DIL && P.pool2) {      // block-uniform: the tile IS the 2x2 pooling window (H, W even: a tile is whole or absent)
     const size_t pimg = (size_t)(H >> 1) * (W >> 1);
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(P.out + (size_t)img * pimg * P.out_cs + P.out_co,
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(PX.out + (size_t)img * pimg * P.out_cs + P.out_co,
                                                 (img_span / ((size_t)H * W)) * pimg * P.out_cs * sizeof(float) - (size_t)P.out_co * sizeof(float));
     const unsigned ppix = (unsigned)(ty * (W >> 1) + tx) + (run_e ? (unsigned)pimg : 0u);
     const f32x4 m = __builtin_elementwise_max(__builtin_elementwise_max(y[0], y[1]), __builtin_elementwise_max(y[2], y[3]));
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, m), rs,
                                            okk[0] ? (int)(ppix * (unsigned)P.out_cs + (unsigned)c_ld) * 4 : OOB, 0, 0);
   } else {
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(P.out + img_base * P.out_cs + P.out_co, img_span * P.out_cs * sizeof(float) - (size_t)P.out_co * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(PX.out + img_base * P.out_cs + P.out_co, img_span * P.out_cs * sizeof(float) - (size_t)P.out_co * sizeof(float));
     const int v = (int)(pix * (unsigned)P.out_cs + (unsigned)c_ld) * 4;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, y[k]), rs, okk[k] ? v : OOB, pk_[k] * P.out_cs * 4, 0);
   }
-  if (affine && P.out2) {
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(P.out2 + img_base * P.out2_cs, img_span * P.out2_cs * sizeof(float));
+  if (affine && PX.out2) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(PX.out2 + img_base * P.out2_cs, img_span * P.out2_cs * sizeof(float));
     const int v = (int)(pix * (unsigned)P.out2_cs + (unsigned)(c_ld >= P.gate_from ? c_ld - P.gate_from : 0)) * 4;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -750,14 +759,30 @@ static hipError_t launch_wino5_t(const ConvLaunch& L, hipStream_t stream) {
   const int tiles_x = DIL ? WnAxis(P.Wout, P.dil).nt : (P.Wout + 1) / 2, tiles_y = DIL ? WnAxis(P.Hout, P.dil).nt : (P.Hout + 1) / 2;
   const long blocks = CAT ? (long)((tiles_y + G::TH - 1) / G::TH) * (((long)P.n_img * tiles_x + G::TW - 1) / G::TW)
                           : (long)P.n_img * ((tiles_y + G::TH - 1) / G::TH) * ((tiles_x + G::TW - 1) / G::TW);
-  const long grid = ((blocks + 7) / 8) * 8 * (P.cout_pad / G::COUT_T);
+  const long grid1 = ((blocks + 7) / 8) * 8 * (P.cout_pad / G::COUT_T), grid = grid1 * L.nprob;
   if (grid > 0x7fffffffL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid, 1, 1), dim3(WN_THREADS), lds, stream, L);
+  ConvLaunch L2 = L;
+  L2.wg_base[0] = 0;
+  L2.wg_base[1] = (int)grid1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid, 1, 1), dim3(WN_THREADS), lds, stream, L2);
   return hipGetLastError();
 }
-// one problem per launch
+// same tiling, same kernel instantiation, same workgroup count: the layers may share a launch
+bool wino_same_geometry(const ConvProblem& a, const ConvProblem& b) {
+  return a.n_img == b.n_img && a.Hin == b.Hin && a.Win == b.Win && a.Hout == b.Hout && a.Wout == b.Wout && a.in_up == b.in_up && a.dil == b.dil &&
+         a.c0 == b.c0 && a.c1 == b.c1 && a.cin_pad == b.cin_pad && a.cout == b.cout && a.cout_pad == b.cout_pad &&
+         (a.in_scale != nullptr) == (b.in_scale != nullptr) && (a.in1 != nullptr) == (b.in1 != nullptr) && (a.add != nullptr) == (b.add != nullptr) &&
+         (a.add_scale != nullptr) == (b.add_scale != nullptr) && (a.out2 != nullptr) == (b.out2 != nullptr) && (a.scale != nullptr) == (b.scale != nullptr) &&
+         (a.bias != nullptr) == (b.bias != nullptr) && a.in0_cs == b.in0_cs && a.in1_cs == b.in1_cs && a.add_cs == b.add_cs && a.out_cs == b.out_cs &&
+         a.out_co == b.out_co && a.out2_cs == b.out2_cs && a.e0_cs == b.e0_cs && a.e1_cs == b.e1_cs && a.act == b.act && a.mode == b.mode &&
+         a.gate_from == b.gate_from && a.clamp_from == b.clamp_from && a.clamp_lo == b.clamp_lo && a.clamp_hi == b.clamp_hi &&
+         a.bias_per_img == b.bias_per_img && a.pool2 == b.pool2 && a.add_up == b.add_up && wino_variant(a) == wino_variant(b);
+}
+// one problem per launch, or up to SF_MAX_GROUP of identical geometry
 hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream) {
-  if (L.nprob != 1 || !wino_takes(L.p[0], epi)) return hipErrorInvalidValue;
+  if (L.nprob < 1 || L.nprob > SF_MAX_GROUP) return hipErrorInvalidValue;
+  for (int i = 0; i < L.nprob; ++i)
+    if (!wino_takes(L.p[i], epi) || !wino_same_geometry(L.p[0], L.p[i])) return hipErrorInvalidValue;
   const bool affine = epi == EPI_AFFINE;
   switch (wino_variant(L.p[0])) {
     case 2: return affine ? launch_wino5_t<EPI_AFFINE>(L, stream) : launch_wino5_t<EPI_BLEND>(L, stream);
