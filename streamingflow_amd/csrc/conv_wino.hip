@@ -178,6 +178,9 @@ struct Wino5Geo {
 #if !defined(SF_W5_ABL)
 #define SF_W5_ABL 0
 #endif
+#if !defined(SF_W5_MAGIC)
+#define SF_W5_MAGIC 1
+#endif
 template <int EPI, bool DIL = false, bool CAT = false>
 __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLaunch L) {
   typedef Wino5Geo<DIL, CAT> G;
@@ -211,12 +214,28 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   const int ncb = P.cout_pad / COUT_T;
   const int nblk = nbx * nby * (CAT ? 1 : P.n_img), per_xcd = (nblk + 7) >> 3;
   const int lin = lin_, xcd = lin & 7, slot_ = lin >> 3;
+  // the block decode divides by four launch constants: the host passes ceil(2^32 / d) (0 for d = 1) and the quotients are one
+  // s_mul_hi each instead of a reciprocal sequence through the vector unit (exact: dividend x divisor < 2^32, checked by the host)
+#if SF_W5_MAGIC
+  auto mdiv = [](const int nn, const unsigned m) { return m ? (int)__umulhi((unsigned)nn, m) : nn; };
+  const unsigned m_ncb = (unsigned)L.wg_base[2], m_nbx = (unsigned)L.wg_base[3], m_nby = (unsigned)L.wg_base[4], m_tpi = (unsigned)L.xcd_shift;
+  (void)m_tpi;
+  const int tb_ = mdiv(slot_, m_ncb);
+  int b = xcd * per_xcd + tb_;
+  if (b >= nblk) return;
+  const int bq_ = mdiv(b, m_nbx);
+  const int bx = b - bq_ * nbx; b = bq_;
+  const int bi_ = mdiv(b, m_nby);
+  const int by = b - bi_ * nby;
+  const int img = CAT ? mdiv(bx * TW, m_tpi) : bi_;
+#else
   const int tb_ = slot_ / ncb;
   int b = xcd * per_xcd + tb_;
   if (b >= nblk) return;
   const int bx = b % nbx; b /= nbx;
   const int by = b % nby;
   const int img = CAT ? (bx * TW) / tpi : b / nby;
+#endif
   const int ct0 = CAT ? bx * TW - img * tpi : 0;
   const int cn0 = CAT ? (tpi - ct0 < TW ? tpi - ct0 : TW) : TW;
   const int ty0 = by * TH, tx0 = CAT ? ct0 : bx * TW;
@@ -764,6 +783,13 @@ static hipError_t launch_wino5_t(const ConvLaunch& L, hipStream_t stream) {
   ConvLaunch L2 = L;
   L2.wg_base[0] = 0;
   L2.wg_base[1] = (int)grid1;
+  // reciprocals of the block decode's divisors (conv_wino5_kernel): ceil(2^32 / d), 0 for d = 1; exact while dividend x d < 2^32
+  const long nbx = ((CAT ? (long)P.n_img * tiles_x : tiles_x) + G::TW - 1) / G::TW, nby = (tiles_y + G::TH - 1) / G::TH, ncb = P.cout_pad / G::COUT_T;
+  auto magic = [](long d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); };
+  if ((grid1 / 8 + 1) * ncb >= 0x100000000L || (blocks + 8) * nbx >= 0x100000000L || (blocks + 8) * nby >= 0x100000000L ||
+      (nbx * G::TW + G::TW) * tiles_x >= 0x100000000L)
+    return hipErrorInvalidValue;
+  L2.wg_base[2] = (int)magic(ncb); L2.wg_base[3] = (int)magic(nbx); L2.wg_base[4] = (int)magic(nby); L2.xcd_shift = (int)magic(tiles_x);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid, 1, 1), dim3(WN_THREADS), lds, stream, L2);
   return hipGetLastError();
 }

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../.."
 name=$1; shift
 out=build_r02/$name; mkdir -p $out
-srcs="conv_igemm conv_sp conv_wino aux_kernels api lift_splat voxelize sparse_index eval_kernels pack $SF_EXTRA_SRCS"
+srcs="conv_igemm conv_sp conv_wino convnext_mlp aux_kernels api lift_splat voxelize sparse_index eval_kernels pack $SF_EXTRA_SRCS"
 pids=()
 for s in $srcs; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function "$@" -c streamingflow_amd/csrc/$s.hip -o $out/$s.o &
