@@ -510,7 +510,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
           same = same && wino_same_geometry(ps[first], ps[i]);
           WG.p[WG.nprob++] = ps[i];
         }
-        if (same) {
+        if (same && wino_tiles(ps[first]) * (ps[first].cout_pad / 64.0) * WG.nprob < 1.0e6) {      // (group decode by multiplication: < 2^32 / workgroups)
           WG.stamp_slot = g_stamp_slot;
           if (g_stamp_on) g_stamp_slot = (g_stamp_slot + 1) % 64;
           if (!g_prof.on) {
@@ -659,6 +659,23 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       }
       for (int i = n; i <= SF_MAX_GROUP; ++i) L.wg_base[i] = base;
       L.xcd_shift = (tune().sp_xcd >> 1) & 1;
+    }
+    // reciprocals of the divisors of the kernel's block decode and pixel decode (conv_sp.hip: sp_mdiv; exact while dividend x
+    // divisor < 2^32: a launch has < 2^16 workgroups and < 2^13 pixels)
+    {
+      static const bool magic_on = [] { const char* v = std::getenv("SF_SP_MAGIC"); return v ? std::atoi(v) != 0 : true; }();
+      auto magic = [](long d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); };
+      for (int i = 0; i < n && magic_on; ++i) {
+        ConvProblem& q = L.p[i];
+        const long Pi = (long)q.n_img * q.Hout * q.Wout, n_pt = (Pi + bn - 1) / bn, n_mt = (q.cout_pad + 63) / 64, tiles = n_pt * n_mt;
+        const int ns = q.nsplit > 1 ? q.nsplit : 1, kcpt = q.cin_pad >> 5, nch_all = (q.KH * q.KW * kcpt + 1) >> 1;
+        if (tiles * ns * tiles >= 0x100000000L || (Pi + 64) * q.Hout * q.Wout >= 0x100000000L) continue;
+        // d = 1 has no reciprocal (0 = "divide"): dividing by one is what the fallback does
+        q.sp_m_tiles = magic(tiles); q.sp_m_npt = magic(n_pt); q.sp_m_hw = magic((long)q.Hout * q.Wout); q.sp_m_w = magic(q.Wout);
+        q.sp_m_kcpt = magic(kcpt); q.sp_m_kw = magic(q.KW);
+        q.sp_cps = (nch_all + ns - 1) / ns;
+        q.sp_bn = bn;
+      }
     }
     bool scaled = false;
     for (int i = 0; i < n; ++i) scaled = scaled || (ps[i].in_scale != nullptr) || (ps[i].se_sum != nullptr);

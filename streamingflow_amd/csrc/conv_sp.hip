@@ -41,6 +41,9 @@ hipError_t set_stamp_buffer_sp(unsigned long long*) { return hipErrorNotSupporte
 #endif
 
 constexpr int SP_BM = 64;                     // output channels per tile
+// n / d with the host's ceil(2^32 / d) (exact for n x d < 2^32, which the host checks); m == 0: d is 1, or no reciprocal was made
+__device__ __forceinline__ int sp_mdiv(const int n, const unsigned m, const int d) { return m ? (int)__umulhi((unsigned)n, m) : (d == 1 ? n : n / d); }
+
 constexpr int SP_NB = 3, SP_LA = SP_NB - 1;   // chunk buffers of the LDS ring / chunks in flight
 constexpr int SP_RED_PITCH = 68;              // reduction buffer [4 quarters][BN px][68] (inside the ring)
 constexpr int SP_SC_IMGS = 4;                 // SE scale rows kept in LDS: images a pixel tile can touch
@@ -189,7 +192,7 @@ struct SpOps {
 // addresses and store nothing.
 template <int EPI, bool VOL = false, class PT = ConvProblem>
 __device__ __forceinline__ void sp_epi_load(const PT& P, const int gp, const int c, const bool on, const int HWout, SpOps& o) {
-  const int img = on ? gp / HWout : 0;
+  const int img = on ? sp_mdiv(gp, P.sp_m_hw, HWout) : 0;
   const size_t gpz = on ? (size_t)gp : 0;
   const int cz = on ? c : 0;
   o.pre = P.acc_in ? sp_gld4<VOL>(P.acc_in + gpz * P.acc_cs + cz) : spm_zero4();
@@ -429,7 +432,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
   const int kcpt = P.cin_pad >> 5;                     // 32-deep sub-chunks per tap
   const int nsub_all = P.KH * P.KW * kcpt;
   const int nch_all = (nsub_all + 1) >> 1;
-  const int cps = (nch_all + nsplit - 1) / nsplit;     // chunks per K slice (host: every slice non-empty)
+  const int cps = P.sp_cps > 0 ? P.sp_cps : (nch_all + nsplit - 1) / nsplit;     // chunks per K slice (host: every slice non-empty)
   const int cb = bz * cps;
   const int nchunks = (nch_all - cb) < cps ? (nch_all - cb) : cps;
 
@@ -437,7 +440,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
   const int lane = tid & 63;
   float* const misc = smem + G::RING;
   float* const sc_lds = misc + SP_MISC;      // SCALE instantiations only
-  const int img0 = (p_tile * BN) / HWout;              // block-uniform: first image this tile touches
+  const int img0 = sp_mdiv(p_tile * BN, P.sp_m_hw, HWout);              // block-uniform: first image this tile touches
   const int cin_pad = P.cin_pad;
 
   f32x4 acc[2][NT];
@@ -648,9 +651,9 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
       b_c4[i] = 4 * ((lane & 7) ^ ((pr >> 1) & SWM));
       const int gp = p_tile * BN + pr;
       const bool pvalid = gp < Ptot;
-      const int img = pvalid ? gp / HWout : 0;
+      const int img = pvalid ? sp_mdiv(gp, P.sp_m_hw, HWout) : 0;
       const int rem = gp - img * HWout;
-      const int oy = rem / P.Wout, ox = rem - oy * P.Wout;
+      const int oy = sp_mdiv(rem, P.sp_m_w, P.Wout), ox = rem - oy * P.Wout;
       iy0[i] = pvalid ? oy * P.stride - P.pad : -(1 << 28);
       ix0[i] = ox * P.stride - P.pad;
       pbase[i] = (pvalid ? img - img0 : 0) * P.Hin * P.Win;
@@ -674,7 +677,8 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
     if constexpr (PST) sp_barrier();                      // flow: the dependency wait of wave 0 is over (weights were issued above)
     // cursor of the next sub-chunk to fetch
     int sc = 2 * cb;
-    int cur_kc = sc % kcpt, cur_ty = (sc / kcpt) / KW, cur_tx = (sc / kcpt) % KW;
+    const int sc_tap = sp_mdiv(sc, P.sp_m_kcpt, kcpt);
+    int cur_kc = sc - sc_tap * kcpt, cur_ty = sp_mdiv(sc_tap, P.sp_m_kw, KW), cur_tx = sc_tap - cur_ty * KW;
     bool tap_fresh = true;
     // Per tap and pixel row block: byte offset of the gathered pixel in either source (channel slot of this lane included),
     // or 0x80000000 outside the image: adding the sub-chunk's channel offset keeps it beyond any buffer (< 2^31 bytes), so the
@@ -806,13 +810,14 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
 #pragma unroll
     for (int n = 0; n < NTW; ++n) b_off[n] = sub_off + (SP_BM + 16 * (nh * NTW + n) + j) * 32;
     // SE-scaled input: the lane's K values of a chunk are channels kc*32 + (kq&1)*16 + 4g .. +3 (fp32) / kc*32 + 8g .. +7 (bf16x3) of its sub-chunk
-    int s_kc = (2 * cb + (B3 ? kh : (kq >> 1))) % kcpt;
-    const int s_step = 2 % kcpt;
+    const int s_k0 = 2 * cb + (B3 ? kh : (kq >> 1));
+    int s_kc = s_k0 - sp_mdiv(s_k0, P.sp_m_kcpt, kcpt) * kcpt;
+    const int s_step = kcpt > 2 ? 2 : 0;      // 2 % kcpt
     int simg[NTW];
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
       const int gp = p_tile * BN + 16 * (nh * NTW + n) + j;
-      simg[n] = SCALE ? (gp < Ptot ? gp / HWout - img0 : 0) * cin_pad + (B3 ? 8 * g : ((kq & 1) << 4) + 4 * g) : 0;
+      simg[n] = SCALE ? (gp < Ptot ? sp_mdiv(gp, P.sp_m_hw, HWout) - img0 : 0) * cin_pad + (B3 ? 8 * g : ((kq & 1) << 4) + 4 * g) : 0;
     }
     f32x4 fa[2][2][B3 ? 2 : 1], fb[2][NTW][B3 ? 2 : 1];
     auto read_frags = [&](const int buf, const int set) {
@@ -1140,9 +1145,10 @@ __device__ __forceinline__ void sp_decode(const PT* ps, const IT* wg_base, const
   const int Ptot = P.n_img * P.Hout * P.Wout;
   const int n_mt = (P.cout_pad + SP_BM - 1) / SP_BM;
   const int n_pt = (Ptot + BN - 1) / BN, tiles = n_pt * n_mt;
-  bz = bx / tiles;
+  const bool mg = P.sp_bn == BN;                      // the reciprocals were made for this tile width
+  bz = sp_mdiv(bx, mg ? P.sp_m_tiles : 0u, tiles);
   bx -= bz * tiles;                                  // tile id (slab / ticket index): cout tile major
-  m_tile = bx / n_pt;
+  m_tile = sp_mdiv(bx, mg ? P.sp_m_npt : 0u, n_pt);
   p_tile = bx - m_tile * n_pt;
 }
 

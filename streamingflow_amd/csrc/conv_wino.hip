@@ -195,11 +195,9 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   // a group of layers of identical geometry (the two branches of a dual cell) shares one launch: problem i owns the workgroups
   // [i * wg_base[1], (i + 1) * wg_base[1]) (a multiple of 8 each, so that workgroup -> XCD stays blockIdx & 7); the tails of the
   // single launches (625 - 1250 workgroups over 512 slots) merge into one
-  int lin_ = (int)blockIdx.x, pi_ = 0;
-  if (L.nprob > 1) {      // block-uniform
-    pi_ = lin_ / L.wg_base[1];
-    lin_ -= pi_ * L.wg_base[1];
-  }
+  int lin_ = (int)blockIdx.x;
+  const int pi_ = (int)__umulhi((unsigned)lin_, L.wn_m[0]);      // wn_m[0] = 1 for a single problem: always 0, no branch
+  lin_ -= pi_ * L.wg_base[1];
   const ConvProblem& P = L.p[0];       // geometry, strides, flags: the same for every problem of the group
   const ConvProblem& PX = L.p[pi_];     // tensors: this workgroup's problem
   const int tid = threadIdx.x, lane = tid & 63;
@@ -218,7 +216,7 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   // s_mul_hi each instead of a reciprocal sequence through the vector unit (exact: dividend x divisor < 2^32, checked by the host)
 #if SF_W5_MAGIC
   auto mdiv = [](const int nn, const unsigned m) { return m ? (int)__umulhi((unsigned)nn, m) : nn; };
-  const unsigned m_ncb = (unsigned)L.wg_base[2], m_nbx = (unsigned)L.wg_base[3], m_nby = (unsigned)L.wg_base[4], m_tpi = (unsigned)L.xcd_shift;
+  const unsigned m_ncb = L.wn_m[1], m_nbx = L.wn_m[2], m_nby = L.wn_m[3], m_tpi = L.wn_m[4];
   (void)m_tpi;
   const int tb_ = mdiv(slot_, m_ncb);
   int b = xcd * per_xcd + tb_;
@@ -565,7 +563,8 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   const bool okk[4] = {c_ok && x0 && y0ok, c_ok && x0 && y1ok, c_ok && x1 && y0ok, c_ok && x1 && y1ok};
   const size_t img_base = (size_t)img * H * W;
   (void)t_a; (void)t_b; (void)cs_a; (void)cs_b; (void)pix; (void)okk; (void)img_base;
-  const size_t img_span = (size_t)((CAT && img + 1 < P.n_img) ? 2 : 1) * H * W;
+  const size_t n_span = (CAT && img + 1 < P.n_img) ? 2 : 1;      // images the workgroup's tiles may lie in
+  const size_t img_span = n_span * H * W;
   const int pk_[4] = {0, ostep * W, ostep, ostep * W + ostep};      // pixel offset of pixel k
   constexpr int OOB = (int)0x80000000;
   const bool has_a = affine ? PX.add != nullptr : true, has_b = affine ? PX.out2 != nullptr : true;
@@ -575,7 +574,7 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
 #if defined(__HIP_DEVICE_COMPILE__)
   if (has_a && affine && !DIL && P.add_up) {      // block-uniform: the tile's four pixels read source pixel (ty, tx) of the half-size tensor
     const size_t pimg = (size_t)(H >> 1) * (W >> 1);
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(t_a + (size_t)img * pimg * cs_a, (img_span / ((size_t)H * W)) * pimg * cs_a * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(t_a + (size_t)img * pimg * cs_a, n_span * pimg * cs_a * sizeof(float));
     const unsigned ppix = (unsigned)(ty * (W >> 1) + tx) + (run_e ? (unsigned)pimg : 0u);
     oa[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, okk[0] ? (int)(ppix * (unsigned)cs_a + (unsigned)c_ld) * 4 : OOB, 0, 0));
     oa[1] = oa[0]; oa[2] = oa[0]; oa[3] = oa[0];
@@ -651,7 +650,7 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   if (affine && !DIL && P.pool2) {      // block-uniform: the tile IS the 2x2 pooling window (H, W even: a tile is whole or absent)
     const size_t pimg = (size_t)(H >> 1) * (W >> 1);
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(PX.out + (size_t)img * pimg * P.out_cs + P.out_co,
-                                                (img_span / ((size_t)H * W)) * pimg * P.out_cs * sizeof(float) - (size_t)P.out_co * sizeof(float));
+                                                n_span * pimg * P.out_cs * sizeof(float) - (size_t)P.out_co * sizeof(float));
     const unsigned ppix = (unsigned)(ty * (W >> 1) + tx) + (run_e ? (unsigned)pimg : 0u);
     const f32x4 m = __builtin_elementwise_max(__builtin_elementwise_max(y[0], y[1]), __builtin_elementwise_max(y[2], y[3]));
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, m), rs,
@@ -789,7 +788,9 @@ static hipError_t launch_wino5_t(const ConvLaunch& L, hipStream_t stream) {
   if ((grid1 / 8 + 1) * ncb >= 0x100000000L || (blocks + 8) * nbx >= 0x100000000L || (blocks + 8) * nby >= 0x100000000L ||
       (nbx * G::TW + G::TW) * tiles_x >= 0x100000000L)
     return hipErrorInvalidValue;
-  L2.wg_base[2] = (int)magic(ncb); L2.wg_base[3] = (int)magic(nbx); L2.wg_base[4] = (int)magic(nby); L2.xcd_shift = (int)magic(tiles_x);
+  if (L.nprob > 1 && grid * grid1 >= 0x100000000L) return hipErrorInvalidValue;      // (callers launch such groups one by one)
+  L2.wn_m[0] = L.nprob > 1 ? magic(grid1) : 1u;
+  L2.wn_m[1] = magic(ncb); L2.wn_m[2] = magic(nbx); L2.wn_m[3] = magic(nby); L2.wn_m[4] = magic(tiles_x);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid, 1, 1), dim3(WN_THREADS), lds, stream, L2);
   return hipGetLastError();
 }

@@ -67,6 +67,12 @@ struct ConvProblem {
   // AFFINE, Winograd kernel only (even Hout, Wout): `out` is the 2x2 max-pooled tensor [n][Hout/2][Wout/2][out_cs] — a thread of the
   // epilogue holds exactly one pooling window (its tile), so the pool costs three maxima and the full-size tensor is never written
   // (res_models.py:101-105: every encoder block is followed by MaxPool2d(2))
+  // small-P kernel: ceil(2^32 / d) of the divisors its block decode and its loaders' pixel decode use (0: divide) — tiles of the
+  // problem, pixel tiles, pixels per image, output width, 32-deep sub-chunks per tap, kernel width — and the chunks per K slice.
+  // Filled by api.hip once the tile width and the split are chosen: an integer division is a ~25-instruction reciprocal sequence
+  // through the vector unit, eight of them sat in front of the first DMA of every launch of a step
+  unsigned sp_m_tiles, sp_m_npt, sp_m_hw, sp_m_w, sp_m_kcpt, sp_m_kw;
+  int sp_cps, sp_bn;
   int pool2;
   // AFFINE, Winograd kernel only: `add` is a half-resolution tensor [n][Hout/2][Wout/2][add_cs] read with nearest x2 upsampling — the
   // four pixels of a tile share one source pixel (the identity skip of a residual block whose input is upsampled on read)
@@ -121,6 +127,9 @@ struct ConvLaunch {
   // small-P kernel, compact 1-D grid: problem i owns the logical workgroups [wg_base[i], wg_base[i + 1]), K slice major,
   // then cout tile, then pixel tile (wg_base[nprob] = grid size; all zero: the 3-D grid of tiles x problems x slices)
   int wg_base[SF_MAX_GROUP + 1];
+  // Winograd kernel: ceil(2^32 / d) of the block decode's divisors (0: d = 1) — workgroups per problem of a group (1: one problem),
+  // cout blocks, tile-block columns, tile-block rows, tile columns per image
+  unsigned wn_m[6];
 };
 
 // Persistent "flow" form of the small-P kernel (conv_sp.hip: sp_flow_kernel, SF_PERSIST=1): every launch group of a rollout —
