@@ -360,6 +360,14 @@ class NNFOwithBayesianJumps(nn.Module):
             self.noise_seed = x & 0x7FFFFFFFFFFFFFFF
         return self.noise_seed
 
+    def __getstate__(self):
+        # captured graphs (hipGraphExec handles + their static buffers) belong to this object alone: a copy starts without them
+        d = runtime.strip_runtime_state(self.__dict__)
+        d["_graphs"] = collections.OrderedDict()
+        d["_graph_structures_seen"] = set()
+        d["_graph_gens"] = None
+        return d
+
     def drop_graphs(self):
         """Destroy every captured rollout graph of this module and release its static buffers."""
         L = _lib.lib()

@@ -71,6 +71,9 @@ class FuturePredictionODE(nn.Module):
         self.spatial_grus = nn.ModuleList(grus)
         self.res_blocks = nn.ModuleList(blocks)
 
+    def __getstate__(self):
+        return runtime.strip_runtime_state(self.__dict__)      # (the folded tail holds device pointers: rebuilt on the next forward)
+
     def observations(self, camera_states, lidar_states, camera_timestamp, lidar_timestamp, bs, with_order=False):
         """Merge + time-sort one sample's observations (:36-49); returns (times, [frames NCHW])
         (+ the (source tensor, frame index) of every observation with ``with_order``)."""

@@ -75,6 +75,16 @@ def to_nchw(x):
 _PACK_GENERATION = [0]      # process-wide, monotonically increasing: never reused (unlike id() of a freed Pack)
 
 
+def strip_runtime_state(d):
+    """A module's ``__dict__`` without what only exists on this process's GPU: packed weight copies (ctypes structs full of device
+    pointers), folded packs, captured graphs.  ``copy.deepcopy(model)`` and ``torch.save(model)`` go through ``__getstate__``; the
+    copy re-packs (and re-captures) on its first forward."""
+    d = dict(d)
+    for k in [k for k in d if k.startswith("_sf_")] + ["_folded_tail"]:
+        d.pop(k, None)
+    return d
+
+
 class PackedModule(torch.nn.Module):
     """Mixin: lazily packs the module's parameters for the HIP library and re-packs when any
     parameter was replaced, moved or modified in place (load_state_dict, .to(), optimiser).
@@ -106,3 +116,6 @@ class PackedModule(torch.nn.Module):
 
     def _pack(self):
         raise NotImplementedError
+
+    def __getstate__(self):
+        return strip_runtime_state(self.__dict__)
