@@ -1202,8 +1202,9 @@ __device__ __forceinline__ bool sp_flow_item(const FT& F, FlowPhaseK& ph, const 
   d.tile_idx = ph.prev_tile_base; d.tile_n = 0; d.tile_expect = ph.prev_tile_expect;
   if (ph.prev_ntiles > 0) {
     const int p0 = p_tile * SpGeo<NT>::BN - ph.halo_px, p1 = p_tile * SpGeo<NT>::BN + SpGeo<NT>::BN - 1 + ph.halo_px;
-    const int lo = (p0 < 0 ? 0 : p0) / ph.prev_bn;
-    int hi = p1 / ph.prev_bn;
+    const int sh = ph.prev_bn == 64 ? 6 : 5;            // tiles are 32 or 64 pixels wide: a shift, not a division
+    const int lo = (p0 < 0 ? 0 : p0) >> sh;
+    int hi = p1 >> sh;
     hi = hi < ph.prev_ntiles - 1 ? hi : ph.prev_ntiles - 1;
     if (ph.dep_full || hi - lo + 1 > 62) {
       d.full_expect = ph.prev_tot_expect;
