@@ -404,18 +404,21 @@ typedef float dw_f2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256, 2) void dwconv7_ln_c64_pk_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                 const float* __restrict__ wdw, const float* __restrict__ bdw,
                                                                 const float* __restrict__ lnw, const float* __restrict__ lnb, int n,
-                                                                int H, int W, float eps, int seg) {
+                                                                int H, int W, float eps, int seg, int nseg, unsigned m_per_img,
+                                                                unsigned m_nseg) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int C = 64, R = 2;
   constexpr unsigned BAD = 0x40000000u;      // added to an offset: beyond any image (the host keeps images below 1 GB)
   const int lane = threadIdx.x & 63, half = lane >> 5, cp = lane & 31;
-  const long wv = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nseg = (W + seg - 1) / seg, nrb = (H + R - 1) / R;
+  const int wv = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nrb = (H + R - 1) / R;
   const int per_img = nrb * nseg;             // even (host)
-  if (2 * wv >= (long)n * per_img) return;
-  const int img = (int)((2 * wv) / per_img);  // wave-uniform
-  const int si = (int)((2 * wv) % per_img) + half;
-  const int sg = si % nseg, rb = si / nseg;
+  if (2 * (long)wv >= (long)n * per_img) return;
+  // strip -> (image, row pair, segment): quotients by the host's ceil(2^32 / d) (0: d = 1) — a wave lives for 80 pixels, four
+  // reciprocal sequences through the vector unit at its start were 5 % of that
+  const int img = m_per_img ? (int)__umulhi((unsigned)(2 * wv), m_per_img) : 2 * wv;  // wave-uniform
+  const int si = 2 * wv - img * per_img + half;
+  const int rb = m_nseg ? (int)__umulhi((unsigned)si, m_nseg) : si, sg = si - rb * nseg;
   const int y0 = rb * R, x0 = sg * seg, x1 = (x0 + seg < W) ? x0 + seg : W;
   const size_t img_off = (size_t)img * H * W * C;
   const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + img_off), (short)0, (int)((unsigned)H * W * C * 4), 0x00020000);
@@ -487,10 +490,14 @@ hipError_t launch_dwconv7_ln(const float* in, float* out, const float* wdw, cons
     const int nrb = (H + 1) / 2;
     if ((nrb * ((W + seg - 1) / seg)) & 1) seg = W;      // one strip per row pair ...
     if (((nrb * ((W + seg - 1) / seg)) & 1) == 0) {      // ... (an odd number of row pairs of one strip each keeps the one-channel kernel)
-      const long waves = ((long)n * nrb * ((W + seg - 1) / seg)) / 2;
-      hipLaunchKernelGGL(dwconv7_ln_c64_pk_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, in, out, wdw, bdw, lnw, lnb, n, H, W, eps,
-                         seg);
-      return hipGetLastError();
+      const int nseg = (W + seg - 1) / seg;
+      const long per_img = (long)nrb * nseg, waves = ((long)n * per_img) / 2;
+      auto magic = [](long d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); };
+      if ((double)n * per_img * per_img < 4.0e9) {      // exact quotients (dividend x divisor < 2^32)
+        hipLaunchKernelGGL(dwconv7_ln_c64_pk_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, in, out, wdw, bdw, lnw, lnb, n, H, W, eps,
+                           seg, nseg, magic(per_img), magic(nseg));
+        return hipGetLastError();
+      }
     }
   }
   if (C == 64 && (long)n * H * W >= 65536) {   // large maps: register-window kernel (below that the LDS-tile kernel has more waves)
