@@ -44,6 +44,9 @@ constexpr int SP_BM = 64;                     // output channels per tile
 // n / d with the host's ceil(2^32 / d) (exact for n x d < 2^32, which the host checks); m == 0: d is 1, or no reciprocal was made
 __device__ __forceinline__ int sp_mdiv(const int n, const unsigned m, const int d) { return m ? (int)__umulhi((unsigned)n, m) : (d == 1 ? n : n / d); }
 
+#if !defined(SF_SP_PIN)
+#define SF_SP_PIN 1
+#endif
 constexpr int SP_NB = 3, SP_LA = SP_NB - 1;   // chunk buffers of the LDS ring / chunks in flight
 constexpr int SP_RED_PITCH = 68;              // reduction buffer [4 quarters][BN px][68] (inside the ring)
 constexpr int SP_SC_IMGS = 4;                 // SE scale rows kept in LDS: images a pixel tile can touch
@@ -424,6 +427,28 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
   // (slots 2g / 2g + 1: conflict-free for the ds_read_b128 lane groups, see conv_igemm.hip)
   constexpr int SWM = B3 ? 5 : 7;
   constexpr int NKR = B3 ? 2 : 4;      // in-workgroup K split: halves (one 32-deep sub-chunk each) or quarters
+#if SF_SP_PIN && defined(__HIP_DEVICE_COMPILE__)
+  // The fields of the problem record that the way to the first DMA reads, requested together and waited for once: left to itself
+  // hipcc loads each field where a branch first needs it — some fifteen dependent scalar-load round trips between the entry of the
+  // kernel and the first weight DMA, on a workgroup that lives for 15-20 us and has no partner on its CU to hide them
+  if constexpr (!PST && SCALE) {      // (the SE-scaled instantiations have fewer scalar registers to spare: what the weight DMAs need)
+    const int q0 = P.Hout, q1 = P.Wout, q2 = P.n_img, q3 = P.nsplit, q4 = P.cin_pad, q5 = P.KH, q6 = P.KW, q18 = P.cout_pad, q19 = P.ktot, q20 = P.sp_cps;
+    const float* r0 = P.w;
+    asm volatile("" ::"s"(q0), "s"(q1), "s"(q2), "s"(q3), "s"(q4), "s"(q5), "s"(q6), "s"(q18), "s"(q19), "s"(q20), "s"(r0));
+  }
+  if constexpr (!PST && !SCALE) {
+#define SP_PIN(x) asm volatile("" ::"s"(x))
+    const int q0 = P.Hout, q1 = P.Wout, q2 = P.n_img, q3 = P.nsplit, q4 = P.cin_pad, q5 = P.KH, q6 = P.KW, q7 = P.c0, q8 = P.c1,
+              q9 = P.in0_cs, q10 = P.in1_cs, q11 = P.Hin, q12 = P.Win, q13 = P.in_up, q14 = P.dil, q15 = P.stride, q16 = P.pad,
+              q17 = P.cout, q18 = P.cout_pad, q19 = P.ktot, q20 = P.sp_cps;
+    const unsigned u0 = P.sp_m_hw, u1 = P.sp_m_w, u2 = P.sp_m_kcpt, u3 = P.sp_m_kw;
+    const float *r0 = P.w, *r1 = P.in0, *r2 = P.in1, *r3 = P.fuse_w, *r4 = P.se_sum, *r5 = P.in_scale;
+    SP_PIN(q0); SP_PIN(q1); SP_PIN(q2); SP_PIN(q3); SP_PIN(q4); SP_PIN(q5); SP_PIN(q6); SP_PIN(q7); SP_PIN(q8); SP_PIN(q9); SP_PIN(q10);
+    SP_PIN(q11); SP_PIN(q12); SP_PIN(q13); SP_PIN(q14); SP_PIN(q15); SP_PIN(q16); SP_PIN(q17); SP_PIN(q18); SP_PIN(q19); SP_PIN(q20);
+    SP_PIN(u0); SP_PIN(u1); SP_PIN(u2); SP_PIN(u3); SP_PIN(r0); SP_PIN(r1); SP_PIN(r2); SP_PIN(r3); SP_PIN(r4); SP_PIN(r5);
+#undef SP_PIN
+  }
+#endif
   const int HWout = P.Hout * P.Wout;
   const int Ptot = P.n_img * HWout;
   if (p_tile * BN >= Ptot) return false;               // block-uniform
@@ -1136,12 +1161,25 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
 template <class PT, class IT>
 __device__ __forceinline__ void sp_decode(const PT* ps, const IT* wg_base, const int nprob, const int lg, const int BN, int& by, int& bx, int& bz,
                                           int& m_tile, int& p_tile) {
+#if SF_SP_PIN && defined(__HIP_DEVICE_COMPILE__)
+  {      // the group's workgroup ranges in one request
+    const int b1 = wg_base[1], b2 = wg_base[2], b3 = wg_base[3];
+    asm volatile("" ::"s"(b1), "s"(b2), "s"(b3));
+  }
+#endif
   by = 0;
 #pragma unroll
   for (int i = 1; i < SF_MAX_GROUP; ++i)
     if (i < nprob && lg >= wg_base[i]) by = i;
   bx = lg - wg_base[by];
   const PT& P = ps[by];
+#if SF_SP_PIN && defined(__HIP_DEVICE_COMPILE__)
+  {      // ... and the fields of the problem this decode reads
+    const int d0 = P.n_img, d1 = P.Hout, d2 = P.Wout, d3 = P.cout_pad, d4 = P.sp_bn;
+    const unsigned d5 = P.sp_m_tiles, d6 = P.sp_m_npt;
+    asm volatile("" ::"s"(d0), "s"(d1), "s"(d2), "s"(d3), "s"(d4), "s"(d5), "s"(d6));
+  }
+#endif
   const int Ptot = P.n_img * P.Hout * P.Wout;
   const int n_mt = (P.cout_pad + SP_BM - 1) / SP_BM;
   const int n_pt = (Ptot + BN - 1) / BN, tiles = n_pt * n_mt;
