@@ -1161,12 +1161,6 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
 template <class PT, class IT>
 __device__ __forceinline__ void sp_decode(const PT* ps, const IT* wg_base, const int nprob, const int lg, const int BN, int& by, int& bx, int& bz,
                                           int& m_tile, int& p_tile) {
-#if SF_SP_PIN && defined(__HIP_DEVICE_COMPILE__)
-  {      // the group's workgroup ranges in one request
-    const int b1 = wg_base[1], b2 = wg_base[2], b3 = wg_base[3];
-    asm volatile("" ::"s"(b1), "s"(b2), "s"(b3));
-  }
-#endif
   by = 0;
 #pragma unroll
   for (int i = 1; i < SF_MAX_GROUP; ++i)
@@ -1198,11 +1192,23 @@ __global__ __launch_bounds__(SP_THREADS) void conv_sp_kernel(const ConvLaunch L)
   // cdna_hip_programming.md T1).  Measured on the 50x50 step: 8 % less fabric traffic, 4 % MORE time — thirty workgroups
   // fetching the same lines from one L2 at the same moment is slower than the same fetches spread over eight.
   int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z, m_tile, p_tile;
-  if (L.wg_base[L.nprob] > 0) {      // block-uniform
+  // the launch record's scalars in ONE request (they are adjacent in the kernel-argument segment): the count of problems, the XCD
+  // flag and the five workgroup bases used to be four dependent round trips
+  const int np_ = L.nprob, xs_ = L.xcd_shift;
+  int wb_[SF_MAX_GROUP + 1];
+#pragma unroll
+  for (int i = 0; i <= SF_MAX_GROUP; ++i) wb_[i] = L.wg_base[i];
+#if SF_SP_PIN && defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" ::"s"(np_), "s"(xs_), "s"(wb_[0]), "s"(wb_[1]), "s"(wb_[2]), "s"(wb_[3]), "s"(wb_[4]));
+#endif
+  int wtot_ = wb_[1];
+#pragma unroll
+  for (int i = 2; i <= SF_MAX_GROUP; ++i) wtot_ = np_ >= i ? wb_[i] : wtot_;      // wg_base[nprob]
+  if (wtot_ > 0) {      // block-uniform
     const int total = (int)gridDim.x, id = bx;
     const int q = total >> 3, r = total & 7, xcd = id & 7, slot = id >> 3;
-    const int lg = L.xcd_shift ? (xcd < r ? xcd * (q + 1) + slot : r * (q + 1) + (xcd - r) * q + slot) : id;
-    sp_decode(L.p, L.wg_base, L.nprob, lg, SpGeo<NT>::BN, by, bx, bz, m_tile, p_tile);
+    const int lg = xs_ ? (xcd < r ? xcd * (q + 1) + slot : r * (q + 1) + (xcd - r) * q + slot) : id;
+    sp_decode(L.p, wb_, np_, lg, SpGeo<NT>::BN, by, bx, bz, m_tile, p_tile);
   } else {
     const int n_mt = (L.p[by].cout_pad + SP_BM - 1) / SP_BM;
     m_tile = bx % n_mt;
