@@ -430,13 +430,14 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
 #if SF_SP_PIN && defined(__HIP_DEVICE_COMPILE__)
   // The fields of the problem record that the way to the first DMA reads, requested together and waited for once: left to itself
   // hipcc loads each field where a branch first needs it — some fifteen dependent scalar-load round trips between the entry of the
-  // kernel and the first weight DMA, on a workgroup that lives for 15-20 us and has no partner on its CU to hide them
-  if constexpr (!PST && SCALE) {      // (the SE-scaled instantiations have fewer scalar registers to spare: what the weight DMAs need)
+  // kernel and the first weight DMA, on a workgroup that lives for 15-20 us and has no partner on its CU to hide them (the items of
+  // the flow kernel read their record from device memory: the same there)
+  if constexpr (SCALE) {      // (the SE-scaled instantiations have fewer scalar registers to spare: what the weight DMAs need)
     const int q0 = P.Hout, q1 = P.Wout, q2 = P.n_img, q3 = P.nsplit, q4 = P.cin_pad, q5 = P.KH, q6 = P.KW, q18 = P.cout_pad, q19 = P.ktot, q20 = P.sp_cps;
     const float* r0 = P.w;
     asm volatile("" ::"s"(q0), "s"(q1), "s"(q2), "s"(q3), "s"(q4), "s"(q5), "s"(q6), "s"(q18), "s"(q19), "s"(q20), "s"(r0));
   }
-  if constexpr (!PST && !SCALE) {
+  if constexpr (!SCALE) {
 #define SP_PIN(x) asm volatile("" ::"s"(x))
     const int q0 = P.Hout, q1 = P.Wout, q2 = P.n_img, q3 = P.nsplit, q4 = P.cin_pad, q5 = P.KH, q6 = P.KW, q7 = P.c0, q8 = P.c1,
               q9 = P.in0_cs, q10 = P.in1_cs, q11 = P.Hin, q12 = P.Win, q13 = P.in_up, q14 = P.dil, q15 = P.stride, q16 = P.pad,

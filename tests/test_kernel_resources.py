@@ -18,7 +18,8 @@ from util import ROOT
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 # kernel-name fragment -> (max scalar spills, where they are)
 SGPR_SPILL_ALLOWED = {
-    "sp_flow_kernel": (16, "SE-gate prologue of the two SE-scaled phases of a step (once per item, not in the K loop)"),
+    "sp_flow_kernel": (20, "SE-gate prologue of the two SE-scaled phases of a step and the grouped scalar loads at the start of an item "
+                           "(once per item, not in the K loop)"),
     "conv_wino_kernel": (8, "tile decode / epilogue address set-up"),
     "conv_wino5_kernel": (8, "tile decode / epilogue address set-up"),
     "conv_sp_kernelILi0ELb1ELi2": (1, "SE-gate prologue of the 32-pixel-tile AFFINE kernel (one v_writelane)"),
