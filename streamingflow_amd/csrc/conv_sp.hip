@@ -1234,10 +1234,13 @@ typedef const __attribute__((address_space(4))) FlowPhase FlowPhaseK;      // ta
 typedef const __attribute__((address_space(4))) ConvProblem ConvProblemK;
 
 template <int EPI, bool SCALE, int NT, bool B3, class FT>
-__device__ __forceinline__ bool sp_flow_item(const FT& F, FlowPhaseK& ph, const int wg, float* smem, const int tid, const int stamp_slot) {
+__device__ __forceinline__ bool sp_flow_item(const FT& F, FlowPhaseK& ph, const int wg, float* smem, const int tid, const int stamp_slot,
+                                             int& p_tile_out) {
   ConvProblemK* const ps = (ConvProblemK*)F.p + ph.prob0;
   int by, bx, bz, m_tile, p_tile;
   sp_decode(ps, ph.wg_base, ph.nprob, wg, SpGeo<NT>::BN, by, bx, bz, m_tile, p_tile);
+  p_tile_out = p_tile;      // the pixel tile whose counter the workgroup signals when it finished one (one scalar carried to the end of
+                            // the phase: decoding it again there was a chain of dependent table loads in front of the signal)
   // tiles of phase q-1 under this item's pixels + halo, in phase q-1's own tiling
   SpDep d;
   d.done = F.done; d.err = F.err; d.timeout = F.timeout_polls;
@@ -1284,19 +1287,20 @@ __global__ __launch_bounds__(SP_THREADS) void sp_flow_kernel(const SpFlow F_by_v
     asm volatile("" : "+s"(Fk), "+v"(tid), "+s"(lds_off));
     float* const smem = smem_base + (lds_off >> 2);
     bool fin = false;
+    int p_tile_done = 0;
     {
       const auto& F = *Fk;
       FlowPhaseK& ph = ((FlowPhaseK*)F.ph)[k];
       if (wg < ph.n_wg) {          // block-uniform
         const int key = ph.epi * 4 + (ph.scaled ? 2 : 0) + (ph.nt == 4 ? 1 : 0);
         switch (key) {
-          case EPI_AFFINE * 4 + 0: fin = sp_flow_item<EPI_AFFINE, false, 2, B3>(F, ph, wg, smem, tid, k & 63); break;
-          case EPI_AFFINE * 4 + 1: fin = sp_flow_item<EPI_AFFINE, false, 4, B3>(F, ph, wg, smem, tid, k & 63); break;
-          case EPI_AFFINE * 4 + 3: fin = sp_flow_item<EPI_AFFINE, true, 4, B3>(F, ph, wg, smem, tid, k & 63); break;
-          case EPI_BLEND * 4 + 1:  fin = sp_flow_item<EPI_BLEND, false, 4, B3>(F, ph, wg, smem, tid, k & 63); break;
-          case EPI_LNG * 4 + 1:    fin = sp_flow_item<EPI_LNG, false, 4, B3>(F, ph, wg, smem, tid, k & 63); break;
-          case EPI_TRUST * 4 + 0:  fin = sp_flow_item<EPI_TRUST, false, 2, B3>(F, ph, wg, smem, tid, k & 63); break;
-          case EPI_SAMPLE * 4 + 3: fin = sp_flow_item<EPI_SAMPLE, true, 4, B3>(F, ph, wg, smem, tid, k & 63); break;
+          case EPI_AFFINE * 4 + 0: fin = sp_flow_item<EPI_AFFINE, false, 2, B3>(F, ph, wg, smem, tid, k & 63, p_tile_done); break;
+          case EPI_AFFINE * 4 + 1: fin = sp_flow_item<EPI_AFFINE, false, 4, B3>(F, ph, wg, smem, tid, k & 63, p_tile_done); break;
+          case EPI_AFFINE * 4 + 3: fin = sp_flow_item<EPI_AFFINE, true, 4, B3>(F, ph, wg, smem, tid, k & 63, p_tile_done); break;
+          case EPI_BLEND * 4 + 1:  fin = sp_flow_item<EPI_BLEND, false, 4, B3>(F, ph, wg, smem, tid, k & 63, p_tile_done); break;
+          case EPI_LNG * 4 + 1:    fin = sp_flow_item<EPI_LNG, false, 4, B3>(F, ph, wg, smem, tid, k & 63, p_tile_done); break;
+          case EPI_TRUST * 4 + 0:  fin = sp_flow_item<EPI_TRUST, false, 2, B3>(F, ph, wg, smem, tid, k & 63, p_tile_done); break;
+          case EPI_SAMPLE * 4 + 3: fin = sp_flow_item<EPI_SAMPLE, true, 4, B3>(F, ph, wg, smem, tid, k & 63, p_tile_done); break;
           default: break;
         }
       }
@@ -1305,12 +1309,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_flow_kernel(const SpFlow F_by_v
     asm volatile("" : "+s"(Fk), "+v"(tid));
     const auto& F = *Fk;
     FlowPhaseK& ph = ((FlowPhaseK*)F.ph)[k];
-    int p_tile_done = 0;
-    if (fin) {                   // block-uniform: which pixel tile this workgroup finished (the counter it signals)
-      ConvProblemK* const ps = (ConvProblemK*)F.p + ph.prob0;
-      int by, bx, bz, m_tile;
-      sp_decode(ps, ph.wg_base, ph.nprob, wg, ph.bn, by, bx, bz, m_tile, p_tile_done);
-    }
+    asm volatile("" : "+s"(p_tile_done));      // (block-uniform: the pixel tile this workgroup finished, from sp_flow_item)
     // state copy-out riding in this phase: src is an output of phase q-1 (all of it), nobody inside the flow reads dst.  The
     // workgroups without an item copy (all of them when every workgroup has one), after their own wait for phase q-1
     const int n_idle = n_grid - ph.n_wg;
