@@ -13,7 +13,8 @@
 //     load per lane from the row-major packed weights.  No LDS, no cross-lane traffic, no barrier: waves are independent;
 //   * W1 / W2 fragments (128 KB per wave and tile, L2-resident, the same for every wave) are requested one 16-row block ahead.
 //
-// GELU is vector work on the port the MFMAs issue from (sf_math.h): one reciprocal, one exp2 and 7 full-rate instructions per value.
+// GELU is vector work on the port the MFMAs issue from (sf_math.h): one reciprocal, one exp2 and about nine full-rate instructions per value
+// (packed two values per instruction where the ISA has a packed form).
 // gfx950 only.
 #include <hip/hip_runtime.h>
 
