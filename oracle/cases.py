@@ -2,7 +2,7 @@
 
 Both ``oracle/gen_golden.py`` (which runs the real reference in the build container) and the tests
 (which run the oracle / the HIP path) regenerate inputs and weights from these definitions with
-``oracle.hashfill``; only expected outputs are stored under ``tests/golden``.
+``workloads.hashfill``; only expected outputs are stored under ``tests/golden``.
 """
 import torch
 

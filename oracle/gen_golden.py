@@ -23,7 +23,8 @@ import sys
 import numpy as np
 import torch
 
-from . import cases, hashfill, refimport
+from workloads import hashfill
+from . import cases, refimport
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 

@@ -43,7 +43,8 @@ def stats_of(lid):
 
 def main():
     import voxelbench
-    from oracle import hashfill, sparse_encoder_ref as SR, voxelize as VZ
+    from workloads import hashfill
+    from oracle import sparse_encoder_ref as SR, voxelize as VZ
     from streamingflow_amd.models import streamingflow as SFM
     torch.set_num_threads(8)
     cfg = SFM.default_cfg()

@@ -1,5 +1,5 @@
 """Shared helpers of the parity tests: the product module and the oracle state_dict are filled
-with the same hashed weights (oracle.cases / oracle.hashfill), nothing is read from disk."""
+with the same hashed weights (oracle.cases / workloads.hashfill), nothing is read from disk."""
 import os
 import sys
 
@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from oracle import cases, hashfill, refimport  # noqa: E402
+from oracle import cases, refimport  # noqa: E402
+from workloads import hashfill  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 

@@ -1,10 +1,10 @@
 #!/bin/bash
-# experiment build of libsfnative.so with extra hipcc flags into build_r02/<name>/ (git-ignored; travels with gpurun)
-# usage: tools/r02/build_variant.sh <name> [flags...]     then run with SF_LIB_PATH=build_r02/<name>/libsfnative.so
+# experiment build of libsfnative.so with extra hipcc flags into build_var/<name>/ (git-ignored; travels with gpurun)
+# usage: tools/build_variant.sh <name> [flags...]     then run with SF_LIB_PATH=build_var/<name>/libsfnative.so
 set -e
-cd "$(dirname "$0")/../.."
+cd "$(dirname "$0")/.."
 name=$1; shift
-out=build_r02/$name; mkdir -p $out
+out=build_var/$name; mkdir -p $out
 srcs="conv_igemm conv_sp conv_wino convnext_mlp aux_kernels api lift_splat voxelize sparse_index eval_kernels pack $SF_EXTRA_SRCS"
 pids=()
 for s in $srcs; do

@@ -1,5 +1,5 @@
-"""In-kernel time stamps of one Euler ode_step (diagnostic build: tools/r02/build_variant.sh stamp -DSF_STAMP).
-Usage: SF_LIB_PATH=build_r02/stamp/libsfnative.so python3 tools/r02/stamps.py <batch> <h> <w>"""
+"""In-kernel time stamps of one Euler ode_step (diagnostic build: tools/build_variant.sh stamp -DSF_STAMP).
+Usage: SF_LIB_PATH=build_var/stamp/libsfnative.so python3 tools/r02/stamps.py <batch> <h> <w>"""
 import os
 import sys
 

@@ -19,7 +19,8 @@ import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from oracle import cases, hashfill, ref_torch as R  # noqa: E402
+from oracle import cases, ref_torch as R  # noqa: E402
+from workloads import hashfill  # noqa: E402
 from util import build_pair  # noqa: E402
 
 MODE = {"n": 0}

@@ -1,5 +1,5 @@
-"""In-kernel time stamps of ONE large convolution on the LDS-DMA kernel (diagnostic build: tools/r02/build_variant.sh stamp -DSF_STAMP).
-Usage: SF_LIB_PATH=build_r02/stamp/libsfnative.so python3 tools/r03/stamps_bigconv.py [cout cin n H W]"""
+"""In-kernel time stamps of ONE large convolution on the LDS-DMA kernel (diagnostic build: tools/build_variant.sh stamp -DSF_STAMP).
+Usage: SF_LIB_PATH=build_var/stamp/libsfnative.so python3 tools/r03/stamps_bigconv.py [cout cin n H W]"""
 import ctypes
 import os
 import sys

@@ -2,7 +2,7 @@
 per phase of the last two steady-state Euler steps of a 1-jump + N-step rollout of one 50x50x64 latent, over the workgroups that
 had an item: dependency wait, acquire + barrier, first chunk, K loop, hand-off, epilogue, drain (10-ns clock, s_memrealtime),
 and the spans / overlaps between consecutive phases.
-Usage: SF_PERSIST=1 SF_LIB_PATH=build_r02/stamp/libsfnative.so python3 tools/r04/flow_stamps.py [n_steps]"""
+Usage: SF_PERSIST=1 SF_LIB_PATH=build_var/stamp/libsfnative.so python3 tools/r04/flow_stamps.py [n_steps]"""
 import os
 import sys
 

@@ -14,7 +14,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from streamingflow_amd.models.sparse_encoder import SparseEncoder   # noqa: E402
 from streamingflow_amd.voxelize import Voxelization, voxelize   # noqa: E402
-from oracle import cases, hashfill, sparse_encoder_ref as SR   # noqa: E402
+from oracle import cases, sparse_encoder_ref as SR   # noqa: E402
+from workloads import hashfill   # noqa: E402
 import voxelbench   # noqa: E402
 
 

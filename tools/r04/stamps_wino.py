@@ -1,7 +1,7 @@
-"""In-kernel time stamps of ONE Winograd launch (diagnostic build: tools/r02/build_variant.sh stamp -DSF_STAMP).
+"""In-kernel time stamps of ONE Winograd launch (diagnostic build: tools/build_variant.sh stamp -DSF_STAMP).
 Per workgroup (the first 4096 of the launch): entry, end of prologue, end of the stage loop, end of the epilogue, stores drained,
 plus HW_ID / XCC_ID -> which workgroups share a CU and how their phases overlap.
-Usage: SF_LIB_PATH=build_r02/stamp/libsfnative.so python3 tools/r04/stamps_wino.py [cout cin n H W dil]"""
+Usage: SF_LIB_PATH=build_var/stamp/libsfnative.so python3 tools/r04/stamps_wino.py [cout cin n H W dil]"""
 import ctypes
 import os
 import sys

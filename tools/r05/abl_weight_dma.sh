@@ -6,7 +6,7 @@ cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for v in product abl_now; do
   rm -rf $R/gpurun_out/trace_abl_$v
-  if [ $v = product ]; then unset SF_LIB_PATH; else export SF_LIB_PATH=$R/build_r02/abl_now/libsfnative.so; fi
+  if [ $v = product ]; then unset SF_LIB_PATH; else export SF_LIB_PATH=$R/build_var/abl_now/libsfnative.so; fi
   SF_PERSIST=0 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trace_abl_$v -- python3 $R/tools/chainbench.py euler 4 8 > $R/gpurun_out/trace_abl_$v.log 2>&1
   echo "== $v"
   grep "per step" $R/gpurun_out/trace_abl_$v.log | tail -1

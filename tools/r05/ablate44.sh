@@ -2,7 +2,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 for v in base abl1 abl2 abl4 abl8 abl16 abl32 abl63; do
-  lib=build_r02/w5_$v/libsfnative.so
+  lib=build_var/w5_$v/libsfnative.so
   [ $v = base ] && lib=streamingflow_amd/libsfnative.so
   for only in "DeepLab" "decoder / encoder 64->64"; do
     SF_LIB_PATH=$lib WINOBENCH_ONLY="$only" timeout 300 python tools/r04/winobench.py 5 2>/dev/null | grep -v '^{"winobench' | python3 -c "

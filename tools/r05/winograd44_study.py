@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools", "r04"))
-from oracle import cases, hashfill, ref_torch as R  # noqa: E402
+from oracle import cases, ref_torch as R  # noqa: E402
+from workloads import hashfill  # noqa: E402
 from util import build_pair  # noqa: E402
 import winograd_study as W22  # noqa: E402  (F(2x2, 3x3) restatement; importing it installs ITS shim, replaced below)
 

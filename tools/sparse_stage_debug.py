@@ -3,7 +3,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from streamingflow_amd.models import sparse_encoder as SE
 from streamingflow_amd.voxelize import Voxelization, voxelize
-from oracle import cases, sparse_encoder_ref as SR, hashfill
+from oracle import cases, sparse_encoder_ref as SR
+from workloads import hashfill
 import voxelbench
 cfg = SR.default_cfg()
 m = SE.SparseEncoder(cfg["in_channels"], cfg["sparse_shape"], base_channels=16, output_channels=128, encoder_channels=cfg["encoder_channels"], encoder_paddings=cfg["encoder_paddings"], block_type="basicblock").eval()
