@@ -460,7 +460,12 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
   const int nch_all = (nsub_all + 1) >> 1;
   const int cps = P.sp_cps > 0 ? P.sp_cps : (nch_all + nsplit - 1) / nsplit;     // chunks per K slice (host: every slice non-empty)
   const int cb = bz * cps;
+#if defined(SF_ABL_K49)      // timing-only ablation (results are garbage): the K loop of every 3x3 layer cut to 4/9 of its chunks — what the products
+  const int nchunks_full = (nch_all - cb) < cps ? (nch_all - cb) : cps;      // of a Winograd F(2x2, 3x3) form would cost at most
+  const int nchunks = (P.KH == 3 && P.KW == 3 && P.dil == 1) ? (nchunks_full * 4 + 8) / 9 : nchunks_full;
+#else
   const int nchunks = (nch_all - cb) < cps ? (nch_all - cb) : cps;
+#endif
 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
