@@ -170,7 +170,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int wino, wino_min_p, flow_timeout, b3_small_tiles, wide64, seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int wino, wino_sp, wsp_minsub, wino_min_p, flow_timeout, b3_small_tiles, wide64, seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -182,6 +182,8 @@ const Tune& tune() {
     x.wino = geti("SF_WINO", 1);                   // layers packed with Winograd weights run conv_wino.hip from wino_min_p pixels (0: direct form everywhere)
     x.wino_min_p = geti("SF_WINO_MIN_P", 14000);       // measured (profiles/r04_zz_wino_min_p_sweep.txt, r04_zz_step_min_p_batched_latents.txt): 6 or more batched 50x50 latents
                                                      // and one 200x200 latent gain 6-11 % per ODE step, 5 latents / one 100x100 latent lose 4-7 %; 32 latents +1.6 % on the headline
+    x.wino_sp = geti("SF_WINO_SP", 1);             // one latent (small-P kernel, launch path): its 3x3 layers run in the Winograd form too (conv_sp.hip; 0: direct form — the round-5 step)
+    x.wsp_minsub = geti("SF_WSP_MINSUB", 2);       // ... a K slice of such a layer is at least this many 32-channel sub-chunks
     x.flow_timeout = geti("SF_FLOW_TIMEOUT", 1 << 22);   // polls before a dependency wait of the flow kernel gives up (~1 us each: seconds); bring-up runs use a small value
     x.fenced = geti("SF_HANDOFF_FENCED", 0);       // 1: split-K hand-offs also run the agent-scope release / acquire fences of round 1 (known-good reference for the fence-free sc1 form; gfx950 only either way)
     x.b3 = geti("SF_BF16X3", 1);                   // layers packed with split-bf16 weights (opt-in at pack time) run the bf16x3 K loop where a kernel has one (0: exact fp32 even then)
@@ -262,8 +264,24 @@ bool sp_takes(const ConvProblem* ps, int n, int epi) {
 // pixels per tile of the small-P kernel.  Measured on the conv launches of an Euler step at 50x50 (profiles/r02_*):
 // 64-pixel tiles with the K range split across workgroups win where a launch has a lot of work (both gate / candidate
 // pairs, the 128 -> 128 layers of p_model, the 7x7), 32-pixel tiles without a hand-off elsewhere
-int sp_bn(const ConvProblem* ps, int n) {
+struct FlowBuilder;
+extern thread_local FlowBuilder* g_seg;
+// ... and which of its 3x3 layers take the Winograd F(2x2, 3x3) form there (conv_sp.hip, ConvProblem::sp_wino): one image with even
+// sides (a 64-pixel tile is then 16 whole Winograd tiles and the tile counts of both forms agree), stride 1, pad 1, no dilation, inputs in
+// whole 32-channel sub-chunks, cout in whole 64-row tiles, transformed weights packed; not inside a persistent flow (its tile-level
+// dependencies are in linear pixels), not the LayerNorm layers (the 7x7 and its fused 1x1)
+bool sp_wino_ok(const ConvProblem& q, int epi) {
+  if (!tune().wino || !tune().wino_sp || g_seg || !q.w_wino || epi == EPI_LNG) return false;
+  if (q.KH != 3 || q.KW != 3 || q.stride != 1 || q.dil != 1 || q.pad != 1 || q.in_up || q.gather || q.gate || q.fuse_w || q.out_planar || q.pool2 || q.add_up) return false;
+  if (q.n_img != 1 || (q.Hout & 1) || (q.Wout & 1) || q.Hin != q.Hout || q.Win != q.Wout || q.Wout < 4 || q.Hout < 4) return false;
+  if ((q.c0 % 32) || (q.c1 % 32) || q.c0 + q.c1 != q.cin_pad || (q.cout_pad % 64)) return false;
+  if (tune().b3 && q.w3) return false;
+  return 4.0 * 16 * q.cout_pad * q.cin_pad < 2147483648.0;
+}
+int sp_bn(const ConvProblem* ps, int n, int epi) {
   if (tune().sp_bn) return tune().sp_bn;
+  for (int i = 0; i < n; ++i)
+    if (sp_wino_ok(ps[i], epi)) return 64;      // the Winograd form lives on the 64-pixel tiles
   double work = 0;
   for (int i = 0; i < n; ++i)
     work += (double)((ps[i].n_img * ps[i].Hout * ps[i].Wout + 63) / 64) * ((ps[i].cout_pad + 63) / 64) * ((ps[i].KH * ps[i].KW * (ps[i].cin_pad / 32) + 1) / 2);
@@ -271,7 +289,7 @@ int sp_bn(const ConvProblem* ps, int n) {
 }
 // pixels per SE partial-sum row the producing conv's epilogue writes (the SE gate kernel sums ceil(P / this) rows)
 // (the producer's whole launch group decides its tile)
-int chansum_tile_px(const ConvProblem* group, int n, int epi) { return sp_takes(group, n, epi) ? sp_bn(group, n) : 16; }
+int chansum_tile_px(const ConvProblem* group, int n, int epi) { return sp_takes(group, n, epi) ? sp_bn(group, n, epi) : 16; }
 
 // ---- persistent flow (one latent inside a rollout, SF_PERSIST=1): run() records its small-P launch groups as phases of ONE
 // persistent launch (conv_sp.hip: sp_flow_kernel) instead of launching them.  The phase / problem tables are built on the host,
@@ -591,11 +609,14 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   if (sp_takes(ps, n, epi)) {
     // K ranges are split across workgroups (sc1 slab hand-off) so that the launch has about sp_split_wgs workgroups of
     // equal length: a 2500-pixel layer has only 40 tiles of 64 pixels per 64 output channels
-    const int bn = sp_bn(ps, n);
+    const int bn = sp_bn(ps, n, epi);
+    bool wn_of[SF_MAX_GROUP];
+    for (int i = 0; i < n; ++i) wn_of[i] = bn == 64 && sp_wino_ok(ps[i], epi);
     double work_total = 0;
     for (int i = 0; i < n; ++i) {
       const int tiles = ((ps[i].n_img * ps[i].Hout * ps[i].Wout + bn - 1) / bn) * ((ps[i].cout_pad + 63) / 64);
-      work_total += (double)tiles * ((ps[i].KH * ps[i].KW * (ps[i].cin_pad / 32) + 1) / 2);
+      // (a 32-channel sub-chunk of the Winograd form costs a 64-pixel tile what a 64-deep chunk of the direct form does: 64 MFMAs per wave)
+      work_total += (double)tiles * (wn_of[i] ? ps[i].cin_pad / 32 : (ps[i].KH * ps[i].KW * (ps[i].cin_pad / 32) + 1) / 2);
     }
     const double per_wg = work_total / tune().sp_split_wgs;      // chunks per workgroup at the target
     int ns_of[SF_MAX_GROUP], tiles_of[SF_MAX_GROUP], nch_of[SF_MAX_GROUP];
@@ -604,9 +625,10 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     for (int i = 0; i < n; ++i) {
       const ConvProblem& q = ps[i];
       tiles_of[i] = ((q.n_img * q.Hout * q.Wout + bn - 1) / bn) * ((q.cout_pad + 63) / 64);
-      nch_of[i] = (q.KH * q.KW * (q.cin_pad / 32) + 1) / 2;
+      nch_of[i] = wn_of[i] ? q.cin_pad / 32 : (q.KH * q.KW * (q.cin_pad / 32) + 1) / 2;
       int ns = (may_split && per_wg > 0) ? (int)(nch_of[i] / per_wg + 0.5) : 1;
-      if (ns > nch_of[i] / 3) ns = nch_of[i] / 3;      // at least 3 chunks per slice
+      const int min_per = wn_of[i] ? (tune().wsp_minsub > 0 ? tune().wsp_minsub : 1) : 3;      // at least 3 chunks (direct) / wsp_minsub sub-chunks (Winograd) per slice
+      if (ns > nch_of[i] / min_per) ns = nch_of[i] / min_per;
       if (ns > 8) ns = 8;
       if (ns < 1) ns = 1;
       ns_of[i] = ns;
@@ -647,6 +669,14 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       slab_off += (size_t)tiles_of[i] * ns * per;
       cnt_off += tiles_of[i];
     }
+    for (int i = 0; i < n; ++i) {
+      ConvProblem& q = L.p[i];
+      q.sp_wino = wn_of[i] ? 1 : 0;
+      if (wn_of[i]) {      // K slices in 32-channel sub-chunks (also when no reciprocals are made below)
+        const int ns = q.nsplit > 1 ? q.nsplit : 1;
+        q.sp_cps = (q.cin_pad / 32 + ns - 1) / ns;
+      }
+    }
     L.stamp_slot = g_stamp_slot;
     if (g_stamp_on) g_stamp_slot = (g_stamp_slot + 1) % 64;
     // compact 1-D grid: problem i owns logical workgroups [wg_base[i], wg_base[i + 1]); bit 0 of sp_xcd: compact grid,
@@ -668,8 +698,9 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       for (int i = 0; i < n && magic_on; ++i) {
         ConvProblem& q = L.p[i];
         const long Pi = (long)q.n_img * q.Hout * q.Wout, n_pt = (Pi + bn - 1) / bn, n_mt = (q.cout_pad + 63) / 64, tiles = n_pt * n_mt;
-        const int ns = q.nsplit > 1 ? q.nsplit : 1, kcpt = q.cin_pad >> 5, nch_all = (q.KH * q.KW * kcpt + 1) >> 1;
+        const int ns = q.nsplit > 1 ? q.nsplit : 1, kcpt = q.cin_pad >> 5, nch_all = wn_of[i] ? kcpt : (q.KH * q.KW * kcpt + 1) >> 1;
         if (tiles * ns * tiles >= 0x100000000L || (Pi + 64) * q.Hout * q.Wout >= 0x100000000L) continue;
+        q.sp_m_tw = magic(q.Wout / 2);
         // d = 1 has no reciprocal (0 = "divide"): dividing by one is what the fallback does
         q.sp_m_tiles = magic(tiles); q.sp_m_npt = magic(n_pt); q.sp_m_hw = magic((long)q.Hout * q.Wout); q.sp_m_w = magic(q.Wout);
         q.sp_m_kcpt = magic(kcpt); q.sp_m_kw = magic(q.KW);

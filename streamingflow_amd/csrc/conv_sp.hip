@@ -74,6 +74,18 @@ struct SpGeo {
 };
 template <int NT>
 constexpr int sp_lds_bytes(bool scale) { return (SpGeo<NT>::RING + SP_MISC + (scale ? SP_SC_FLOATS : 0)) * 4; }
+// Winograd F(2x2, 3x3) form of a 3x3 layer on one latent (ConvProblem::sp_wino; see the block in sp_body): a 64-pixel tile is 16
+// Winograd tiles; per 32-channel sub-chunk the gathered 4x4 patches [16 tiles][16 px][32] and their transform V[16 positions][16 tiles][32],
+// two buffers each; the products M[16 positions][16 tiles][SP_RED_PITCH] land over both after the loop
+constexpr int SPW_SUB = 16 * 16 * 32;             // floats of one raw / one V buffer (32 KB)
+constexpr int SPW_REGION = 4 * SPW_SUB;           // 128 KB
+static_assert(16 * 16 * SP_RED_PITCH + 512 <= SPW_REGION, "M + channel-sum scratch live in the region");
+// which instantiations carry the Winograd block: 64-pixel tiles, exact fp32, launch path (the flow kernel keeps the direct form), no fused 1x1
+template <int EPI, int NT, bool B3, bool PST>
+constexpr bool sp_has_wino() { return NT == 4 && !B3 && !PST && EPI != EPI_LNG; }
+// floats in front of misc / SE rows / fused-layer buffer
+template <int EPI, int NT, bool B3, bool PST>
+constexpr int sp_region() { return sp_has_wino<EPI, NT, B3, PST>() && SPW_REGION > SpGeo<NT>::RING ? SPW_REGION : SpGeo<NT>::RING; }
 
 #if defined(SF_ABL_NO_WEIGHT_DMA)
 #define SP_ABL_NO_W 1
@@ -422,6 +434,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
   typedef SpGeo<NT> G;
   constexpr int BN = G::BN;
   constexpr bool VOL = PST && (SF_FLOW_SC1 != 0);      // flow mode: L1-bypassing loads of activations instead of an acquire
+  constexpr bool WINO = sp_has_wino<EPI, NT, B3, PST>();
   constexpr int PX_AUX = VOL ? 16 : 0;                 // aux bits of the pixel DMAs (16 = sc1)
   // XOR mask of the 16-byte slot swizzle of the ring: 7 for the fp32 fragment reads (slots c + g), 5 for the bf16x3 loop
   // (slots 2g / 2g + 1: conflict-free for the ds_read_b128 lane groups, see conv_igemm.hip)
@@ -457,19 +470,21 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
   if (bz >= nsplit) return false;                      // block-uniform
   const int kcpt = P.cin_pad >> 5;                     // 32-deep sub-chunks per tap
   const int nsub_all = P.KH * P.KW * kcpt;
-  const int nch_all = (nsub_all + 1) >> 1;
+  bool wn = false;                                     // block-uniform: this problem runs in the Winograd form (K slices count 32-channel sub-chunks)
+  if constexpr (WINO) wn = P.sp_wino != 0;
+  const int nch_all = wn ? kcpt : (nsub_all + 1) >> 1;
   const int cps = P.sp_cps > 0 ? P.sp_cps : (nch_all + nsplit - 1) / nsplit;     // chunks per K slice (host: every slice non-empty)
   const int cb = bz * cps;
 #if defined(SF_ABL_K49)      // timing-only ablation (results are garbage): the K loop of every 3x3 layer cut to 4/9 of its chunks — what the products
   const int nchunks_full = (nch_all - cb) < cps ? (nch_all - cb) : cps;      // of a Winograd F(2x2, 3x3) form would cost at most
-  const int nchunks = (P.KH == 3 && P.KW == 3 && P.dil == 1) ? (nchunks_full * 4 + 8) / 9 : nchunks_full;
+  const int nchunks = (!wn && P.KH == 3 && P.KW == 3 && P.dil == 1) ? (nchunks_full * 4 + 8) / 9 : nchunks_full;
 #else
   const int nchunks = (nch_all - cb) < cps ? (nch_all - cb) : cps;
 #endif
 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  float* const misc = smem + G::RING;
+  float* const misc = smem + sp_region<EPI, NT, B3, PST>();
   float* const sc_lds = misc + SP_MISC;      // SCALE instantiations only
   const int img0 = sp_mdiv(p_tile * BN, P.sp_m_hw, HWout);              // block-uniform: first image this tile touches
   const int cin_pad = P.cin_pad;
@@ -584,13 +599,23 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
   // K loop would carry beside its accumulators and fragment sets — the 64-pixel kernels sat at the 168-register cap of a
   // 768-thread workgroup and the TRUST one spilled; the two barriers of the K-quarter reduction and the split-K hand-off cover the loads).
   constexpr bool OPS_EARLY = (NT != 4);
-  int px[G::NPX];
+  int px[G::NPX], gpx[G::NPX];      // pixel of the tile / of the tensor
   bool on_item[G::NPX];
   SpOps ops[G::NPX];
 #pragma unroll
   for (int i = 0; i < G::NPX; ++i) {
     px[i] = (wave < 8 ? 4 * wave : 0) + (lane >> 4) + 32 * i;
-    on_item[i] = (wave < 8) && (p_tile * BN + px[i]) < Ptot && c_out < P.cout;
+    gpx[i] = p_tile * BN + px[i];
+    if constexpr (WINO) {
+      if (wn) {      // Winograd form (one image, even H and W): tile pixel 4 t + 2 dy + dx is output (2 ty + dy, 2 tx + dx) of Winograd tile p_tile * 16 + t
+        const int TW = P.Wout >> 1;
+        const int t = p_tile * (BN / 4) + (px[i] >> 2);
+        const int ty = sp_mdiv(t, P.sp_m_tw, TW), tx = t - ty * TW;
+        const int gq = (2 * ty + ((px[i] >> 1) & 1)) * P.Wout + 2 * tx + (px[i] & 1);
+        gpx[i] = 4 * t < Ptot ? gq : Ptot;
+      }
+    }
+    on_item[i] = (wave < 8) && gpx[i] < Ptot && c_out < P.cout;
   }
   // fused 1x1 layer (LNG launches, block-uniform): its weights and this tile's output meet in a chunk-shaped buffer behind
   // the ring — [2 sub-chunks][64 weight rows | BN pixel rows][32] — and run through the consumers' fragment / MFMA code once more
@@ -657,7 +682,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
   auto consumer_operands = [&]() {              // consumer waves, behind the flow wait
     if (OPS_EARLY) {
 #pragma unroll
-      for (int i = 0; i < G::NPX; ++i) sp_epi_load<EPI, VOL>(P, p_tile * BN + px[i], c_out, on_item[i], HWout, ops[i]);
+      for (int i = 0; i < G::NPX; ++i) sp_epi_load<EPI, VOL>(P, gpx[i], c_out, on_item[i], HWout, ops[i]);
     }
   };
   if constexpr (!PST) {
@@ -665,6 +690,202 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
     SF_STAMP_AT(L, 0);
   }
 
+
+  float4 v[G::NPX];
+  float* const red = smem;                                // direct form: [4][BN][SP_RED_PITCH]; Winograd form: M[16][16][SP_RED_PITCH]
+  bool wn_done = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (WINO) {
+    if (wn) {      // block-uniform
+      // ============================ Winograd F(2x2, 3x3) form of a 3x3 layer on one latent ===========================================
+      // Y = A^T [ (G g G^T) . (B^T d B) ] A per 2x2 outputs: 16 products instead of 36 (conv_wino.hip has the batched form; the transformed
+      // weights U[cin / 16][16 positions][cout_pad][16] are the same copy).  The workgroup owns 16 consecutive Winograd tiles (= the 64 pixels
+      // of its tile, in 2x2 blocks) x 64 cout x a slice of the input channels (K is split ACROSS workgroups by channel; the output
+      // transform is linear, so every workgroup transforms its own partial products and the slabs / tickets / epilogues below are the
+      // direct form's).  Per 32-channel sub-chunk:
+      //   loader lw    gathers the 4x4 patches of ITS four tiles (8 LDS-DMAs: 8 pixels x 128 B each, zero fill outside the image),
+      //                transforms them — lane = (tile, channel quad, row i of B^T d B): 8 ds_read_b128, 8 packed-width adds, 4 ds_write_b128
+      //                — into V[position][tile][32] (slots XOR-swizzled by the tile like the ring's pixel rows) and joins ONE barrier;
+      //                it only ever reads what it fetched itself, so nothing but its own vmcnt stands between a DMA and its transform
+      //   consumer w   owns positions 2w, 2w+1: per 16 channels 2 ds_read_b128 (V) + 8 buffer_load_dwordx4 straight from U (1 KB contiguous
+      //                per fragment, a 16-channel group ahead, no LDS) feed 32 MFMAs
+      // then M -> LDS, and lane (pixel, channel quad) sums the 9 signed terms of A^T M A of its pixel: this replaces the direct form's
+      // reduction over K quarters.  Fixed orders everywhere: bitwise reproducible.
+      float* const raw = smem;                  // [2][16 tiles][16 px][32]
+      float* const Vb = smem + 2 * SPW_SUB;     // [2][16 positions][16 tiles][32]
+      const int nsc = nchunks;                  // 32-channel sub-chunks of this slice: cb .. cb + nsc - 1
+      const int TW = P.Wout >> 1, ntiles = (P.Hout >> 1) * TW;
+      f32x4 wacc[2][4];                         // consumers: positions 2w, 2w+1 x the four 16-row cout fragments
+      if (wave >= 8) {
+        // ---------------------------------------------- loader ------------------------------------------------------------------
+        const int slotl = lane & 7, row8 = lane >> 3;
+        int vb0[8], vb1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int t = p_tile * 16 + 4 * lw + (i >> 1);
+          const int r = 2 * (i & 1) + (row8 >> 2), c = row8 & 3;
+          const int ty = sp_mdiv(t, P.sp_m_tw, TW), tx = t - ty * TW;
+          const int iy = 2 * ty - 1 + r, ix = 2 * tx - 1 + c;
+          const bool in = (t < ntiles) & (iy >= 0) & (iy < P.Hin) & (ix >= 0) & (ix < P.Win);
+          const int pxo = in ? iy * P.Win + ix : 0;
+          vb0[i] = in ? (pxo * P.in0_cs + 4 * slotl) * 4 : (int)0x80000000;
+          vb1[i] = in ? (pxo * P.in1_cs - P.c0 + 4 * slotl) * 4 : (int)0x80000000;
+        }
+        const __amdgpu_buffer_rsrc_t rsrc0 = make_rsrc(P.in0, (size_t)P.Hin * P.Win * P.in0_cs * sizeof(float));
+        const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(P.in1 ? P.in1 : P.in0, P.in1 ? (size_t)P.Hin * P.Win * P.in1_cs * sizeof(float) : 0);
+        const int c0 = P.c0;
+        auto issue_raw = [&](const int sidx) {      // sub-chunk cb + sidx into raw buffer sidx & 1: this loader's 4 tiles
+          const int kc = cb + sidx;
+          const bool from1 = kc * 32 >= c0;         // wave-uniform
+          const int koff = kc * 128;
+          float* const dst = raw + (sidx & 1) * SPW_SUB + (4 * lw) * 512;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (sp_lds_void*)(dst + i * 256), 16, vb1[i] + koff, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (sp_lds_void*)(dst + i * 256), 16, vb0[i] + koff, 0, 0, 0);
+          }
+        };
+        issue_raw(0);
+        if (nsc > 1) issue_raw(1);
+        // the two items of this lane: (tile tl, row i of the transform, channel quad q)
+        int rd_a[2], rd_b[2], wr[2], q4[2];
+        float sg[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const int id = lane + 64 * n;
+          const int q = id & 7, i = (id >> 3) & 3, tl = id >> 5;
+          // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: row i of B^T d = d[ra] + sg d[rb]
+          const int ra = i == 0 ? 0 : (i == 2 ? 2 : 1), rb = i == 0 ? 2 : (i == 1 ? 2 : (i == 2 ? 1 : 3));
+          sg[n] = i == 1 ? 1.f : -1.f;
+          const int tbase = (4 * lw + tl) * 512 + 4 * q;
+          rd_a[n] = tbase + ra * 128; rd_b[n] = tbase + rb * 128;
+          const int tile_l = 4 * lw + tl;
+          wr[n] = ((4 * i) * 16 + tile_l) * 32 + 4 * (q ^ ((tile_l >> 1) & 7));
+          q4[n] = 4 * q;
+        }
+        fill_scale_rows();
+        if constexpr (SCALE) sp_barrier();                        // the SE rows (every wave wrote a part) are published
+        for (int sidx = 0; sidx < nsc; ++sidx) {
+          if (sidx + 1 < nsc) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the older of two sub-chunks in flight has landed
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const float* const rbuf = raw + (sidx & 1) * SPW_SUB;
+          float* const vbuf = Vb + (sidx & 1) * SPW_SUB;
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            f32x4 da[4], db[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { da[c] = sp_lds_read128(rbuf + rd_a[n] + c * 32); db[c] = sp_lds_read128(rbuf + rd_b[n] + c * 32); }
+            f32x4 t[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) t[c] = da[c] + sg[n] * db[c];
+            f32x4 o[4];
+            o[0] = t[0] - t[2]; o[1] = t[1] + t[2]; o[2] = t[2] - t[1]; o[3] = t[1] - t[3];
+            if constexpr (SCALE) {      // SE gate of the input: per channel, commutes with the transform
+              const f32x4 sc4 = sp_lds_read128(sc_lds + (cb + sidx) * 32 + q4[n]);
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) o[jj] = o[jj] * sc4;
+            }
+            typedef __attribute__((address_space(3))) f32x4 lds_f4w;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) *(lds_f4w*)(vbuf + wr[n] + jj * 512) = o[jj];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // V written, the raw buffer read
+          if (sidx + 2 < nsc) issue_raw(sidx + 2);                // into the buffer just transformed (this loader's own region)
+          sp_barrier();                                           // V[sidx] published
+        }
+      } else {
+        // ---------------------------------------------- consumer ----------------------------------------------------------------
+        const int j = lane & 15, g = lane >> 4;
+        const __amdgpu_buffer_rsrc_t rsrc_u = make_rsrc(P.w_wino, (size_t)16 * P.cout_pad * P.cin_pad * sizeof(float));
+        const int a_voff = (j * 16 + 4 * g) * 4;
+        const int pos0 = 2 * wave;
+        const int u_pos = P.cout_pad * 64;                        // bytes between positions
+        const int u_grp = 16 * u_pos;                             // bytes between 16-channel groups
+        int u_so = (2 * cb * 16 + pos0) * u_pos + m_tile * (SP_BM * 64);      // group 2 cb, position pos0, this cout tile
+        int b_off[2];
+#pragma unroll
+        for (int pz = 0; pz < 2; ++pz) b_off[pz] = ((pos0 + pz) * 16 + j) * 32;
+        const int sxm = (j >> 1) & 7;
+        const int slot_h0 = (g ^ sxm) * 4, slot_h1 = ((4 + g) ^ sxm) * 4;
+        typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+        f32x4 fa[2][2][4], fb[2];
+#pragma unroll
+        for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) wacc[pz][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto load_a = [&](const int set) {      // the 8 A fragments of the next 16-channel group
+#pragma unroll
+          for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+              fa[set][pz][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, a_voff + m * 1024, u_so + pz * u_pos, 0));
+          u_so += u_grp;
+        };
+        auto mfma_grp = [&](const int set) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+              for (int m = 0; m < 4; ++m)
+                wacc[pz][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][pz][m][e], fb[pz][e], wacc[pz][m], 0, 0, 0);
+        };
+        load_a(0);
+        fill_scale_rows();
+        if constexpr (SCALE) sp_barrier();
+        for (int sidx = 0; sidx < nsc; ++sidx) {
+          const float* const vbuf = Vb + (sidx & 1) * SPW_SUB;
+          sp_barrier();                                           // V[sidx] published
+#pragma unroll
+          for (int pz = 0; pz < 2; ++pz) fb[pz] = sp_lds_read128(vbuf + b_off[pz] + slot_h0);
+          load_a(1);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_grp(0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int pz = 0; pz < 2; ++pz) fb[pz] = sp_lds_read128(vbuf + b_off[pz] + slot_h1);
+          if (sidx + 1 < nsc) load_a(0);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_grp(1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // epilogue operands (two items per lane): behind the loop, as in the direct form on 64-pixel tiles
+#pragma unroll
+        for (int i = 0; i < G::NPX; ++i) sp_epi_load<EPI, VOL>(P, gpx[i], c_out, on_item[i], HWout, ops[i]);
+      }
+      __syncthreads();                                            // every V read and every DMA is done: M may land over the buffers
+      if (wave < 8) {
+        const int j = lane & 15, g = lane >> 4, pos0 = 2 * wave;
+#pragma unroll
+        for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            spm_st4(red + ((pos0 + pz) * 16 + j) * SP_RED_PITCH + 16 * m + 4 * g, make_float4(wacc[pz][m][0], wacc[pz][m][1], wacc[pz][m][2], wacc[pz][m][3]));
+      }
+      __syncthreads();
+      // A^T = [1 1 1 0; 0 1 -1 -1]: output (dy, dx) of a tile = sum over rows dy .. dy+2, columns dx .. dx+2 of M, a term negative when
+      // exactly one of (dy and row > dy), (dx and column > dx) holds
+#pragma unroll
+      for (int i = 0; i < G::NPX; ++i) {
+        v[i] = spm_zero4();
+        if (wave < 8) {
+          const int tl = px[i] >> 2, dy = (px[i] >> 1) & 1, dx = px[i] & 1;
+          const float* const mb = red + ((4 * dy + dx) * 16 + tl) * SP_RED_PITCH + 4 * quad;
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+              const float sgn = ((dy && a) != (dx && b)) ? -1.f : 1.f;
+              const float4 t = spm_ld4(mb + ((4 * a + b) * 16) * SP_RED_PITCH);
+              v[i].x += sgn * t.x; v[i].y += sgn * t.y; v[i].z += sgn * t.z; v[i].w += sgn * t.w;
+            }
+        }
+      }
+      wn_done = true;
+    }
+  }
+#endif
+  if (!wn_done) {
   if (wave >= 8) {
     // ================================= loader =================================================================
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -976,10 +1197,9 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
   SF_STAMP_AT(L, 3);
   if (!OPS_EARLY && wave < 8) {
 #pragma unroll
-    for (int i = 0; i < G::NPX; ++i) sp_epi_load<EPI, VOL>(P, p_tile * BN + px[i], c_out, on_item[i], HWout, ops[i]);
+    for (int i = 0; i < G::NPX; ++i) sp_epi_load<EPI, VOL>(P, gpx[i], c_out, on_item[i], HWout, ops[i]);
   }
   __syncthreads();                                        // every fragment read and every DMA of the ring is done
-  float* const red = smem;                                // [4][BN][SP_RED_PITCH]
   if (wave < 8) {
     const int mh = wave & 1, j = lane & 15, g = lane >> 4;
     constexpr int NTW = B3 ? NT / 2 : NT;
@@ -992,7 +1212,6 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
                 make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]));
   }
   __syncthreads();
-  float4 v[G::NPX];
 #pragma unroll
   for (int i = 0; i < G::NPX; ++i) {
     v[i] = spm_zero4();
@@ -1004,6 +1223,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
       }
     }
   }
+  }      // direct form
   if (nsplit > 1) {        // block-uniform: cross-workgroup split-K hand-off, sc1 stores / ticket / sc1 loads
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
@@ -1057,7 +1277,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
 #pragma unroll
     for (int i = 0; i < G::NPX; ++i) {
       float4 y = spm_zero4();
-      sp_epilogue<EPI, PST>(P, v[i], p_tile * BN + px[i], c, on_item[i], ops[i], y);
+      sp_epilogue<EPI, PST>(P, v[i], gpx[i], c, on_item[i], ops[i], y);
       ysum.x += y.x; ysum.y += y.y; ysum.z += y.z; ysum.w += y.w;
     }
   }
@@ -1068,7 +1288,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
 #pragma unroll
       for (int i = 0; i < G::NPX; ++i) {
         float4 y = spm_zero4();
-        sp_epilogue<EPI, PST>(P, v[i], p_tile * BN + px[i], c, on_item[i], ops[i], y);
+        sp_epilogue<EPI, PST>(P, v[i], gpx[i], c, on_item[i], ops[i], y);
         if (wave < 8) {
           const int row = SP_BM + px[i];
           spm_st4(fz + (quad >> 3) * G::SUBF + row * 32 + (((quad & 7) ^ ((row >> 1) & 7)) << 2), y);
@@ -1123,7 +1343,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
           float4 y;
           y.x = spm_gelu(fuse_lw.x * (dx * rstd) + fuse_lb.x); y.y = spm_gelu(fuse_lw.y * (dy * rstd) + fuse_lb.y);
           y.z = spm_gelu(fuse_lw.z * (dz * rstd) + fuse_lb.z); y.w = spm_gelu(fuse_lw.w * (dw * rstd) + fuse_lb.w);
-          const int gp = p_tile * BN + px[i];
+          const int gp = gpx[i];
           if (gp < Ptot && cv) sp_gst4<PST>(P.fuse_out, (size_t)gp * P.fuse_cout + c, y);
         }
       }
@@ -1373,6 +1593,11 @@ hipError_t launch_flow_write(const void* host_src, void* dev_dst, size_t bytes, 
   return hipSuccess;
 }
 
+// dynamic LDS of a conv_sp_kernel launch: region (ring, or the Winograd buffers where the instantiation has that block) | misc | SE rows | fused-layer buffer
+template <int EPI, bool SCALE, int NT, bool B3>
+constexpr int sp_launch_lds(bool fused) {
+  return (sp_region<EPI, NT, B3, false>() + SP_MISC + (SCALE ? SP_SC_FLOATS : 0) + (fused ? SpGeo<NT>::BUFF : 0)) * 4;
+}
 template <int EPI, bool SCALE, int NT, bool B3>
 static hipError_t launch_sp_tb(const ConvLaunch& L, hipStream_t stream);
 template <int EPI, bool SCALE, int NT>
@@ -1388,7 +1613,7 @@ static hipError_t launch_sp_tb(const ConvLaunch& L, hipStream_t stream) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
   if (!attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, sp_lds_bytes<NT>(SCALE) + SpGeo<NT>::BUFF * 4);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, sp_launch_lds<EPI, SCALE, NT, B3>(EPI == EPI_LNG));      // (only a LayerNorm launch can carry a fused 1x1 layer)
     if (e != hipSuccess) return e;
     attr_done[dev] = true;
   }
@@ -1403,7 +1628,8 @@ static hipError_t launch_sp_tb(const ConvLaunch& L, hipStream_t stream) {
     zs = P.nsplit > zs ? P.nsplit : zs;
   }
   if (maxblocks == 0) return hipSuccess;
-  const int lds = sp_lds_bytes<NT>(SCALE) + (fused ? SpGeo<NT>::BUFF * 4 : 0);      // + the fused 1x1 layer's chunk buffer
+  if (fused && EPI != EPI_LNG) return hipErrorInvalidValue;
+  const int lds = sp_launch_lds<EPI, SCALE, NT, B3>(fused);      // + the fused 1x1 layer's chunk buffer
   if (L.wg_base[L.nprob] > 0) {      // compact 1-D grid (the host filled wg_base for this tile size)
     hipLaunchKernelGGL(kern, dim3(L.wg_base[L.nprob], 1, 1), dim3(SP_THREADS), lds, stream, L);
     return hipGetLastError();

@@ -118,7 +118,8 @@ static int packed_dims(int cout, int cin, int flags, int* cout_pad, int* cin_pad
 
 // the Winograd copy exists for 3x3 layers whose input is whole 16-channel chunks and whose outputs fill 64-row tiles (conv_wino.hip)
 static bool wino_packable(int cp, int ip, int cin, int kh, int kw, int flags) {
-  return (flags & SF_PACK_WINOGRAD) && !(flags & SF_PACK_INTERLEAVE) && kh == 3 && kw == 3 && cin == ip && (cp % 64) == 0;
+  // (interleaved rows — the sampling layer — are transformed in their packed order: only the small-P kernel's SAMPLE epilogue reads them)
+  return (flags & SF_PACK_WINOGRAD) && kh == 3 && kw == 3 && cin == ip && (cp % 64) == 0;
 }
 
 size_t sf_pack_conv_bytes(int cout, int cin, int kh, int kw, int flags) {

@@ -73,6 +73,10 @@ struct ConvProblem {
   // through the vector unit, eight of them sat in front of the first DMA of every launch of a step
   unsigned sp_m_tiles, sp_m_npt, sp_m_hw, sp_m_w, sp_m_kcpt, sp_m_kw;
   int sp_cps, sp_bn;
+  // small-P kernel, 64-pixel tiles: 1 = this 3x3 layer (one image, even H and W, w_wino present) runs in the Winograd F(2x2, 3x3) form;
+  // its K slices then count 32-channel sub-chunks (sp_cps of them per slice) and sp_m_tw is ceil(2^32 / (Wout / 2)) (0: divide)
+  int sp_wino;
+  unsigned sp_m_tw;
   int pool2;
   // AFFINE, Winograd kernel only: `add` is a half-resolution tensor [n][Hout/2][Wout/2][add_cs] read with nearest x2 upsampling — the
   // four pixels of a tile share one source pixel (the identity skip of a residual block whose input is upsampled on read)
