@@ -205,57 +205,86 @@ struct SpOps {
 };
 // `on`: the lane owns a real element (consumer wave, pixel < P, channel < cout); lanes that are not `on` load from safe
 // addresses and store nothing.
-template <int EPI, bool VOL = false, class PT = ConvProblem>
-__device__ __forceinline__ void sp_epi_load(const PT& P, const int gp, const int c, const bool on, const int HWout, SpOps& o) {
-  const int img = on ? sp_mdiv(gp, P.sp_m_hw, HWout) : 0;
-  const size_t gpz = on ? (size_t)gp : 0;
-  const int cz = on ? c : 0;
-  o.pre = P.acc_in ? sp_gld4<VOL>(P.acc_in + gpz * P.acc_cs + cz) : spm_zero4();
+// PART: 0 = everything; 1 = what depends on the channel only (the same for every pixel of the lane: the Winograd block fetches it once,
+// before its loop); 2 = what depends on the pixel
+template <int EPI, bool VOL = false, int PART = 0, class PT = ConvProblem>
+__device__ __forceinline__ void sp_epi_load(const PT& P, const int gp, const int c, const bool on, const int HWout, SpOps& o, const bool one_img = false) {
+  constexpr bool CH = PART != 2, PX = PART != 1;
+  const int img = (on && !one_img) ? sp_mdiv(gp, P.sp_m_hw, HWout) : 0;
+  // element offsets in 32 bits (the small-P kernel: < 4096 pixels, strides of a few hundred channels): a uniform base + a zero-extended
+  // 32-bit lane offset is one multiply-add and the scalar-base form of the load; size_t arithmetic was ten vector instructions per load
+  const unsigned gpz = on ? (unsigned)gp : 0u;
+  const unsigned cz = on ? (unsigned)c : 0u;
+  const unsigned ucout = (unsigned)P.cout;
+  if (PX) o.pre = P.acc_in ? sp_gld4<VOL>(P.acc_in + (gpz * (unsigned)P.acc_cs + cz)) : spm_zero4();
   if constexpr (EPI == EPI_AFFINE || EPI == EPI_BLEND) {
-    o.a[0] = P.scale ? sp_gld4<VOL>(P.scale + cz) : make_float4(1.f, 1.f, 1.f, 1.f);
-    o.a[1] = P.bias ? sp_gld4<VOL>(P.bias + (P.bias_per_img ? (size_t)img * P.cout : 0) + cz) : spm_zero4();
+    if (CH) {
+      o.a[0] = P.scale ? sp_gld4<VOL>(P.scale + cz) : make_float4(1.f, 1.f, 1.f, 1.f);
+      o.a[1] = P.bias ? sp_gld4<VOL>(P.bias + ((P.bias_per_img ? (unsigned)img * ucout : 0u) + cz)) : spm_zero4();
+    }
     if constexpr (EPI == EPI_AFFINE) {
       if (P.mode & 4) {      // block-uniform: conv-GRU blend inside an AFFINE launch (a candidate grouped with plain layers)
-        o.a[2] = sp_gld4<VOL>(P.e0 + gpz * P.e0_cs + cz);
-        o.a[3] = sp_gld4<VOL>(P.e1 + gpz * P.e1_cs + cz);
+        if (PX) {
+          o.a[2] = sp_gld4<VOL>(P.e0 + (gpz * (unsigned)P.e0_cs + cz));
+          o.a[3] = sp_gld4<VOL>(P.e1 + (gpz * (unsigned)P.e1_cs + cz));
+        }
       } else {
-        o.a[2] = P.add ? sp_gld4<VOL>(P.add + gpz * P.add_cs + cz) : spm_zero4();
-        o.a[3] = (P.add && P.add_scale) ? sp_gld4<VOL>(P.add_scale + (size_t)img * P.cout + cz) : make_float4(1.f, 1.f, 1.f, 1.f);
+        if (PX) o.a[2] = P.add ? sp_gld4<VOL>(P.add + (gpz * (unsigned)P.add_cs + cz)) : spm_zero4();
+        if (CH) o.a[3] = (P.add && P.add_scale) ? sp_gld4<VOL>(P.add_scale + ((unsigned)img * ucout + cz)) : make_float4(1.f, 1.f, 1.f, 1.f);
       }
-      const int cg = (P.out2 && cz >= P.gate_from) ? cz - P.gate_from : 0;
-      o.a[4] = P.out2 ? sp_gld4<VOL>(P.e1 + gpz * P.e1_cs + cg) : spm_zero4();
-    } else {
-      o.a[2] = sp_gld4<VOL>(P.e0 + gpz * P.e0_cs + cz);
-      o.a[3] = sp_gld4<VOL>(P.e1 + gpz * P.e1_cs + cz);
+      if (PX) {
+        const unsigned cg = (P.out2 && (int)cz >= P.gate_from) ? cz - (unsigned)P.gate_from : 0u;
+        o.a[4] = P.out2 ? sp_gld4<VOL>(P.e1 + (gpz * (unsigned)P.e1_cs + cg)) : spm_zero4();
+      }
+    } else if (PX) {
+      o.a[2] = sp_gld4<VOL>(P.e0 + (gpz * (unsigned)P.e0_cs + cz));
+      o.a[3] = sp_gld4<VOL>(P.e1 + (gpz * (unsigned)P.e1_cs + cz));
     }
   }
   if constexpr (EPI == EPI_LNG || EPI == EPI_TRUST) {
-    const size_t po = gpz * P.cout + cz;
+    const unsigned po = gpz * ucout + cz;
     const bool do_ln = (EPI == EPI_TRUST) || (P.mode & 1);      // a plain GELU layer (the gate's 1x1 projection) has no LayerNorm parameters
-    o.a[0] = do_ln ? sp_gld4<VOL>(P.scale + cz) : spm_zero4();
-    o.a[1] = do_ln ? sp_gld4<VOL>(P.bias + cz) : spm_zero4();
-    o.c0f = 0.f; o.c1f = 0.f;
-    if constexpr (EPI == EPI_LNG) o.a[2] = P.add ? sp_gld4<VOL>(P.add + gpz * P.add_cs + cz) : spm_zero4();
+    if (CH) {
+      o.a[0] = do_ln ? sp_gld4<VOL>(P.scale + cz) : spm_zero4();
+      o.a[1] = do_ln ? sp_gld4<VOL>(P.bias + cz) : spm_zero4();
+      o.c0f = 0.f; o.c1f = 0.f;
+    }
+    if constexpr (EPI == EPI_LNG) {
+      if (PX) o.a[2] = P.add ? sp_gld4<VOL>(P.add + (gpz * (unsigned)P.add_cs + cz)) : spm_zero4();
+    }
     if constexpr (EPI == EPI_TRUST) {
-      o.a[2] = sp_gld4<VOL>(P.e0 + po);
-      o.a[3] = sp_gld4<VOL>(P.e1 + cz); o.a[4] = sp_gld4<VOL>(P.e1 + P.cout + cz);
-      o.a[5] = sp_gld4<VOL>(P.e2 + po); o.a[6] = sp_gld4<VOL>(P.e3 + po);
-      const bool deriv = (P.mode & 1) != 0;
-      o.a[7] = deriv ? sp_gld4<VOL>(P.e4 + po) : spm_zero4();
-      o.a[8] = deriv ? sp_gld4<VOL>(P.e5 + po) : spm_zero4();
-      o.a[9] = (P.out2 && (P.mode & 2)) ? sp_gld4<VOL>(P.out2 + po) : spm_zero4();
-      const float* cf = P.coef ? P.coef + (size_t)img * P.coef_stride : nullptr;
-      o.c0f = cf ? cf[0] : 0.f;
-      o.c1f = (cf && P.out2) ? cf[1] : 0.f;
+      if (CH) {
+        o.a[3] = sp_gld4<VOL>(P.e1 + cz); o.a[4] = sp_gld4<VOL>(P.e1 + (ucout + cz));
+        const float* cf = P.coef ? P.coef + (size_t)img * P.coef_stride : nullptr;
+        o.c0f = cf ? cf[0] : 0.f;
+        o.c1f = (cf && P.out2) ? cf[1] : 0.f;
+      }
+      if (PX) {
+        o.a[2] = sp_gld4<VOL>(P.e0 + po);
+        o.a[5] = sp_gld4<VOL>(P.e2 + po); o.a[6] = sp_gld4<VOL>(P.e3 + po);
+        const bool deriv = (P.mode & 1) != 0;
+        o.a[7] = deriv ? sp_gld4<VOL>(P.e4 + po) : spm_zero4();
+        o.a[8] = deriv ? sp_gld4<VOL>(P.e5 + po) : spm_zero4();
+        o.a[9] = (P.out2 && (P.mode & 2)) ? sp_gld4<VOL>(P.out2 + po) : spm_zero4();
+      }
     }
   }
   if constexpr (EPI == EPI_SAMPLE) {
-    const int Chalf = P.cout >> 1;
-    const int ch = ((c >> 4) << 3) + 2 * ((c >> 2) & 3);
+    const unsigned Chalf = ucout >> 1;
+    const unsigned ch = (((unsigned)c >> 4) << 3) + 2 * (((unsigned)c >> 2) & 3);
     const bool ok = on && ch < Chalf;
-    o.a[0] = P.bias ? sp_gld4<VOL>(P.bias + cz) : spm_zero4();
-    o.e = P.e0 ? *reinterpret_cast<const float2*>(P.e0 + (ok ? gpz : 0) * Chalf + (ok ? ch : 0)) : make_float2(0.f, 0.f);      // eps: an input of the call
+    if (CH) o.a[0] = P.bias ? sp_gld4<VOL>(P.bias + cz) : spm_zero4();
+    if (PX) o.e = P.e0 ? *reinterpret_cast<const float2*>(P.e0 + ((ok ? gpz : 0u) * Chalf + (ok ? ch : 0u))) : make_float2(0.f, 0.f);      // eps: an input of the call
   }
+}
+// the channel-only operands of one item handed to another item of the same lane (same channel quad)
+template <int EPI>
+__device__ __forceinline__ void sp_epi_copy_chan(const SpOps& s, SpOps& d) {
+  d.a[0] = s.a[0];
+  if constexpr (EPI != EPI_SAMPLE) d.a[1] = s.a[1];
+  if constexpr (EPI == EPI_AFFINE) d.a[3] = s.a[3];      // (blend mode: the pixel part overwrites it afterwards)
+  if constexpr (EPI == EPI_TRUST) { d.a[3] = s.a[3]; d.a[4] = s.a[4]; d.c0f = s.c0f; d.c1f = s.c1f; }
+  if constexpr (EPI == EPI_LNG) { d.c0f = s.c0f; d.c1f = s.c1f; }
 }
 
 // ---- epilogues in the (pixel, channel-quad) layout -------------------------------------------------------------------
@@ -547,7 +576,9 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
         for (int q = 0; q < SE_Q; ++q) acc4[q & 3] += r[q];
         if (grp < G) part[grp * C + ch] = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
       }
+      SF_STAMP_AT(L, 11);
       __syncthreads();
+      SF_STAMP_AT(L, 12);
       if (wave < 8) {
         // channel means of lane and lane + 64: the G <= 8 partial sums are read together (clamped, selected afterwards —
         // a dependent LDS round trip per partial cost ~300 cycles each)
@@ -569,6 +600,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
         if (lane == 63 && wave + 8 < Cr) hid[wave + 8] = u > 0.f ? u : 0.f;
       }
       __syncthreads();
+      SF_STAMP_AT(L, 13);
       for (int idx = tid; idx < SP_SC_IMGS * cin_pad; idx += SP_THREADS) {
         float sv = 0.f;
         if (idx < C) {      // idx == tid here (C <= 128: consumer waves 0 and 1, which hold f2)
@@ -707,15 +739,14 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
       //                transforms them — lane = (tile, channel quad, row i of B^T d B): 8 ds_read_b128, 8 packed-width adds, 4 ds_write_b128
       //                — into V[position][tile][32] (slots XOR-swizzled by the tile like the ring's pixel rows) and joins ONE barrier;
       //                it only ever reads what it fetched itself, so nothing but its own vmcnt stands between a DMA and its transform
-      //   consumer w   owns positions 2w, 2w+1: per 16 channels 2 ds_read_b128 (V) + 8 buffer_load_dwordx4 straight from U (1 KB contiguous
-      //                per fragment, a 16-channel group ahead, no LDS) feed 32 MFMAs
-      // then M -> LDS, and lane (pixel, channel quad) sums the 9 signed terms of A^T M A of its pixel: this replaces the direct form's
-      // reduction over K quarters.  Fixed orders everywhere: bitwise reproducible.
+      //   consumer     (i, mh) owns row i of the 4 x 4 positions and a cout half: per 16 channels 4 ds_read_b128 (V) + 8 buffer_load_dwordx4
+      //                straight from U (1 KB contiguous per fragment, a 16-channel group ahead, no LDS) feed 32 MFMAs
+      // then the output transform: its row pass in the owner's registers, the column pass through LDS by the lane that owns the pixel.
       float* const raw = smem;                  // [2][16 tiles][16 px][32]
       float* const Vb = smem + 2 * SPW_SUB;     // [2][16 positions][16 tiles][32]
       const int nsc = nchunks;                  // 32-channel sub-chunks of this slice: cb .. cb + nsc - 1
       const int TW = P.Wout >> 1, ntiles = (P.Hout >> 1) * TW;
-      f32x4 wacc[2][4];                         // consumers: positions 2w, 2w+1 x the four 16-row cout fragments
+      f32x4 wacc[4][2];                         // consumers: the four positions of a row x the two 16-row cout fragments of a cout half
       if (wave >= 8) {
         // ---------------------------------------------- loader ------------------------------------------------------------------
         const int slotl = lane & 7, row8 = lane >> 3;
@@ -795,29 +826,32 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
         }
       } else {
         // ---------------------------------------------- consumer ----------------------------------------------------------------
+        // wave (i, mh): row i of the 4 x 4 positions, cout half mh (the ownership of conv_wino.hip's kernel: the row pass of the output
+        // transform then happens in this wave's registers and half as much leaves for LDS)
         const int j = lane & 15, g = lane >> 4;
+        const int wi = wave >> 1, mh = wave & 1;
         const __amdgpu_buffer_rsrc_t rsrc_u = make_rsrc(P.w_wino, (size_t)16 * P.cout_pad * P.cin_pad * sizeof(float));
         const int a_voff = (j * 16 + 4 * g) * 4;
-        const int pos0 = 2 * wave;
         const int u_pos = P.cout_pad * 64;                        // bytes between positions
         const int u_grp = 16 * u_pos;                             // bytes between 16-channel groups
-        int u_so = (2 * cb * 16 + pos0) * u_pos + m_tile * (SP_BM * 64);      // group 2 cb, position pos0, this cout tile
-        int b_off[2];
-#pragma unroll
-        for (int pz = 0; pz < 2; ++pz) b_off[pz] = ((pos0 + pz) * 16 + j) * 32;
+        int u_so = (2 * cb * 16 + 4 * wi) * u_pos + (m_tile * SP_BM + 32 * mh) * 64;      // group 2 cb, position (wi, 0), this cout half
+        const int b_off = ((4 * wi) * 16 + j) * 32;               // V row of (position (wi, 0), tile j); + 512 per position
         const int sxm = (j >> 1) & 7;
         const int slot_h0 = (g ^ sxm) * 4, slot_h1 = ((4 + g) ^ sxm) * 4;
-        typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
-        f32x4 fa[2][2][4], fb[2];
+        // A fragments: two register sets, one 16-channel group ahead of the MFMAs.  (Three sets, two groups ahead, do not fit beside the 32
+        // accumulator registers of a 768-thread workgroup: 60-146 spills.  Nor are they needed: two consumers share a SIMD, so a sub-chunk is
+        // 2 x 64 MFMAs = 4096 cycles of its matrix pipe and the measured 4.7 us per two sub-chunks is 75-80 % of that rate; touch loads of the
+        // workgroup's slice of U by the loaders left the loop where it was and delayed the patches by 1.8 us: profiles/r06_d_*.)
+        f32x4 fa[2][4][2], fb[4];
 #pragma unroll
-        for (int pz = 0; pz < 2; ++pz)
+        for (int pz = 0; pz < 4; ++pz)
 #pragma unroll
-          for (int m = 0; m < 4; ++m) wacc[pz][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int m = 0; m < 2; ++m) wacc[pz][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         auto load_a = [&](const int set) {      // the 8 A fragments of the next 16-channel group
 #pragma unroll
-          for (int pz = 0; pz < 2; ++pz)
+          for (int pz = 0; pz < 4; ++pz)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 2; ++m)
               fa[set][pz][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, a_voff + m * 1024, u_so + pz * u_pos, 0));
           u_so += u_grp;
         };
@@ -825,62 +859,117 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int pz = 0; pz < 2; ++pz)
+            for (int pz = 0; pz < 4; ++pz)
 #pragma unroll
-              for (int m = 0; m < 4; ++m)
+              for (int m = 0; m < 2; ++m)
                 wacc[pz][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][pz][m][e], fb[pz][e], wacc[pz][m], 0, 0, 0);
         };
         load_a(0);
-        fill_scale_rows();
+        if constexpr (SCALE) {      // the SE gate's row loads go out before anything of this wave waits for scalar loads
+          fill_scale_rows();
+        }
+        // operands that depend on the channel only (scale / bias / LayerNorm and logit rows / SE scale of the residual): once per lane, now
+        sp_epi_load<EPI, VOL, 1>(P, 0, c_out, c_out < P.cout, HWout, ops[0], true);
+#if SF_SP_PIN
+        {      // the problem-record fields that the operand loads, the hand-off and the epilogue read: requested together now, in the shadow of the
+               // patch DMAs (left to itself hipcc loads each where the tail first needs it: a chain of dependent scalar-load round trips
+               // between the last MFMA and the first operand load)
+#define SP_PIN(x) asm volatile("" ::"s"(x))
+          const float *t0 = P.acc_in, *t1 = P.scale, *t2 = P.bias, *t3 = P.e0, *t4 = P.e1, *t5 = P.out, *t6 = P.out2, *t7 = P.slab;
+          const unsigned* t8 = P.counters;
+          const int i0 = P.acc_cs, i1 = P.cout, i2 = P.mode, i3 = P.nsplit, i4 = P.act, i5 = P.fenced;
+          SP_PIN(t0); SP_PIN(t1); SP_PIN(t2); SP_PIN(t3); SP_PIN(t4); SP_PIN(t5); SP_PIN(t6); SP_PIN(t7); SP_PIN(t8);
+          SP_PIN(i0); SP_PIN(i1); SP_PIN(i2); SP_PIN(i3); SP_PIN(i4); SP_PIN(i5);
+          if constexpr (EPI == EPI_AFFINE || EPI == EPI_BLEND) {
+            const float *u0 = P.add, *u1 = P.add_scale, *u2 = P.chansum;
+            const int j0 = P.bias_per_img, j1 = P.e0_cs, j2 = P.e1_cs, j3 = P.add_cs, j4 = P.out_cs, j5 = P.out_co, j6 = P.out2_cs, j7 = P.gate_from, j8 = P.clamp_from;
+            SP_PIN(u0); SP_PIN(u1); SP_PIN(u2); SP_PIN(j0); SP_PIN(j1); SP_PIN(j2); SP_PIN(j3); SP_PIN(j4); SP_PIN(j5); SP_PIN(j6); SP_PIN(j7); SP_PIN(j8);
+          }
+          if constexpr (EPI == EPI_TRUST) {
+            const float *u0 = P.e2, *u1 = P.e3, *u2 = P.e4, *u3 = P.e5, *u4 = P.coef;
+            const int j0 = P.coef_stride;
+            const float f0 = P.eps;
+            SP_PIN(u0); SP_PIN(u1); SP_PIN(u2); SP_PIN(u3); SP_PIN(u4); SP_PIN(j0); SP_PIN(f0);
+          }
+          if constexpr (EPI == EPI_SAMPLE) {
+            const unsigned long long* u0 = P.philox;
+            const int j0 = P.draw;
+            SP_PIN(u0); SP_PIN(j0);
+          }
+#undef SP_PIN
+        }
+#endif
         if constexpr (SCALE) sp_barrier();
+        SF_STAMP_AT(L, 1);
         for (int sidx = 0; sidx < nsc; ++sidx) {
-          const float* const vbuf = Vb + (sidx & 1) * SPW_SUB;
+          const float* const vbuf = Vb + (sidx & 1) * SPW_SUB + b_off;
           sp_barrier();                                           // V[sidx] published
+#ifdef SF_STAMP
+          if (sidx == 0) SF_STAMP_AT(L, 2);
+#endif
 #pragma unroll
-          for (int pz = 0; pz < 2; ++pz) fb[pz] = sp_lds_read128(vbuf + b_off[pz] + slot_h0);
+          for (int pz = 0; pz < 4; ++pz) fb[pz] = sp_lds_read128(vbuf + pz * 512 + slot_h0);
+#if defined(SF_ABL_WSP_NO_A)      // timing-only ablation (garbage results): the loop without its A loads — what their latency costs at most
+          if (sidx < 0) load_a(1);
+#else
           load_a(1);
+#endif
           __builtin_amdgcn_sched_barrier(0);
           mfma_grp(0);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int pz = 0; pz < 2; ++pz) fb[pz] = sp_lds_read128(vbuf + b_off[pz] + slot_h1);
+          for (int pz = 0; pz < 4; ++pz) fb[pz] = sp_lds_read128(vbuf + pz * 512 + slot_h1);
+#if defined(SF_ABL_WSP_NO_A)
+          if (sidx < 0) load_a(0);
+#else
           if (sidx + 1 < nsc) load_a(0);
+#endif
           __builtin_amdgcn_sched_barrier(0);
           mfma_grp(1);
           __builtin_amdgcn_sched_barrier(0);
         }
-        // epilogue operands (two items per lane): behind the loop, as in the direct form on 64-pixel tiles
+        SF_STAMP_AT(L, 3);
+        // epilogue operands (two items per lane): behind the loop, as in the direct form on 64-pixel tiles; they stay in flight across the
+        // two barriers below (raw barriers: __syncthreads would wait for them)
 #pragma unroll
-        for (int i = 0; i < G::NPX; ++i) sp_epi_load<EPI, VOL>(P, gpx[i], c_out, on_item[i], HWout, ops[i]);
+        for (int i = 1; i < G::NPX; ++i) sp_epi_copy_chan<EPI>(ops[0], ops[i]);
+#pragma unroll
+        for (int i = 0; i < G::NPX; ++i) sp_epi_load<EPI, VOL, 2>(P, gpx[i], c_out, on_item[i], HWout, ops[i], true);
+        SF_STAMP_AT(L, 10);
       }
-      __syncthreads();                                            // every V read and every DMA is done: M may land over the buffers
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      sp_barrier();                                               // every V read and every DMA is done (the loaders drained theirs): T may land over the buffers
+      SF_STAMP_AT(L, 14);
+      // output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  Row pass in the registers of the wave that owns row i of M:
+      // T[i][0] = M[i][0] + M[i][1] + M[i][2], T[i][1] = M[i][1] - M[i][2] - M[i][3]  ->  T[4 rows][2][16 tiles][SP_RED_PITCH] in LDS ...
       if (wave < 8) {
-        const int j = lane & 15, g = lane >> 4, pos0 = 2 * wave;
+        const int j = lane & 15, g = lane >> 4, wi = wave >> 1, mh = wave & 1;
 #pragma unroll
-        for (int pz = 0; pz < 2; ++pz)
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-            spm_st4(red + ((pos0 + pz) * 16 + j) * SP_RED_PITCH + 16 * m + 4 * g, make_float4(wacc[pz][m][0], wacc[pz][m][1], wacc[pz][m][2], wacc[pz][m][3]));
+        for (int m = 0; m < 2; ++m) {
+          const f32x4 t0 = (wacc[0][m] + wacc[1][m]) + wacc[2][m], t1 = (wacc[1][m] - wacc[2][m]) - wacc[3][m];
+          float* const dst = red + ((2 * wi) * 16 + j) * SP_RED_PITCH + 32 * mh + 16 * m + 4 * g;
+          spm_st4(dst, make_float4(t0[0], t0[1], t0[2], t0[3]));
+          spm_st4(dst + 16 * SP_RED_PITCH, make_float4(t1[0], t1[1], t1[2], t1[3]));
+        }
       }
-      __syncthreads();
-      // A^T = [1 1 1 0; 0 1 -1 -1]: output (dy, dx) of a tile = sum over rows dy .. dy+2, columns dx .. dx+2 of M, a term negative when
-      // exactly one of (dy and row > dy), (dx and column > dx) holds
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      sp_barrier();
+      SF_STAMP_AT(L, 15);
+      // ... column pass by the lane that owns the pixel: output (dy, dx) of a tile = T[dy][dx] + T[dy+1][dx] + T[dy+2][dx] with the signs
+      // of A^T's row dy (this replaces the direct form's reduction over K quarters).  Fixed order: bitwise reproducible.
 #pragma unroll
       for (int i = 0; i < G::NPX; ++i) {
         v[i] = spm_zero4();
         if (wave < 8) {
           const int tl = px[i] >> 2, dy = (px[i] >> 1) & 1, dx = px[i] & 1;
-          const float* const mb = red + ((4 * dy + dx) * 16 + tl) * SP_RED_PITCH + 4 * quad;
-#pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-              const float sgn = ((dy && a) != (dx && b)) ? -1.f : 1.f;
-              const float4 t = spm_ld4(mb + ((4 * a + b) * 16) * SP_RED_PITCH);
-              v[i].x += sgn * t.x; v[i].y += sgn * t.y; v[i].z += sgn * t.z; v[i].w += sgn * t.w;
-            }
+          const float* const mb = red + ((2 * dy + dx) * 16 + tl) * SP_RED_PITCH + 4 * quad;
+          const float sgn = dy ? -1.f : 1.f;
+          const float4 r0 = spm_ld4(mb), r1 = spm_ld4(mb + 32 * SP_RED_PITCH), r2 = spm_ld4(mb + 64 * SP_RED_PITCH);
+          v[i].x = (r0.x + sgn * r1.x) + sgn * r2.x; v[i].y = (r0.y + sgn * r1.y) + sgn * r2.y;
+          v[i].z = (r0.z + sgn * r1.z) + sgn * r2.z; v[i].w = (r0.w + sgn * r1.w) + sgn * r2.w;
         }
       }
+      SF_STAMP_AT(L, 9);      // (output transform done; the operand loads may still be in flight)
       wn_done = true;
     }
   }
@@ -1518,6 +1607,9 @@ __global__ __launch_bounds__(SP_THREADS) void sp_flow_kernel(const SpFlow F_by_v
       FlowPhaseK& ph = ((FlowPhaseK*)F.ph)[k];
       if (wg < ph.n_wg) {          // block-uniform
         const int key = ph.epi * 4 + (ph.scaled ? 2 : 0) + (ph.nt == 4 ? 1 : 0);
+#if defined(SF_STAMP) && !defined(SF_STAMP_FLOW)      // diagnostic builds stamp the launch path; the flow kernel's stamps are their own build (-DSF_STAMP -DSF_STAMP_FLOW:
+        (void)key; (void)smem; (void)p_tile_done;       // since the round-5 scalar pins hipcc fails on it with "illegal VGPR to SGPR copy")
+#else
         switch (key) {
           case EPI_AFFINE * 4 + 0: fin = sp_flow_item<EPI_AFFINE, false, 2, B3>(F, ph, wg, smem, tid, k & 63, p_tile_done); break;
           case EPI_AFFINE * 4 + 1: fin = sp_flow_item<EPI_AFFINE, false, 4, B3>(F, ph, wg, smem, tid, k & 63, p_tile_done); break;
@@ -1528,6 +1620,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_flow_kernel(const SpFlow F_by_v
           case EPI_SAMPLE * 4 + 3: fin = sp_flow_item<EPI_SAMPLE, true, 4, B3>(F, ph, wg, smem, tid, k & 63, p_tile_done); break;
           default: break;
         }
+#endif
       }
     }
     // second cut: what follows re-derives the phase record from the laundered pointer, so nothing of it is carried through the body
