@@ -163,7 +163,12 @@ int sf_set_flow_mode(int on);
 /* Every dependency wait of the flow kernel is bounded (SF_FLOW_TIMEOUT polls).  A rollout in which one gave up does NOT return its
  * half-finished results: a tail kernel of the same call (captured with it in a graph) overwrites out_states / final_state with NaN.
  * sf_flow_errors synchronises `stream` and returns the number of timed-out waits of the calling thread's most recent persistent
- * rollout (0 = healthy), SF_ERR_INVALID if the thread has not run one.  The launch-per-layer form (the default) has no such waits. */
+ * rollout (0 = healthy), SF_ERR_INVALID if the thread's most recent rollout was not a persistent one.  The launch-per-layer form (the
+ * default) has no such waits.
+ * Lifetime and threads: the count lives in the WORKSPACE the caller passed to that rollout (the library owns no device memory), and
+ * "most recent" means most recently ENQUEUED BY THIS THREAD — call sf_flow_errors from the thread that enqueued the rollout, before
+ * that workspace is freed or reused, and not for a graph replay (a replay enqueues nothing: read the outputs — a rollout with a
+ * timed-out wait has NaN in every element of out_states and final_state — as streamingflow_amd's checked mode does). */
 int sf_flow_errors(void* stream);
 
 /* ---- ABI guard ---------------------------------------------------------------------------------------------------------

@@ -183,7 +183,7 @@ const Tune& tune() {
     x.wino_min_p = geti("SF_WINO_MIN_P", 14000);       // measured (profiles/r04_zz_wino_min_p_sweep.txt, r04_zz_step_min_p_batched_latents.txt): 6 or more batched 50x50 latents
                                                      // and one 200x200 latent gain 6-11 % per ODE step, 5 latents / one 100x100 latent lose 4-7 %; 32 latents +1.6 % on the headline
     x.wino_sp = geti("SF_WINO_SP", 1);             // one latent (small-P kernel, launch path): its 3x3 layers run in the Winograd form too (conv_sp.hip; 0: direct form — the round-5 step)
-    x.wsp_minsub = geti("SF_WSP_MINSUB", 2);       // ... a K slice of such a layer is at least this many 32-channel sub-chunks
+    x.wsp_minsub = geti("SF_WSP_MINSUB", 1);       // ... a K slice of such a layer is at least this many 32-channel sub-chunks (measured: 1 -> 148.2 us per step, 2 -> 150.3)
     x.flow_timeout = geti("SF_FLOW_TIMEOUT", 1 << 22);   // polls before a dependency wait of the flow kernel gives up (~1 us each: seconds); bring-up runs use a small value
     x.fenced = geti("SF_HANDOFF_FENCED", 0);       // 1: split-K hand-offs also run the agent-scope release / acquire fences of round 1 (known-good reference for the fence-free sc1 form; gfx950 only either way)
     x.b3 = geti("SF_BF16X3", 1);                   // layers packed with split-bf16 weights (opt-in at pack time) run the bf16x3 K loop where a kernel has one (0: exact fp32 even then)
@@ -1764,6 +1764,8 @@ static int rollout_core(const sf_dual_w* gru_c, const sf_dual_w* gru_obs, const 
     hipLaunchKernelGGL(flow_poison_kernel, dim3(256), dim3(256), 0, st, flow_err, out_states, (size_t)n_targets * PC, final_state, final_state ? PC : 0);
     SF_HIP(hipGetLastError());
     g_flow_err_last = flow_err;
+  } else {
+    g_flow_err_last = nullptr;      // this thread's most recent rollout has no bounded waits: sf_flow_errors says so instead of reporting an older one
   }
   return SF_OK;
 }

@@ -223,19 +223,25 @@ __device__ __forceinline__ void sp_epi_load(const PT& P, const int gp, const int
       o.a[1] = P.bias ? sp_gld4<VOL>(P.bias + ((P.bias_per_img ? (unsigned)img * ucout : 0u) + cz)) : spm_zero4();
     }
     if constexpr (EPI == EPI_AFFINE) {
-      if (P.mode & 4) {      // block-uniform: conv-GRU blend inside an AFFINE launch (a candidate grouped with plain layers)
-        if (PX) {
-          o.a[2] = sp_gld4<VOL>(P.e0 + (gpz * (unsigned)P.e0_cs + cz));
-          o.a[3] = sp_gld4<VOL>(P.e1 + (gpz * (unsigned)P.e1_cs + cz));
-        }
-      } else {
-        if (PX) o.a[2] = P.add ? sp_gld4<VOL>(P.add + (gpz * (unsigned)P.add_cs + cz)) : spm_zero4();
-        if (CH) o.a[3] = (P.add && P.add_scale) ? sp_gld4<VOL>(P.add_scale + ((unsigned)img * ucout + cz)) : make_float4(1.f, 1.f, 1.f, 1.f);
-      }
+      // (values, not fields, are chosen under the branches: with `o.a[k] = ...` on both sides hipcc merged the stores into ONE store through a
+      // selected address and the whole operand record moved to scratch memory — 416 bytes per lane, the step 151 -> 217 us)
+      const bool blend = (P.mode & 4) != 0;      // block-uniform: conv-GRU blend inside an AFFINE launch (a candidate grouped with plain layers)
+      float4 a3 = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (PART == 2) a3 = o.a[3];
+      else if (P.add && P.add_scale) a3 = sp_gld4<VOL>(P.add_scale + ((unsigned)img * ucout + cz));
       if (PX) {
+        float4 a2 = spm_zero4();
+        if (blend) {
+          a2 = sp_gld4<VOL>(P.e0 + (gpz * (unsigned)P.e0_cs + cz));
+          a3 = sp_gld4<VOL>(P.e1 + (gpz * (unsigned)P.e1_cs + cz));
+        } else if (P.add) {
+          a2 = sp_gld4<VOL>(P.add + (gpz * (unsigned)P.add_cs + cz));
+        }
+        o.a[2] = a2;
         const unsigned cg = (P.out2 && (int)cz >= P.gate_from) ? cz - (unsigned)P.gate_from : 0u;
         o.a[4] = P.out2 ? sp_gld4<VOL>(P.e1 + (gpz * (unsigned)P.e1_cs + cg)) : spm_zero4();
       }
+      o.a[3] = a3;
     } else if (PX) {
       o.a[2] = sp_gld4<VOL>(P.e0 + (gpz * (unsigned)P.e0_cs + cz));
       o.a[3] = sp_gld4<VOL>(P.e1 + (gpz * (unsigned)P.e1_cs + cz));
@@ -542,9 +548,14 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
       float f0a = 0.f, f0b = 0.f, f0c = 0.f, f0d = 0.f;
       if (wave < 8) {
         const bool mine = tid < C;                      // the thread that produces the gate of channel tid
+        // (every vector load of the prologue queues in the CU's one address unit in front of the first A fragments and patches: the rows
+        // took 3.2 us to arrive, profiles/r06_i_*; so only what is needed is requested — fc2 by the two waves that own a channel (C <= 128),
+        // the second half of the row slots only when there are that many rows — under wave- / block-uniform branches)
 #pragma unroll
-        for (int h = 0; h < 16; ++h) {
-          f2[h] = P.se_fc2[min(tid, C - 1) * Cr + min(h, Cr - 1)];      // clamped, never predicated (selected after the pins below)
+        for (int h = 0; h < 16; ++h) f2[h] = 0.f;
+        if (wave < 2) {
+#pragma unroll
+          for (int h = 0; h < 16; ++h) f2[h] = P.se_fc2[min(tid, C - 1) * Cr + min(h, Cr - 1)];      // clamped, never predicated (selected after the pins below)
         }
         // hidden units `wave` and `wave + 8`: their fc0 rows, channels lane and lane + 64
         const int h0 = min(wave, Cr - 1), h1 = min(wave + 8, Cr - 1);
@@ -552,9 +563,18 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
         float a0 = P.se_fc0[h0 * C + l0], b0 = P.se_fc0[h0 * C + l1], c0v = P.se_fc0[h1 * C + l0], d0 = P.se_fc0[h1 * C + l1];
         float r[SE_Q];
 #pragma unroll
-        for (int q = 0; q < SE_Q; ++q) {                // rows grp, grp + G, ...: unconditional loads, selected afterwards
+        for (int q = 0; q < SE_Q / 2; ++q) {            // rows grp, grp + G, ...: unconditional loads, selected afterwards
           const int t = grp + q * G;
           r[q] = sp_gld1<VOL>(P.se_sum + (size_t)min(t, nt - 1) * C + ch);
+        }
+#pragma unroll
+        for (int q = SE_Q / 2; q < SE_Q; ++q) r[q] = 0.f;
+        if (nt > (SE_Q / 2) * G) {
+#pragma unroll
+          for (int q = SE_Q / 2; q < SE_Q; ++q) {
+            const int t = grp + q * G;
+            r[q] = sp_gld1<VOL>(P.se_sum + (size_t)min(t, nt - 1) * C + ch);
+          }
         }
         // hipcc sinks a load whose value is only needed under a lane mask into that region and drains vmcnt(0) behind it:
         // every value is "used" here, unconditionally, after ALL the loads were issued -> one wait for the lot
@@ -838,10 +858,13 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
         const int b_off = ((4 * wi) * 16 + j) * 32;               // V row of (position (wi, 0), tile j); + 512 per position
         const int sxm = (j >> 1) & 7;
         const int slot_h0 = (g ^ sxm) * 4, slot_h1 = ((4 + g) ^ sxm) * 4;
-        // A fragments: two register sets, one 16-channel group ahead of the MFMAs.  (Three sets, two groups ahead, do not fit beside the 32
-        // accumulator registers of a 768-thread workgroup: 60-146 spills.  Nor are they needed: two consumers share a SIMD, so a sub-chunk is
-        // 2 x 64 MFMAs = 4096 cycles of its matrix pipe and the measured 4.7 us per two sub-chunks is 75-80 % of that rate; touch loads of the
-        // workgroup's slice of U by the loaders left the loop where it was and delayed the patches by 1.8 us: profiles/r06_d_*.)
+        // A fragments: two register sets, one 16-channel group ahead of the MFMAs (buffer_load_dwordx4: 1 KB contiguous per fragment).
+        // Measured alternatives (profiles/r06_*): three sets / two groups ahead do not fit beside 32 accumulator registers in a 768-thread
+        // workgroup (60-146 spills); a ring of four HALF groups in the same 64 registers (8-byte loads, 1.5 groups ahead) made the loop
+        // 25 % SLOWER — the address unit spends 16 cycles per load instruction whatever its width, and 16 half-width loads per group and wave
+        // are as many cycles as the group's MFMAs; touch loads of the slice by the loaders delayed the patches by 1.8 us for nothing.  With
+        // no A loads at all (timing-only) the loop is 0.5 us shorter: two consumers share a SIMD, a sub-chunk is 2 x 64 MFMAs = 4096
+        // cycles of its matrix pipe, and the loop runs at 75-80 % of that.
         f32x4 fa[2][4][2], fb[4];
 #pragma unroll
         for (int pz = 0; pz < 4; ++pz)
@@ -869,7 +892,8 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
           fill_scale_rows();
         }
         // operands that depend on the channel only (scale / bias / LayerNorm and logit rows / SE scale of the residual): once per lane, now
-        sp_epi_load<EPI, VOL, 1>(P, 0, c_out, c_out < P.cout, HWout, ops[0], true);
+        SpOps chan;
+        sp_epi_load<EPI, VOL, 1>(P, 0, c_out, c_out < P.cout, HWout, chan, true);
 #if SF_SP_PIN
         {      // the problem-record fields that the operand loads, the hand-off and the epilogue read: requested together now, in the shadow of the
                // patch DMAs (left to itself hipcc loads each where the tail first needs it: a chain of dependent scalar-load round trips
@@ -932,9 +956,10 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
         // epilogue operands (two items per lane): behind the loop, as in the direct form on 64-pixel tiles; they stay in flight across the
         // two barriers below (raw barriers: __syncthreads would wait for them)
 #pragma unroll
-        for (int i = 1; i < G::NPX; ++i) sp_epi_copy_chan<EPI>(ops[0], ops[i]);
-#pragma unroll
-        for (int i = 0; i < G::NPX; ++i) sp_epi_load<EPI, VOL, 2>(P, gpx[i], c_out, on_item[i], HWout, ops[i], true);
+        for (int i = 0; i < G::NPX; ++i) {
+          sp_epi_copy_chan<EPI>(chan, ops[i]);
+          sp_epi_load<EPI, VOL, 2>(P, gpx[i], c_out, on_item[i], HWout, ops[i], true);
+        }
         SF_STAMP_AT(L, 10);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

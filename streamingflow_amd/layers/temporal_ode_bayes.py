@@ -473,6 +473,26 @@ class NNFOwithBayesianJumps(nn.Module):
             out, final = g["out"], g["final"]      # valid until the next replay of this graph
             if auto_graph:                          # nobody asked for the zero-copy form: hand out fresh tensors
                 out, final = out.clone(), final.clone()
+        from .. import packing as _pk
+        if _pk.flow_active() and _pk.flow_checked() and not torch.cuda.is_current_stream_capturing():
+            # persistent flow kernel: a dependency wait that gave up (device shared with another stream / process) must cost time, not a
+            # result — the same rollout again on the launch-per-layer path, in this process, counted
+            # (read from THIS rollout's own output — the poison kernel turns every element into NaN — not from sf_flow_errors, whose
+            # "most recent rollout of the thread" is the most recent one ENQUEUED, not the graph that was just replayed)
+            if bool(torch.isnan(final.reshape(-1)[:1]).item()):
+                _pk.FLOW_FALLBACKS[0] += 1
+                was = L.sf_set_flow_mode(0)
+                try:
+                    if philox is None:
+                        eps_c, hx_c = eps.contiguous(), hx_obs.contiguous()
+                    else:
+                        eps_c, hx_c = eps, hx_obs.contiguous()
+                    out = torch.empty((len(s0.sel_nops), B, h, w, C), dtype=torch.float32, device=dev)
+                    final = torch.empty((B, h, w, C), dtype=torch.float32, device=dev)
+                    ws2 = runtime.workspace(nbytes, dev)
+                    self._enqueue_rollout(s0, per_image, hx_c, eps_c, coef, out, final, ws2, B, h, w, philox)
+                finally:
+                    L.sf_set_flow_mode(int(bool(was)) if _pk._FLOW[0] is not None else -1)
         return (out[:, 0], final[0]) if one else (out, final)
 
     def make_schedule(self, times, delta_t, T):

@@ -129,11 +129,30 @@ def null_conv():
 
 
 _FLOW = [None]
+_FLOW_CHECK = [True]
+FLOW_FALLBACKS = [0]      # rollouts of this process whose persistent launch timed out and that were re-run on the launch-per-layer path
 
 
-def set_persistent_flow(on):
+def set_persistent_flow(on, check=True):
     """Opt in to (True) / out of (False) the persistent flow kernel for single-latent rollouts, or back to the SF_PERSIST
     environment default (None).  It needs an otherwise idle device: include/sfnative.h, sf_set_flow_mode.  Graphs captured
-    before the switch keep the form they were captured in (NNFOwithBayesianJumps.drop_graphs() re-captures)."""
+    before the switch keep the form they were captured in (NNFOwithBayesianJumps.drop_graphs() re-captures).
+
+    ``check`` (default on): after every persistent rollout the host reads the kernel's count of timed-out dependency waits
+    (``sf_flow_errors``: one stream synchronisation per rollout) and, when it is not zero, runs the same rollout again on the
+    launch-per-layer path IN THIS PROCESS and counts it in ``FLOW_FALLBACKS`` — a device that turns out to be shared costs time,
+    never a result.  ``check=False`` keeps the rollout asynchronous; a timeout then shows as NaN outputs (never as numbers)."""
     _FLOW[0] = None if on is None else bool(on)
+    _FLOW_CHECK[0] = bool(check)
     return bool(_lib.lib().sf_set_flow_mode(-1 if on is None else int(bool(on))))
+
+
+def flow_active():
+    """Whether single-latent rollouts of this process run as the persistent flow kernel."""
+    if _FLOW[0] is not None:
+        return _FLOW[0]
+    return _os.environ.get("SF_PERSIST", "0") not in ("", "0")
+
+
+def flow_checked():
+    return _FLOW_CHECK[0]
