@@ -139,6 +139,16 @@ def dry_run(a, world):
         dist.destroy_process_group()
 
 
+def _family(calls_per_forward, ms_per_forward, flops, nbytes, ms):
+    """one launch family of the per-launch profiler: rate, the roof that bounds it (by arithmetic intensity) and the fraction of THAT roof"""
+    t = ms * 1e-3
+    tfl, gbs = flops / t / 1e12, nbytes / t / 1e9
+    intensity = flops / nbytes if nbytes else float("inf")
+    bound = "mfma" if intensity >= PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
+    return {"calls_per_forward": calls_per_forward, "ms_per_forward": ms_per_forward, "tflops": tfl, "algorithmic_gbs": gbs,
+            "flop_per_byte": intensity, "bound": bound, "frac_of_bound": tfl / PEAK_F32_MFMA_TFLOPS if bound == "mfma" else gbs / PEAK_HBM_GBS}
+
+
 def _all_ranks(value, world, device):
     """every rank's integer `value` (all-gather of one int64 each)"""
     import torch
@@ -253,12 +263,32 @@ def main():
             gms = sorted(ts)[2]
             ok = all(g.shape == grid.shape for g in gathered[0]) and torch.equal(gathered[0][rank], grid)
             assert ok, "all-gather returned a wrong slot"
+        # what gathering the WHOLE shard (every sample's grid, not one per rank) would cost: measured on up to 4 samples per rank, outside the
+        # timed region (the figure for B samples is linear in the bytes)
+        shard_ms = shard_n = None
+        try:
+            shard_n = min(B, 4)
+            loc = {rank + world * i: y[i] for i in range(shard_n)}      # sample i of this rank's shard: index i * W + rank (dist.shard_indices)
+            sfd.gather_predictions(loc, world * shard_n)
+            fence()
+            tg = time.perf_counter()
+            sfd.gather_predictions(loc, world * shard_n)
+            torch.cuda.synchronize()
+            shard_ms = 1e3 * (time.perf_counter() - tg)
+        except Exception as ex:
+            shard_ms = repr(ex)
         cnt = torch.ones(8, device=dev if backend == "nccl" else "cpu")
         sfd.reduce_counters(cnt)
         assert float(cnt[0]) == world
         multi = {"rccl_world": dist.get_world_size(), "backend": dist.get_backend(), "gather_in_timed_region": do_gather,
                  "gather_bytes_per_rank": gbytes, "gather_bytes_total": gbytes * world, "gather_ms_standalone": gms,
                  "gather_estimate_ms": gbytes / 153e9 * 1e3,      # one xGMI hop at ~153 GB/s per link
+                 "whole_shard_gather": {"samples_per_rank_measured": shard_n, "bytes_per_rank_measured": None if shard_n is None else gbytes * shard_n,
+                                        "ms_standalone": shard_ms, "samples_per_rank_in_a_forward": B, "bytes_per_rank_in_a_forward": gbytes * B,
+                                        "ms_per_forward_if_gathered_linear_estimate": (shard_ms * B / shard_n) if isinstance(shard_ms, float) and shard_n else None,
+                                        "xgmi_estimate_ms_per_forward": gbytes * B * (world - 1) / (min(world - 1, 7) * 153e9) * 1e3 if world > 1 else None,
+                                        "what": "all_gather_into_tensor of every sample's grid of the shard (not in the timed region: the reference evaluates its metrics per sample and "
+                                                "all-reduces counters; SURVEY 8e)"},
                  "devices": sorted({int(v) for v in _all_ranks(local, world, dev if backend == "nccl" else "cpu")}),
                  "what": "all_gather_into_tensor of one sample's [T, C, H, W] fp32 BEV grid per rank (streamingflow_amd.dist.gather_predictions), side stream, overlapped with the next forward"
                          + ("" if backend == "nccl" else " [gloo: staged through the host, the host blocks on it]") + "; metric counters: all_reduce(SUM)"}
@@ -385,12 +415,12 @@ def main():
                     "hbm_frac": by / t / 1e9 / PEAK_HBM_GBS}
         step_only = {"single_sample": time_step(1, H // 4, W // 4, 50), "batch8": time_step(8, H // 4, W // 4, 20),
                      "stress_latent_200x200": time_step(1, H, W, 5),
-                     # `tflops` / `mfma_frac` here divide the reference's (direct-form) FLOPs of a step by its time.  From 14 000 pixels per
-                     # launch the gates / candidates of a step run in Winograd form (2.25x fewer executed products): for batch8 and the
-                     # 200x200 latent these are direct-form-EQUIVALENT rates, not matrix-pipe utilisation; the single latent runs no
-                     # Winograd layer
-                     "flop_accounting": "algorithmic (direct-form) FLOPs / time; batch8 and stress_latent_200x200 include Winograd layers "
-                                        "(SF_WINO_MIN_P = 14000): direct-form-equivalent rates"}
+                     # `tflops` / `mfma_frac` here divide the reference's (direct-form) FLOPs of a step by its time.  The 3x3 layers of a step
+                     # run in Winograd form (2.25x fewer executed products) — from 14 000 pixels per launch on conv_wino.hip, and since
+                     # round 6 on the single latent too (conv_sp.hip, SF_WINO_SP) — so these are direct-form-EQUIVALENT rates, not
+                     # matrix-pipe utilisation
+                     "flop_accounting": "algorithmic (direct-form) FLOPs / time; every case includes Winograd layers (SF_WINO_MIN_P = 14000 on the large tiles, "
+                                        "SF_WINO_SP on the single latent): direct-form-equivalent rates"}
         if rank == 0 and world == 1 and not a.no_cpu_baseline:      # the same unit of work on the host cores (oracle, 16 threads)
             from oracle import ref_torch as R
             torch.set_num_threads(min(os.cpu_count() or 1, 16))
@@ -597,9 +627,9 @@ def main():
                 "hbm_frac_if_bytes_bound": (pby[k] / (pms[k] * 1e-3) / 1e9) / PEAK_HBM_GBS,
                 "share_of_conv_time": pms[k] / tot if tot else None,
                 "all_conv_tflops": sum(pfl) / (tot * 1e-3) / 1e12 if tot else None,
-                "per_kernel": {_lib.KERNEL_NAMES.get(i, str(i)): {
-                    "calls_per_forward": calls[i] // 2, "ms_per_forward": pms[i] / 2,
-                    "tflops": pfl[i] / (pms[i] * 1e-3) / 1e12} for i in range(NK) if calls[i]}}
+                # every launch family against ITS roof: arithmetic intensity (FLOPs / algorithmic bytes: each input pixel, weight and output once)
+                # against the machine balance (fp32 MFMA peak / HBM peak = 19.7 FLOP/B) decides which
+                "per_kernel": {_lib.KERNEL_NAMES.get(i, str(i)): _family(calls[i] // 2, pms[i] / 2, pfl[i], pby[i], pms[i]) for i in range(NK) if calls[i]}}
 
     # flat scalars of the GRU-ODE step inside `roofline` (the driver's record keeps the scalar members of that object)
     if roof is not None and isinstance(roof_step, dict) and "error" not in roof_step:
@@ -745,6 +775,58 @@ def main():
         finally:
             sfa.set_math_mode("fp32")
 
+    # ---- BASELINE configs 4 and 5 as whole forwards (evaluate.py:43 --future-frames 16; evaluate_streaming.py:119-126): batch 1 and a batch ----
+    other_cfgs = {}
+    if rank == 0 and world == 1 and not a.no_extras and not a.headline_only:
+        for key, ts_name, Bc, cpu_targets in (("config4_future16", "future16", 8, None), ("config5_stream40", "stream40", 4, 13)):
+            try:
+                c_, l_, t_, dt_ = cases.timeset(ts_name)
+                net_c = sfa.FuturePredictionODE(C, C, 4, cfg, n_gru_blocks=2, n_res_layers=1, delta_t=dt_).eval()
+                net_c.load_state_dict(sd)
+                net_c = net_c.to(dev)
+                tm_, _ = S.merge_observations(c_[0].tolist(), l_[0].tolist())
+                sc_ = S.build_schedule(tm_, t_[0].tolist(), dt_, True, a.solver)
+
+                def run_c(nb, reps):
+                    cam_c, lid_c = cam_d[:nb], lid_d[:nb]
+                    x_c = cases.present_input(cam_c, lid_c)
+                    args = (x_c, cam_c, lid_c, c_.repeat(nb, 1), l_.repeat(nb, 1), t_.repeat(nb, 1))
+                    for _ in range(2):
+                        yc, _ = net_c(*args)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        yc, _ = net_c(*args)
+                    torch.cuda.synchronize()
+                    assert yc.shape[1] == t_.shape[1]
+                    del yc
+                    return 1e3 * (time.perf_counter() - t0) / reps
+                m1, mb = run_c(1, 5), run_c(Bc, 3)
+                obj = {"workload": f"timeset '{ts_name}': {len(tm_)} observations, {t_.shape[1]} decoded frames, {sc_.n_steps} ODE steps + {sc_.n_jumps} jumps per sample "
+                                   f"(variable-step {a.solver}), C=64, BEV 200x200; whole FuturePredictionODE.forward",
+                       "batch1": {"ms_per_forward": m1, "ode_steps_per_s": sc_.n_steps / (m1 * 1e-3), "frames_per_s": t_.shape[1] / (m1 * 1e-3)},
+                       "batched": {"samples_per_forward": Bc, "ms_per_forward": mb, "ms_per_sample": mb / Bc, "ode_steps_per_s": sc_.n_steps * Bc / (mb * 1e-3),
+                                   "frames_per_s": t_.shape[1] * Bc / (mb * 1e-3)}}
+                if not a.no_cpu_baseline:
+                    from oracle import ref_torch as R
+                    cores = min(os.cpu_count() or 1, 16)
+                    torch.set_num_threads(cores)
+                    t_cpu = t_ if cpu_targets is None else t_[:, :cpu_targets]      # bounded sample: the first targets only
+                    sc_cpu = S.build_schedule(tm_, t_cpu[0].tolist(), dt_, True, a.solver)
+                    with torch.no_grad():
+                        t0 = time.perf_counter()
+                        R.future_prediction_ode_forward(sd, cases.present_input(cam, lid), cam, lid, c_, l_, t_cpu, dt_, 2, a.solver, True, True, hashfill.HashedNoise(0))
+                        tc = time.perf_counter() - t0
+                    obj["cpu_baseline"] = {"value": sc_cpu.n_steps / tc, "unit": "ODE-steps/s", "cores": cores, "kind": "port",
+                                           "sample": f"ONE single-sample forward (no warm-up pass) of the oracle, oracle/ref_torch.py, on the first {t_cpu.shape[1]} of the {t_.shape[1]} target "
+                                                     f"frames ({sc_cpu.n_steps} ODE steps + {sc_cpu.n_jumps} jumps, {t_cpu.shape[1]} decoded frames at 200x200x64): {tc:.1f} s",
+                                           "frames_per_s": t_cpu.shape[1] / tc}
+                other_cfgs[key] = obj
+                del net_c
+                torch.cuda.empty_cache()
+            except Exception as ex:
+                other_cfgs[key] = {"error": repr(ex)}
+
     # ---- CPU baseline: the oracle (torch-CPU port of the reference path) on the host cores --------
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.headline_only:
@@ -785,6 +867,7 @@ def main():
                "single_sample_forward_ms": single_ms,
                "single_sample_ode_steps_per_s": None if single_ms is None else n_ode / (single_ms * 1e-3),
                "roofline_ode_step": roof_step, "multi_gpu": multi,
+               "config4_future16": other_cfgs.get("config4_future16"), "config5_stream40": other_cfgs.get("config5_stream40"),
                "ode_rollout_only": rollout, "ode_step_only": step_only, "lift_splat": lift, "lidar_voxelize": vox, "bev_decoder": dec, "direct_form_3x3": direct, "bf16x3_mode": b3, "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -150,7 +150,9 @@ def test_golden_and_config5_statistics_on_the_flow_kernel():
                        env=env, capture_output=True, text=True, timeout=3000, cwd=ROOT)
     tail = r.stdout[-1500:] + r.stderr[-1500:]
     assert r.returncode == 0, tail
-    assert "2 passed" in r.stdout, tail
+    import re
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 2 and "failed" not in r.stdout, tail
 
 
 FALLBACK_SCRIPT = r"""

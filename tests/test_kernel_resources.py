@@ -23,6 +23,12 @@ SGPR_SPILL_ALLOWED = {
     "conv_wino_kernel": (8, "tile decode / epilogue address set-up"),
     "conv_wino5_kernel": (8, "tile decode / epilogue address set-up"),
     "conv_sp_kernelILi0ELb1ELi2": (1, "SE-gate prologue of the 32-pixel-tile AFFINE kernel (one v_writelane)"),
+    # 64-pixel tiles with the Winograd block (round 6): the epilogue's scalars are requested in one batch before the loop and live across it
+    # beside the SE gate's / the trusting gate's own; the overflow sits in v_writelane / v_readlane pairs outside the MFMA loop
+    "conv_sp_kernelILi0ELb1ELi4ELb0": (12, "SE-scaled AFFINE, 64-pixel tiles: SE prologue + the epilogue's scalar batch"),
+    "conv_sp_kernelILi4ELb1ELi4ELb0": (12, "SE-scaled SAMPLE, 64-pixel tiles: SE prologue + the epilogue's scalar batch"),
+    "conv_sp_kernelILi3ELb0ELi4ELb0": (4, "TRUST, 64-pixel tiles: ten operand tensors' scalars held across the Winograd loop"),
+    "conv_sp_kernelILi0ELb0ELi4ELb0": (4, "AFFINE, 64-pixel tiles: the epilogue's scalar batch held across the Winograd loop"),
     "dwconv7_ln_c64_kernel": (40, "row / column addresses kept in scalar registers by design (csrc/aux_kernels.hip)"),
 }
 
