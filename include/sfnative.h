@@ -104,6 +104,11 @@ typedef struct sf_dual_w {
    * bias and the sigmoid, gates1_s = W[:, C:] on s with neither.  In a rollout the s half is accumulated beside the
    * previous infer_state (the state is known five launches before x is) and added to the x half's sums. */
   sf_conv_w gates1_x, gates1_s;
+  /* optional (w == NULL: unused), round 6: the two input halves of the trusting gate's 7x7 packed on their own — tg7_h = W[:, :C] on rnn_state1
+   * with the LayerNorm weight / bias, tg7_r = W[:, C:] on rnn_state2 with neither.  In a rollout rnn_state2 = conv_decoder_2(h2) is a
+   * function of the state alone: its half of the 7x7 (half of the longest launch of a step) runs on a forked stream beside the previous
+   * infer_state and is added to the rnn_state1 half's sums. */
+  sf_conv_w tg7_h, tg7_r;
 } sf_dual_w;
 
 /* ResBlock (streamingflow/layers/res_models.py:52-79) */
@@ -179,7 +184,7 @@ int sf_flow_errors(void* stream);
  * anything else unless it returns SF_OK; bindings without a C compiler (ctypes, cgo, JNI) compare their own struct sizes
  * with sf_abi_sizeof() the same way (streamingflow_amd/_lib.py does, INTEGRATION.md shows it).  Hosts must zero-initialise
  * the structs (optional members are "NULL = absent") and recompile when SF_ABI_VERSION changes. */
-#define SF_ABI_VERSION 5
+#define SF_ABI_VERSION 6
 enum {
   SF_STRUCT_CONV_W = 0, SF_STRUCT_GRU_W, SF_STRUCT_DUAL_W, SF_STRUCT_RES_W, SF_STRUCT_PMODEL_W, SF_STRUCT_ENCODER_W,
   SF_STRUCT_DECODER_W, SF_STRUCT_CONVNEXT_W, SF_STRUCT_DEEPLAB_W, SF_STRUCT_BOTTLENECK_W, SF_STRUCT_BOTTLE_W, SF_STRUCT_COUNT
@@ -498,7 +503,7 @@ int sf_event_destroy(void* ev);
 /* Per-launch profiler for bench.py (off by default): when enabled every implicit-GEMM launch is
  * bracketed by hipEvents on its own stream.  sf_prof_collect fills SF_PROF_KEYS-entry arrays indexed by
  * kernel key = tile_config*8 + epilogue (calls, total ms, algorithmic flops, algorithmic bytes). */
-#define SF_PROF_KEYS 168
+#define SF_PROF_KEYS 168      /* part of SF_ABI_VERSION: sf_prof_collect fills this many entries of each of its four arrays (160 -> 168 was version 5 -> 6) */
 int sf_prof_enable(int on);
 int sf_prof_collect(int32_t* calls, double* ms, double* flops, double* bytes);
 

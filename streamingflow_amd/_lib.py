@@ -13,7 +13,7 @@ f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
 
 SF_COEF_STRIDE = 12
-SF_ABI_VERSION = 5       # include/sfnative.h: changes whenever a public struct changes layout
+SF_ABI_VERSION = 6       # include/sfnative.h: changes whenever a public struct changes layout
 SF_PROF_KEYS = 168
 PACK_TRANSPOSED, PACK_FOLD_DUP, PACK_INTERLEAVE, PACK_BF16X3, PACK_WINOGRAD = 1, 2, 4, 8, 16      # SF_PACK_* of sfnative.h
 ACT = {"none": 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4, "gelu": 5}
@@ -35,7 +35,7 @@ class GruW(C.Structure):
 class DualW(C.Structure):
     _fields_ = [("gates1", ConvW), ("cand1", ConvW), ("gates2", ConvW), ("cand2", ConvW), ("dec2", ConvW),
                 ("tg7", ConvW), ("tgproj", ConvW), ("tg1", ConvW), ("tg3", ConvW),
-                ("w_logit", C.c_void_p), ("C", C.c_int32), ("gates1_x", ConvW), ("gates1_s", ConvW)]
+                ("w_logit", C.c_void_p), ("C", C.c_int32), ("gates1_x", ConvW), ("gates1_s", ConvW), ("tg7_h", ConvW), ("tg7_r", ConvW)]
 
 
 class BottleW(C.Structure):

@@ -170,7 +170,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int wino, wino_sp, wsp_minsub, wino_min_p, flow_timeout, b3_small_tiles, wide64, seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int wino, wino_sp, wsp_minsub, fork7, fork7_wgs, wino_min_p, flow_timeout, b3_small_tiles, wide64, seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -184,6 +184,8 @@ const Tune& tune() {
                                                      // and one 200x200 latent gain 6-11 % per ODE step, 5 latents / one 100x100 latent lose 4-7 %; 32 latents +1.6 % on the headline
     x.wino_sp = geti("SF_WINO_SP", 1);             // one latent (small-P kernel, launch path): its 3x3 layers run in the Winograd form too (conv_sp.hip; 0: direct form — the round-5 step)
     x.wsp_minsub = geti("SF_WSP_MINSUB", 1);       // ... a K slice of such a layer is at least this many 32-channel sub-chunks (measured: 1 -> 148.2 us per step, 2 -> 150.3)
+    x.fork7 = geti("SF_FORK7", 0);                 // 1: one latent inside a rollout: conv_decoder_2 rides beside rb1.conv1 and the r2 half of the next cell's 7x7 runs on a forked stream beside the rest of infer_state.  Built, bitwise reproducible, oracle-tested (tests/test_gpu_persistent.py) and measured SLOWER: the 7x7 launch halves (38.5 -> 25.7 us) and the side launch does run beside the chain, but the two cross-queue dependencies per step cost more than they free — 159.5-161 us per step in a replayed hipGraph against 148.5 (profiles/r06_r_*).  Off by default
+    x.fork7_wgs = geti("SF_FORK7_WGS", 88);        // ... workgroup budget of that side launch (the main stream's launches of the window have <= 160)
     x.flow_timeout = geti("SF_FLOW_TIMEOUT", 1 << 22);   // polls before a dependency wait of the flow kernel gives up (~1 us each: seconds); bring-up runs use a small value
     x.fenced = geti("SF_HANDOFF_FENCED", 0);       // 1: split-K hand-offs also run the agent-scope release / acquire fences of round 1 (known-good reference for the fence-free sc1 form; gfx950 only either way)
     x.b3 = geti("SF_BF16X3", 1);                   // layers packed with split-bf16 weights (opt-in at pack time) run the bf16x3 K loop where a kernel has one (0: exact fp32 even then)
@@ -244,7 +246,7 @@ constexpr size_t SPLIT_WS_FLOATS = SPLIT_SLAB_FLOATS + SPLIT_COUNTERS + 128;
 // an SE input scale only on a single input of <= 256 channels (all problems or none), 32-bit DMA offsets
 bool sp_takes(const ConvProblem* ps, int n, int epi) {
   if (!tune().sp) return false;
-  int scaled = 0;
+  int scaled = 0, unscalable = 0;
   for (int i = 0; i < n; ++i) {
     const ConvProblem& q = ps[i];
     const long Pi = (long)q.n_img * q.Hout * q.Wout;
@@ -254,11 +256,15 @@ bool sp_takes(const ConvProblem* ps, int n, int epi) {
       ++scaled;
       if (q.c1 != 0 || q.cin_pad > 256 || (long)q.Hout * q.Wout < 32) return false;   // a 64-pixel tile touches <= 4 images
       if (q.se_sum && (q.n_img != 1 || q.c0 > 128 || q.c0 < 64 || q.se_cr < 1 || q.se_cr > 16 || q.c0 != q.cin_pad || q.se_nt > 20 * (512 / q.c0))) return false;
+    } else if (q.c1 != 0 || q.cin_pad > 256 || (long)q.Hout * q.Wout < 32) {
+      ++unscalable;      // could not ride in an SE-scaled launch (whose kernel multiplies every problem's input by a scale row: ones for this one)
     }
     const double span = (64.0 / ((double)q.Hout * q.Wout) + 2.0) * q.Hin * q.Win * 4.0;
     if (span * q.in0_cs >= 2147483648.0 || span * q.in1_cs >= 2147483648.0 || 4.0 * q.cout_pad * q.ktot >= 2147483648.0) return false;
   }
-  if (scaled && (scaled != n || (epi != EPI_AFFINE && epi != EPI_SAMPLE))) return false;
+  // an SE-scaled launch may carry problems without a scale (round 6: conv_decoder_2 beside rb1.conv1) as long as each fits the scaled kernel's
+  // staging — their rows of the scale table are ones
+  if (scaled && (unscalable || (epi != EPI_AFFINE && epi != EPI_SAMPLE))) return false;
   return true;
 }
 // pixels per tile of the small-P kernel.  Measured on the conv launches of an Euler step at 50x50 (profiles/r02_*):
@@ -266,6 +272,10 @@ bool sp_takes(const ConvProblem* ps, int n, int epi) {
 // pairs, the 128 -> 128 layers of p_model, the 7x7), 32-pixel tiles without a hand-off elsewhere
 struct FlowBuilder;
 extern thread_local FlowBuilder* g_seg;
+// forked side launch of a rollout (fork_run below): > 0 while the side launch is being enqueued = its workgroup budget; g_fork_halves: the
+// rollout uses the fork, so main-stream launches keep to the lower half of the split-K scratch
+thread_local int g_fork_side = 0;
+thread_local bool g_fork_halves = false;
 // ... and which of its 3x3 layers take the Winograd F(2x2, 3x3) form there (conv_sp.hip, ConvProblem::sp_wino): one image with even
 // sides (a 64-pixel tile is then 16 whole Winograd tiles and the tile counts of both forms agree), stride 1, pad 1, no dilation, inputs in
 // whole 32-channel sub-chunks, cout in whole 64-row tiles, transformed weights packed; not inside a persistent flow (its tile-level
@@ -532,8 +542,13 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
           WG.stamp_slot = g_stamp_slot;
           if (g_stamp_on) g_stamp_slot = (g_stamp_slot + 1) % 64;
           if (!g_prof.on) {
-            SF_HIP(launch_conv_wino(WG, epi, st));
-            return SF_OK;
+            // (the kernel's block decode multiplies by host-made reciprocals and refuses — hipErrorInvalidValue, nothing launched — a size whose
+            // exactness check fails: the heuristic above is not that check, so a refused group runs as one launch per problem below)
+            const hipError_t ge = launch_conv_wino(WG, epi, st);
+            if (ge == hipSuccess) return SF_OK;
+            if (ge != hipErrorInvalidValue) return SF_ERR_LAUNCH;
+            (void)hipGetLastError();
+            goto wino_one_by_one;
           }
           ProfRec r;
           const int wv = wino_variant(ps[first]);
@@ -552,6 +567,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
           return SF_OK;
         }
       }
+    wino_one_by_one:
       for (int i = 0; i < n; ++i) {
         if (!takes[i]) continue;
         ConvLaunch W1;
@@ -618,7 +634,8 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       // (a 32-channel sub-chunk of the Winograd form costs a 64-pixel tile what a 64-deep chunk of the direct form does: 64 MFMAs per wave)
       work_total += (double)tiles * (wn_of[i] ? ps[i].cin_pad / 32 : (ps[i].KH * ps[i].KW * (ps[i].cin_pad / 32) + 1) / 2);
     }
-    const double per_wg = work_total / tune().sp_split_wgs;      // chunks per workgroup at the target
+    const int wg_target = g_fork_side > 0 ? g_fork_side : tune().sp_split_wgs, wg_cap = g_fork_side > 0 ? g_fork_side : 256;
+    const double per_wg = work_total / wg_target;      // chunks per workgroup at the target
     int ns_of[SF_MAX_GROUP], tiles_of[SF_MAX_GROUP], nch_of[SF_MAX_GROUP];
     int wgs = 0;
     const bool may_split = g_split && tune().split && bn == 64;
@@ -636,7 +653,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     }
     // one workgroup owns a whole CU: a launch of more than 256 of them runs a second round for the few that are left
     // (measured: the 7x7 + projection launch at 280 workgroups took 54 us for 26 us of work per workgroup)
-    while (may_split && wgs > 256) {
+    while (may_split && wgs > wg_cap) {
       int k = -1;
       for (int i = 0; i < n; ++i)
         if (ns_of[i] > 1 && (k < 0 || tiles_of[i] * ns_of[i] > tiles_of[k] * ns_of[k])) k = i;
@@ -649,11 +666,14 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     // only when phase q is complete)
     // (a running count of recorded phases, NOT the index inside the flow under construction: add() may flush first and the phase then
     // opens a new flow — with the index, the phase before the flush and the one after it could land on the same half)
-    const int parity = g_seg ? (g_seg->recorded & 1) : 0;
-    const size_t slab_lim = g_split ? (g_seg ? (parity + 1) * (g_split->slab_floats / 2) : g_split->slab_floats) : 0;
-    const int cnt_lim = g_split ? (g_seg ? (parity + 1) * (g_split->ncounters / 2) : g_split->ncounters) : 0;
-    size_t slab_off = (g_seg && g_split) ? parity * (g_split->slab_floats / 2) : 0;
-    int cnt_off = (g_seg && g_split) ? parity * (g_split->ncounters / 2) : 0;
+    // (the same halves keep a launch on the forked side stream — fork_run: the r2 half of the next cell's 7x7 beside infer_state — apart from
+    // the launches of the main stream that run at the same time: g_fork_halves is set for the whole rollout, g_fork_side inside fork_run)
+    const bool halves = g_seg || g_fork_halves;
+    const int parity = g_seg ? (g_seg->recorded & 1) : (g_fork_side ? 1 : 0);
+    const size_t slab_lim = g_split ? (halves ? (parity + 1) * (g_split->slab_floats / 2) : g_split->slab_floats) : 0;
+    const int cnt_lim = g_split ? (halves ? (parity + 1) * (g_split->ncounters / 2) : g_split->ncounters) : 0;
+    size_t slab_off = (halves && g_split) ? parity * (g_split->slab_floats / 2) : 0;
+    int cnt_off = (halves && g_split) ? parity * (g_split->ncounters / 2) : 0;
     for (int i = 0; i < n && may_split; ++i) {
       ConvProblem& q = L.p[i];
       int ns = ns_of[i];
@@ -1012,11 +1032,19 @@ bool fuse_following_1x1(ConvProblem* ps, int n, const ConvProblem& q, const sf_c
   return true;
 }
 
+int fork_join(hipStream_t st);
 // trusting gate + mix + integrator update   (:124-131, convolutions.py:348-380)
 int cell_tail(const sf_dual_w& w, const float* s, float* out, int derivative, const float* base, const float* coef,
-              int coef_stride, float* out2, int acc2, const CellBufs& b, int B, int H, int W, hipStream_t st) {
+              int coef_stride, float* out2, int acc2, const CellBufs& b, int B, int H, int W, hipStream_t st, const float* acc7 = nullptr) {
   ConvProblem ps[2];
-  ps[0] = problem(w.tg7, b.h1, b.r2, b.t1, B, H, W); ps[0].mode = 1;       // 7x7 + LN + GELU
+  if (acc7) {      // the r2 half of the 7x7 was computed on the forked stream: wait for it, then the h1 half + its sums
+    SF_TRY(fork_join(st));
+    ps[0] = problem(w.tg7_h, b.h1, nullptr, b.t1, B, H, W);
+    ps[0].acc_in = acc7; ps[0].acc_cs = w.C;
+  } else {
+    ps[0] = problem(w.tg7, b.h1, b.r2, b.t1, B, H, W);
+  }
+  ps[0].mode = 1;                                                            // 7x7 + LN + GELU
   ps[1] = problem(w.tgproj, b.h1, b.r2, b.sk, B, H, W); ps[1].mode = 0;   // 1x1 projection + GELU
   ConvProblem q = problem(w.tg1, b.t1, nullptr, b.t2, B, H, W); q.mode = 1;
   // one latent on the small-P kernel: the 1x1 + LN + GELU layer is applied to the 7x7 layer's tile before it leaves the
@@ -1040,11 +1068,64 @@ int cell_tail(const sf_dual_w& w, const float* s, float* out, int derivative, co
 struct Carry {
   float *g2, *rs2, *h2;      // gates2 output [P][2C], (1 - r2) * s [P][C], blended hidden state of cell 2 [P][C]
   float* g1s;                // state half of gates1, raw sums [P][2C] (null: not carried)
+  // round 6: rnn_state2 = conv_decoder_2(h2) [P][C] computed beside rb1.conv1, and the raw sums [P][C] of the r2 HALF of the trusting gate's
+  // 7x7 (K = 49 x C of its 49 x 2C) computed on a forked stream beside the rest of infer_state and the next cell's first two launches
+  // (null: not carried — the cell computes both itself)
+  float *r2, *acc7;
 };
 struct Side {                // extra problems for infer_state's launches (AFFINE): [0] with conv1 + projection, [1], [2] with conv2
   ConvProblem p[3];
   int n;                     // 2 or 3
+  ConvProblem dec2, s7;      // has_r2: conv_decoder_2 beside rb1.conv1, then the r2 half of the 7x7 on the forked stream
+  bool has_r2;
 };
+
+// ---- fork / join around one side launch (one latent inside a rollout).  A launch of a step's chain rarely has more than 160 workgroups of
+// 768 threads (one per CU): a third of the chip idles while the serial chain runs.  The r2 half of the next cell's 7x7 — half of the
+// longest launch of a step, and a function of the state alone — is enqueued on a second stream between two events: eager, that is a
+// second hardware queue; captured, a parallel branch of the hipGraph.  The library owns one non-blocking side stream and two events per
+// host thread, created on first use (a creation that fails — e.g. inside a capture that forbids it — switches the fork off: the cell then
+// computes the whole 7x7 itself).  Results do not depend on timing: the side launch writes its own tensor and its own half of the split-K
+// scratch, and the main stream waits for it before the 7x7's launch.
+struct Fork {
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int state = 0;             // 0: not tried, 1: ready, -1: unavailable
+  bool pending = false;
+};
+thread_local Fork g_fork;
+bool fork_ready() {
+  Fork& f = g_fork;
+  if (f.state == 0) {
+    f.state = -1;
+    if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&f.ev_join, hipEventDisableTiming) == hipSuccess)
+      f.state = 1;
+    else
+      (void)hipGetLastError();
+  }
+  return f.state == 1;
+}
+int fork_run(const ConvProblem& q, int epi, int wgs, hipStream_t st) {
+  Fork& f = g_fork;
+  if (!fork_ready() || f.pending) return SF_ERR_UNSUPPORTED;
+  SF_HIP(hipEventRecord(f.ev_fork, st));
+  SF_HIP(hipStreamWaitEvent(f.side, f.ev_fork, 0));
+  g_fork_side = wgs;
+  const int rc = run(&q, 1, epi, f.side);
+  g_fork_side = 0;
+  SF_HIP(hipEventRecord(f.ev_join, f.side));      // (also after a failed launch: the side stream must rejoin a capture)
+  f.pending = true;
+  return rc;
+}
+int fork_join(hipStream_t st) {
+  Fork& f = g_fork;
+  if (!f.pending) return SF_OK;
+  f.pending = false;
+  SF_HIP(hipStreamWaitEvent(st, f.ev_join, 0));
+  return SF_OK;
+}
 bool carry_ok(const sf_dual_w& w, const sf_pmodel_w& pm, int B, int H, int W) {
   const long P = (long)B * H * W;
   // One latent only.  (Measured with the blend mode / acc_in also in the large-tile AFFINE epilogues: per steady-state step 8 samples
@@ -1075,6 +1156,20 @@ bool carry_ok(const sf_dual_w& w, const sf_pmodel_w& pm, int B, int H, int W) {
   g[1] = prob(w.dec2, false);
   return sp_takes(g, 2, EPI_AFFINE);
 }
+// ... and whether conv_decoder_2 / the r2 half of the 7x7 can be carried too (the launch groups this adds must be ones the small-P kernel takes)
+bool fork7_ok(const sf_dual_w& w, const sf_pmodel_w& pm, int B, int H, int W) {
+  if (!tune().fork7 || g_seg || !w.tg7_h.w || !w.tg7_r.w || !w.gates1_x.w || !w.gates1_s.w || tune().pipe < 2 || !g_split || !fork_ready()) return false;
+  float* const ph = reinterpret_cast<float*>(uintptr_t(64));
+  ConvProblem g[2];
+  g[0] = problem(pm.rb1.conv1, ph, nullptr, ph, B, H, W); g[0].se_sum = ph; g[0].se_fc0 = ph; g[0].se_fc2 = ph; g[0].se_cr = 2 * w.C / 8; g[0].se_nt = 1;
+  g[1] = problem(w.dec2, ph, nullptr, ph, B, H, W);
+  if (!sp_takes(g, 2, EPI_AFFINE)) return false;
+  g[0] = problem(w.tg7_r, ph, nullptr, ph, B, H, W);
+  if (!sp_takes(g, 1, EPI_AFFINE)) return false;
+  g[0] = problem(w.tg7_h, ph, nullptr, ph, B, H, W); g[0].acc_in = ph; g[0].mode = 1;
+  g[1] = problem(w.tgproj, ph, ph, ph, B, H, W);
+  return sp_takes(g, 2, EPI_LNG);
+}
 // the two side problems of cell `w` on state `s` (= the output of the cell before it)
 void side_problems(const sf_dual_w& w, const float* s, const Carry& c, int B, int H, int W, Side& sd) {
   const int C = w.C;
@@ -1089,6 +1184,11 @@ void side_problems(const sf_dual_w& w, const float* s, const Carry& c, int B, in
   if (c.g1s && w.gates1_x.w && w.gates1_s.w && tune().pipe >= 2) {      // gates1 = sigmoid(W_x x + [W_s s] + b): the bracket now, raw
     sd.p[2] = problem(w.gates1_s, s, nullptr, c.g1s, B, H, W);
     sd.n = 3;
+  }
+  sd.has_r2 = c.r2 != nullptr && c.acc7 != nullptr;
+  if (sd.has_r2) {
+    sd.dec2 = problem(w.dec2, c.h2, nullptr, c.r2, B, H, W);        // rnn_state2 = conv_decoder_2(h2)
+    sd.s7 = problem(w.tg7_r, c.r2, nullptr, c.acc7, B, H, W);       // raw sums of the r2 half of trusting_gate.0.layers.0
   }
 }
 
@@ -1116,6 +1216,11 @@ int dual_cell(const sf_dual_w& w, const float* x, const float* s, float* out, in
     SF_TRY(run(ps, 1, EPI_AFFINE, st));                             // gates of cell 1
     cell_cand_problems(w, x, s, b, pre, B, H, W, ps[0], unused);
     ps[0].mode = 4;                                                 // candidate of cell 1 + blend ...
+    if (carry->r2 && carry->acc7) {                                 // rnn_state2 and the r2 half of the 7x7 are carried too
+      SF_TRY(run(ps, 1, EPI_AFFINE, st));
+      b.r2 = carry->r2;
+      return cell_tail(w, s, out, derivative, base, coef, coef_stride, out2, acc2, b, B, H, W, st, carry->acc7);
+    }
     ps[1] = problem(w.dec2, carry->h2, nullptr, b.r2, B, H, W);     // ... beside rnn_state2 = conv_decoder_2(h2)
     SF_TRY(run(ps, 2, EPI_AFFINE, st));
     return cell_tail(w, s, out, derivative, base, coef, coef_stride, out2, acc2, b, B, H, W, st);
@@ -1200,7 +1305,15 @@ int infer_state(const sf_pmodel_w& w, const float* s, const float* eps, float* p
     SF_TRY(gate(y1, cs1, nt1, w.se0_fc0, w.se0_fc2, sc1));
     c3.in_scale = sc1;
   }
-  SF_TRY(run1(c3, EPI_AFFINE, st));
+  if (side && side->has_r2 && fuse_se) {      // rnn_state2 = conv_decoder_2(h2) of the next cell rides here; the r2 half of its 7x7 forks off behind it
+    ps[0] = c3; ps[1] = side->dec2;
+    SF_TRY(run(ps, 2, EPI_AFFINE, st));
+    SF_TRY(fork_run(side->s7, EPI_AFFINE, tune().fork7_wgs, st));
+  } else if (side && side->has_r2) {
+    return SF_ERR_UNSUPPORTED;                 // (fork7_ok promised the fused SE gate)
+  } else {
+    SF_TRY(run1(c3, EPI_AFFINE, st));
+  }
   ConvProblem c4 = problem(w.rb1.conv2, b, nullptr, y2, B, H, W);
   c4.add = y1; c4.add_scale = sc1; c4.chansum = tiles ? cs2 : nullptr;
   SF_TRY(run1(c4, EPI_AFFINE, st));
@@ -1633,7 +1746,7 @@ size_t rollout_ws_floats(int C, int P) {
   // the persistent flow's tables and counters (5 MB) only where the flow form is switched on at the time of the query: the size query and
   // the call see the same setting (a workspace sized without them makes a flow-mode call fail with SF_ERR_WORKSPACE, not overrun)
   const bool flow = g_flow_mode < 0 ? tune().persist != 0 : g_flow_mode != 0;
-  return (cellw > inf ? cellw : inf) + 15 * al((size_t)P * C) + SPLIT_WS_FLOATS + (flow ? FLOW_WS_FLOATS : 0) + 256;
+  return (cellw > inf ? cellw : inf) + 17 * al((size_t)P * C) + SPLIT_WS_FLOATS + (flow ? FLOW_WS_FLOATS : 0) + 256;
 }
 
 int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const float* eps, const unsigned long long* philox, int coef_stride,
@@ -1642,6 +1755,8 @@ int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const fl
   // buffers of the carried branch 2 (outside the per-stage arenas: written during one stage's infer_state, read by the next cell)
   Carry cb, cnow;
   cb.g2 = A.take(2 * PC); cb.rs2 = A.take(PC); cb.h2 = A.take(PC); cb.g1s = A.take(2 * PC);
+  cb.r2 = A.take(PC); cb.acc7 = A.take(PC);
+  cnow = cb;
   // one latent: the launch groups of the stages become phases of ONE persistent flow launch (conv_sp.hip: sp_flow_kernel)
   const bool persist = (g_flow_mode < 0 ? tune().persist : g_flow_mode) && B == 1 && (long)B * H * W < tune().sp_max_p && tune().sp && g_split != nullptr;
   unsigned char* table = persist ? reinterpret_cast<unsigned char*>(A.take(FLOW_TABLE_BYTES / 4)) : nullptr;
@@ -1655,6 +1770,11 @@ int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const fl
   } seg_scope(&seg, persist);
   if (persist) SF_HIP(zero_fill(done, (FLOW_DONE_COUNTERS + 64) * sizeof(unsigned), st));
   *flow_err = persist ? done + FLOW_DONE_COUNTERS : nullptr;
+  struct HalvesScope {      // the forked side launch and the main stream's launches keep to their own halves of the split-K scratch
+    bool was;
+    HalvesScope(bool on) : was(g_fork_halves) { g_fork_halves = on; }
+    ~HalvesScope() { g_fork_halves = was; }
+  } halves_scope(!persist && B == 1 && tune().fork7 != 0);
   bool carried = false;
   for (size_t j = 0; j < stages.size(); ++j) {
     const Stage& g = stages[j];
@@ -1675,8 +1795,10 @@ int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const fl
       const Stage* nx = j + 1 < stages.size() ? &stages[j + 1] : nullptr;
       const bool pipe = nx && nx->s == g.out && carry_ok(*nx->w, pm, B, H, W);
       if (pipe) {
-        side_problems(*nx->w, g.out, cb, B, H, W, sd);
-        cnow = cb;
+        Carry cuse = cb;
+        if (!fork7_ok(*nx->w, pm, B, H, W)) { cuse.r2 = nullptr; cuse.acc7 = nullptr; }
+        side_problems(*nx->w, g.out, cuse, B, H, W, sd);
+        cnow = cuse;
         if (sd.n < 3) cnow.g1s = nullptr;
       }
       SF_TRY(infer_state(pm, g.out, eps ? eps + (size_t)g.draw * PC : nullptr, g.p_out, nullptr, B, H, W, Ai, st, philox, g.draw, pipe ? &sd : nullptr));
@@ -1684,6 +1806,7 @@ int run_stages(const std::vector<Stage>& stages, const sf_pmodel_w& pm, const fl
     }
   }
   SF_TRY(seg_flush());
+  SF_TRY(fork_join(st));      // (every forked launch is joined by the cell that follows it; this one only after an error path left one pending)
   return SF_OK;
 }
 
@@ -2077,7 +2200,7 @@ int sf_prof_enable(int on) {
   g_prof.on = on != 0;
   return SF_OK;
 }
-// Aggregates (and clears) the recorded launches by kernel key = cfg*8 + epi.  Arrays of length 32:
+// Aggregates (and clears) the recorded launches by kernel key = cfg*8 + epi.  Arrays of length SF_PROF_KEYS (include/sfnative.h; part of the ABI version):
 // calls, total ms, total algorithmic flops, total algorithmic bytes.  Synchronises.
 int sf_prof_collect(int32_t* calls, double* ms, double* flops, double* bytes) {
   if (!calls || !ms || !flops || !bytes) return SF_ERR_INVALID;

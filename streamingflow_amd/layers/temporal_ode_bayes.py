@@ -114,6 +114,9 @@ class _DualCell(PackedModule):
         bb = self.trusting_gate[0]
         L = bb.layers
         s.tg7 = packing.conv_w(pk, L[0].weight, C, C, scale=L[1].weight, bias=L[1].bias)
+        # its two input halves on their own (rollout: the rnn_state2 half is accumulated on a forked stream beside the previous infer_state)
+        s.tg7_h = packing.conv_w(pk, L[0].weight[:, :C], C, scale=L[1].weight, bias=L[1].bias)
+        s.tg7_r = packing.conv_w(pk, L[0].weight[:, C:], C)
         s.tg1 = packing.conv_w(pk, L[3].weight, C, scale=L[4].weight, bias=L[4].bias)
         s.tg3 = packing.conv_w(pk, L[6].weight, C, scale=L[7].weight, bias=L[7].bias)
         s.tgproj = packing.conv_w(pk, bb.projection[0].weight, C, C)
@@ -351,6 +354,7 @@ class NNFOwithBayesianJumps(nn.Module):
         """Pin the seed of the in-kernel (Philox) noise and restart its call counter."""
         self.noise_seed = int(seed) & 0x7FFFFFFFFFFFFFFF
         self._noise_calls = 0
+        self._noise_pinned = True
 
     def _philox_seed(self):
         if self.noise_seed is None:
@@ -366,6 +370,13 @@ class NNFOwithBayesianJumps(nn.Module):
         d["_graphs"] = collections.OrderedDict()
         d["_graph_structures_seen"] = set()
         d["_graph_gens"] = None
+        # a copy (copy.deepcopy, an EMA twin, torch.save / load) draws its OWN Philox stream: new instance serial, seed derived again on
+        # first use, call counter restarted — unless seed_noise() pinned the seed, which a copy keeps on purpose
+        if not d.get("_noise_pinned", False):
+            NNFOwithBayesianJumps._serial += 1
+            d["_noise_serial"] = NNFOwithBayesianJumps._serial
+            d["noise_seed"] = None
+            d["_noise_calls"] = 0
         return d
 
     def drop_graphs(self):
@@ -404,8 +415,12 @@ class NNFOwithBayesianJumps(nn.Module):
         if auto_graph:
             # not from inside somebody else's capture (warm-up, synchronize and a nested capture would break it), and not for an
             # endless variety of schedule structures
-            self._graph_structures_seen.add(s0.key())
-            if torch.cuda.is_current_stream_capturing() or len(self._graph_structures_seen) > self.GRAPH_AUTO_MAX_STRUCTURES:
+            # (the set stops growing at the cap: a stream of ever new timestamp structures then runs eagerly, while structures whose graph is
+            # still cached keep replaying it)
+            if len(self._graph_structures_seen) <= self.GRAPH_AUTO_MAX_STRUCTURES:
+                self._graph_structures_seen.add(s0.key())
+            cached = any(k[0] == s0.key() for k in self._graphs)
+            if torch.cuda.is_current_stream_capturing() or (len(self._graph_structures_seen) > self.GRAPH_AUTO_MAX_STRUCTURES and not cached):
                 auto_graph = False
         if eps is None and in_kernel and self.noise is None:
             self._noise_calls += 1

@@ -28,7 +28,7 @@ def test_build_and_symbols():
 def test_struct_sizes_match_header_layout():
     from streamingflow_amd import _lib
     assert ctypes.sizeof(_lib.ConvW) == 3 * 8 + 12 * 4 + 2 * 8  # 3 pointers + 11 int32 + 1 reserved + the optional split-bf16 and Winograd weight pointers
-    assert ctypes.sizeof(_lib.DualW) == 11 * ctypes.sizeof(_lib.ConvW) + 16
+    assert ctypes.sizeof(_lib.DualW) == 13 * ctypes.sizeof(_lib.ConvW) + 16      # + gates1_x / gates1_s (round 3), tg7_h / tg7_r (round 6)
     assert ctypes.sizeof(_lib.GruW) == 3 * ctypes.sizeof(_lib.ConvW)
     assert ctypes.sizeof(_lib.ResW) == 3 * ctypes.sizeof(_lib.ConvW)
 

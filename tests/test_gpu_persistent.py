@@ -121,7 +121,7 @@ print("ORACLE", worst, int(packing.flow_active()), packing.FLOW_FALLBACKS[0])
 """ % (ROOT, os.path.join(ROOT, "tests"))
 
 
-@pytest.mark.parametrize("persist", [1, 0])
+@pytest.mark.parametrize("persist", [1, 0, "fork7"])
 @pytest.mark.parametrize("solver", ["euler", "rk4"])
 def test_c64_stream40_rollout_vs_oracle(solver, persist):
     """One C = 64, 50x50 rollout over the 46-step streaming schedule (8 jumps + 46 steps chained, eager and as a replayed hipGraph)
@@ -129,6 +129,9 @@ def test_c64_stream40_rollout_vs_oracle(solver, persist):
     persist = 1: on the persistent flow kernel, in a fresh process (and no wait may have timed out: no fallback counted);
     persist = 0: the default launch path (Winograd form of the 3x3 layers)."""
     env = dict(os.environ)
+    if persist == "fork7":      # opt-in form: the r2 half of the next cell's 7x7 on a forked stream beside infer_state (csrc/api.hip: fork_run)
+        env["SF_FORK7"] = "1"
+        persist = 0
     env["SF_PERSIST"] = str(persist)
     r = subprocess.run([sys.executable, "-c", ORACLE_SCRIPT, solver], env=env, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stderr[-3000:]

@@ -4,11 +4,12 @@ set -uo pipefail
 : "${GRAFT_REPO_ROOT:?run through gpurun}"
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "c64_cells or golden_ode_step or golden_cells or odd_latent or infer_state_of_batched or split_k" 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_persistent.py tests/test_gpu_configs.py -q -m gpu -x -k "c64_stream40_rollout_vs_oracle or stream40_hipgraph_equals_eager" 2>&1 | tail -3
 for k in 1 0 1; do
   echo "== chain SF_WINO_SP=$k"
   SF_WINO_SP=$k SF_PERSIST=0 timeout 300 python3 tools/chainbench.py euler 10 30 2>/dev/null | tail -1
 done
-for v in ${WSP_VARIANTS:-"SF_WSP_MINSUB=1"}; do
+for v in ${WSP_VARIANTS:-SF_FORK7=0 SF_FORK7_WGS=120 SF_FORK7_WGS=160}; do
   echo "== chain $v"
   env $v SF_PERSIST=0 timeout 300 python3 tools/chainbench.py euler 10 30 2>/dev/null | tail -1
 done
