@@ -456,6 +456,14 @@ int sf_sparse_table_fwd(const int32_t* in_coords, int n_in, const int32_t* out_c
                         int32_t* nbr, void* ws, size_t ws_bytes, void* stream);
 int sf_sparse_conv_fwd(const sf_conv_w* w, const float* feats, int feats_cs, int n_in, const int32_t* nbr, int n_out,
                        const float* add, int act_after_add, float* out, float* ws, size_t ws_bytes, void* stream);
+/* sf_sparse_conv_masked_fwd — the same convolution with a TAP MASK (round 6): tile_mask64[i], i < ceil(n_out / 64), has bit t set when at
+ *   least one of the output rows 64 i .. 64 i + 63 reads an input row through tap t (nbr[j][t] >= 0).  A pixel tile of the kernel then
+ *   walks only the taps that are live for its rows; a skipped tap would have gathered zero rows, so the sums are bitwise those of
+ *   sf_sparse_conv_fwd.  It pays when the caller keeps the output rows of a stage sorted by neighbour mask (rows with equal masks
+ *   together: streamingflow_amd/models/sparse_encoder.py does; 38 % of the (site, tap) products of the shipped cloud have no input row and
+ *   a tile of stored-order rows can drop < 1 % of them, a tile of mask-sorted rows 25 %).  NULL mask = sf_sparse_conv_fwd. */
+int sf_sparse_conv_masked_fwd(const sf_conv_w* w, const float* feats, int feats_cs, int n_in, const int32_t* nbr, const uint32_t* tile_mask64,
+                              int n_out, const float* add, int act_after_add, float* out, float* ws, size_t ws_bytes, void* stream);
 int sf_sparse_to_dense_fwd(const float* feats, const int32_t* coords, int n, int C, int batch, int X, int Y, int D, float* out,
                            void* stream);
 

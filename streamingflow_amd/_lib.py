@@ -153,6 +153,7 @@ SIGNATURES = {
     "sf_sparse_out_sites_fwd": (_i, [_vp, _i, _i, _i3, _i3, _i3, _i3, _vp, _i, _vp, _vp, _sz, _vp]),
     "sf_sparse_table_fwd": (_i, [_vp, _i, _vp, _i, _i, _i3, _i3, _i3, _i3, _i, _vp, _vp, _sz, _vp]),
     "sf_sparse_conv_fwd": (_i, [C.POINTER(ConvW), _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "sf_sparse_conv_masked_fwd": (_i, [C.POINTER(ConvW), _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "sf_sparse_to_dense_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sf_warp_affine_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "sf_confusion_fwd": (_i, [_vp, _vp, C.c_long, _i, _vp, _vp, _vp]),

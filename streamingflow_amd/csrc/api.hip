@@ -1547,6 +1547,25 @@ int sf_sparse_conv_fwd(const sf_conv_w* w, const float* feats, int feats_cs, int
   return run1(p, EPI_AFFINE, (hipStream_t)stream);
 }
 
+/* the same with a tap mask: tile_mask64[i] bit t = some row of 64 i .. 64 i + 63 has an input row under tap t (see sfnative.h) */
+int sf_sparse_conv_masked_fwd(const sf_conv_w* w, const float* feats, int feats_cs, int n_in, const int32_t* nbr, const uint32_t* tile_mask64, int n_out,
+                              const float* add, int act_after_add, float* out, float* ws, size_t ws_bytes, void* stream) {
+  if (!w || !valid_w(*w) || !feats || !nbr || !out || n_out < 0 || n_in < 1 || w->kw != 1 || w->c1 != 0 || feats_cs < w->c0 ||
+      (feats_cs % 4))
+    return SF_ERR_INVALID;
+  if (n_out == 0) return SF_OK;
+  Arena A(ws, ws_bytes);
+  SplitScope sp(A, (hipStream_t)stream);
+  ConvProblem p = problem(*w, feats, nullptr, out, 1, 1, n_in, 0);
+  p.in0_cs = feats_cs;
+  p.Hout = 1; p.Wout = n_out;
+  p.gather = nbr;
+  p.tap_mask = tile_mask64; p.tap_mask_n = tile_mask64 ? (n_out + 63) / 64 : 0;
+  p.add = add;
+  if (act_after_add) p.mode |= 2;
+  return run1(p, EPI_AFFINE, (hipStream_t)stream);
+}
+
 /* per-image channel means of an NHWC tensor (fixed-order two-level sum: reproducible) */
 size_t sf_channel_mean_ws_bytes(int C, int n) { return al((size_t)n * 64 * C) * sizeof(float); }
 int sf_channel_mean_fwd(const float* x, float* out, int n, int HW, int C, float* ws, size_t ws_bytes, void* stream) {

@@ -872,7 +872,19 @@ __global__ __launch_bounds__(64 * WM * WN, (B3 && !SF_B3_DEEP && WM * WN >= 8 ? 
   if ((int)blockIdx.z >= nsplit) return;   // block-uniform
   const int cps = (nchunks_all + nsplit - 1) / nsplit;
   const int cb = (int)blockIdx.z * cps;
-  const int nchunks = (nchunks_all - cb) < cps ? (nchunks_all - cb) : cps;
+  // sparse convolution with a tap mask (ConvProblem::tap_mask): the taps that are live for this tile's rows, 0 = walk every tap
+  unsigned live_taps = 0;
+  if (gather && P.tap_mask && nsplit == 1 && KW == 1 && KHg <= 32 && (BN % 64) == 0) {      // block-uniform
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < BN / 64; ++i) {
+      const int idx = p_tile * (BN / 64) + i;
+      if (idx < P.tap_mask_n) m |= P.tap_mask[idx];
+    }
+    if (KHg < 32) m &= (1u << KHg) - 1u;
+    live_taps = m;      // (no live tap at all cannot happen for a stored site; 0 falls back to the full walk)
+  }
+  const int nchunks = live_taps ? __popc(live_taps) * kcpt : ((nchunks_all - cb) < cps ? (nchunks_all - cb) : cps);
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -880,7 +892,7 @@ __global__ __launch_bounds__(64 * WM * WN, (B3 && !SF_B3_DEEP && WM * WN >= 8 ? 
 #pragma unroll
     for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  int cur_kc = cb % kcpt, cur_ty = (cb / kcpt) / KW, cur_tx = (cb / kcpt) % KW;     // cursor of the next chunk to ISSUE
+  int cur_kc = cb % kcpt, cur_ty = live_taps ? __ffs((int)live_taps) - 1 : (cb / kcpt) / KW, cur_tx = (cb / kcpt) % KW;     // cursor of the next chunk to ISSUE
   // per tap and pixel slot: byte offset of the gathered pixel in either source, this lane's 16-byte channel slot included, or
   // 0x80000000 outside the image / the table (beyond any buffer: the range check zero-fills).  Per chunk a DMA then needs no
   // vector arithmetic at all — the channel chunk goes into the scalar offset (fp32 MFMAs share the vector ALU)
@@ -906,7 +918,8 @@ __global__ __launch_bounds__(64 * WM * WN, (B3 && !SF_B3_DEEP && WM * WN >= 8 ? 
     if (q < GA) {
       float* dst = smem + buf * BUF + (wave * GA + q) * 8 * 32;
 #if defined(__HIP_DEVICE_COMPILE__)     // the host pass must not see the target builtins (it silently drops the kernel stub)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)dst, 16, a_voff[q], chunk * (BK * 4), 0, 0);
+      const int wchunk = live_taps ? cur_ty * kcpt + cur_kc : chunk;      // (the cursor still points at this chunk: it moves with the last slot)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)dst, 16, a_voff[q], wchunk * (BK * 4), 0, 0);
 #else
       (void)dst; (void)chunk;
 #endif
@@ -950,7 +963,10 @@ __global__ __launch_bounds__(64 * WM * WN, (B3 && !SF_B3_DEEP && WM * WN >= 8 ? 
       if (cur_kc == kcpt) {
         cur_kc = 0;
         tap_fresh = true;
-        if (++cur_tx == KW) { cur_tx = 0; ++cur_ty; }
+        if (live_taps) {      // the next live tap
+          const unsigned rest = cur_ty + 1 < 32 ? live_taps >> (cur_ty + 1) : 0u;
+          cur_ty = rest ? cur_ty + __ffs((int)rest) : KHg;
+        } else if (++cur_tx == KW) { cur_tx = 0; ++cur_ty; }
       }
     }
 #endif

@@ -85,6 +85,11 @@ struct ConvProblem {
   // sparse (gather) convolution: the input row of output row p under kernel tap t is gather[p*KH + t]
   // (-1: inactive site); geometry is then n_img = 1, Hout = 1, Wout = number of output rows, KW = 1
   const int* gather;
+  // ... and, optional (LDS-DMA kernel): one word per 64 consecutive output rows, bit t set when at least one of them has an input row under
+  // tap t.  A pixel tile then walks only the taps that are live for it (the rows are kept sorted by neighbour mask so that whole taps
+  // drop out of a tile: models/sparse_encoder.py); dropped taps would have gathered zero rows, the sums are bitwise the same
+  const unsigned* tap_mask;
+  int tap_mask_n;
   // small-P kernel, one image: the SE gate of the input (res_models.py:161-165) is computed in the consuming layer's
   // prologue from the per-tile channel sums the producer wrote: scale = sigmoid(fc2 relu(fc0 mean)), every workgroup
   // for itself; workgroup 0 also stores it to se_out (the residual of the next layer is scaled by it)

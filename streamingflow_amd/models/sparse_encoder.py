@@ -150,14 +150,57 @@ class SparseEncoder(PackedModule):
         return out[: int(cnt.item())], oshape
 
     @staticmethod
-    def _conv(w, feats, nbr, n_out, add=None, act_after_add=False):
+    def _conv(w, feats, nbr, n_out, add=None, act_after_add=False, mask=None):
         L = _lib.lib()
         dev = feats.device
         out = torch.empty((n_out, w.cout), dtype=torch.float32, device=dev)
         ws = runtime.workspace(L.sf_conv2d_ex_ws_bytes(), dev)
-        _lib.check(L.sf_sparse_conv_fwd(C.byref(w), ptr(feats), feats.shape[1], feats.shape[0], ptr(nbr), n_out, ptr(add), int(act_after_add), ptr(out),
-                                        ptr(ws), ws.numel() * 4, runtime.stream_ptr(dev)), "sparse_conv")
+        _lib.check(L.sf_sparse_conv_masked_fwd(C.byref(w), ptr(feats), feats.shape[1], feats.shape[0], ptr(nbr), ptr(mask), n_out, ptr(add), int(act_after_add),
+                                               ptr(out), ptr(ws), ws.numel() * 4, runtime.stream_ptr(dev)), "sparse_conv")
         return out
+
+    # ---- rows sorted by neighbour mask + per-tile tap masks (round 6) --------------------------------------------------------------
+    # 38 % of the (site, tap) products of a shipped-size cloud have no input site.  In stored order a 64/128-row tile of the kernel still
+    # needs every tap (some row of it always has one); with the rows of a stage sorted by their neighbour mask — read as a number whose
+    # most significant bits are the rarest taps — the rows of a tile agree on those taps and a quarter of the (tile, tap) pairs drop out
+    # (profiles/r06_s_sparse_mask_sort.jsonl).  The order of the rows is free: tables, features and coordinates are permuted together
+    # and dense() scatters by coordinate.
+    # MEASURED NO-GO, kept opt-in (SF_SPARSE_SORT=1; tests/test_sparse_encoder.py runs it): the kernels then walk 78 % of the dense-tap
+    # products, bitwise the same results — and the encoder takes 15.5 ms instead of 12.1 (profiles/r06_t_sparse_mask_sort_ab.txt): rows
+    # that are neighbours in the sorted order are not neighbours in space, so the 27 gathers of a tile no longer share input rows in L2
+    # (in coordinate order each input row is read by up to 27 nearby output rows), and the sort / permutation passes cost time of their own.
+    # In stored order the masks are all-ones in practice (a tile drops 0.3 % of its taps) and are not even computed.
+    SORT = __import__("os").environ.get("SF_SPARSE_SORT", "0") != "0"
+
+    @staticmethod
+    def _mask_order(tab, n):
+        live = tab[:n] >= 0
+        taps = live.shape[1]
+        order = torch.argsort(live.sum(0))                                             # rarest tap first
+        w = (1 << torch.arange(taps - 1, -1, -1, device=tab.device, dtype=torch.int64))
+        key = (live[:, order].to(torch.int64) * w).sum(1)
+        return torch.argsort(key)
+
+    @staticmethod
+    def _permute_subm(tab, perm):
+        """neighbour table of a submanifold stage after its rows (= its input rows) were permuted"""
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel(), device=perm.device)
+        t = tab[perm]
+        return torch.where(t >= 0, inv[t.clamp_min(0).long()].to(torch.int32), t).contiguous()
+
+    @staticmethod
+    def _tile_mask(nbr, n):
+        taps = nbr.shape[1]
+        if n == 0 or taps > 31:
+            return None
+        live = nbr[:n] >= 0
+        pad = (-n) % 64
+        if pad:
+            live = torch.cat([live, live.new_zeros((pad, taps))], 0)
+        any_ = live.view(-1, 64, taps).any(1)
+        w = (1 << torch.arange(taps, device=nbr.device, dtype=torch.int64))
+        return (any_.to(torch.int64) * w).sum(1).to(torch.int32).contiguous()
 
     def forward(self, voxel_features, coors, batch_size, nhwc=False, **kwargs):
         """voxel_features [N, Cin] f32, coors [N, 4] int (batch, x, y, z) -> [B, C*D, H, W] (sparse_encoder.py:100-139)."""
@@ -174,34 +217,53 @@ class SparseEncoder(PackedModule):
         x[:, : self.in_channels] = voxel_features
         k3, one3, zero3 = [3, 3, 3], [1, 1, 1], [0, 0, 0]
         tab = self._table(coords, coords, B, shape, k3, one3, zero3, True) if n else None
-        x = self._conv(W["conv_input"], x, tab, n)
+        tmask = None
+        if n and self.SORT:      # the voxels in neighbour-mask order (features, coordinates and the table together)
+            perm = self._mask_order(tab, n)
+            x, coords, tab = x[perm].contiguous(), coords[perm].contiguous(), self._permute_subm(tab, perm)
+        if n and self.SORT:
+            tmask = self._tile_mask(tab, n)
+        x = self._conv(W["conv_input"], x, tab, n, mask=tmask)
         for i, stage in enumerate(self.encoder_layers):
             for j, blk in enumerate(stage):
                 if isinstance(blk, SparseBasicBlock):
                     if tab is None and n:
                         tab = self._table(coords, coords, B, shape, k3, one3, zero3, True)
-                    y = self._conv(W[f"{i}.{j}.c1"], x, tab, n)
-                    x = self._conv(W[f"{i}.{j}.c2"], y, tab, n, add=x, act_after_add=True)
+                        tmask = self._tile_mask(tab, n) if self.SORT else None
+                    y = self._conv(W[f"{i}.{j}.c1"], x, tab, n, mask=tmask)
+                    x = self._conv(W[f"{i}.{j}.c2"], y, tab, n, add=x, act_after_add=True, mask=tmask)
                 elif blk[0].subm:                       # conv_module: submanifold conv + BN + ReLU
                     if tab is None and n:
                         tab = self._table(coords, coords, B, shape, k3, one3, zero3, True)
-                    x = self._conv(W[f"{i}.{j}"], x, tab, n)
+                        tmask = self._tile_mask(tab, n) if self.SORT else None
+                    x = self._conv(W[f"{i}.{j}"], x, tab, n, mask=tmask)
                 else:
-                    x, coords, shape, n = self._strided(W[f"{i}.{j}"], blk[0], x, coords, B, shape, n)
-                    tab = None
-        x, coords, shape, n = self._strided(W["conv_out"], self.conv_out[0], x, coords, B, shape, n)
+                    nxt = stage[j + 1] if j + 1 < len(stage) else (self.encoder_layers[i + 1][0] if i + 1 < len(self.encoder_layers) else None)
+                    subm_next = nxt is not None and (isinstance(nxt, SparseBasicBlock) or nxt[0].subm)
+                    x, coords, shape, n, tab, tmask = self._strided(W[f"{i}.{j}"], blk[0], x, coords, B, shape, n, sort_for_subm=subm_next and self.SORT)
+        x, coords, shape, n, _, _ = self._strided(W["conv_out"], self.conv_out[0], x, coords, B, shape, n)
         Cc = x.shape[1] if n else self.output_channels
         out = torch.empty((B, shape[0], shape[1], Cc * shape[2]), dtype=torch.float32, device=dev)
         _lib.check(_lib.lib().sf_sparse_to_dense_fwd(ptr(x), ptr(coords), n, Cc, B, shape[0], shape[1], shape[2], ptr(out),
                                                      runtime.stream_ptr(dev)), "sparse_to_dense")
         return out if nhwc else runtime.to_nchw(out)
 
-    def _strided(self, w, conv, x, coords, B, shape, n):
+    def _strided(self, w, conv, x, coords, B, shape, n, sort_for_subm=False):
+        """strided SparseConv3d; returns (features, coordinates, grid, sites, submanifold table of the new sites or None, its tile masks).
+        sort_for_subm: submanifold convolutions follow on the new sites — their table is built here and the new sites are put in the order
+        of ITS masks (the four 3x3x3 layers of a stage are 8x the strided layer's work) before the strided layer writes them."""
         k, s, p = conv.kernel_size, conv.stride, conv.padding
         oshape = [(shape[a] + 2 * p[a] - (k[a] - 1) - 1) // s[a] + 1 for a in range(3)]
         if n == 0:
-            return x.new_zeros((0, w.cout)), coords, oshape, 0
+            return x.new_zeros((0, w.cout)), coords, oshape, 0, None, None
         oc, oshape = self._out_sites(coords, B, shape, k, s, p)
+        oc = oc.contiguous()
         m = oc.shape[0]
+        tab = tmask = None
+        if sort_for_subm and m:
+            tab = self._table(oc, oc, B, oshape, [3, 3, 3], [1, 1, 1], [0, 0, 0], True)
+            perm = self._mask_order(tab, m)
+            oc, tab = oc[perm].contiguous(), self._permute_subm(tab, perm)
+            tmask = self._tile_mask(tab, m)
         nbr = self._table(coords, oc, B, shape, k, s, p, False)
-        return self._conv(w, x, nbr, m), oc.contiguous(), oshape, m
+        return self._conv(w, x, nbr, m, mask=self._tile_mask(nbr, m) if self.SORT else None), oc, oshape, m, tab, tmask

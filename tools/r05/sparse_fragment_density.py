@@ -47,7 +47,7 @@ def main():
         tables[t.data_ptr()] = out_coords
         return t
 
-    def spy_conv(w, f, nbr, n_out, add=None, act_after_add=False):
+    def spy_conv(w, f, nbr, n_out, add=None, act_after_add=False, mask=None):
         live = nbr[:n_out] >= 0
         oc = tables[nbr.data_ptr()][:n_out]
         taps = live.shape[1]
@@ -61,7 +61,7 @@ def main():
                 q = torch.cat([lv, torch.zeros((pad, taps), dtype=torch.bool, device=lv.device)], 0).view(-1, T, taps).any(1)
                 r[f"{name}_frag{T}_tap_live"] = float(q.float().mean())
         rows.append(r)
-        return orig_conv(w, f, nbr, n_out, add, act_after_add)
+        return orig_conv(w, f, nbr, n_out, add, act_after_add, mask=mask)
 
     m._table, m._conv = spy_table, spy_conv
     with torch.no_grad():

@@ -44,7 +44,7 @@ def main():
     rows = []
     orig_conv = m._conv
 
-    def spy_conv(w, f, nbr, n_out, add=None, act_after_add=False):
+    def spy_conv(w, f, nbr, n_out, add=None, act_after_add=False, mask=None):
         live = nbr[:n_out] >= 0
         taps = live.shape[1]
         cin = w.c0 + w.c1
@@ -62,7 +62,7 @@ def main():
             r[f"count_mask_sorted_tile{T}"] = tile_live(live[by_count], T)
         r["distinct_masks"] = int(torch.unique(key).numel())
         rows.append(r)
-        return orig_conv(w, f, nbr, n_out, add, act_after_add)
+        return orig_conv(w, f, nbr, n_out, add, act_after_add, mask=mask)
 
     m._conv = spy_conv
     with torch.no_grad():

@@ -51,17 +51,26 @@ def run(reps=5, cpu=False, dev=None):
     # FLOPs of the encoder's convolutions on this cloud: "dense-tap" = what the kernels execute (every output row x all 27 / 3 taps,
     # the implicit GEMM gathers a zero row for a missing neighbour), "useful" = only the (output site, tap) pairs that have an input site
     # (what spconv's rule-based gather / GEMM / scatter would multiply: spconv_ops.h:302-348)
-    fl = {"dense": 0.0, "useful": 0.0, "convs": 0}
+    fl = {"dense": 0.0, "useful": 0.0, "executed": 0.0, "convs": 0}
     orig_conv = m._conv
 
-    def spy_conv(w, f, nbr, n_out, add=None, act_after_add=False):
+    def spy_conv(w, f, nbr, n_out, add=None, act_after_add=False, mask=None):
         taps = nbr.shape[1]
         live = float((nbr[:n_out] >= 0).sum().item())
         cin = w.c0 + w.c1
         fl["dense"] += 2.0 * n_out * taps * cin * w.cout
         fl["useful"] += 2.0 * live * cin * w.cout
+        if mask is None:
+            fl["executed"] += 2.0 * n_out * taps * cin * w.cout
+        else:      # what the kernel walks: per 128-row tile (the tiles of these layers) the taps of its two 64-row mask words
+            mk = mask.to(torch.int64) & 0xFFFFFFFF
+            if mk.numel() % 2:
+                mk = torch.cat([mk, mk.new_zeros(1)])
+            both = mk[0::2] | mk[1::2]
+            pc = sum(((both >> t) & 1) for t in range(taps)).sum().item()
+            fl["executed"] += 2.0 * 128.0 * float(pc) * cin * w.cout
         fl["convs"] += 1
-        return orig_conv(w, f, nbr, n_out, add, act_after_add)
+        return orig_conv(w, f, nbr, n_out, add, act_after_add, mask=mask)
     m._conv = spy_conv
     with torch.no_grad():
         m(feats, coords, 1, nhwc=True)
@@ -74,12 +83,14 @@ def run(reps=5, cpu=False, dev=None):
          "occupied_bev_fraction": float((out.abs().amax(1) > 0).float().mean()),
          # the whole encoder call (index kernels: out sites + neighbour tables, and the convolutions) against the fp32 MFMA peak
          "roofline": {"bound": "mfma", "kernel": "SparseEncoder.forward: sf_sparse_out_sites / sf_sparse_table + %d sf_sparse_conv_fwd (conv_glds gather tiles)" % fl["convs"],
-                      "flops_executed_dense_taps": fl["dense"], "flops_useful_site_tap_pairs": fl["useful"],
-                      "achieved": fl["dense"] / (enc_ms * 1e-3) / 1e12, "achieved_useful": fl["useful"] / (enc_ms * 1e-3) / 1e12,
-                      "peak": PEAK, "unit": "TFLOP/s", "frac": fl["dense"] / (enc_ms * 1e-3) / 1e12 / PEAK,
+                      "flops_dense_taps": fl["dense"], "flops_executed": fl["executed"], "flops_useful_site_tap_pairs": fl["useful"],
+                      "achieved": fl["executed"] / (enc_ms * 1e-3) / 1e12, "achieved_useful": fl["useful"] / (enc_ms * 1e-3) / 1e12,
+                      "peak": PEAK, "unit": "TFLOP/s", "frac": fl["executed"] / (enc_ms * 1e-3) / 1e12 / PEAK,
                       "frac_useful": fl["useful"] / (enc_ms * 1e-3) / 1e12 / PEAK, "traffic": None,
-                      "note": "dense-tap execution: %.1f %% of the executed products have an input site; a 16-row fragment x tap skip would drop "
-                              "nothing on the heavy stages (profiles/r05_sparse_fragment_density.jsonl)" % (100.0 * fl["useful"] / max(fl["dense"], 1.0))}}
+                      "row_order": "sorted by neighbour mask" if m.SORT else "stored",
+                      "note": "rows of every stage sorted by neighbour mask, per-tile tap masks (round 6): the kernels walk %.1f %% of the dense-tap products (128-row tiles), "
+                              "%.1f %% of all (site, tap) pairs have an input site; index work (tables, sort, masks) is inside the time"
+                              % (100.0 * fl["executed"] / max(fl["dense"], 1.0), 100.0 * fl["useful"] / max(fl["dense"], 1.0))}}
     if cpu:
         from oracle import sparse_encoder_ref as SR      # the checker, timed as the reported CPU baseline only
         n = 20000                     # bounded sample: the numpy oracle is ~linear in the number of voxels
