@@ -52,10 +52,18 @@ def _build(tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sort", [False, True])
 @pytest.mark.parametrize("tag", list(cases.SPARSE_CASES))
-def test_gpu_forward(tag):
+def test_gpu_forward(tag, sort, monkeypatch):
+    """sort=True: the opt-in form with the rows of every stage in neighbour-mask order and per-tile tap masks (sf_sparse_conv_masked_fwd):
+    a dropped tap would have gathered zero rows, so the output must equal the stored-order output BIT FOR BIT."""
+    from streamingflow_amd.models.sparse_encoder import SparseEncoder
     m, sd, cfg = _build(tag)
     f, c, B = cases.sparse_inputs(tag)
+    if sort:
+        plain = m(f.cuda(), c.cuda(), B)
+        monkeypatch.setattr(SparseEncoder, "SORT", True)
+        assert torch.equal(m(f.cuda(), c.cuda(), B), plain)
     out = m(f.cuda(), c.cuda(), B)
     want = SR.sparse_encoder_forward(sd, f.numpy(), c.numpy(), B, cfg)
     err = maxabs(out, want)
