@@ -338,3 +338,23 @@ def test_grad_enabled_inputs_are_refused_parameters_are_not():
     with torch.no_grad():
         y2, _ = net(xg[:, -1:], xg, None, cts, None, tts)
     assert y2.shape == y.shape
+
+
+def test_single_sample_head_in_wavefront_order_equals_the_serial_head(monkeypatch):
+    """One sample per call (evaluate.py:46): the two SpatialGRUs and the ConvNeXt block between them run in wavefront order
+    (sf_spatial_gru_pair_fwd: frame k of the first GRU shares its launches with frame k - 1 of the second).  Same arithmetic per frame:
+    the forward must equal the one-GRU-after-the-other form bit for bit, at the shipped size and on an odd one."""
+    from streamingflow_amd.models import future_prediction_ode as M
+    for C, H, W, ts in ((64, 200, 200, "shipped"), (8, 20, 28, "camera_only")):
+        cts, lts, tts, dt = cases.timeset(ts)
+        net, _ = build_pair(C, "euler", True, True, dt)
+        cam, lid = cases.bev_inputs(C, H, W, cts.shape[1], lts.shape[1])
+        args = (cases.present_input(cam, lid).cuda(), cam.cuda(), lid.cuda() if lts.shape[1] else None, cts, lts if lts.shape[1] else None, tts)
+        outs = []
+        for pair in (True, False):
+            monkeypatch.setattr(M, "_GRU_PAIR", pair)
+            net.gru_ode.noise = hashfill.HashedNoise(cases.EPS_SEED)
+            y, _ = net(*args)
+            outs.append(y.clone())
+        assert torch.isfinite(outs[0]).all()
+        assert torch.equal(outs[0], outs[1]), (C, H, W, float((outs[0] - outs[1]).abs().max()))
