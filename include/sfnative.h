@@ -231,13 +231,6 @@ int sf_gru_ode_cell_fwd(const sf_gru_w* w, const float* x, const float* s, float
  * x [T][n_img][H*W][Cx], state0 [n_img][H*W][C] -> out [T][n_img][H*W][Cx] */
 int sf_spatial_gru_fwd(const sf_gru_w* w, const float* x, const float* state0, float* out, int T, int n_img, int H,
                        int W, float* ws, size_t ws_bytes, void* stream);
-/* Two stacked SpatialGRUs with the ConvNeXt blocks between them (streamingflow/models/future_prediction_ode.py:56-62: spatial_grus[0] ->
- * res_blocks[0] -> spatial_grus[1]) in wavefront order: frame k of the first GRU and frame k - 1 of the second share their launches.  Bitwise the
- * results of sf_spatial_gru_fwd / sf_convnext_block_fwd called one after the other; for ONE sample per call (a frame's launch alone leaves
- * the chip half empty).  w0 needs its 1x1 decoder; out: [T][P][w1's decoder width, or C for a w1 without decoder]. */
-size_t sf_spatial_gru_pair_ws_bytes(int C, int T, int n_img, int H, int W);
-int sf_spatial_gru_pair_fwd(const sf_gru_w* w0, const sf_convnext_w* blocks, int n_blocks, const sf_gru_w* w1, const float* x, const float* state0,
-                            float* out, int T, int n_img, int H, int W, float* ws, size_t ws_bytes, void* stream);
 size_t sf_spatial_gru_ws_bytes(int C, int n_img, int H, int W);
 
 /* The latent-space operators below take n_img >= 1 samples ([n_img][H][W][C] tensors) that are

@@ -101,8 +101,6 @@ SIGNATURES = {
     "sf_gru_cell_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "sf_gru_ode_cell_fwd": (_i, [C.POINTER(GruW), _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sf_spatial_gru_fwd": (_i, [C.POINTER(GruW), _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
-    "sf_spatial_gru_pair_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "sf_spatial_gru_pair_fwd": (_i, [C.POINTER(GruW), _vp, _i, C.POINTER(GruW), _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sf_spatial_gru_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "sf_dual_cell_fwd": (_i, [C.POINTER(DualW), _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sf_dual_cell_ws_bytes": (_sz, [_i, _i, _i, _i]),

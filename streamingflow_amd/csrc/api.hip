@@ -1656,81 +1656,6 @@ int sf_spatial_gru_fwd(const sf_gru_w* w, const float* x, const float* state0, f
   return SF_OK;
 }
 
-/* Two stacked SpatialGRUs with the ConvNeXt blocks between them (future_prediction_ode.py:56-62: gru 0 -> res_blocks[0] -> gru 1), in WAVEFRONT
- * order: frame k of the first GRU and frame k - 1 of the second do not depend on each other, so their gate convolutions share one launch
- * and their candidate convolutions another (run() groups Winograd launches of identical geometry).  Same arithmetic per frame as
- * sf_spatial_gru_fwd + sf_convnext_block_fwd, bitwise; it pays where one frame's launch leaves the chip half empty — ONE sample per call
- * (626 / 313 workgroups for 512 slots: the reference's own operating point, evaluate.py:46).  w0 must have its 1x1 decoder; w1's output is
- * its decoder's where it has one, else the hidden states.  Both GRUs start from state0 (future_prediction_ode.py:56). */
-static int convnext_block(const sf_convnext_w* w, const float* x, float* out, int n, int H, int W, Arena& A, hipStream_t st);
-size_t sf_spatial_gru_pair_ws_bytes(int C, int T, int n_img, int H, int W) {
-  const size_t P = (size_t)n_img * H * W;
-  return (2 * al(P * 2 * C) + 8 * al(P * C) + al((size_t)T * P * C) + al(P * C) + al(P * 4 * C)) * sizeof(float);
-}
-int sf_spatial_gru_pair_fwd(const sf_gru_w* w0, const sf_convnext_w* blocks, int n_blocks, const sf_gru_w* w1, const float* x, const float* state0,
-                            float* out, int T, int n_img, int H, int W, float* ws, size_t ws_bytes, void* stream) {
-  if (!w0 || !w1 || !x || !state0 || !out || T < 1 || n_blocks < 0 || (n_blocks > 0 && !blocks) || !valid_w(w0->gates) || !valid_w(w0->cand) ||
-      !valid_w(w1->gates) || !valid_w(w1->cand) || !w0->decoder.w || !valid_w(w0->decoder))
-    return SF_ERR_INVALID;
-  const bool dec1 = w1->decoder.w != nullptr;
-  if (dec1 && !valid_w(w1->decoder)) return SF_ERR_INVALID;
-  const int C = w0->cand.cout, Cx = w0->gates.c0;
-  if (w1->cand.cout != C || w1->gates.c0 != w0->decoder.cout || w0->decoder.cout != Cx) return SF_ERR_UNSUPPORTED;      // (in == hidden == decoded width, as the reference builds them)
-  for (int i = 0; i < n_blocks; ++i)
-    if (blocks[i].C != Cx) return SF_ERR_UNSUPPORTED;
-  const size_t P = (size_t)n_img * H * W;
-  Arena A(ws, ws_bytes);
-  float *g[2], *sa[2], *sb[2], *rs[2];
-  for (int i = 0; i < 2; ++i) { g[i] = A.take(P * 2 * C); sa[i] = A.take(P * C); sb[i] = A.take(P * C); rs[i] = A.take(P * C); }
-  float* y = A.take(P * Cx);                  // decoded frame of the first GRU
-  float* yb = A.take(P * Cx);                 // ping-pong between the ConvNeXt blocks
-  float* z = A.take((size_t)T * P * Cx);      // inputs of the second GRU
-  if (!A.ok()) return SF_ERR_WORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
-  const sf_gru_w* wv[2] = {w0, w1};
-  const float* cur[2] = {state0, state0};
-  const bool pre[2] = {pregate((long)P, w0->cand), pregate((long)P, w1->cand)};
-  for (int k = 0; k <= T; ++k) {
-    // which cells run in this wave: frame k of GRU 0, frame k - 1 of GRU 1
-    int idx[2], n = 0;
-    if (k < T) idx[n++] = 0;
-    if (k >= 1) idx[n++] = 1;
-    const float* xin[2] = {x + (size_t)k * P * Cx, k >= 1 ? z + (size_t)(k - 1) * P * Cx : nullptr};
-    float* nxt[2];
-    ConvProblem pa[2], pb[2];
-    for (int q = 0; q < n; ++q) {
-      const int i = idx[q], t = i == 0 ? k : k - 1;
-      const sf_gru_w& w = *wv[i];
-      nxt[i] = (i == 1 && !dec1) ? out + (size_t)t * P * C : ((t & 1) ? sb[i] : sa[i]);
-      ConvProblem a = problem(w.gates, xin[i], cur[i], g[i], n_img, H, W);
-      if (pre[i]) { a.out2 = rs[i]; a.out2_cs = C; a.e1 = cur[i]; a.e1_cs = C; a.gate_from = C; }
-      ConvProblem b = problem(w.cand, xin[i], pre[i] ? rs[i] : cur[i], nxt[i], n_img, H, W);
-      if (!pre[i]) { b.gate = g[i]; b.gate_cs = 2 * C; b.gate_co = C; }
-      b.e0 = g[i]; b.e0_cs = 2 * C; b.e1 = cur[i]; b.e1_cs = C;
-      pa[q] = a; pb[q] = b;
-    }
-    SF_TRY(run(pa, n, EPI_AFFINE, st));
-    SF_TRY(run(pb, n, EPI_BLEND, st));
-    if (k < T) {      // decoded frame of GRU 0 -> the ConvNeXt blocks -> frame k of GRU 1's input
-      float* zk = z + (size_t)k * P * Cx;
-      SF_TRY(run1(problem(w0->decoder, nxt[0], nullptr, n_blocks ? y : zk, n_img, H, W), EPI_AFFINE, st));
-      const float* src = y;
-      for (int bi = 0; bi < n_blocks; ++bi) {
-        float* dst = bi == n_blocks - 1 ? zk : (src == y ? yb : y);
-        Arena Ab = A;
-        SF_TRY(convnext_block(blocks + bi, src, dst, n_img, H, W, Ab, st));
-        src = dst;
-      }
-      cur[0] = nxt[0];
-    }
-    if (k >= 1) {
-      if (dec1) SF_TRY(run1(problem(w1->decoder, nxt[1], nullptr, out + (size_t)(k - 1) * P * w1->decoder.cout, n_img, H, W), EPI_AFFINE, st));
-      cur[1] = nxt[1];
-    }
-  }
-  return SF_OK;
-}
-
 size_t sf_dual_cell_ws_bytes(int C, int n_img, int H, int W) {
   return (dual_ws_floats(C, n_img * H * W) + SPLIT_WS_FLOATS) * sizeof(float);
 }
@@ -2150,11 +2075,9 @@ size_t sf_convnext_block_ws_bytes(int C, int n, int H, int W) {
 int sf_convnext_block_fwd(const sf_convnext_w* w, const float* x, float* out, int n, int H, int W, float* ws,
                           size_t ws_bytes, void* stream) {
   if (!w || !x || !out) return SF_ERR_INVALID;
-  Arena A(ws, ws_bytes);
-  return convnext_block(w, x, out, n, H, W, A, (hipStream_t)stream);
-}
-static int convnext_block(const sf_convnext_w* w, const float* x, float* out, int n, int H, int W, Arena& A, hipStream_t st) {
   const int C = w->C;
+  hipStream_t st = (hipStream_t)stream;
+  Arena A(ws, ws_bytes);
   const size_t P = (size_t)n * H * W;
   float* t = A.take(P * C);
   float* u = A.take(P * 4 * C);

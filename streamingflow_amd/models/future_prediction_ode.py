@@ -24,10 +24,6 @@ _HEAD_PLANAR = os.environ.get("SF_HEAD_PLANAR", "1") != "0"
 # SF_FOLD_DECODER=0: the last SpatialGRU runs its 1x1 conv_decoder on every frame (T launches) instead of handing its hidden states
 # to a DeepLabHead packed with the decoder folded into its input convolutions (A/B aid)
 _FOLD_DECODER = os.environ.get("SF_FOLD_DECODER", "1") != "0"
-# SF_GRU_PAIR=0: the two SpatialGRUs of a single-sample forward run one after the other (the form before round 6; A/B aid).  Default: in
-# wavefront order — frame k of the first and frame k - 1 of the second share their launches (sf_spatial_gru_pair_fwd): a frame's gate /
-# candidate launch alone has 626 / 313 workgroups for the chip's 512 slots
-_GRU_PAIR = os.environ.get("SF_GRU_PAIR", "1") != "0"
 
 
 class _FoldedTail(runtime.PackedModule):
@@ -93,11 +89,6 @@ class FuturePredictionODE(nn.Module):
         T, B, H, W, C = x.shape
         hidden = x[0]
         last = len(self.spatial_grus) - 1
-        paired = None
-        if (_GRU_PAIR and B == 1 and len(self.spatial_grus) == 2 and not isinstance(self.res_blocks[0], DeepLabHead)
-                and all(isinstance(b, Block) for b in self.res_blocks[0]) and len(self.res_blocks[0]) <= 8
-                and self.spatial_grus[0].input_size == self.spatial_grus[0].hidden_size == self.spatial_grus[1].hidden_size == C):
-            paired = True
         for i, (gru, blk) in enumerate(zip(self.spatial_grus, self.res_blocks)):
             gst = hst = None
             if (_FOLD_DECODER and i == last and isinstance(blk, DeepLabHead) and gru.conv_decoder.bias is None
@@ -108,21 +99,7 @@ class FuturePredictionODE(nn.Module):
                     tail = self.__dict__["_folded_tail"] = _FoldedTail(gru, blk)
                 gpk, hpk = tail.packed()
                 gst, hst = gpk.struct, hpk.struct
-            if paired and i == 0:
-                continue                                     # runs together with the second GRU below
-            if paired and i == 1:
-                g0, blocks = self.spatial_grus[0], list(self.res_blocks[0])
-                L = _lib.lib()
-                arr = (_lib.ConvNextW * max(1, len(blocks)))(*[b.packed().struct for b in blocks])
-                st1 = gru.packed().struct if gst is None else gst
-                width = gru.input_size if gst is None else gru.hidden_size
-                ws = runtime.workspace(L.sf_spatial_gru_pair_ws_bytes(C, T, B, H, W), x.device)
-                y = torch.empty((T, B, H, W, width), dtype=torch.float32, device=x.device)
-                _lib.check(L.sf_spatial_gru_pair_fwd(g0.packed().struct, arr, len(blocks), st1, runtime.ptr(x), runtime.ptr(hidden), runtime.ptr(y),
-                                                     T, B, H, W, runtime.ptr(ws), ws.numel() * 4, runtime.stream_ptr(x.device)), "spatial_gru_pair")
-                x = y
-            else:
-                x = gru.forward_nhwc(x, hidden, gst)
+            x = gru.forward_nhwc(x, hidden, gst)
             x = x.view(T * B, H, W, x.shape[-1])
             if isinstance(blk, DeepLabHead):
                 if res is not None and i == last:
