@@ -170,7 +170,7 @@ struct Profiler {
 // Tuning knobs, read once from the environment (experiments only; defaults are the shipped choice):
 //   SF_DIRECT=0 disables the direct-fragment kernel, SF_DIRECT_MT / SF_DIRECT_KS force its tile
 //   height / K-group count, SF_DIRECT_CPW sets the target chunks per wave.
-struct Tune { int wino, wino_sp, wsp_minsub, fork7, fork7_wgs, wino_min_p, flow_timeout, b3_small_tiles, wide64, seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
+struct Tune { int wino, wino_sp, wino_sp7, sp_short_tail, wsp_minsub, fork7, fork7_wgs, wino_min_p, flow_timeout, b3_small_tiles, wide64, seg_maxph, persist, fenced, b3, pipe, sp_fuse_1x1, mid_minch_ln, sp, sp_xcd, sp_split_wgs, sp_bn, sp_max_p, sp_wide_work, sp_fuse_se, direct, mt, ks, chunks_per_wave, split, split_target, split_min_chunks, split_from, mid_tiles, split_cfg, glds, glds_var, small_dma, large_p, narrow; };
 const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
@@ -183,6 +183,8 @@ const Tune& tune() {
     x.wino_min_p = geti("SF_WINO_MIN_P", 14000);       // measured (profiles/r04_zz_wino_min_p_sweep.txt, r04_zz_step_min_p_batched_latents.txt): 6 or more batched 50x50 latents
                                                      // and one 200x200 latent gain 6-11 % per ODE step, 5 latents / one 100x100 latent lose 4-7 %; 32 latents +1.6 % on the headline
     x.wino_sp = geti("SF_WINO_SP", 1);             // one latent (small-P kernel, launch path): its 3x3 layers run in the Winograd form too (conv_sp.hip; 0: direct form — the round-5 step)
+    x.wino_sp7 = geti("SF_WINO_SP7", 1);           // ... and the trusting gate's 7x7 as nine Winograd 3x3 sub-kernels (144 instead of 196 products per 2x2 outputs; 0: direct form)
+    x.sp_short_tail = geti("SF_SP_SHORT_TAIL", 1);  // ... short trailing problems of a group do not count against the 256-workgroup cap (see run())
     x.wsp_minsub = geti("SF_WSP_MINSUB", 1);       // ... a K slice of such a layer is at least this many 32-channel sub-chunks (measured: 1 -> 148.2 us per step, 2 -> 150.3)
     x.fork7 = geti("SF_FORK7", 0);                 // 1: one latent inside a rollout: conv_decoder_2 rides beside rb1.conv1 and the r2 half of the next cell's 7x7 runs on a forked stream beside the rest of infer_state.  Built, bitwise reproducible, oracle-tested (tests/test_gpu_persistent.py) and measured SLOWER: the 7x7 launch halves (38.5 -> 25.7 us) and the side launch does run beside the chain, but the two cross-queue dependencies per step cost more than they free — 159.5-161 us per step in a replayed hipGraph against 148.5 (profiles/r06_r_*).  Off by default
     x.fork7_wgs = geti("SF_FORK7_WGS", 88);        // ... workgroup budget of that side launch (the main stream's launches of the window have <= 160)
@@ -281,13 +283,18 @@ thread_local bool g_fork_halves = false;
 // whole 32-channel sub-chunks, cout in whole 64-row tiles, transformed weights packed; not inside a persistent flow (its tile-level
 // dependencies are in linear pixels), not the LayerNorm layers (the 7x7 and its fused 1x1)
 bool sp_wino_ok(const ConvProblem& q, int epi) {
-  if (!tune().wino || !tune().wino_sp || g_seg || !q.w_wino || epi == EPI_LNG) return false;
-  if (q.KH != 3 || q.KW != 3 || q.stride != 1 || q.dil != 1 || q.pad != 1 || q.in_up || q.gather || q.gate || q.fuse_w || q.out_planar || q.pool2 || q.add_up) return false;
+  if (!tune().wino || !tune().wino_sp || g_seg || !q.w_wino) return false;
+  // 3x3, or the trusting gate's 7x7 as nine 3x3 sub-kernels (SF_WINO_SP7=0: the 7x7 keeps the direct form)
+  const bool k3 = q.KH == 3 && q.KW == 3 && q.pad == 1, k7 = q.KH == 7 && q.KW == 7 && q.pad == 3 && tune().wino_sp7 && epi == EPI_LNG;      // (the kernel carries the tap groups in its LayerNorm instantiation only)
+  if (!(k3 || k7) || q.stride != 1 || q.dil != 1 || q.in_up || q.gather || q.gate || q.out_planar || q.pool2 || q.add_up) return false;
+  if (q.fuse_w && epi != EPI_LNG) return false;
   if (q.n_img != 1 || (q.Hout & 1) || (q.Wout & 1) || q.Hin != q.Hout || q.Win != q.Wout || q.Wout < 4 || q.Hout < 4) return false;
   if ((q.c0 % 32) || (q.c1 % 32) || q.c0 + q.c1 != q.cin_pad || (q.cout_pad % 64)) return false;
   if (tune().b3 && q.w3) return false;
-  return 4.0 * 16 * q.cout_pad * q.cin_pad < 2147483648.0;
+  return 4.0 * (k7 ? 9 : 1) * 16 * q.cout_pad * q.cin_pad < 2147483648.0;
 }
+// K units of a problem in the Winograd form: (tap group, 32-channel sub-chunk) pairs
+int sp_wino_units(const ConvProblem& q) { return (q.KH == 7 ? 9 : 1) * (q.cin_pad / 32); }
 int sp_bn(const ConvProblem* ps, int n, int epi) {
   if (tune().sp_bn) return tune().sp_bn;
   for (int i = 0; i < n; ++i)
@@ -632,7 +639,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     for (int i = 0; i < n; ++i) {
       const int tiles = ((ps[i].n_img * ps[i].Hout * ps[i].Wout + bn - 1) / bn) * ((ps[i].cout_pad + 63) / 64);
       // (a 32-channel sub-chunk of the Winograd form costs a 64-pixel tile what a 64-deep chunk of the direct form does: 64 MFMAs per wave)
-      work_total += (double)tiles * (wn_of[i] ? ps[i].cin_pad / 32 : (ps[i].KH * ps[i].KW * (ps[i].cin_pad / 32) + 1) / 2);
+      work_total += (double)tiles * (wn_of[i] ? sp_wino_units(ps[i]) : (ps[i].KH * ps[i].KW * (ps[i].cin_pad / 32) + 1) / 2);
     }
     const int wg_target = g_fork_side > 0 ? g_fork_side : tune().sp_split_wgs, wg_cap = g_fork_side > 0 ? g_fork_side : 256;
     const double per_wg = work_total / wg_target;      // chunks per workgroup at the target
@@ -642,7 +649,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     for (int i = 0; i < n; ++i) {
       const ConvProblem& q = ps[i];
       tiles_of[i] = ((q.n_img * q.Hout * q.Wout + bn - 1) / bn) * ((q.cout_pad + 63) / 64);
-      nch_of[i] = wn_of[i] ? q.cin_pad / 32 : (q.KH * q.KW * (q.cin_pad / 32) + 1) / 2;
+      nch_of[i] = wn_of[i] ? sp_wino_units(q) : (q.KH * q.KW * (q.cin_pad / 32) + 1) / 2;
       int ns = (may_split && per_wg > 0) ? (int)(nch_of[i] / per_wg + 0.5) : 1;
       const int min_per = wn_of[i] ? (tune().wsp_minsub > 0 ? tune().wsp_minsub : 1) : 3;      // at least 3 chunks (direct) / wsp_minsub sub-chunks (Winograd) per slice
       if (ns > nch_of[i] / min_per) ns = nch_of[i] / min_per;
@@ -653,7 +660,21 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
     }
     // one workgroup owns a whole CU: a launch of more than 256 of them runs a second round for the few that are left
     // (measured: the 7x7 + projection launch at 280 workgroups took 54 us for 26 us of work per workgroup)
-    while (may_split && wgs > wg_cap) {
+    // ... unless the ones that are left are SHORT and come last (round 6, SF_SP_SHORT_TAIL): problems whose workgroups do less than a third of the
+    // longest one's chunks — the trusting gate's 1x1 projection beside its 7x7 — are not counted against the cap when they are the last
+    // problems of the group: the dispatcher hands them to the few free CUs while the long ones run
+    auto long_wgs = [&]() {
+      if (!tune().sp_short_tail) return wgs;
+      double cmax = 0;
+      for (int i = 0; i < n; ++i) cmax = std::max(cmax, (double)nch_of[i] / ns_of[i]);
+      int cnt = wgs;
+      for (int i = n - 1; i >= 1; --i) {      // trailing problems only
+        if ((double)nch_of[i] / ns_of[i] * 3.0 > cmax) break;
+        cnt -= tiles_of[i] * ns_of[i];
+      }
+      return cnt;
+    };
+    while (may_split && long_wgs() > wg_cap) {
       int k = -1;
       for (int i = 0; i < n; ++i)
         if (ns_of[i] > 1 && (k < 0 || tiles_of[i] * ns_of[i] > tiles_of[k] * ns_of[k])) k = i;
@@ -694,7 +715,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       q.sp_wino = wn_of[i] ? 1 : 0;
       if (wn_of[i]) {      // K slices in 32-channel sub-chunks (also when no reciprocals are made below)
         const int ns = q.nsplit > 1 ? q.nsplit : 1;
-        q.sp_cps = (q.cin_pad / 32 + ns - 1) / ns;
+        q.sp_cps = (sp_wino_units(q) + ns - 1) / ns;
       }
     }
     L.stamp_slot = g_stamp_slot;
@@ -718,7 +739,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
       for (int i = 0; i < n && magic_on; ++i) {
         ConvProblem& q = L.p[i];
         const long Pi = (long)q.n_img * q.Hout * q.Wout, n_pt = (Pi + bn - 1) / bn, n_mt = (q.cout_pad + 63) / 64, tiles = n_pt * n_mt;
-        const int ns = q.nsplit > 1 ? q.nsplit : 1, kcpt = q.cin_pad >> 5, nch_all = wn_of[i] ? kcpt : (q.KH * q.KW * kcpt + 1) >> 1;
+        const int ns = q.nsplit > 1 ? q.nsplit : 1, kcpt = q.cin_pad >> 5, nch_all = wn_of[i] ? sp_wino_units(q) : (q.KH * q.KW * kcpt + 1) >> 1;
         if (tiles * ns * tiles >= 0x100000000L || (Pi + 64) * q.Hout * q.Wout >= 0x100000000L) continue;
         q.sp_m_tw = magic(q.Wout / 2);
         // d = 1 has no reciprocal (0 = "divide"): dividing by one is what the fallback does

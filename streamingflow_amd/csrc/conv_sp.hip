@@ -74,7 +74,7 @@ struct SpGeo {
 };
 template <int NT>
 constexpr int sp_lds_bytes(bool scale) { return (SpGeo<NT>::RING + SP_MISC + (scale ? SP_SC_FLOATS : 0)) * 4; }
-// Winograd F(2x2, 3x3) form of a 3x3 layer on one latent (ConvProblem::sp_wino; see the block in sp_body): a 64-pixel tile is 16
+// Winograd F(2x2, 3x3) form of a 3x3 layer — and of the trusting gate's 7x7 as nine 3x3 sub-kernels — on one latent (ConvProblem::sp_wino; see the block in sp_body): a 64-pixel tile is 16
 // Winograd tiles; per 32-channel sub-chunk the gathered 4x4 patches [16 tiles][16 px][32] and their transform V[16 positions][16 tiles][32],
 // two buffers each; the products M[16 positions][16 tiles][SP_RED_PITCH] land over both after the loop
 constexpr int SPW_SUB = 16 * 16 * 32;             // floats of one raw / one V buffer (32 KB)
@@ -82,8 +82,9 @@ constexpr int SPW_REGION = 4 * SPW_SUB;           // 128 KB
 static_assert(16 * 16 * SP_RED_PITCH + 512 <= SPW_REGION, "M + channel-sum scratch live in the region");
 // which instantiations carry the Winograd block: 64-pixel tiles, exact fp32, launch path (the flow kernel keeps the direct form), no fused 1x1
 template <int EPI, int NT, bool B3, bool PST>
-constexpr bool sp_has_wino() { return NT == 4 && !B3 && !PST && EPI != EPI_LNG; }
-// floats in front of misc / SE rows / fused-layer buffer
+constexpr bool sp_has_wino() { return NT == 4 && !B3 && !PST; }
+// floats in front of misc / SE rows / fused-layer buffer: a problem in the Winograd form has the two raw + two V buffers there, a problem in
+// the direct form (also in a kernel that carries the block) the ring
 template <int EPI, int NT, bool B3, bool PST>
 constexpr int sp_region() { return sp_has_wino<EPI, NT, B3, PST>() && SPW_REGION > SpGeo<NT>::RING ? SPW_REGION : SpGeo<NT>::RING; }
 
@@ -505,9 +506,13 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
   if (bz >= nsplit) return false;                      // block-uniform
   const int kcpt = P.cin_pad >> 5;                     // 32-deep sub-chunks per tap
   const int nsub_all = P.KH * P.KW * kcpt;
-  bool wn = false;                                     // block-uniform: this problem runs in the Winograd form (K slices count 32-channel sub-chunks)
+  bool wn = false;                                     // block-uniform: this problem runs in the Winograd form (K slices count (tap group, 32-channel sub-chunk) pairs)
   if constexpr (WINO) wn = P.sp_wino != 0;
-  const int nch_all = wn ? kcpt : (nsub_all + 1) >> 1;
+  // Winograd form: 3x3 sub-kernels of the layer (7x7: the 3 x 3 cuts of its 9x9 frame).  The only 7x7 of the path is the trusting gate's first
+  // layer, a LayerNorm launch: the other instantiations compile the group logic away (with it they spilled 11-16 scalar registers and
+  // every 3x3 launch of a step lost 0.3 us)
+  const int wgroups = (EPI == EPI_LNG && P.KH == 7) ? 9 : 1;
+  const int nch_all = wn ? wgroups * kcpt : (nsub_all + 1) >> 1;
   const int cps = P.sp_cps > 0 ? P.sp_cps : (nch_all + nsplit - 1) / nsplit;     // chunks per K slice (host: every slice non-empty)
   const int cb = bz * cps;
 #if defined(SF_ABL_K49)      // timing-only ablation (results are garbage): the K loop of every 3x3 layer cut to 4/9 of its chunks — what the products
@@ -519,7 +524,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  float* const misc = smem + sp_region<EPI, NT, B3, PST>();
+  float* const misc = smem + (wn ? SPW_REGION : G::RING);
   float* const sc_lds = misc + SP_MISC;      // SCALE instantiations only
   const int img0 = sp_mdiv(p_tile * BN, P.sp_m_hw, HWout);              // block-uniform: first image this tile touches
   const int cin_pad = P.cin_pad;
@@ -672,7 +677,8 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
   // fused 1x1 layer (LNG launches, block-uniform): its weights and this tile's output meet in a chunk-shaped buffer behind
   // the ring — [2 sub-chunks][64 weight rows | BN pixel rows][32] — and run through the consumers' fragment / MFMA code once more
   const bool fuse = (EPI == EPI_LNG) && P.fuse_w != nullptr;
-  float* const fz = misc + SP_MISC + (SCALE ? SP_SC_FLOATS : 0);
+  // (Winograd form: over the second V buffer, which is dead once the loop is over — the fused weights are fetched behind it)
+  float* const fz = wn ? smem + 3 * SPW_SUB : misc + SP_MISC + (SCALE ? SP_SC_FLOATS : 0);
   // ---- loader constants that do not depend on activations (flow mode issues the weight DMAs before the dependency wait) ----
   const int lw = wave - 8;      // loader index (waves 8-11)
   // a sub-chunk is 8 + BN/8 DMA instructions of 8 rows x 128 B: loader lw takes the weight row blocks lw and lw + 4
@@ -771,22 +777,33 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
         // ---------------------------------------------- loader ------------------------------------------------------------------
         const int slotl = lane & 7, row8 = lane >> 3;
         int vb0[8], vb1[8];
+        // patch offsets of this lane's eight DMA rows for tap group `grp` (3x3: the one group, no shift; 7x7: group (a, b) reads the input
+        // shifted by (3a - 3, 3b - 3)): recomputed when a sub-chunk starts a new group (a slice of 6 sub-chunks meets at most 3)
+        int cur_grp = -1;
+        auto set_group = [&](const int grp) {
+          const int ga = grp / 3, gb = grp - 3 * ga;
+          const int sy = wgroups == 9 ? 3 * ga - 3 : 0, sx = wgroups == 9 ? 3 * gb - 3 : 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int t = p_tile * 16 + 4 * lw + (i >> 1);
-          const int r = 2 * (i & 1) + (row8 >> 2), c = row8 & 3;
-          const int ty = sp_mdiv(t, P.sp_m_tw, TW), tx = t - ty * TW;
-          const int iy = 2 * ty - 1 + r, ix = 2 * tx - 1 + c;
-          const bool in = (t < ntiles) & (iy >= 0) & (iy < P.Hin) & (ix >= 0) & (ix < P.Win);
-          const int pxo = in ? iy * P.Win + ix : 0;
-          vb0[i] = in ? (pxo * P.in0_cs + 4 * slotl) * 4 : (int)0x80000000;
-          vb1[i] = in ? (pxo * P.in1_cs - P.c0 + 4 * slotl) * 4 : (int)0x80000000;
-        }
+          for (int i = 0; i < 8; ++i) {
+            const int t = p_tile * 16 + 4 * lw + (i >> 1);
+            const int r = 2 * (i & 1) + (row8 >> 2), c = row8 & 3;
+            const int ty = sp_mdiv(t, P.sp_m_tw, TW), tx = t - ty * TW;
+            const int iy = 2 * ty - 1 + r + sy, ix = 2 * tx - 1 + c + sx;
+            const bool in = (t < ntiles) & (iy >= 0) & (iy < P.Hin) & (ix >= 0) & (ix < P.Win);
+            const int pxo = in ? iy * P.Win + ix : 0;
+            vb0[i] = in ? (pxo * P.in0_cs + 4 * slotl) * 4 : (int)0x80000000;
+            vb1[i] = in ? (pxo * P.in1_cs - P.c0 + 4 * slotl) * 4 : (int)0x80000000;
+          }
+          cur_grp = grp;
+        };
         const __amdgpu_buffer_rsrc_t rsrc0 = make_rsrc(P.in0, (size_t)P.Hin * P.Win * P.in0_cs * sizeof(float));
         const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(P.in1 ? P.in1 : P.in0, P.in1 ? (size_t)P.Hin * P.Win * P.in1_cs * sizeof(float) : 0);
         const int c0 = P.c0;
         auto issue_raw = [&](const int sidx) {      // sub-chunk cb + sidx into raw buffer sidx & 1: this loader's 4 tiles
-          const int kc = cb + sidx;
+          const int sg = cb + sidx;                 // (tap group, channel sub-chunk), group major
+          const int grp = wgroups == 9 ? sp_mdiv(sg, P.sp_m_kcpt, kcpt) : 0;
+          const int kc = sg - grp * kcpt;
+          if (grp != cur_grp) set_group(grp);       // wave-uniform
           const bool from1 = kc * 32 >= c0;         // wave-uniform
           const int koff = kc * 128;
           float* const dst = raw + (sidx & 1) * SPW_SUB + (4 * lw) * 512;
@@ -832,7 +849,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
             f32x4 o[4];
             o[0] = t[0] - t[2]; o[1] = t[1] + t[2]; o[2] = t[2] - t[1]; o[3] = t[1] - t[3];
             if constexpr (SCALE) {      // SE gate of the input: per channel, commutes with the transform
-              const f32x4 sc4 = sp_lds_read128(sc_lds + (cb + sidx) * 32 + q4[n]);
+              const f32x4 sc4 = sp_lds_read128(sc_lds + ((cb + sidx) % kcpt) * 32 + q4[n]);
 #pragma unroll
               for (int jj = 0; jj < 4; ++jj) o[jj] = o[jj] * sc4;
             }
@@ -850,7 +867,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
         // transform then happens in this wave's registers and half as much leaves for LDS)
         const int j = lane & 15, g = lane >> 4;
         const int wi = wave >> 1, mh = wave & 1;
-        const __amdgpu_buffer_rsrc_t rsrc_u = make_rsrc(P.w_wino, (size_t)16 * P.cout_pad * P.cin_pad * sizeof(float));
+        const __amdgpu_buffer_rsrc_t rsrc_u = make_rsrc(P.w_wino, (size_t)wgroups * 16 * P.cout_pad * P.cin_pad * sizeof(float));      // [group][cin / 16][16][cout_pad][16]: consecutive (group, 16-channel) steps are contiguous
         const int a_voff = (j * 16 + 4 * g) * 4;
         const int u_pos = P.cout_pad * 64;                        // bytes between positions
         const int u_grp = 16 * u_pos;                             // bytes between 16-channel groups
@@ -964,6 +981,7 @@ __device__ __forceinline__ bool sp_body(const PT& P, const SpStamp L, int bx, in
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       sp_barrier();                                               // every V read and every DMA is done (the loaders drained theirs): T may land over the buffers
+      if (fuse && wave >= 8) issue_fuse_weights();                // over the second V buffer; they land under the exchange, the hand-off and the first epilogue
       SF_STAMP_AT(L, 14);
       // output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  Row pass in the registers of the wave that owns row i of M:
       // T[i][0] = M[i][0] + M[i][1] + M[i][2], T[i][1] = M[i][1] - M[i][2] - M[i][3]  ->  T[4 rows][2][16 tiles][SP_RED_PITCH] in LDS ...
@@ -1714,7 +1732,11 @@ hipError_t launch_flow_write(const void* host_src, void* dev_dst, size_t bytes, 
 // dynamic LDS of a conv_sp_kernel launch: region (ring, or the Winograd buffers where the instantiation has that block) | misc | SE rows | fused-layer buffer
 template <int EPI, bool SCALE, int NT, bool B3>
 constexpr int sp_launch_lds(bool fused) {
-  return (sp_region<EPI, NT, B3, false>() + SP_MISC + (SCALE ? SP_SC_FLOATS : 0) + (fused ? SpGeo<NT>::BUFF : 0)) * 4;
+  // direct form: ring | misc | SE rows | fused-layer buffer; Winograd form (where the instantiation has it): buffers | misc | SE rows, the
+  // fused-layer buffer over the second V buffer
+  const int direct = SpGeo<NT>::RING + SP_MISC + (SCALE ? SP_SC_FLOATS : 0) + (fused ? SpGeo<NT>::BUFF : 0);
+  const int wino = sp_has_wino<EPI, NT, B3, false>() ? SPW_REGION + SP_MISC + (SCALE ? SP_SC_FLOATS : 0) : 0;
+  return (direct > wino ? direct : wino) * 4;
 }
 template <int EPI, bool SCALE, int NT, bool B3>
 static hipError_t launch_sp_tb(const ConvLaunch& L, hipStream_t stream);

@@ -677,16 +677,27 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
 #endif
 }
 
-// weights: packed direct form w[cout_pad][9 * cin_pad] (tap-major, channel-minor) -> U[cin_pad/16][16][cout_pad][16] = G g G^T
-__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int cout_pad, int cin_pad) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (co, ci)
-  if (idx >= (long)cout_pad * cin_pad) return;
-  const int co = (int)(idx / cin_pad), ci = (int)(idx - (long)co * cin_pad);
+// weights: packed direct form w[cout_pad][kh * kw * cin_pad] (tap-major, channel-minor) -> U[group][cin_pad/16][16][cout_pad][16] = G g G^T.
+// 3x3: one group.  7x7 (round 6, the small-P kernel's Winograd block only): the kernel sits in a 9x9 frame of zeros and is cut into 3 x 3
+// sub-kernels of 3x3 — group (a, b) = rows 3a .. 3a+2, columns 3b .. 3b+2 of the frame, applied to the input shifted by (3a - 3, 3b - 3) —
+// so that the layer is nine F(2x2, 3x3) convolutions accumulating into the same Winograd-domain sums: 9 x 16 = 144 products per 2x2 outputs
+// and (cin, cout) pair instead of 4 x 49 = 196.
+__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int cout_pad, int cin_pad, int ksz) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (group, co, ci)
+  const int ngrp = ksz == 7 ? 9 : 1;
+  if (idx >= (long)ngrp * cout_pad * cin_pad) return;
+  const int grp = (int)(idx / ((long)cout_pad * cin_pad));
+  const long rem = idx - (long)grp * cout_pad * cin_pad;
+  const int co = (int)(rem / cin_pad), ci = (int)(rem - (long)co * cin_pad);
+  const int ga = grp / 3, gb = grp - 3 * ga;
   float g[3][3];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int b = 0; b < 3; ++b) g[a][b] = w[(size_t)co * 9 * cin_pad + (a * 3 + b) * cin_pad + ci];
+    for (int b = 0; b < 3; ++b) {
+      const int ky = ksz == 7 ? 3 * ga + a - 1 : a, kx = ksz == 7 ? 3 * gb + b - 1 : b;
+      g[a][b] = (ky >= 0 && ky < ksz && kx >= 0 && kx < ksz) ? w[(size_t)co * ksz * ksz * cin_pad + (size_t)(ky * ksz + kx) * cin_pad + ci] : 0.f;
+    }
   // G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]]
   float t[4][3];
 #pragma unroll
@@ -696,18 +707,18 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restri
     t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
     t[3][b] = g[2][b];
   }
-  const int kc = ci >> 4, cl = ci & 15;
+  const int kc = ci >> 4, cl = ci & 15, nkc = cin_pad >> 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]), u3 = t[i][2];
     const float uu[4] = {u0, u1, u2, u3};
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) U[(((size_t)kc * 16 + i * 4 + jj) * cout_pad + co) * 16 + cl] = uu[jj];
+    for (int jj = 0; jj < 4; ++jj) U[((((size_t)grp * nkc + kc) * 16 + i * 4 + jj) * cout_pad + co) * 16 + cl] = uu[jj];
   }
 }
-hipError_t launch_wino_weights(const float* w, float* U, int cout_pad, int cin_pad, hipStream_t stream) {
-  const long n = (long)cout_pad * cin_pad;
-  hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, U, cout_pad, cin_pad);
+hipError_t launch_wino_weights(const float* w, float* U, int cout_pad, int cin_pad, int ksz, hipStream_t stream) {
+  const long n = (long)(ksz == 7 ? 9 : 1) * cout_pad * cin_pad;
+  hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, U, cout_pad, cin_pad, ksz);
   return hipGetLastError();
 }
 

@@ -100,7 +100,7 @@ __global__ void pack_affine_kernel(const float* __restrict__ conv_bias, const fl
 }  // namespace sf
 
 namespace sf {
-hipError_t launch_wino_weights(const float* w, float* U, int cout_pad, int cin_pad, hipStream_t stream);
+hipError_t launch_wino_weights(const float* w, float* U, int cout_pad, int cin_pad, int ksz, hipStream_t stream);
 }
 using namespace sf;
 
@@ -118,15 +118,17 @@ static int packed_dims(int cout, int cin, int flags, int* cout_pad, int* cin_pad
 
 // the Winograd copy exists for 3x3 layers whose input is whole 16-channel chunks and whose outputs fill 64-row tiles (conv_wino.hip)
 static bool wino_packable(int cp, int ip, int cin, int kh, int kw, int flags) {
-  // (interleaved rows — the sampling layer — are transformed in their packed order: only the small-P kernel's SAMPLE epilogue reads them)
-  return (flags & SF_PACK_WINOGRAD) && kh == 3 && kw == 3 && cin == ip && (cp % 64) == 0;
+  // (interleaved rows — the sampling layer — are transformed in their packed order: only the small-P kernel's SAMPLE epilogue reads them;
+  //  7x7: nine 3x3 sub-kernels, conv_wino.hip: wino_weights_kernel — the trusting gate's first layer on one latent)
+  return (flags & SF_PACK_WINOGRAD) && ((kh == 3 && kw == 3) || (kh == 7 && kw == 7)) && cin == ip && (cp % 64) == 0;
 }
+static size_t wino_floats(int cp, int ip, int kh) { return (size_t)(kh == 7 ? 9 : 1) * 16 * cp * ip; }
 
 size_t sf_pack_conv_bytes(int cout, int cin, int kh, int kw, int flags) {
   int cp = 0, ip = 0;
   if (packed_dims(cout, cin, flags, &cp, &ip) != SF_OK || kh < 1 || kw < 1) return 0;
   return (a64((size_t)cp * kh * kw * ip) * ((flags & SF_PACK_BF16X3) ? 2 : 1) + 2 * a64((size_t)cp) +
-          (wino_packable(cp, ip, cin, kh, kw, flags) ? a64((size_t)16 * cp * ip) : 0)) * sizeof(float);
+          (wino_packable(cp, ip, cin, kh, kw, flags) ? a64(wino_floats(cp, ip, kh)) : 0)) * sizeof(float);
 }
 
 int sf_pack_conv(const float* weight, const float* conv_bias, const float* scale, const float* bn_weight, const float* bn_bias,
@@ -157,9 +159,10 @@ int sf_pack_conv(const float* weight, const float* conv_bias, const float* scale
     hipLaunchKernelGGL(pack_split_bf16_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, wp, groups, reinterpret_cast<unsigned*>(w3));
   }
   float* wu = nullptr;
-  if (wino_packable(cp, ip, cin, kh, kw, flags) && stride == 1 && (pad < 0 || pad == dil) && (c0 % 16) == 0 && (c1 % 16) == 0) {
+  if (wino_packable(cp, ip, cin, kh, kw, flags) && stride == 1 && (pad < 0 || pad == dil * (kh - 1) / 2) && (kh == 3 || dil == 1) && (c0 % 16) == 0 &&
+      (c1 % 16) == 0) {
     wu = bp + a64((size_t)cp) + ((flags & SF_PACK_BF16X3) ? a64((size_t)total) : 0);
-    if (launch_wino_weights(wp, wu, cp, ip, st) != hipSuccess) return SF_ERR_LAUNCH;
+    if (launch_wino_weights(wp, wu, cp, ip, kh, st) != hipSuccess) return SF_ERR_LAUNCH;
   }
   if (hipGetLastError() != hipSuccess) return SF_ERR_LAUNCH;
   std::memset(out, 0, sizeof(*out));

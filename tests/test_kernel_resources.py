@@ -29,6 +29,8 @@ SGPR_SPILL_ALLOWED = {
     "conv_sp_kernelILi4ELb1ELi4ELb0": (12, "SE-scaled SAMPLE, 64-pixel tiles: SE prologue + the epilogue's scalar batch"),
     "conv_sp_kernelILi3ELb0ELi4ELb0": (4, "TRUST, 64-pixel tiles: ten operand tensors' scalars held across the Winograd loop"),
     "conv_sp_kernelILi0ELb0ELi4ELb0": (4, "AFFINE, 64-pixel tiles: the epilogue's scalar batch held across the Winograd loop"),
+    "conv_sp_kernelILi2ELb0ELi4ELb0": (30, "LayerNorm launch, 64-pixel tiles: the trusting gate's 7x7 as nine Winograd sub-kernels (tap-group cursor of the loaders, fused 1x1 "
+                                           "layer's scalars) beside the direct form; outside the MFMA loop"),
     "dwconv7_ln_c64_kernel": (40, "row / column addresses kept in scalar registers by design (csrc/aux_kernels.hip)"),
 }
 

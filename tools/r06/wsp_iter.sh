@@ -9,7 +9,7 @@ for k in 1 0 1; do
   echo "== chain SF_WINO_SP=$k"
   SF_WINO_SP=$k SF_PERSIST=0 timeout 300 python3 tools/chainbench.py euler 10 30 2>/dev/null | tail -1
 done
-for v in ${WSP_VARIANTS:-SF_FORK7=0 SF_FORK7_WGS=120 SF_FORK7_WGS=160}; do
+for v in ${WSP_VARIANTS:-SF_WINO_SP7=0}; do
   echo "== chain $v"
   env $v SF_PERSIST=0 timeout 300 python3 tools/chainbench.py euler 10 30 2>/dev/null | tail -1
 done
