@@ -13,4 +13,4 @@ print(json.dumps({k: v for k, v in r.items() if not isinstance(v, dict)}))
 print(json.dumps(r.get('roofline', {})))
 " 2>&1 | tail -4
 done
-true
+timeout 1500 python -m pytest tests/test_sparse_encoder.py tests/test_gpu_random_next_rows.py tests/test_gpu_end_to_end.py -q -m gpu -x 2>&1 | tail -4

@@ -1,3 +1,8 @@
+#!/bin/bash
+# same-box A/B of the single-latent step under environment switches: steady-state step time + stamps of two launches (diagnostic build present)
+# usage (through gpurun): AB_VARIANTS="SF_SP_SHORT_TAIL=1 SF_SP_SHORT_TAIL=0 SF_WINO_SP7=0" bash tools/r06/step_ab.sh
+set -uo pipefail
+: "${GRAFT_REPO_ROOT:?run through gpurun}"
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 for v in ${AB_VARIANTS:-SF_SP_SHORT_TAIL=1 SF_SP_SHORT_TAIL=0 SF_WINO_SP7=0}; do
   echo "== $v"
