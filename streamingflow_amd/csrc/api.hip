@@ -175,7 +175,12 @@ const Tune& tune() {
   static const Tune t = [] {
     auto geti = [](const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; };
     Tune x;
-    x.persist = geti("SF_PERSIST", 0);             // 1: one latent: consecutive launches of a rollout run as phases of persistent segment launches (conv_sp.hip: sp_segment_kernel).  Built, bitwise equal to the launch-per-layer path (tests/test_gpu_persistent.py) and measured SLOWER: 228 us per steady-state step against 179 (one phase per segment launch: 201) — a grid-wide phase hand-off (write-through stores, drain, one atomic per workgroup, 256 pollers, acquire) costs more than the 3-4 us kernel boundary it replaces (MI355X_MICROARCH.md prices barrier-xcd at 4.1-4.8 us against 1.45-1.9 for a boundary).  Off by default
+    // 1: one latent: the launches of a rollout run as phases of ONE persistent flow kernel per cell boundary (conv_sp.hip: sp_flow_kernel;
+    // workgroups flow from one layer's tile to the next on per-tile dependency counters, every wait bounded: sf_flow_errors).  Bitwise equal
+    // to the launch-per-layer path in the same form of the layers, <= 1e-3 against the oracle (tests/test_gpu_persistent.py).  Round 6,
+    // both measured in one session (profiles/r06_z_bench.json): 174.2 us per steady-state step against 141.5 for the launch path, whose
+    // 3x3 / 7x7 layers run in the Winograd form the flow kernel does not have.  Off by default
+    x.persist = geti("SF_PERSIST", 0);
     x.b3_small_tiles = geti("SF_B3_SMALL_TILES", 0);   // experiment: bf16x3 layers with 128-multiple cout on 64 x 128 tiles (3 workgroups per CU) instead of 128 x 128 (2)
     x.wide64 = geti("SF_WIDE64", 0);               // 1: 64-cout layers at >= 131072 pixels on 64 x 256 tiles (variant 10) instead of 64 x 128
     x.seg_maxph = geti("SF_SEG_MAXPH", 1 << 30);   // diagnostic: at most this many phases per persistent flow launch (1: every phase its own launch of the flow kernel)

@@ -153,10 +153,14 @@ __device__ __forceinline__ void wn5_act16(f32x4 (&y)[4], const int act) {
         for (int q = 0; q < 4; ++q) y[k][q] = spm_act(y[k][q], act);
   }
 }
-template <bool DIL, bool CAT>
+// TH_: tile rows of the workgroup's block — 4 (8 x 16 output pixels, 32 tiles: the kernel as measured in DESIGN 4.3) or 2 (4 x 16 pixels, 16
+// tiles: round 6, for launches that do not fill the chip's 512 workgroup slots once — a single 200x200 frame with 64 output channels is
+// 313 workgroups of 32 tiles; launch_conv_wino holds the measured rule)
+template <bool DIL, bool CAT, int TH_ = 4>
 struct Wino5Geo {
   static_assert(!(DIL && CAT), "one run structure at a time");
-  static constexpr int COUT_T = 64, TH = 4, TW = 8, WT = TH * TW;
+  static_assert(TH_ == 4 || (TH_ == 2 && !DIL), "tile rows per block");
+  static constexpr int COUT_T = 64, TH = TH_, TW = 8, WT = TH * TW, NB = WT / 16;
   static constexpr int RY = 2, RX = 4;
   static constexpr int PH = 2 * TH + (DIL ? 2 * RY : 2), PW = 2 * TW + (DIL ? 2 * RX : (CAT ? 4 : 2));
   static constexpr int NPX = PH * PW;
@@ -181,9 +185,10 @@ struct Wino5Geo {
 #if !defined(SF_W5_MAGIC)
 #define SF_W5_MAGIC 1
 #endif
-template <int EPI, bool DIL = false, bool CAT = false>
+template <int EPI, bool DIL = false, bool CAT = false, int TH_ = 4>
 __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLaunch L) {
-  typedef Wino5Geo<DIL, CAT> G;
+  typedef Wino5Geo<DIL, CAT, TH_> G;
+  constexpr int NB = G::NB;                                    // 16-tile fragments of the block
   constexpr int COUT_T = G::COUT_T, TH = G::TH, TW = G::TW, WT = G::WT, PW = G::PW, NP = G::NP;
   constexpr bool MODE_A = G::NVB == 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -389,6 +394,9 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
     *(__attribute__((address_space(3))) int*)(Park + tid) = ((2 * tyl + 2 * ry) * PW + 2 * txl + 2 * rx) * 16 + quad * 4;
   }
   auto transform = [&](const int kc) {
+    if constexpr (WT == 16) {
+      if (hh) return;                                           // 64 tasks per row of positions: the first wave of the pair has them all
+    }
     const float* const src = Pbuf + (G::NPB == 2 ? (kc & 1) : 0) * G::P_FLOATS;
     float* const dst = Vbuf + (G::NVB == 2 ? (kc & 1) : 0) * G::V_FLOATS;
     const int quad = lane & 3, wt = (tid >> 2) & (WT - 1);
@@ -448,21 +456,21 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   wn_barrier();                                                 // V(0) published; Mode A: the patch buffer is free
   SF_STAMP_AT(L, 1);
 
-  f32x4 acc[4][2][2];
+  f32x4 acc[4][2][NB];
   auto step = [&](const int kc, auto p_c, auto first_c) {
     constexpr int p = decltype(p_c)::value, slot = p & 1;
     constexpr bool first = decltype(first_c)::value;
     const float* const vb = Vbuf + (G::NVB == 2 ? (kc & 1) : 0) * G::V_FLOATS + p * WT * 16 + b_off;
-    f32x4 Bf[2];
-    Bf[0] = wn_lds_read128(vb);
-    Bf[1] = wn_lds_read128(vb + 256);
+    f32x4 Bf[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) Bf[nb] = wn_lds_read128(vb + nb * 256);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
           const f32x4 cin = (first && e == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[p][mb][nb];
           if (SF_W5_ABL & 16) acc[p][mb][nb] = (e == 0 && nb == 0 && mb == 0) ? cin + A[slot][mb] * Bf[nb] : cin;
           else acc[p][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[slot][mb][e], Bf[nb][e], cin, 0, 0, 0);
@@ -514,7 +522,7 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) sacc += acc[p][mb][nb];
+        for (int nb = 0; nb < NB; ++nb) sacc += acc[p][mb][nb];
     if (sacc[0] + sacc[1] + sacc[2] + sacc[3] == 1.2345f) PX.out[tid] = sacc[0];
     return;
   }
@@ -527,7 +535,7 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
     for (int mb = 0; mb < 2; ++mb) {
       const int tw = tw_base + (((hh * 8 + mb * 4 + g) ^ j) << 2);
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
+      for (int nb = 0; nb < NB; ++nb) {
         const f32x4 m0 = acc[0][mb][nb], m1 = acc[1][mb][nb], m2 = acc[2][mb][nb], m3 = acc[3][mb][nb];
         *(lds_f4w*)(Tb + tw + nb * 16 * 64) = (m0 + m1) + m2;
         *(lds_f4w*)(Tb + tw + nb * 16 * 64 + WT * 64) = wn5_sub4(m1, m2 + m3);
@@ -535,7 +543,8 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
     }
   }
   // ---- second half + epilogue: thread = (tile wt, channel quad cq), the 16 quads of a pixel in consecutive lanes --------------------------------
-  const int cq = tid & 15, wt_e = tid >> 4;
+  const int cq = tid & 15, wt_e = WT == 32 ? tid >> 4 : (tid >> 4) & (WT - 1);
+  const bool has_tile = WT == 32 || tid < 16 * WT;             // 16-tile blocks: half of the threads have no tile (they load and store nothing)
   const int tyl_e = wt_e >> 3, txl_e = wt_e & 7;
   const bool run_e = CAT && txl_e >= cn0;
   const int ty = ty0 + tyl_e, tx = run_e ? txl_e - cn0 : tx0 + txl_e;
@@ -549,7 +558,7 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   const float* const t_a = affine ? PX.add : PX.e0;
   const float* const t_b = PX.e1;
   const int cs_a = affine ? P.add_cs : P.e0_cs, cs_b = P.e1_cs;
-  const bool img_ok = !CAT || img + (run_e ? 1 : 0) < P.n_img;
+  const bool img_ok = has_tile && (!CAT || img + (run_e ? 1 : 0) < P.n_img);
   const bool x0 = img_ok && ox0 < W, x1 = img_ok && ox0 + ostep < W, y0ok = oy0 < H, y1ok = oy0 + ostep < H;
   const unsigned pix = (x0 && y0ok) ? (unsigned)(oy0 * W + ox0 + (run_e ? H * W : 0)) : 0u;      // lanes without a tile compute on pixel 0 and store nothing
   const int cl = cq * 4;
@@ -771,10 +780,17 @@ double wino_tiles(const ConvProblem& q) {
   if (q.dil > 1) return (double)q.n_img * WnAxis(q.Hout, q.dil).nt * WnAxis(q.Wout, q.dil).nt;
   return (double)q.n_img * ((q.Hout + 1) / 2) * ((q.Wout + 1) / 2);
 }
-template <int EPI, bool DIL = false, bool CAT = false>
+// workgroups a launch of the group would have with 32-tile blocks (the choice between the two block sizes)
+static long wino5_wgs32(const ConvLaunch& L, bool cat) {
+  const ConvProblem& P = L.p[0];
+  const int tiles_x = (P.Wout + 1) / 2, tiles_y = (P.Hout + 1) / 2;
+  const long blocks = cat ? (long)((tiles_y + 3) / 4) * (((long)P.n_img * tiles_x + 7) / 8) : (long)P.n_img * ((tiles_y + 3) / 4) * ((tiles_x + 7) / 8);
+  return ((blocks + 7) / 8) * 8 * (P.cout_pad / 64) * L.nprob;
+}
+template <int EPI, bool DIL = false, bool CAT = false, int TH_ = 4>
 static hipError_t launch_wino5_t(const ConvLaunch& L, hipStream_t stream) {
-  typedef Wino5Geo<DIL, CAT> G;
-  auto kern = conv_wino5_kernel<EPI, DIL, CAT>;
+  typedef Wino5Geo<DIL, CAT, TH_> G;
+  auto kern = conv_wino5_kernel<EPI, DIL, CAT, TH_>;
   constexpr int lds = G::LDS_FLOATS * 4;
   static bool attr_done[64] = {};
   int dev = 0;
@@ -822,10 +838,21 @@ hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream) {
   for (int i = 0; i < L.nprob; ++i)
     if (!wino_takes(L.p[i], epi) || !wino_same_geometry(L.p[0], L.p[i])) return hipErrorInvalidValue;
   const bool affine = epi == EPI_AFFINE;
-  switch (wino_variant(L.p[0])) {
-    case 2: return affine ? launch_wino5_t<EPI_AFFINE>(L, stream) : launch_wino5_t<EPI_BLEND>(L, stream);
+  const int var = wino_variant(L.p[0]);
+  // 16-tile blocks where 32-tile blocks would not fill the chip's 512 workgroup slots once (SF_WINO_SMALL_WGS workgroups; 0: never).
+  // Measured (profiles/r06_wino16_ab.txt): the 313-workgroup BLEND launches of a single 200x200 frame 0.609 -> 0.553 ms per forward;
+  // above one round the 16-tile form LOSES (626-workgroup AFFINE launches 2.90 -> 2.94 ms: every workgroup loads the whole U of its 64
+  // output channels whatever its tile count, and the loop is bound by the address unit's 16 cycles per load instruction)
+  static const long small_wgs = [] { const char* v = std::getenv("SF_WINO_SMALL_WGS"); return v ? std::atol(v) : 512L; }();
+  const bool small = (var == 2 || var == 4) && wino5_wgs32(L, var == 4) < small_wgs;
+  switch (var) {
+    case 2:
+      if (small) return affine ? launch_wino5_t<EPI_AFFINE, false, false, 2>(L, stream) : launch_wino5_t<EPI_BLEND, false, false, 2>(L, stream);
+      return affine ? launch_wino5_t<EPI_AFFINE>(L, stream) : launch_wino5_t<EPI_BLEND>(L, stream);
     case 3: return affine ? launch_wino5_t<EPI_AFFINE, true>(L, stream) : hipErrorInvalidValue;
-    case 4: return affine ? launch_wino5_t<EPI_AFFINE, false, true>(L, stream) : launch_wino5_t<EPI_BLEND, false, true>(L, stream);
+    case 4:
+      if (small) return affine ? launch_wino5_t<EPI_AFFINE, false, true, 2>(L, stream) : launch_wino5_t<EPI_BLEND, false, true, 2>(L, stream);
+      return affine ? launch_wino5_t<EPI_AFFINE, false, true>(L, stream) : launch_wino5_t<EPI_BLEND, false, true>(L, stream);
   }
   return hipErrorInvalidValue;
 }

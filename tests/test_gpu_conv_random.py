@@ -213,6 +213,11 @@ _WINO = [
     # nearest x2 upsampling on read (the decoder's upsampling layers): H, W are the INPUT size here
     dict(c0=128, c1=0, cout=128, n=3, H=100, W=100, in_up=1),
     dict(c0=32, c1=32, cout=64, n=4, H=67, W=71, in_up=1),
+    # a single frame with 64 output channels: fewer 32-tile workgroups than the chip has slots -> the 16-tile blocks (round 6; 4 x 16
+    # output pixels per workgroup: ragged bottom rows of two tile rows instead of four)
+    dict(c0=64, c1=0, cout=64, n=1, H=200, W=200),
+    dict(c0=64, c1=64, cout=64, n=1, H=181, W=187),
+    dict(c0=32, c1=0, cout=64, n=2, H=150, W=131),
 ]
 
 
@@ -333,3 +338,20 @@ def test_winograd_epilogues_of_the_batched_latents_against_the_direct_form():
     assert not any(k.startswith("conv_wino") for k in used_b), used_b
     for a, b in ((ya, yb), (pa, pb), (qa, qb)):
         assert a.shape == b.shape and maxabs(a, b) <= 2e-5, maxabs(a, b)
+
+
+@pytest.mark.parametrize("thr", [0, 1000000000])
+def test_winograd_cases_under_both_block_sizes(thr):
+    """conv_wino5_kernel has two block sizes (32 and 16 Winograd tiles per workgroup; launch_conv_wino picks by the launch's workgroup
+    count).  Every Winograd case of this file and of test_gpu_ops.py again in a child process with the choice forced: never / always the
+    16-tile form — the same oracle, the same tolerances."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["SF_WINO_SMALL_WGS"] = str(thr)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-x",
+                        os.path.join(root, "tests", "test_gpu_conv_random.py"), os.path.join(root, "tests", "test_gpu_ops.py"),
+                        "-k", "winograd and not both_block_sizes"], env=env, capture_output=True, text=True, timeout=2400, cwd=root)
+    tail = r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, tail

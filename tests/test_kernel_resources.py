@@ -99,7 +99,7 @@ def test_no_kernel_spills_vector_registers_and_scalar_spills_are_bounded():
         assert int(k["vgpr_count"]) <= 168 and int(k["private_segment_fixed_size"]) == 0, k
     # the Winograd kernel of the large launches: two workgroups of 8 waves per CU = 128 registers, no scratch
     wino = [k for k in ours if "conv_wino5_kernel" in k["name"]]
-    assert len(wino) == 5                        # AFFINE / BLEND x (plain, concatenated images) + the dilated AFFINE form
+    assert len(wino) == 9                        # AFFINE / BLEND x (plain, concatenated images) x (32, 16 tiles) + the dilated AFFINE form
     for k in wino:
         assert int(k["vgpr_count"]) <= 128 and int(k["private_segment_fixed_size"]) == 0, k
     # the fused ConvNeXt MLP: two waves per SIMD (<= 256 registers between the vector and accumulator files), no scratch
