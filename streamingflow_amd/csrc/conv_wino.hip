@@ -154,8 +154,8 @@ __device__ __forceinline__ void wn5_act16(f32x4 (&y)[4], const int act) {
   }
 }
 // TH_: tile rows of the workgroup's block — 4 (8 x 16 output pixels, 32 tiles: the kernel as measured in DESIGN 4.3) or 2 (4 x 16 pixels, 16
-// tiles: round 6, for launches that do not fill the chip's 512 workgroup slots once — a single 200x200 frame with 64 output channels is
-// 313 workgroups of 32 tiles; launch_conv_wino holds the measured rule)
+// tiles, three workgroups per CU: round 6, for launches of fewer than two rounds of the chip's 512 workgroup slots — a single 200x200 frame
+// with 64 / 128 output channels is 313 / 626 workgroups of 32 tiles; launch_conv_wino holds the measured rule)
 template <bool DIL, bool CAT, int TH_ = 4>
 struct Wino5Geo {
   static_assert(!(DIL && CAT), "one run structure at a time");
@@ -173,8 +173,9 @@ struct Wino5Geo {
   static constexpr int SB = 2 * COUT_T, SC = DIL ? 0 : 256;
   static constexpr int T_FLOATS = 4 * 2 * WT * COUT_T;          // the exchange of the output transform: [row i][b][tile][cout]
   static_assert(NVB * V_FLOATS + NPB * P_FLOATS >= T_FLOATS, "the exchange lives over V and the patch");
-  static constexpr int LDS_FLOATS = NVB * V_FLOATS + NPB * P_FLOATS + PARK + SB + SC;
-  static_assert(2 * LDS_FLOATS * 4 <= 160 * 1024, "two workgroups per CU");
+  static constexpr int PV = TH_ == 2 ? 2 * 512 : 0;             // 16-tile form (80 registers): the lanes' two patch offsets live in LDS between the chunks
+  static constexpr int LDS_FLOATS = NVB * V_FLOATS + NPB * P_FLOATS + PARK + SB + SC + PV;
+  static_assert((TH_ == 2 ? 3 : 2) * LDS_FLOATS * 4 <= 160 * 1024, "two workgroups per CU (three of the 16-tile form)");
 };
 
 // timing-only ablations (tools/r05/ablate.sh; wrong results by construction): -DSF_W5_ABL=<bits>  1: no input transform in the loop,
@@ -186,7 +187,7 @@ struct Wino5Geo {
 #define SF_W5_MAGIC 1
 #endif
 template <int EPI, bool DIL = false, bool CAT = false, int TH_ = 4>
-__global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLaunch L) {
+__global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kernel(const ConvLaunch L) {
   typedef Wino5Geo<DIL, CAT, TH_> G;
   constexpr int NB = G::NB;                                    // 16-tile fragments of the block
   constexpr int COUT_T = G::COUT_T, TH = G::TH, TW = G::TW, WT = G::WT, PW = G::PW, NP = G::NP;
@@ -197,6 +198,8 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   float* const Park = Pbuf + G::NPB * G::P_FLOATS;
   float* const SBuf = Park + G::PARK;                          // [scale COUT_T][bias COUT_T]
   float* const SCbuf = SBuf + G::SB;                           // [c0] input scales (SCALED)
+  float* const PVbuf = SCbuf + G::SC;                          // [2][512] patch offsets of the lanes (16-tile form)
+  (void)PVbuf;
   // a group of layers of identical geometry (the two branches of a dual cell) shares one launch: problem i owns the workgroups
   // [i * wg_base[1], (i + 1) * wg_base[1]) (a multiple of 8 each, so that workgroup -> XCD stays blockIdx & 7); the tails of the
   // single launches (625 - 1250 workgroups over 512 slots) merge into one
@@ -328,10 +331,26 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
     if constexpr (!DIL) pv1[d] = ok ? (pofs * P.in1_cs + quad * 4) * 4 : (int)0x80000000;
   }
   SF_STAMP_AT(L, 15);
+  if constexpr (G::PV > 0) {
+    static_assert(G::PV == 0 || NP == 1, "one piece per wave");
+    *(lds_int*)(PVbuf + tid) = pv0[0];
+    *(lds_int*)(PVbuf + 512 + tid) = pv1[0];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   auto issue_patch = [&](const int kc) {
     float* const dst = Pbuf + (G::NPB == 2 ? (kc & 1) : 0) * G::P_FLOATS;
     const bool from1 = !DIL && kc * 16 >= c0;                   // wave-uniform: the whole chunk reads in1 (c0 % 16 == 0)
 #if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (G::PV > 0) {
+      if (npw > 0) {
+        int pv;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pv) : "v"((int)(size_t)(lds_int*)(PVbuf + (from1 ? 512 : 0) + tid)) : "memory");
+        float* const dB = dst + wave * 256;
+        if (from1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (wn_lds_void*)dB, 16, pv, (kc * 16 - c0) * 4, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, pv, kc * 64, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int d = 0; d < NP; ++d) {
       if (d >= npw) continue;
@@ -457,10 +476,11 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   SF_STAMP_AT(L, 1);
 
   f32x4 acc[4][2][NB];
+  int b_cur = b_off;
   auto step = [&](const int kc, auto p_c, auto first_c) {
     constexpr int p = decltype(p_c)::value, slot = p & 1;
     constexpr bool first = decltype(first_c)::value;
-    const float* const vb = Vbuf + (G::NVB == 2 ? (kc & 1) : 0) * G::V_FLOATS + p * WT * 16 + b_off;
+    const float* const vb = Vbuf + (G::NVB == 2 ? (kc & 1) : 0) * G::V_FLOATS + p * WT * 16 + b_cur;
     f32x4 Bf[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) Bf[nb] = wn_lds_read128(vb + nb * 256);
@@ -510,6 +530,12 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   };
   chunk(0, std::true_type{}, std::true_type{});
   for (int kc = 1; kc + 1 < nkc; ++kc) chunk(kc, std::false_type{}, std::true_type{});
+  if constexpr (WT == 16) {      // (80 registers: the last chunk is its own copy of the code, and hipcc carries its fragment offset past the loop in scratch)
+    int t2 = tid;
+    asm volatile("" : "+v"(t2));
+    const int j2 = t2 & 15, g2 = (t2 & 63) >> 4;
+    b_cur = (ih * 4 * WT + j2) * 16 + ((g2 ^ ((j2 >> 2) & 2)) << 2);
+  }
   chunk(nkc - 1, std::false_type{}, std::false_type{});
   SF_STAMP_AT(L, 2);
 
@@ -528,8 +554,13 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
   }
   float* const Tb = Vbuf;                                      // [ih][b][tile][64 cout], 16-byte slot cq of a tile's row at cq ^ (tile & 15)
   wn_barrier();                                                 // every wave is done with V (and nothing is in flight into the patch)
+  // 16-tile form (80 registers): what the exchange and the epilogue derive from the thread index is derived HERE — hipcc would compute it in
+  // front of the loop and carry it through in scratch
+  int tid_e = tid;
+  if constexpr (WT == 16) asm volatile("" : "+v"(tid_e));
   {
     typedef __attribute__((address_space(3))) f32x4 lds_f4w;
+    const int j = tid_e & 15, g = (tid_e & 63) >> 4;
     const int tw_base = ((ih * 2) * WT + j) * 64;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
@@ -543,8 +574,8 @@ __global__ __launch_bounds__(WN_THREADS, 4) void conv_wino5_kernel(const ConvLau
     }
   }
   // ---- second half + epilogue: thread = (tile wt, channel quad cq), the 16 quads of a pixel in consecutive lanes --------------------------------
-  const int cq = tid & 15, wt_e = WT == 32 ? tid >> 4 : (tid >> 4) & (WT - 1);
-  const bool has_tile = WT == 32 || tid < 16 * WT;             // 16-tile blocks: half of the threads have no tile (they load and store nothing)
+  const int cq = tid_e & 15, wt_e = WT == 32 ? tid_e >> 4 : (tid_e >> 4) & (WT - 1);
+  const bool has_tile = WT == 32 || tid_e < 16 * WT;           // 16-tile blocks: half of the threads have no tile (they load and store nothing)
   const int tyl_e = wt_e >> 3, txl_e = wt_e & 7;
   const bool run_e = CAT && txl_e >= cn0;
   const int ty = ty0 + tyl_e, tx = run_e ? txl_e - cn0 : tx0 + txl_e;
@@ -839,11 +870,12 @@ hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream) {
     if (!wino_takes(L.p[i], epi) || !wino_same_geometry(L.p[0], L.p[i])) return hipErrorInvalidValue;
   const bool affine = epi == EPI_AFFINE;
   const int var = wino_variant(L.p[0]);
-  // 16-tile blocks where 32-tile blocks would not fill the chip's 512 workgroup slots once (SF_WINO_SMALL_WGS workgroups; 0: never).
-  // Measured (profiles/r06_wino16_ab.txt): the 313-workgroup BLEND launches of a single 200x200 frame 0.609 -> 0.553 ms per forward;
-  // above one round the 16-tile form LOSES (626-workgroup AFFINE launches 2.90 -> 2.94 ms: every workgroup loads the whole U of its 64
-  // output channels whatever its tile count, and the loop is bound by the address unit's 16 cycles per load instruction)
-  static const long small_wgs = [] { const char* v = std::getenv("SF_WINO_SMALL_WGS"); return v ? std::atol(v) : 512L; }();
+  // 16-tile blocks where 32-tile blocks would leave the launch below SF_WINO_SMALL_WGS workgroups (two rounds of the chip's 512 slots; 0: never).
+  // The 16-tile form runs THREE workgroups per CU (80 registers, 46 KB of LDS), so a launch of 313 / 626 32-tile workgroups becomes 626 / 1252
+  // of 768 slots.  Measured per threshold (profiles/r06_wino16_ab.txt, single-sample forward): BLEND launches 0.608 -> 0.514 ms, AFFINE 2.880 ->
+  // 2.841, forward 7.44 -> 7.27 ms; at two samples per forward 13.18 -> 13.14; above ~1 400 workgroups the 32-tile form wins (every workgroup
+  // loads the whole U of its 64 output channels whatever its tile count: 16 tiles double the load instructions per MFMA)
+  static const long small_wgs = [] { const char* v = std::getenv("SF_WINO_SMALL_WGS"); return v ? std::atol(v) : 1000L; }();
   const bool small = (var == 2 || var == 4) && wino5_wgs32(L, var == 4) < small_wgs;
   switch (var) {
     case 2:
