@@ -518,7 +518,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   }
   // Winograd F(2x2, 3x3) for the 3x3 / stride-1 layers of large launches (conv_wino.hip): 2.25x fewer MACs, exact fp32 arithmetic.
   // Groups are launched problem by problem (the kernel takes one); the profiler prices the launch at its EXECUTED FLOPs (key 16).
-  if (tune().wino && P >= tune().wino_min_p && (epi == EPI_AFFINE || epi == EPI_BLEND)) {
+  if (tune().wino && P >= tune().wino_min_p && (epi == EPI_AFFINE || epi == EPI_BLEND || epi == EPI_LNG)) {      // (EPI_LNG: the 7x7 + LayerNorm layer as nine 3x3 tap groups)
     // the members of a group are independent layers: those the kernel takes run on it one by one, the others stay one group
     // (the ASPP group: three dilated 3x3 branches + the 1x1 branch)
     bool takes[SF_MAX_GROUP];
@@ -568,8 +568,8 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
           r.flops = 0; r.bytes = 0;
           for (int i = 0; i < WG.nprob; ++i) {
             const ConvProblem& q = WG.p[i];
-            r.flops += 2.0 * 16.0 * wino_tiles(q) * q.cout * (q.c0 + q.c1);
-            r.bytes += 4.0 * ((double)q.n_img * q.Hin * q.Win * (q.c0 + q.c1) + 16.0 * q.cout * (q.c0 + q.c1) + (double)q.n_img * q.Hout * q.Wout * q.cout);
+            r.flops += 2.0 * 16.0 * wino_tiles(q) * q.cout * (q.c0 + q.c1) * (q.KH == 7 ? 9 : 1);
+            r.bytes += 4.0 * ((double)q.n_img * q.Hin * q.Win * (q.c0 + q.c1) + 16.0 * (q.KH == 7 ? 9 : 1) * q.cout * (q.c0 + q.c1) + (double)q.n_img * q.Hout * q.Wout * q.cout);
           }
           r.a = g_prof.get(); r.b = g_prof.get();
           SF_HIP(hipEventRecord(r.a, st));
@@ -615,8 +615,9 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
         const int wv = wino_variant(q);
         r.key = (16 + (wv == 4 ? 2 : wv)) * 8 + epi;   // _lib.KERNEL_NAMES: wino128x32t / wino64x64t / wino64x32t2 (also its form with concatenated images) / wino64x32t2dil
         const double tiles = wino_tiles(q);
-        r.flops = 2.0 * 16.0 * tiles * q.cout * (q.c0 + q.c1);      // executed: 16 products per 2x2 outputs and (cin, cout) pair
-        r.bytes = 4.0 * ((double)q.n_img * q.Hin * q.Win * (q.c0 + q.c1) + 16.0 * q.cout * (q.c0 + q.c1) + (double)q.n_img * q.Hout * q.Wout * q.cout);
+        const double grp = q.KH == 7 ? 9.0 : 1.0;                   // tap groups of the 7x7 form
+        r.flops = 2.0 * 16.0 * grp * tiles * q.cout * (q.c0 + q.c1);      // executed: 16 products per 2x2 outputs, (cin, cout) pair and tap group
+        r.bytes = 4.0 * ((double)q.n_img * q.Hin * q.Win * (q.c0 + q.c1) + 16.0 * grp * q.cout * (q.c0 + q.c1) + (double)q.n_img * q.Hout * q.Wout * q.cout);
         r.a = g_prof.get(); r.b = g_prof.get();
         SF_HIP(hipEventRecord(r.a, st));
         SF_HIP(launch_conv_wino(W1, epi, st));
@@ -1076,8 +1077,17 @@ int cell_tail(const sf_dual_w& w, const float* s, float* out, int derivative, co
   // one latent on the small-P kernel: the 1x1 + LN + GELU layer is applied to the 7x7 layer's tile before it leaves the
   // workgroup (one launch and one 0.64-MB round trip fewer per cell evaluation)
   const bool fuse_1x1 = fuse_following_1x1(ps, 2, q, w.tg1, b.t2);
-  SF_TRY(run(ps, 2, EPI_LNG, st));
-  if (!fuse_1x1) SF_TRY(run1(q, EPI_LNG, st));
+  // batched latents: the 7x7 runs on the Winograd kernel (nine 3x3 tap groups, conv_wino.hip GRP = 9) by itself — the 1x1 projection, which only
+  // reads h1 / r2, then shares the launch of the 1x1 + LN layer behind it instead of the 7x7's
+  const bool wino7 = !fuse_1x1 && !acc7 && tune().wino && (double)B * H * W >= tune().wino_min_p && wino_takes(ps[0], EPI_LNG) && !(tune().b3 && ps[0].w3);
+  if (wino7) {
+    SF_TRY(run1(ps[0], EPI_LNG, st));
+    ConvProblem g2[2] = {q, ps[1]};
+    SF_TRY(run(g2, 2, EPI_LNG, st));
+  } else {
+    SF_TRY(run(ps, 2, EPI_LNG, st));
+    if (!fuse_1x1) SF_TRY(run1(q, EPI_LNG, st));
+  }
   ConvProblem f = problem(w.tg3, b.t2, nullptr, out, B, H, W);
   f.e0 = b.sk; f.e1 = w.w_logit; f.e2 = b.r2; f.e3 = b.h1; f.e4 = s; f.e5 = base ? base : s;
   f.coef = coef; f.coef_stride = coef_stride; f.out2 = out2; f.mode = (derivative ? 1 : 0) | (acc2 ? 2 : 0);

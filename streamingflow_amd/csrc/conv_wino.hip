@@ -153,6 +153,18 @@ __device__ __forceinline__ void wn5_act16(f32x4 (&y)[4], const int act) {
         for (int q = 0; q < 4; ++q) y[k][q] = spm_act(y[k][q], act);
   }
 }
+// sum over the 16 lanes of a DPP row (the 16 channel quads of a pixel in the epilogue's lane order), in every lane of the row
+__device__ __forceinline__ float wn_row16_sum(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));       // quad_perm [1, 0, 3, 2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));       // quad_perm [2, 3, 0, 1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));      // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));      // row_mirror
+#endif
+  return v;
+}
+__device__ __forceinline__ float wn_gelu(float v) { return 0.5f * v * (1.f + spm_erf(v * 0.70710678118654752440f)); }      // (= gelu_f of conv_igemm.hip)
+
 // TH_: tile rows of the workgroup's block — 4 (8 x 16 output pixels, 32 tiles: the kernel as measured in DESIGN 4.3) or 2 (4 x 16 pixels, 16
 // tiles, three workgroups per CU: round 6, for launches of fewer than two rounds of the chip's 512 workgroup slots — a single 200x200 frame
 // with 64 / 128 output channels is 313 / 626 workgroups of 32 tiles; launch_conv_wino holds the measured rule)
@@ -186,8 +198,13 @@ struct Wino5Geo {
 #if !defined(SF_W5_MAGIC)
 #define SF_W5_MAGIC 1
 #endif
-template <int EPI, bool DIL = false, bool CAT = false, int TH_ = 4>
+// GRP = 9 (round 6, EPI_LNG only): a 7x7 / pad-3 layer as nine 3x3 sub-kernels of its 9x9 zero frame (wino_weights_kernel) — tap group (a, b)
+// convolves the input shifted by (3a - 3, 3b - 3), all nine accumulate into the same Winograd-domain sums: the K loop runs over
+// 9 x cin/16 chunks, the patch offsets move when a chunk starts a new group, everything else is the 3x3 kernel
+template <int EPI, bool DIL = false, bool CAT = false, int TH_ = 4, int GRP = 1>
 __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kernel(const ConvLaunch L) {
+  static_assert(GRP == 1 || (GRP == 9 && !DIL && TH_ == 4), "tap groups: the 7x7 form");
+  static_assert((EPI == EPI_LNG) == (GRP == 9), "the LayerNorm epilogue belongs to the 7x7 form");
   typedef Wino5Geo<DIL, CAT, TH_> G;
   constexpr int NB = G::NB;                                    // 16-tile fragments of the block
   constexpr int COUT_T = G::COUT_T, TH = G::TH, TW = G::TW, WT = G::WT, PW = G::PW, NP = G::NP;
@@ -254,7 +271,8 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
   SF_STAMP_VAL(L, 10, (unsigned long long)nkc_stamp(P));
 #endif
   const int cout0 = (slot_ - tb_ * ncb) * COUT_T;
-  const int nkc = P.cin_pad >> 4;                              // 16-channel chunks (>= 2: cin_pad is a multiple of 32)
+  const int nkc_g = P.cin_pad >> 4;                            // 16-channel chunks (>= 2: cin_pad is a multiple of 32) of a tap group
+  const int nkc = GRP * nkc_g;
   const int NS = nkc * 4;                                      // steps: (chunk, position of the wave's row)
   const int c0 = P.c0;
   const int img_px_i = P.Hin * P.Win;
@@ -308,6 +326,8 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
   // ---- patch DMA: element e = (pixel, channel quad) of the patch, 16 bytes each, LDS linear in e; piece idx = d * 8 + wave --------------
   SF_STAMP_AT(L, 14);
   int pv0[NP], pv1[DIL ? 1 : NP];
+  int piy[GRP > 1 ? NP : 1], pix_[GRP > 1 ? NP : 1];           // tap groups: the element's input pixel without the group's shift (piy < -16: never valid)
+  (void)piy; (void)pix_;
   const int npw = G::ND / 8 + (wave < G::ND % 8 ? 1 : 0);      // wave-uniform
 #pragma unroll
   for (int d = 0; d < NP; ++d) {
@@ -327,9 +347,19 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
       ok = pix < G::NPX && ix >= 0 && iy >= 0;
     }
     const int pofs = DIL ? iy * W + ix : (iy >> up) * Win + (ix >> up) + (CAT ? run * img_px_i : 0);
-    pv0[d] = ok ? (pofs * P.in0_cs + quad * 4) * 4 : (int)0x80000000;
-    if constexpr (!DIL) pv1[d] = ok ? (pofs * P.in1_cs + quad * 4) * 4 : (int)0x80000000;
+    if constexpr (GRP > 1) {      // the range check waits for the group's shift (issue_patch)
+      const bool in_blk = pix < G::NPX && (!CAT || (img + run < P.n_img && (run == 0 || cn0 < TW)));
+      piy[d] = in_blk ? iy : -(1 << 20);
+      pix_[d] = ix;
+      pv0[d] = (pofs * P.in0_cs + quad * 4) * 4;
+      pv1[d] = (pofs * P.in1_cs + quad * 4) * 4;
+    } else {
+      pv0[d] = ok ? (pofs * P.in0_cs + quad * 4) * 4 : (int)0x80000000;
+      if constexpr (!DIL) pv1[d] = ok ? (pofs * P.in1_cs + quad * 4) * 4 : (int)0x80000000;
+    }
   }
+  int g_kc = 0, g_grp = 0;                                      // tap groups: issue_patch is called for chunks 0, 1, 2, ... in order
+  (void)g_kc; (void)g_grp;
   SF_STAMP_AT(L, 15);
   if constexpr (G::PV > 0) {
     static_assert(G::PV == 0 || NP == 1, "one piece per wave");
@@ -341,6 +371,30 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
     float* const dst = Pbuf + (G::NPB == 2 ? (kc & 1) : 0) * G::P_FLOATS;
     const bool from1 = !DIL && kc * 16 >= c0;                   // wave-uniform: the whole chunk reads in1 (c0 % 16 == 0)
 #if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (GRP > 1) {
+      const int ga = (g_grp * 11) >> 5, gb = g_grp - 3 * ga;    // group (a, b): rows 3a .. 3a+2, columns 3b .. 3b+2 of the 9x9 frame
+      const int sy = 3 * ga - 3, sx = 3 * gb - 3;
+      const bool f1 = g_kc * 16 >= c0;
+      const int dlt = (sy * Win + sx) * (f1 ? P.in1_cs : P.in0_cs) * 4;
+      const int so = f1 ? (g_kc * 16 - c0) * 4 : g_kc * 64;
+#pragma unroll
+      for (int d = 0; d < NP; ++d) {
+        if (d >= npw) continue;
+        float* const dB = dst + (d * 8 + wave) * 256;
+        const bool okg = (unsigned)(piy[d] + sy) < (unsigned)H && (unsigned)(pix_[d] + sx) < (unsigned)W;
+        const int v = okg ? (f1 ? pv1[d] : pv0[d]) + dlt : (int)0x80000000;
+        if (f1) {
+          asm volatile("; patch from in1");
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (wn_lds_void*)dB, 16, v, so, 0, 0);
+        } else {
+          asm volatile("; patch from in0");
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, v, so, 0, 0);
+        }
+      }
+      if (++g_kc == nkc_g) { g_kc = 0; ++g_grp; }
+      (void)kc; (void)from1;
+      return;
+    }
     if constexpr (G::PV > 0) {
       if (npw > 0) {
         int pv;
@@ -585,10 +639,10 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
     ox0 = tab(48 + txl_e);
     oy0 = tab(56 + tyl_e);
   }
-  constexpr bool affine = EPI == EPI_AFFINE;
-  const float* const t_a = affine ? PX.add : PX.e0;
+  constexpr bool affine = EPI == EPI_AFFINE, lng = EPI == EPI_LNG;
+  const float* const t_a = (affine || lng) ? PX.add : PX.e0;
   const float* const t_b = PX.e1;
-  const int cs_a = affine ? P.add_cs : P.e0_cs, cs_b = P.e1_cs;
+  const int cs_a = (affine || lng) ? P.add_cs : P.e0_cs, cs_b = P.e1_cs;
   const bool img_ok = has_tile && (!CAT || img + (run_e ? 1 : 0) < P.n_img);
   const bool x0 = img_ok && ox0 < W, x1 = img_ok && ox0 + ostep < W, y0ok = oy0 < H, y1ok = oy0 + ostep < H;
   const unsigned pix = (x0 && y0ok) ? (unsigned)(oy0 * W + ox0 + (run_e ? H * W : 0)) : 0u;      // lanes without a tile compute on pixel 0 and store nothing
@@ -607,7 +661,7 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
   const size_t img_span = n_span * H * W;
   const int pk_[4] = {0, ostep * W, ostep, ostep * W + ostep};      // pixel offset of pixel k
   constexpr int OOB = (int)0x80000000;
-  const bool has_a = affine ? PX.add != nullptr : true, has_b = affine ? PX.out2 != nullptr : true;
+  const bool has_a = (affine || lng) ? PX.add != nullptr : true, has_b = lng ? false : (affine ? PX.out2 != nullptr : true);
   const bool gate_lane = affine && PX.out2 != nullptr && c >= P.gate_from;      // GRU gates, reset half: also emits (1 - r) * s
   (void)img_span; (void)pk_; (void)OOB; (void)has_a; (void)has_b; (void)gate_lane;
   f32x4 oa[4], ob[4];
@@ -647,10 +701,32 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
     y[2 * bq + 1] = wn5_sub4(t1, t2 + t3);
   }
   SF_STAMP_AT(L, 6);
+  if constexpr (!lng) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) y[k] = __builtin_elementwise_fma(y[k], sc, bi);
+    for (int k = 0; k < 4; ++k) y[k] = __builtin_elementwise_fma(y[k], sc, bi);
+  }
   f32x4 y2[4];
-  if constexpr (affine) {
+  if constexpr (lng) {      // [LayerNorm over the 64 channels of the pixel (convolutions.py:303-308): 16 lanes x 4] -> GELU [-> + residual]
+    if (P.mode & 1) {
+      const float inv_c = 1.f / (float)P.cout;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float mean = wn_row16_sum((y[k][0] + y[k][1]) + (y[k][2] + y[k][3])) * inv_c;
+        const f32x4 dv = y[k] - (f32x4){mean, mean, mean, mean};
+        const float var = wn_row16_sum((dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3])) * inv_c;
+        const float rstd = 1.f / sqrtf(var + P.eps);
+        y[k] = __builtin_elementwise_fma(dv * (f32x4){rstd, rstd, rstd, rstd}, sc, bi);      // SBuf carries the LayerNorm's weight / bias here
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y[k][q] = wn_gelu(y[k][q]);
+    if (PX.add) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = y[k] + oa[k];
+    }
+  } else if constexpr (affine) {
     const bool act_last = (P.mode & 2) != 0;
     if (!act_last) wn5_act16(y, P.act);
     if (P.clamp_from >= 0) {
@@ -764,7 +840,23 @@ hipError_t launch_wino_weights(const float* w, float* U, int cout_pad, int cin_p
 
 // what the kernel takes: 3x3, stride 1, pad 1, no dilation / upsampling / gather / gate / SE scale / split-K / channel sums; inputs
 // in whole 16-channel chunks; transformed weights present; images of at least one workgroup tile
+// EPI_LNG (round 6): the 7x7 / pad-3 + LayerNorm + GELU layer of the batched cells as nine 3x3 tap groups (GRP = 9): 64 output channels = one
+// cout block (the LayerNorm needs a pixel's channels in one workgroup), LayerNorm on, plain inputs, [+ residual]
+static bool wino_takes_ln7(const ConvProblem& q) {
+  static const int on = [] { const char* v = std::getenv("SF_WINO_LN7"); return v ? std::atoi(v) : 1; }();
+  if (!on || !q.w_wino || q.KH != 7 || q.KW != 7 || q.stride != 1 || q.dil != 1 || q.pad != 3 || q.in_up || q.gather || q.gate || q.se_sum || q.in_scale ||
+      q.nsplit > 1 || q.chansum || q.acc_in || q.fuse_w || q.out_planar || q.pool2 || q.add_up || q.add_scale || q.bias_per_img || q.out2)
+    return false;
+  if (q.cout != 64 || q.cout_pad != 64 || (q.c0 % 16) || (q.c1 % 16) || q.c0 + q.c1 != q.cin_pad || (q.cin_pad % 32)) return false;
+  if (q.Hout != q.Hin || q.Wout != q.Win || q.Hout < 16 || q.Wout < 32) return false;
+  const double img_bytes = 4.0 * q.Hin * q.Win;
+  if (img_bytes * q.out_cs >= 2147483648.0 || img_bytes * q.add_cs >= 2147483648.0 || img_bytes * q.in0_cs >= 2147483648.0 ||
+      img_bytes * q.in1_cs >= 2147483648.0 || 4.0 * 9 * 16 * q.cout_pad * q.cin_pad >= 2147483648.0)
+    return false;
+  return true;
+}
 bool wino_takes(const ConvProblem& q, int epi) {
+  if (epi == EPI_LNG) return wino_takes_ln7(q);
   if (epi != EPI_AFFINE && epi != EPI_BLEND) return false;
   if (!q.w_wino || q.KH != 3 || q.KW != 3 || q.stride != 1 || q.dil < 1 || q.pad != q.dil || (q.in_up && q.dil != 1) || q.gather || q.gate || q.se_sum ||
       (q.in_scale && (epi != EPI_AFFINE || q.dil != 1 || q.c0 > 256)) ||      // SE-scaled input: plain AFFINE form, scales staged in LDS
@@ -818,10 +910,10 @@ static long wino5_wgs32(const ConvLaunch& L, bool cat) {
   const long blocks = cat ? (long)((tiles_y + 3) / 4) * (((long)P.n_img * tiles_x + 7) / 8) : (long)P.n_img * ((tiles_y + 3) / 4) * ((tiles_x + 7) / 8);
   return ((blocks + 7) / 8) * 8 * (P.cout_pad / 64) * L.nprob;
 }
-template <int EPI, bool DIL = false, bool CAT = false, int TH_ = 4>
+template <int EPI, bool DIL = false, bool CAT = false, int TH_ = 4, int GRP = 1>
 static hipError_t launch_wino5_t(const ConvLaunch& L, hipStream_t stream) {
   typedef Wino5Geo<DIL, CAT, TH_> G;
-  auto kern = conv_wino5_kernel<EPI, DIL, CAT, TH_>;
+  auto kern = conv_wino5_kernel<EPI, DIL, CAT, TH_, GRP>;
   constexpr int lds = G::LDS_FLOATS * 4;
   static bool attr_done[64] = {};
   int dev = 0;
@@ -870,6 +962,11 @@ hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream) {
     if (!wino_takes(L.p[i], epi) || !wino_same_geometry(L.p[0], L.p[i])) return hipErrorInvalidValue;
   const bool affine = epi == EPI_AFFINE;
   const int var = wino_variant(L.p[0]);
+  if (epi == EPI_LNG) {
+    if (var == 2) return launch_wino5_t<EPI_LNG, false, false, 4, 9>(L, stream);
+    if (var == 4) return launch_wino5_t<EPI_LNG, false, true, 4, 9>(L, stream);
+    return hipErrorInvalidValue;
+  }
   // 16-tile blocks where 32-tile blocks would leave the launch below SF_WINO_SMALL_WGS workgroups (two rounds of the chip's 512 slots; 0: never).
   // The 16-tile form runs THREE workgroups per CU (80 registers, 46 KB of LDS), so a launch of 313 / 626 32-tile workgroups becomes 626 / 1252
   // of 768 slots.  Measured per threshold (profiles/r06_wino16_ab.txt, single-sample forward): BLEND launches 0.608 -> 0.514 ms, AFFINE 2.880 ->

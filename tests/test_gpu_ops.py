@@ -3,6 +3,7 @@
 (b) the oracle on the same hashed inputs at the shipped channel count (C=64, 50x50 latent).
 Tolerance: 1e-4 max-abs per op, fp32 everywhere."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -330,6 +331,39 @@ def test_c64_cells_vs_oracle(pair64):
             sr, ir = R.ode_step(sd, "gru_ode", s, x, 0.5, solver, True, _noise())
             assert maxabs(st, sr) <= TOL and maxabs(inp, ir) <= TOL, solver
         ode.solver, ode.noise = "euler", None
+
+
+@pytest.mark.parametrize("B,h,w", [(8, 50, 50), (9, 37, 45), (1, 200, 200), (3, 101, 75)])
+def test_batched_cells_7x7_in_winograd_tap_groups_vs_oracle(pair64, B, h, w):
+    """Round 6: with >= 14000 pixels per launch the trusting gate's 7x7 + LayerNorm + GELU layer runs on conv_wino5_kernel as nine 3x3 tap
+    groups (csrc/conv_wino.hip, GRP = 9; images concatenated along x when 8 tile columns fit them badly).  Both dual cells on batched
+    latents — 50x50 (the shipped size), odd sizes (ragged tiles, seams between images under every shift of a tap group), one large image —
+    against the oracle, and the profiler must show the launch."""
+    from streamingflow_amd import _lib
+    net, sd = pair64
+    C = 64
+    x = hashfill.normal(f"x7g{B}", (B, C, h, w), 41)
+    s = hashfill.normal(f"s7g{B}", (B, C, h, w), 42) * 0.5
+    ode = net.gru_ode
+    L = _lib.lib()
+    NK = _lib.SF_PROF_KEYS
+    calls, ms, fl, by = (ctypes.c_int32 * NK)(), (ctypes.c_double * NK)(), (ctypes.c_double * NK)(), (ctypes.c_double * NK)()
+    L.sf_prof_enable(1)
+    try:
+        with torch.no_grad():
+            a = ode.gru_c(x.cuda(), s.cuda())
+            b = ode.gru_obs(s.cuda(), None, x.cuda())[0]
+        torch.cuda.synchronize()
+        L.sf_prof_collect(calls, ms, fl, by)
+    finally:
+        L.sf_prof_enable(0)
+    used = {_lib.KERNEL_NAMES[k]: calls[k] for k in range(NK) if calls[k]}
+    if os.environ.get("SF_WINO_LN7", "1") != "0" and os.environ.get("SF_WINO", "1") != "0":
+        assert used.get("conv_wino<64x32t2,ln_gelu>", 0) == 2, used
+    with torch.no_grad():
+        for i in range(B):
+            assert maxabs(a[i:i + 1], R.dual_cell(sd, "gru_ode.gru_c", x[i:i + 1], s[i:i + 1], True)) <= TOL, i
+            assert maxabs(b[i:i + 1], R.dual_cell(sd, "gru_ode.gru_obs.gru_d", x[i:i + 1], s[i:i + 1], False)) <= TOL, i
 
 
 def test_c64_stress_latent_200(pair64):
