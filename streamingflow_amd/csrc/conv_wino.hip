@@ -7,6 +7,8 @@
 // (north-star tolerance 1e-3).  FLOP accounting: bench.py prices these launches at their EXECUTED FLOPs for the roofline and keeps the
 // algorithmic (direct-form) count for ODE-steps/s (savings are not credited as achieved FLOPs).
 //
+// Round 6: a 16-tile / three-workgroups-per-CU form for under-filled launches (Wino5Geo TH_ = 2) and the 7x7 + LayerNorm layer of the batched
+// cells as nine 3x3 tap groups (GRP = 9, EPI_LNG); both in front of conv_wino5_kernel.
 // Weights are transformed once at pack time (pack.hip: U[cin/16][16 positions][cout_pad][16], sf_conv_w::w_wino).  The kernel
 // (conv_wino5_kernel, round 5) is described in front of it; the round-4 kernel it replaced (U through an LDS ring, one wave = 16 cout x
 // 16 tiles x all 16 positions: 0.57-0.66 of the fp32 MFMA peak against 0.64-0.74) lives in the history of this file, the F(4x4, 3x3)
@@ -327,7 +329,8 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
   SF_STAMP_AT(L, 14);
   int pv0[NP], pv1[DIL ? 1 : NP];
   int piy[GRP > 1 ? NP : 1], pix_[GRP > 1 ? NP : 1];           // tap groups: the element's input pixel without the group's shift (piy < -16: never valid)
-  (void)piy; (void)pix_;
+  int pvs0[GRP > 1 ? NP : 1], pvs1[GRP > 1 ? NP : 1];           // ... and its two offsets under the current group's shift
+  (void)piy; (void)pix_; (void)pvs0; (void)pvs1;
   const int npw = G::ND / 8 + (wave < G::ND % 8 ? 1 : 0);      // wave-uniform
 #pragma unroll
   for (int d = 0; d < NP; ++d) {
@@ -372,23 +375,29 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
     const bool from1 = !DIL && kc * 16 >= c0;                   // wave-uniform: the whole chunk reads in1 (c0 % 16 == 0)
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (GRP > 1) {
-      const int ga = (g_grp * 11) >> 5, gb = g_grp - 3 * ga;    // group (a, b): rows 3a .. 3a+2, columns 3b .. 3b+2 of the 9x9 frame
-      const int sy = 3 * ga - 3, sx = 3 * gb - 3;
+      if (g_kc == 0) {      // a new tap group: the lanes' offsets under its shift (range check included), once for the group's chunks
+        const int ga = (g_grp * 11) >> 5, gb = g_grp - 3 * ga;    // group (a, b): rows 3a .. 3a+2, columns 3b .. 3b+2 of the 9x9 frame
+        const int sy = 3 * ga - 3, sx = 3 * gb - 3;
+        const int dlt = (sy * Win + sx) * 4;
+#pragma unroll
+        for (int d = 0; d < NP; ++d) {
+          const bool okg = (unsigned)(piy[d] + sy) < (unsigned)H && (unsigned)(pix_[d] + sx) < (unsigned)W;
+          pvs0[d] = okg ? pv0[d] + dlt * P.in0_cs : (int)0x80000000;
+          pvs1[d] = okg ? pv1[d] + dlt * P.in1_cs : (int)0x80000000;
+        }
+      }
       const bool f1 = g_kc * 16 >= c0;
-      const int dlt = (sy * Win + sx) * (f1 ? P.in1_cs : P.in0_cs) * 4;
       const int so = f1 ? (g_kc * 16 - c0) * 4 : g_kc * 64;
 #pragma unroll
       for (int d = 0; d < NP; ++d) {
         if (d >= npw) continue;
         float* const dB = dst + (d * 8 + wave) * 256;
-        const bool okg = (unsigned)(piy[d] + sy) < (unsigned)H && (unsigned)(pix_[d] + sx) < (unsigned)W;
-        const int v = okg ? (f1 ? pv1[d] : pv0[d]) + dlt : (int)0x80000000;
         if (f1) {
           asm volatile("; patch from in1");
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (wn_lds_void*)dB, 16, v, so, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (wn_lds_void*)dB, 16, pvs1[d], so, 0, 0);
         } else {
           asm volatile("; patch from in0");
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, v, so, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (wn_lds_void*)dB, 16, pvs0[d], so, 0, 0);
         }
       }
       if (++g_kc == nkc_g) { g_kc = 0; ++g_grp; }
