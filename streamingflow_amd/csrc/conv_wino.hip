@@ -858,6 +858,10 @@ static bool wino_takes_ln7(const ConvProblem& q) {
     return false;
   if (q.cout != 64 || q.cout_pad != 64 || (q.c0 % 16) || (q.c1 % 16) || q.c0 + q.c1 != q.cin_pad || (q.cin_pad % 32)) return false;
   if (q.Hout != q.Hin || q.Wout != q.Win || q.Hout < 16 || q.Wout < 32) return false;
+  // one cout block and 9 x cin/16 chunks per workgroup: the launch needs a full round of workgroups (2 x 256 blocks of 32 tiles = 65536 pixels) to
+  // pay — 8 latents of 50x50 are 175 workgroups of ~200 us each and LOSE to the direct form (batch-8 step 549 -> 563 us, profiles/r06_ln7_ab.txt)
+  static const double min_p = [] { const char* v = std::getenv("SF_WINO_LN7_MIN_P"); return v ? std::atof(v) : 65536.0; }();
+  if ((double)q.n_img * q.Hout * q.Wout < min_p) return false;
   const double img_bytes = 4.0 * q.Hin * q.Win;
   if (img_bytes * q.out_cs >= 2147483648.0 || img_bytes * q.add_cs >= 2147483648.0 || img_bytes * q.in0_cs >= 2147483648.0 ||
       img_bytes * q.in1_cs >= 2147483648.0 || 4.0 * 9 * 16 * q.cout_pad * q.cin_pad >= 2147483648.0)

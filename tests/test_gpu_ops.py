@@ -333,12 +333,16 @@ def test_c64_cells_vs_oracle(pair64):
         ode.solver, ode.noise = "euler", None
 
 
-@pytest.mark.parametrize("B,h,w", [(8, 50, 50), (9, 37, 45), (1, 200, 200), (3, 101, 75)])
+_TAP_SMALL = [(8, 50, 50), (9, 37, 45), (1, 200, 200), (3, 101, 75)]      # below the form's default size: reached with SF_WINO_LN7_MIN_P=0
+
+
+@pytest.mark.parametrize("B,h,w", [(32, 50, 50), (27, 37, 67), (1, 262, 258)] + _TAP_SMALL)
 def test_batched_cells_7x7_in_winograd_tap_groups_vs_oracle(pair64, B, h, w):
-    """Round 6: with >= 14000 pixels per launch the trusting gate's 7x7 + LayerNorm + GELU layer runs on conv_wino5_kernel as nine 3x3 tap
+    """Round 6: with >= 65536 pixels per launch the trusting gate's 7x7 + LayerNorm + GELU layer runs on conv_wino5_kernel as nine 3x3 tap
     groups (csrc/conv_wino.hip, GRP = 9; images concatenated along x when 8 tile columns fit them badly).  Both dual cells on batched
-    latents — 50x50 (the shipped size), odd sizes (ragged tiles, seams between images under every shift of a tap group), one large image —
-    against the oracle, and the profiler must show the launch."""
+    latents — 32 x 50x50 (the headline's launch), odd sizes (ragged tiles, seams between images under every shift of a tap group), one
+    large image — against the oracle, and the profiler must show the launch.  The small cases run on the direct form here and on the tap
+    groups in test_tap_groups_on_small_launches (a child process with the size rule off)."""
     from streamingflow_amd import _lib
     net, sd = pair64
     C = 64
@@ -359,11 +363,27 @@ def test_batched_cells_7x7_in_winograd_tap_groups_vs_oracle(pair64, B, h, w):
         L.sf_prof_enable(0)
     used = {_lib.KERNEL_NAMES[k]: calls[k] for k in range(NK) if calls[k]}
     if os.environ.get("SF_WINO_LN7", "1") != "0" and os.environ.get("SF_WINO", "1") != "0":
-        assert used.get("conv_wino<64x32t2,ln_gelu>", 0) == 2, used
+        big = B * h * w >= float(os.environ.get("SF_WINO_LN7_MIN_P", "65536"))
+        assert used.get("conv_wino<64x32t2,ln_gelu>", 0) == (2 if big else 0), used
     with torch.no_grad():
         for i in range(B):
             assert maxabs(a[i:i + 1], R.dual_cell(sd, "gru_ode.gru_c", x[i:i + 1], s[i:i + 1], True)) <= TOL, i
             assert maxabs(b[i:i + 1], R.dual_cell(sd, "gru_ode.gru_obs.gru_d", x[i:i + 1], s[i:i + 1], False)) <= TOL, i
+
+
+def test_tap_groups_on_small_launches():
+    """The small cases of the test above with SF_WINO_LN7_MIN_P=0: every one of them on the tap-group form (the assertion on the profiler's
+    kernel list follows the variable)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["SF_WINO_LN7_MIN_P"] = "0"
+    ids = " or ".join(f"{B}-{h}-{w}" for B, h, w in _TAP_SMALL)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-x", os.path.join(root, "tests", "test_gpu_ops.py"),
+                        "-k", f"tap_groups_vs_oracle and ({ids})"], env=env, capture_output=True, text=True, timeout=1800, cwd=root)
+    tail = r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.returncode == 0 and f"{len(_TAP_SMALL)} passed" in r.stdout, tail
 
 
 def test_c64_stress_latent_200(pair64):
