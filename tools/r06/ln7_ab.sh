@@ -14,7 +14,5 @@ d=json.loads(open("$out/bench_$v.json").read().strip().splitlines()[-1])
 print("bench SF_WINO_LN7=$v", d["value"], d["ms_per_step"], d["roofline"]["frac"])
 for n, k in d["roofline"]["per_kernel"].items():
     if "ln_gelu" in n or "trust" in n: print("   ", n, k["calls_per_forward"], round(k["ms_per_forward"],3), round(k["tflops"],1), k.get("frac_of_bound"))
-for k in []:
-    pass
 PY
 done
