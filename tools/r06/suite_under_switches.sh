@@ -1,6 +1,6 @@
 #!/bin/bash
 # the whole GPU suite again under the opt-in / fallback switches of the library (each a separate pytest process): failures here are bugs of
-# paths the default suite reaches only through their own tests
+# paths the default suite reaches only through their own tests.  usage: suite_under_switches.sh [name ...]   (default: all)
 set -u
 : "${GRAFT_REPO_ROOT:?run through gpurun}"
 cd "$GRAFT_REPO_ROOT"
@@ -11,7 +11,15 @@ run() {
   echo "$name rc=$? $(grep -E 'passed|failed' gpurun_out/switches/$name.log | tail -1)"
   grep -E "^(FAILED|ERROR)" gpurun_out/switches/$name.log | head -20
 }
-run persist1 SF_PERSIST=1
-run wino_sp0 SF_WINO_SP=0
-run wino16_always SF_WINO_SMALL_WGS=1000000000
-run wino_sp7_0 SF_WINO_SP7=0
+want() { [ $# -eq 0 ] && return 0; for w in "$@"; do [ "$w" = "$cur" ] && return 0; done; return 1; }
+for cur in persist1 wino_sp0 wino16_always wino_sp7_0 ln7_off ln7_always; do
+  want "$@" || continue
+  case $cur in
+    persist1)      run $cur SF_PERSIST=1 ;;
+    wino_sp0)      run $cur SF_WINO_SP=0 ;;
+    wino16_always) run $cur SF_WINO_SMALL_WGS=1000000000 ;;
+    wino_sp7_0)    run $cur SF_WINO_SP7=0 ;;
+    ln7_off)       run $cur SF_WINO_LN7=0 ;;
+    ln7_always)    run $cur SF_WINO_LN7_MIN_P=0 ;;
+  esac
+done
