@@ -701,7 +701,7 @@ def main():
                 forward()
             torch.cuda.synchronize()
             msd = 1e3 * (time.perf_counter() - t0) / nd
-            direct = {"what": "streamingflow_amd.set_winograd(False) / SF_WINO=0: every 3x3 layer in direct form on the implicit-GEMM tiles (rounds 1-3)",
+            direct = {"what": "streamingflow_amd.set_winograd(False) / SF_WINO=0: every 3x3 layer and the cells' 7x7 in direct form on the implicit-GEMM tiles (rounds 1-3)",
                       "ms_per_step": msd, "ode_steps_per_s": n_ode * B / (msd * 1e-3), "headline_over_this": msd / ms_per_step,
                       "max_abs_winograd_vs_direct_same_forward": errd, "absmax_of_output": float(yd.abs().max())}
         except Exception as ex:
