@@ -518,7 +518,7 @@ int run(const ConvProblem* ps, int n, int epi, hipStream_t st) {
   }
   // Winograd F(2x2, 3x3) for the 3x3 / stride-1 layers of large launches (conv_wino.hip): 2.25x fewer MACs, exact fp32 arithmetic.
   // Groups are launched problem by problem (the kernel takes one); the profiler prices the launch at its EXECUTED FLOPs (key 16).
-  if (tune().wino && P >= tune().wino_min_p && (epi == EPI_AFFINE || epi == EPI_BLEND || epi == EPI_LNG)) {      // (EPI_LNG: the 7x7 + LayerNorm layer as nine 3x3 tap groups)
+  if (tune().wino && P >= tune().wino_min_p && (epi == EPI_AFFINE || epi == EPI_BLEND || epi == EPI_LNG || epi == EPI_SAMPLE)) {      // (EPI_LNG: the 7x7 + LayerNorm layer as nine 3x3 tap groups; EPI_SAMPLE: the sampling layer)
     // the members of a group are independent layers: those the kernel takes run on it one by one, the others stay one group
     // (the ASPP group: three dilated 3x3 branches + the 1x1 branch)
     bool takes[SF_MAX_GROUP];

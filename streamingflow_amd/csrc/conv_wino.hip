@@ -207,6 +207,7 @@ template <int EPI, bool DIL = false, bool CAT = false, int TH_ = 4, int GRP = 1>
 __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kernel(const ConvLaunch L) {
   static_assert(GRP == 1 || (GRP == 9 && !DIL && TH_ == 4), "tap groups: the 7x7 form");
   static_assert((EPI == EPI_LNG) == (GRP == 9), "the LayerNorm epilogue belongs to the 7x7 form");
+  static_assert(EPI != EPI_SAMPLE || (!DIL && TH_ == 4), "the sampling layer: plain / concatenated 32-tile forms");
   typedef Wino5Geo<DIL, CAT, TH_> G;
   constexpr int NB = G::NB;                                    // 16-tile fragments of the block
   constexpr int COUT_T = G::COUT_T, TH = G::TH, TW = G::TW, WT = G::WT, PW = G::PW, NP = G::NP;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
   const __amdgpu_buffer_rsrc_t rsrc1 = make_rsrc(PX.in1 ? PX.in1 + (size_t)img * img_px * P.in1_cs : PX.in0, PX.in1 ? n_in * img_px * P.in1_cs * sizeof(float) : 0);
   const __amdgpu_buffer_rsrc_t rsrc_u = make_rsrc(PX.w_wino, (size_t)nkc * 16 * P.cout_pad * 16 * sizeof(float));
 #endif
-  constexpr bool SCALED = G::SC > 0 && EPI == EPI_AFFINE;
+  constexpr bool SCALED = G::SC > 0 && (EPI == EPI_AFFINE || EPI == EPI_SAMPLE);
   const bool scaled = SCALED && PX.in_scale != nullptr;
   // DIL: what depends on one axis only is computed once per block by 36 + 12 lanes and shared through LDS (every lane walking the run
   // lists itself — twice per patch element, twice for its transform task, twice for its output tile — was 300 of the kernel's ~650
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
     ox0 = tab(48 + txl_e);
     oy0 = tab(56 + tyl_e);
   }
-  constexpr bool affine = EPI == EPI_AFFINE, lng = EPI == EPI_LNG;
+  constexpr bool affine = EPI == EPI_AFFINE, lng = EPI == EPI_LNG, smp = EPI == EPI_SAMPLE;
   const float* const t_a = (affine || lng) ? PX.add : PX.e0;
   const float* const t_b = PX.e1;
   const int cs_a = (affine || lng) ? P.add_cs : P.e0_cs, cs_b = P.e1_cs;
@@ -670,7 +671,13 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
   const size_t img_span = n_span * H * W;
   const int pk_[4] = {0, ostep * W, ostep, ostep * W + ostep};      // pixel offset of pixel k
   constexpr int OOB = (int)0x80000000;
-  const bool has_a = (affine || lng) ? PX.add != nullptr : true, has_b = lng ? false : (affine ? PX.out2 != nullptr : true);
+  const bool has_a = smp ? false : ((affine || lng) ? PX.add != nullptr : true), has_b = (lng || smp) ? false : (affine ? PX.out2 != nullptr : true);
+  // SAMPLE (round 6): the packed cout rows are interleaved — rows 4q .. 4q+3 = (loc ch, loc ch+1, raw ch, raw ch+1), ch = 8 (row >> 4) + 2 ((row >> 2) & 3)
+  // (pack.hip) — so the lane's four channels are two (loc, raw) pairs; eps is an input of the call or drawn here (Philox, keyed by pixel and channel)
+  const int s_half = P.cout >> 1, s_ch = ((c >> 4) << 3) + 2 * ((c >> 2) & 3);
+  const bool s_ok = c_ok && s_ch < s_half;
+  f32x2 ev[4];
+  (void)s_half; (void)s_ch; (void)s_ok; (void)ev;
   const bool gate_lane = affine && PX.out2 != nullptr && c >= P.gate_from;      // GRU gates, reset half: also emits (1 - r) * s
   (void)img_span; (void)pk_; (void)OOB; (void)has_a; (void)has_b; (void)gate_lane;
   f32x4 oa[4], ob[4];
@@ -686,6 +693,15 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
     const int v = (int)(pix * (unsigned)cs_a + (unsigned)c_ld) * 4;
 #pragma unroll
     for (int k = 0; k < 4; ++k) oa[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, okk[k] ? v : OOB, pk_[k] * cs_a * 4, 0));
+  }
+  if constexpr (smp) {
+    if (PX.e0) {
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(PX.e0 + img_base * s_half, img_span * s_half * sizeof(float));
+      const int v = (int)(pix * (unsigned)s_half + (unsigned)(s_ok ? s_ch : 0)) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        ev[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (okk[k] && s_ok) ? v : OOB, pk_[k] * s_half * 4, 0));
+    }
   }
   if (has_b) {
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(t_b + img_base * cs_b, img_span * cs_b * sizeof(float));
@@ -715,7 +731,33 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
     for (int k = 0; k < 4; ++k) y[k] = __builtin_elementwise_fma(y[k], sc, bi);
   }
   f32x4 y2[4];
-  if constexpr (lng) {      // [LayerNorm over the 64 channels of the pixel (convolutions.py:303-308): 16 lanes x 4] -> GELU [-> + residual]
+  if constexpr (smp) {      // q = act(conv + bias); p = loc + eps (softplus(raw) + 1e-8)   (model_utils.py:84, 107-108; as conv_igemm.hip / conv_sp.hip)
+    wn5_act16(y, P.act);
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2;
+    const __amdgpu_buffer_rsrc_t rs_p = make_rsrc(PX.out + img_base * s_half, img_span * s_half * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(PX.out2 ? PX.out2 + img_base * P.cout : PX.out, PX.out2 ? img_span * P.cout * sizeof(float) : 0);
+    const unsigned gp0 = (unsigned)img_base + pix;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool okp = okk[k] && s_ok;
+      f32x2 e = ev[k];
+      if (!PX.e0) {      // block-uniform
+        const float2 d = spm_philox_normal2(P.philox, P.draw, okp ? gp0 + (unsigned)pk_[k] : 0u, (unsigned)(s_ok ? s_ch : 0));
+        e = (f32x2){d.x, d.y};
+      }
+      const f32x2 r = {y[k][0] + e[0] * (spm_softplus(y[k][2]) + 1e-8f), y[k][1] + e[1] * (spm_softplus(y[k][3]) + 1e-8f)};
+      const int vp = (int)(pix * (unsigned)s_half + (unsigned)s_ch) * 4, vq = (int)(pix * (unsigned)P.cout + (unsigned)s_ch) * 4;
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, r), rs_p, okp ? vp : OOB, pk_[k] * s_half * 4, 0);
+      if (PX.out2) {      // raw q parameters, reference channel order [loc | raw]
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){y[k][0], y[k][1]}), rs_q, okp ? vq : OOB, pk_[k] * P.cout * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){y[k][2], y[k][3]}), rs_q, okp ? vq + s_half * 4 : OOB, pk_[k] * P.cout * 4, 0);
+      }
+    }
+#endif
+    SF_STAMP_AT(L, 3);
+    return;
+  } else if constexpr (lng) {      // [LayerNorm over the 64 channels of the pixel (convolutions.py:303-308): 16 lanes x 4] -> GELU [-> + residual]
     if (P.mode & 1) {
       const float inv_c = 1.f / (float)P.cout;
 #pragma unroll
@@ -870,6 +912,14 @@ static bool wino_takes_ln7(const ConvProblem& q) {
 }
 bool wino_takes(const ConvProblem& q, int epi) {
   if (epi == EPI_LNG) return wino_takes_ln7(q);
+  if (epi == EPI_SAMPLE) {      // the sampling layer of the batched infer_state (round 6): the plain AFFINE rules + what its epilogue addresses
+    static const int on = [] { const char* v = std::getenv("SF_WINO_SAMPLE"); return v ? std::atoi(v) : 1; }();
+    const double img_px = (double)q.Hin * q.Win;
+    if (!on || q.dil != 1 || q.in_up || q.add || q.add_scale || q.pool2 || q.add_up || q.bias_per_img || q.scale || (q.cout % 8) || (q.c1 != 0) ||
+        2.0 * 4.0 * img_px * q.cout >= 2147483648.0 || (!q.e0 && !q.philox))
+      return false;
+    return wino_takes(q, EPI_AFFINE);      // (out2 here is the q tensor: no gate_from semantics — the kernel's SAMPLE branch never reads it as a gate)
+  }
   if (epi != EPI_AFFINE && epi != EPI_BLEND) return false;
   if (!q.w_wino || q.KH != 3 || q.KW != 3 || q.stride != 1 || q.dil < 1 || q.pad != q.dil || (q.in_up && q.dil != 1) || q.gather || q.gate || q.se_sum ||
       (q.in_scale && (epi != EPI_AFFINE || q.dil != 1 || q.c0 > 256)) ||      // SE-scaled input: plain AFFINE form, scales staged in LDS
@@ -975,6 +1025,11 @@ hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream) {
     if (!wino_takes(L.p[i], epi) || !wino_same_geometry(L.p[0], L.p[i])) return hipErrorInvalidValue;
   const bool affine = epi == EPI_AFFINE;
   const int var = wino_variant(L.p[0]);
+  if (epi == EPI_SAMPLE) {
+    if (var == 2) return launch_wino5_t<EPI_SAMPLE>(L, stream);
+    if (var == 4) return launch_wino5_t<EPI_SAMPLE, false, true>(L, stream);
+    return hipErrorInvalidValue;
+  }
   if (epi == EPI_LNG) {
     if (var == 2) return launch_wino5_t<EPI_LNG, false, false, 4, 9>(L, stream);
     if (var == 4) return launch_wino5_t<EPI_LNG, false, true, 4, 9>(L, stream);

@@ -335,6 +335,8 @@ def test_winograd_epilogues_of_the_batched_latents_against_the_direct_form():
     (yb, pb, qb), used_b = build(False)
     assert any(k.startswith("conv_wino") and k.endswith("blend>") for k in used_a), used_a
     assert any(k.startswith("conv_wino") and k.endswith("affine>") for k in used_a), used_a
+    if os.environ.get("SF_WINO_SAMPLE", "1") != "0":      # round 6: the sampling layer (SE-scaled input, (loc, raw) interleaved rows, eps from the hashed stream)
+        assert any(k.startswith("conv_wino") and k.endswith("sample>") for k in used_a), used_a
     assert not any(k.startswith("conv_wino") for k in used_b), used_b
     for a, b in ((ya, yb), (pa, pb), (qa, qb)):
         assert a.shape == b.shape and maxabs(a, b) <= 2e-5, maxabs(a, b)
