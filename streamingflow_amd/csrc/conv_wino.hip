@@ -184,7 +184,7 @@ struct Wino5Geo {
   static constexpr int V_FLOATS = 16 * WT * 16;
   static constexpr int NVB = DIL ? 1 : 2, NPB = DIL ? 2 : 1;
   static constexpr int PARK = DIL ? 512 + 64 : 0;               // DIL: the patch offset of every transform task + the per-axis tables of the block
-  static constexpr int SB = 2 * COUT_T, SC = DIL ? 0 : 256;
+  static constexpr int SB = 2 * COUT_T, SC = DIL ? 0 : (CAT ? 512 : 256);      // SE input scales: [c0 <= 256] of the image (CAT: and of the next one)
   static constexpr int T_FLOATS = 4 * 2 * WT * COUT_T;          // the exchange of the output transform: [row i][b][tile][cout]
   static_assert(NVB * V_FLOATS + NPB * P_FLOATS >= T_FLOATS, "the exchange lives over V and the patch");
   static constexpr int PV = TH_ == 2 ? 2 * 512 : 0;             // 16-tile form (80 registers): the lanes' two patch offsets live in LDS between the chunks
@@ -363,6 +363,18 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
     }
   }
   int g_kc = 0, g_grp = 0;                                      // tap groups: issue_patch is called for chunks 0, 1, 2, ... in order
+  // CAT + SE-scaled input (round 6; 32-tile form only — the 16-tile form has no register for it and the host never asks): bit d = patch
+  // element d of this lane lies in the NEXT image, whose scales sit behind this image's in SCbuf
+  constexpr bool CAT_SC = CAT && G::PV == 0 && G::SC > 0;
+  int run_bits = 0;
+  if constexpr (CAT_SC) {
+#pragma unroll
+    for (int d = 0; d < NP; ++d) {
+      const int pix = ((d * 8 + wave) * 64 + lane) >> 2;
+      run_bits |= ((pix - (pix / PW) * PW) >= 2 * cn0 + 2 ? 1 : 0) << d;
+    }
+  }
+  (void)run_bits;
   (void)g_kc; (void)g_grp;
   SF_STAMP_AT(L, 15);
   if constexpr (G::PV > 0) {
@@ -441,12 +453,14 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
     if constexpr (SCALED) {
       if (scaled && kc * 16 < c0) {
         const f32x4 s4 = wn_lds_read128(SCbuf + kc * 16 + (lane & 3) * 4);
+        f32x4 s4n = s4;
+        if constexpr (CAT_SC) s4n = wn_lds_read128(SCbuf + c0 + kc * 16 + (lane & 3) * 4);      // the next image's scales (c0 <= 256)
         typedef __attribute__((address_space(3))) f32x4 lds_f4w;
 #pragma unroll
         for (int d = 0; d < NP; ++d) {
           if (d >= npw) continue;
           float* const q = Pbuf + ((d * 8 + wave) * 64 + lane) * 4;
-          *(lds_f4w*)q = wn_lds_read128(q) * s4;
+          *(lds_f4w*)q = wn_lds_read128(q) * ((CAT_SC && ((run_bits >> d) & 1)) ? s4n : s4);
         }
       }
     }
@@ -506,6 +520,7 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
   float scv = 1.f;
   if constexpr (SCALED)
     if (scaled && tid < c0) scv = PX.in_scale[(size_t)img * c0 + tid];
+    if (CAT_SC && scaled && tid >= c0 && tid < 2 * c0 && img + 1 < P.n_img) scv = PX.in_scale[(size_t)(img + 1) * c0 + (tid - c0)];
   issue_patch(0);
   f32x4 A[2][2];                                                // [ring slot = step & 1][mb]
   A[0][0] = load_A(0, 0); A[0][1] = load_A(0, 1);
@@ -711,7 +726,7 @@ __global__ __launch_bounds__(WN_THREADS, TH_ == 2 ? 6 : 4) void conv_wino5_kerne
   }
 #endif
   f32x4 as = (f32x4){1.f, 1.f, 1.f, 1.f};
-  if (affine && PX.add && PX.add_scale) as = wn5_ld4(PX.add_scale + (size_t)img * P.cout + c_ld);
+  if (affine && PX.add && PX.add_scale) as = wn5_ld4(PX.add_scale + (size_t)(img + ((CAT && run_e && img_ok) ? 1 : 0)) * P.cout + c_ld);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   wn_barrier();                                                 // the exchange is complete
   const f32x4 sc = wn_lds_read128(SBuf + cl), bi = wn_lds_read128(SBuf + COUT_T + cl);
@@ -944,7 +959,8 @@ bool wino_takes(const ConvProblem& q, int epi) {
 static bool wino_cat(const ConvProblem& q) {
   static const int on = [] { const char* v = std::getenv("SF_WINO_CAT"); return v ? std::atoi(v) : 1; }();
   const int tpi = (q.Wout + 1) / 2;
-  if (!on || q.dil != 1 || q.in_up || q.n_img < 2 || tpi < 8 || q.in_scale || q.bias_per_img || q.add_scale) return false;
+  static const int cat_scaled = [] { const char* v = std::getenv("SF_WINO_CAT_SCALED"); return v ? std::atoi(v) : 1; }();      // round 6: SE scales of both images of a block
+  if (!on || q.dil != 1 || q.in_up || q.n_img < 2 || tpi < 8 || q.bias_per_img || ((q.in_scale || q.add_scale) && !cat_scaled)) return false;
   const int plain = (tpi + 7) / 8 * 8;
   if (plain * 100 < tpi * 110) return false;      // less than 10 % empty columns: keep the plain form
   const double img_bytes = 4.0 * q.Hin * q.Win;
@@ -1041,7 +1057,7 @@ hipError_t launch_conv_wino(const ConvLaunch& L, int epi, hipStream_t stream) {
   // 2.841, forward 7.44 -> 7.27 ms; at two samples per forward 13.18 -> 13.14; above ~1 400 workgroups the 32-tile form wins (every workgroup
   // loads the whole U of its 64 output channels whatever its tile count: 16 tiles double the load instructions per MFMA)
   static const long small_wgs = [] { const char* v = std::getenv("SF_WINO_SMALL_WGS"); return v ? std::atol(v) : 1000L; }();
-  const bool small = (var == 2 || var == 4) && wino5_wgs32(L, var == 4) < small_wgs;
+  const bool small = (var == 2 || var == 4) && wino5_wgs32(L, var == 4) < small_wgs && !(var == 4 && L.p[0].in_scale);      // (SE-scaled CAT: 32-tile form only)
   switch (var) {
     case 2:
       if (small) return affine ? launch_wino5_t<EPI_AFFINE, false, false, 2>(L, stream) : launch_wino5_t<EPI_BLEND, false, false, 2>(L, stream);
