@@ -12,7 +12,7 @@ run() {
   grep -E "^(FAILED|ERROR)" gpurun_out/switches/$name.log | head -20
 }
 want() { [ $# -eq 0 ] && return 0; for w in "$@"; do [ "$w" = "$cur" ] && return 0; done; return 1; }
-for cur in persist1 wino_sp0 wino16_always wino_sp7_0 ln7_off ln7_always; do
+for cur in persist1 wino_sp0 wino16_always wino_sp7_0 ln7_off ln7_always sample_off cat_scaled_off; do
   want "$@" || continue
   case $cur in
     persist1)      run $cur SF_PERSIST=1 ;;
@@ -21,5 +21,7 @@ for cur in persist1 wino_sp0 wino16_always wino_sp7_0 ln7_off ln7_always; do
     wino_sp7_0)    run $cur SF_WINO_SP7=0 ;;
     ln7_off)       run $cur SF_WINO_LN7=0 ;;
     ln7_always)    run $cur SF_WINO_LN7_MIN_P=0 ;;
+    sample_off)    run $cur SF_WINO_SAMPLE=0 ;;
+    cat_scaled_off) run $cur SF_WINO_CAT_SCALED=0 ;;
   esac
 done
